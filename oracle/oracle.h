@@ -1,0 +1,128 @@
+/* oracle/oracle.h — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C CPU restatement of the reference algorithms on the hot path
+ * (JSzitas/nlsolver, nlsolver.h / tinyqr.h). Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library; the product (include/, nlsolver_amd/) never links or calls it.
+ *
+ * Parity status: PINNED. The serial-compat functions (orc_*_serial,
+ * orc_xorshift_*, orc_splitmix_*) reproduce bit-for-bit the golden vectors in
+ * the JSON files under tests/golden/, which were produced by running the unmodified reference
+ * (oracle/_ref/ref_driver, built from /root/reference by oracle/Makefile) in
+ * this container; see tests/golden/gen_golden.py and tests/test_oracle_golden.py.
+ *
+ * Two families of functions live here:
+ *   1. "serial" — the reference's own (asynchronous, single RNG stream)
+ *      algorithm, restated line by line with file:line citations.
+ *   2. "sync"   — the synchronous, counter-RNG, fixed-reduction-tree form of
+ *      the same algorithm that a GPU generation kernel can execute. The HIP
+ *      kernels must match these bit-for-bit (selection indices, populations,
+ *      scores). The relation sync <-> serial is algorithmic (same update rule
+ *      per agent, different scheduling/RNG), checked by convergence tests.
+ */
+#ifndef NLSG_ORACLE_H_
+#define NLSG_ORACLE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ RNG --- */
+/* nlsolver.h:1263-1288 rng::splitmix (seed 12374563468 at :1265). */
+#define ORC_SPLITMIX_SEED 12374563468ull
+uint64_t orc_splitmix_next(uint64_t *state); /* yield_init(), :1273-1278 */
+/* nlsolver.h:1343-1381 rng::xorshift<double> (xorshift128+, shifts 23/18/5). */
+typedef struct {
+  uint64_t x[2];
+} orc_xorshift;
+void orc_xorshift_init(orc_xorshift *g);   /* ctor :1345-1349 */
+double orc_xorshift_next(orc_xorshift *g); /* yield() :1350-1361 */
+
+/* Counter-based generator used by every "sync" restatement and by the HIP
+ * kernels: three nested splitmix64 steps (each level is "output #(n+1) of a
+ * splitmix64 stream seeded with the parent key", i.e. nlsolver.h:1273-1278
+ * applied as a random-access function). */
+uint64_t orc_mix64(uint64_t z);
+uint64_t orc_ctr_key(uint64_t parent, uint64_t index); /* mix(parent+G*(index+1)) */
+double orc_u01(uint64_t bits); /* (double)bits * 2^-64, cf. nlsolver.h:1358 */
+
+/* ------------------------------------------------------------ objectives --- */
+enum {
+  ORC_OBJ_ROSENBROCK = 0,      /* example.cpp:41-48 generalised to N-D chain  */
+  ORC_OBJ_SPHERE = 1,          /* test_functions.h:52-57                      */
+  ORC_OBJ_STYBLINSKI_TANG = 2, /* test_functions.h:249-260 (x^4 as products)  */
+  ORC_OBJ_RASTRIGIN = 3        /* test_functions.h:69-78, N-D                 */
+};
+/* Sequential left-to-right evaluation = "the reference arithmetic" of a user
+ * functor written the obvious way. */
+double orc_objective_seq(int obj, const double *x, size_t D);
+/* Same terms, summed in the device's fixed tree: element e belongs to lane
+ * (e % 128) / 2 of chunk e / 128; a lane adds its terms in increasing element
+ * order; then a 64-lane xor butterfly (32,16,8,4,2,1). */
+double orc_objective_tree(int obj, const double *x, size_t D);
+
+/* ---------------------------------------------------------------- std_err --- */
+/* nlsolver.h:2037-2052: two serial passes, pow(.,2), divide by n-1. */
+double orc_std_err_serial(const double *x, size_t n);
+/* Fixed tree used on device: 256-thread block tree over tiles of 1024, then the
+ * same block tree over the tile partials. */
+double orc_block_tree_sum(const double *v, size_t n);
+double orc_tiled_sum(const double *v, size_t n);
+double orc_tiled_sumsq_dev(const double *v, size_t n, double mean);
+double orc_std_err_tree(const double *x, size_t n);
+
+/* --------------------------------------------------------------------- DE --- */
+/* Evaluation recorder shared by the serial restatements. */
+typedef struct {
+  double *xs; /* capacity * D */
+  double *fs; /* capacity */
+  size_t capacity, count, D;
+} orc_eval_log;
+
+typedef struct {
+  double f_value;
+  uint64_t iteration, function_calls_used, gradient_evals_used, hessian_evals_used;
+} orc_status; /* nlsolver.h:2054-2097 */
+
+/* DE::solve<minimize> (nlsolver.h:2414-2476), strategy 0 = best, 1 = random
+ * (enum order of nlsolver.h:2377). `gen` is the caller's generator and is
+ * advanced exactly as the reference advances it. x is in/out. */
+orc_status orc_de_serial(int obj, int minimize, int strategy, double *x, size_t D,
+                         orc_xorshift *gen, double CR, double F, double eps,
+                         size_t pop, size_t max_iter, size_t best_val_no_change,
+                         orc_eval_log *log);
+
+/* Synchronous restatement (what the GPU executes). All state is caller-owned. */
+typedef struct {
+  int obj, minimize, strategy;
+  size_t pop, D;      /* global population */
+  size_t n_shards;    /* island model: donors are drawn inside the agent's shard */
+  double CR, F, eps;
+  size_t max_iter, best_val_no_change;
+  uint64_t seed;
+  /* state */
+  double *cur, *nxt;  /* pop*D each, row-major */
+  double *scores;     /* pop */
+  uint64_t best_id;
+  uint64_t iter, val_no_change, fcalls;
+  int done;
+  double std_err;
+  /* optional trace of the last generation: per agent r1,r2,r3,jrand,accept */
+  uint64_t *trace; /* pop*5 or NULL */
+} orc_de_sync;
+
+void orc_de_sync_init(orc_de_sync *s, const double *x0); /* generation 0 */
+/* One reference loop turn: best scan + stop tests (nlsolver.h:2429-2447), then
+ * if not done one synchronous generation (2449-2472) and iter++. */
+void orc_de_sync_step(orc_de_sync *s);
+/* Multi-threaded variant of the generation (OpenMP over agents); identical
+ * results. Used only for the CPU baseline timing. */
+void orc_de_sync_step_omp(orc_de_sync *s, int threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NLSG_ORACLE_H_ */

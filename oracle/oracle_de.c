@@ -1,0 +1,235 @@
+/* oracle/oracle_de.c — TEST INFRASTRUCTURE, NOT PRODUCT CODE (see oracle.h).
+ *
+ * Differential Evolution, restated from nlsolver.h:2302-2477.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "oracle.h"
+
+static void log_eval(orc_eval_log *log, const double *x, double f) {
+  if (!log || log->count >= log->capacity) {
+    if (log) log->count++;
+    return;
+  }
+  memcpy(log->xs + log->count * log->D, x, log->D * sizeof(double));
+  log->fs[log->count] = f;
+  log->count++;
+}
+
+/* generate_index, nlsolver.h:2325-2329: size_t(u * max). */
+static size_t gen_index(size_t max, orc_xorshift *g) {
+  return (size_t)(orc_xorshift_next(g) * (double)max);
+}
+
+/* generate_indices, nlsolver.h:2331-2355: three distinct proposals != fixed by
+ * rejection; the unordered_set is a membership test over <= 3 values. */
+static void gen_indices(size_t fixed, size_t max, orc_xorshift *g, size_t out[4]) {
+  out[0] = fixed;
+  size_t samples = 1;
+  for (;;) {
+    const size_t proposal = gen_index(max, g);
+    int used = 0;
+    for (size_t k = 0; k < samples; k++) used |= (out[k] == proposal);
+    if (!used) {
+      out[samples++] = proposal;
+      if (samples == 4) return;
+    }
+  }
+}
+
+orc_status orc_de_serial(int obj, int minimize, int strategy, double *x, size_t D,
+                         orc_xorshift *gen, double CR, double F, double eps,
+                         size_t pop, size_t max_iter, size_t best_val_no_change,
+                         orc_eval_log *log) {
+  double *agents = (double *)malloc(pop * D * sizeof(double));
+  double *scores = (double *)malloc(pop * sizeof(double));
+  double *proposal = (double *)malloc(D * sizeof(double));
+  /* init_agents / generate_sequence, nlsolver.h:2302-2323: (u - 0.5) * x0[i],
+   * agent-major draw order. */
+  for (size_t a = 0; a < pop; a++)
+    for (size_t i = 0; i < D; i++)
+      agents[a * D + i] = (orc_xorshift_next(gen) - 0.5) * x[i];
+  const double fm = minimize ? 1.0 : -1.0; /* :2418 */
+  for (size_t a = 0; a < pop; a++) {       /* :2423-2425 */
+    const double f = orc_objective_seq(obj, agents + a * D, D);
+    log_eval(log, agents + a * D, f);
+    scores[a] = fm * f;
+  }
+  size_t fcalls = pop, iter = 0, best_id = 0, val_no_change = 0;
+  for (;;) {
+    int not_updated = 1;
+    for (size_t i = 0; i < pop; i++) { /* :2432-2437 strict '<' vs incumbent */
+      if (scores[i] < scores[best_id]) {
+        best_id = i;
+        not_updated = 0;
+      }
+    }
+    val_no_change = (size_t)not_updated * (val_no_change + 1); /* :2439 */
+    if (iter >= max_iter || val_no_change >= best_val_no_change ||
+        orc_std_err_serial(scores, pop) < eps) { /* :2441-2447 */
+      memcpy(x, agents + best_id * D, D * sizeof(double));
+      orc_status st = {scores[best_id], iter, fcalls, 0, 0};
+      free(agents);
+      free(scores);
+      free(proposal);
+      return st;
+    }
+    for (size_t i = 0; i < pop; i++) { /* :2449 */
+      size_t ids[4];
+      gen_indices(strategy == 1 ? i : best_id, pop, gen, ids); /* :2451-2457 */
+      /* propose_new_agent, :2357-2375 */
+      const size_t dim = gen_index(D, gen);
+      for (size_t d = 0; d < D; d++) {
+        const double u = orc_xorshift_next(gen); /* always drawn (left operand) */
+        if (u < CR || d == dim) {
+          proposal[d] = agents[ids[1] * D + d] +
+                        F * (agents[ids[2] * D + d] - agents[ids[3] * D + d]);
+        } else {
+          proposal[d] = agents[ids[0] * D + d];
+        }
+      }
+      const double f = orc_objective_seq(obj, proposal, D);
+      log_eval(log, proposal, f);
+      const double score = fm * f; /* :2463 */
+      fcalls++;
+      if (score < scores[i]) { /* :2466-2471 in-place replacement */
+        memcpy(agents + i * D, proposal, D * sizeof(double));
+        scores[i] = score;
+      }
+    }
+    iter++;
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Synchronous restatement                                                    */
+/* ------------------------------------------------------------------------- */
+#define ORC_DE_MAX_TRIES 64
+
+static size_t clamp_index(double u, size_t n) {
+  size_t p = (size_t)(u * (double)n); /* nlsolver.h:2328 */
+  return p >= n ? n - 1 : p;          /* B10: u can be exactly 1.0 */
+}
+
+void orc_de_sync_init(orc_de_sync *s, const double *x0) {
+  const uint64_t kg = orc_ctr_key(s->seed, 0);
+  const double fm = s->minimize ? 1.0 : -1.0;
+  for (size_t a = 0; a < s->pop; a++) {
+    const uint64_t ka = orc_ctr_key(kg, a);
+    double *row = s->cur + a * s->D;
+    for (size_t d = 0; d < s->D; d++) /* nlsolver.h:2309 */
+      row[d] = (orc_u01(orc_ctr_key(ka, d)) - 0.5) * x0[d];
+    s->scores[a] = fm * orc_objective_tree(s->obj, row, s->D); /* :2423-2425 */
+  }
+  s->best_id = 0;
+  s->iter = 0;
+  s->val_no_change = 0;
+  s->fcalls = s->pop;
+  s->done = 0;
+  s->std_err = NAN;
+}
+
+/* Best scan with the reference's tie rule (nlsolver.h:2432-2437): the result
+ * is the incumbent when its score equals the minimum, otherwise the first
+ * index holding the minimum; NaN is never "less". */
+static int best_scan(const double *scores, size_t pop, uint64_t *best_id) {
+  int not_updated = 1;
+  for (size_t i = 0; i < pop; i++) {
+    if (scores[i] < scores[*best_id]) {
+      *best_id = i;
+      not_updated = 0;
+    }
+  }
+  return not_updated;
+}
+
+static void sync_agent(const orc_de_sync *s, uint64_t kg, size_t a, double *trial) {
+  const size_t D = s->D, pop = s->pop;
+  const size_t shard_n = pop / s->n_shards;
+  const size_t lo = (a / shard_n) * shard_n;
+  const uint64_t ka = orc_ctr_key(kg, a);
+  const size_t fixed = s->strategy == 1 ? a : (size_t)s->best_id; /* :2451-2457 */
+  /* donors: slots D+1+k, rejection as in generate_indices (2331-2355), drawn
+   * inside the agent's shard (island model); bounded number of tries. */
+  size_t r[3];
+  size_t have = 0;
+  for (size_t k = 0; k < ORC_DE_MAX_TRIES && have < 3; k++) {
+    const size_t p = lo + clamp_index(orc_u01(orc_ctr_key(ka, D + 1 + k)), shard_n);
+    int used = (p == fixed);
+    for (size_t j = 0; j < have; j++) used |= (r[j] == p);
+    if (!used) r[have++] = p;
+  }
+  for (size_t p = lo; have < 3; p++) { /* fallback: lowest unused indices */
+    int used = (p == fixed);
+    for (size_t j = 0; j < have; j++) used |= (r[j] == p);
+    if (!used) r[have++] = p;
+  }
+  const size_t dim = clamp_index(orc_u01(orc_ctr_key(ka, D)), D); /* :2364 */
+  const double *r1 = s->cur + r[0] * D, *r2 = s->cur + r[1] * D, *r3 = s->cur + r[2] * D;
+  const double *base = s->cur + fixed * D;
+  for (size_t d = 0; d < D; d++) { /* :2365-2374 */
+    const double u = orc_u01(orc_ctr_key(ka, d));
+    trial[d] = (u < s->CR || d == dim) ? r1[d] + s->F * (r2[d] - r3[d]) : base[d];
+  }
+  const double fm = s->minimize ? 1.0 : -1.0;
+  const double score = fm * orc_objective_tree(s->obj, trial, D); /* :2463 */
+  const int accept = score < s->scores[a];                         /* :2466 */
+  memcpy(s->nxt + a * D, accept ? trial : s->cur + a * D, D * sizeof(double));
+  if (accept) s->scores[a] = score;
+  if (s->trace) {
+    uint64_t *t = s->trace + a * 5;
+    t[0] = r[0];
+    t[1] = r[1];
+    t[2] = r[2];
+    t[3] = dim;
+    t[4] = (uint64_t)accept;
+  }
+}
+
+static int sync_prologue(orc_de_sync *s) {
+  if (s->done) return 1;
+  const int not_updated = best_scan(s->scores, s->pop, &s->best_id);
+  s->val_no_change = (uint64_t)not_updated * (s->val_no_change + 1); /* :2439 */
+  /* std_err is only evaluated when it can decide something (eps > 0): for
+   * eps <= 0 or NaN the test `std_err < eps` (:2443) is false for every value
+   * std_err can take (>= 0 or NaN). */
+  if (s->eps > 0) s->std_err = orc_std_err_tree(s->scores, s->pop);
+  if (s->iter >= s->max_iter || s->val_no_change >= s->best_val_no_change ||
+      (s->eps > 0 && s->std_err < s->eps)) { /* :2441-2443 */
+    s->done = 1;
+    return 1;
+  }
+  return 0;
+}
+
+static void sync_epilogue(orc_de_sync *s) {
+  double *t = s->cur;
+  s->cur = s->nxt;
+  s->nxt = t;
+  s->fcalls += s->pop;
+  s->iter++;
+}
+
+void orc_de_sync_step(orc_de_sync *s) {
+  if (sync_prologue(s)) return;
+  const uint64_t kg = orc_ctr_key(s->seed, s->iter + 1);
+  double *trial = (double *)malloc(s->D * sizeof(double));
+  for (size_t a = 0; a < s->pop; a++) sync_agent(s, kg, a, trial);
+  free(trial);
+  sync_epilogue(s);
+}
+
+void orc_de_sync_step_omp(orc_de_sync *s, int threads) {
+  if (sync_prologue(s)) return;
+  const uint64_t kg = orc_ctr_key(s->seed, s->iter + 1);
+#pragma omp parallel num_threads(threads)
+  {
+    double *trial = (double *)malloc(s->D * sizeof(double));
+#pragma omp for schedule(static)
+    for (long a = 0; a < (long)s->pop; a++) sync_agent(s, kg, (size_t)a, trial);
+    free(trial);
+  }
+  sync_epilogue(s);
+}

@@ -1,0 +1,123 @@
+"""ctypes binding of oracle/liboracle.so — the CHECKER (test infrastructure).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import
+this module. The product package (nlsolver_amd) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "oracle", "liboracle.so")
+
+u64 = C.c_uint64
+f64 = C.c_double
+sz = C.c_size_t
+pd = C.POINTER(C.c_double)
+pu = C.POINTER(C.c_uint64)
+
+
+class XorShift(C.Structure):
+    _fields_ = [("x", u64 * 2)]
+
+
+class EvalLog(C.Structure):
+    _fields_ = [("xs", pd), ("fs", pd), ("capacity", sz), ("count", sz), ("D", sz)]
+
+
+class Status(C.Structure):
+    _fields_ = [("f_value", f64), ("iteration", u64), ("function_calls_used", u64),
+                ("gradient_evals_used", u64), ("hessian_evals_used", u64)]
+
+
+class DESync(C.Structure):
+    _fields_ = [("obj", C.c_int), ("minimize", C.c_int), ("strategy", C.c_int),
+                ("pop", sz), ("D", sz), ("n_shards", sz),
+                ("CR", f64), ("F", f64), ("eps", f64),
+                ("max_iter", sz), ("best_val_no_change", sz), ("seed", u64),
+                ("cur", pd), ("nxt", pd), ("scores", pd),
+                ("best_id", u64), ("iter", u64), ("val_no_change", u64), ("fcalls", u64),
+                ("done", C.c_int), ("std_err", f64), ("trace", pu)]
+
+
+def _ptr(a):
+    return a.ctypes.data_as(pd)
+
+
+def load():
+    if not os.path.exists(LIB):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
+    lib = C.CDLL(LIB)
+    lib.orc_splitmix_next.restype = u64
+    lib.orc_splitmix_next.argtypes = [pu]
+    lib.orc_xorshift_init.argtypes = [C.POINTER(XorShift)]
+    lib.orc_xorshift_next.restype = f64
+    lib.orc_xorshift_next.argtypes = [C.POINTER(XorShift)]
+    lib.orc_mix64.restype = u64
+    lib.orc_mix64.argtypes = [u64]
+    lib.orc_ctr_key.restype = u64
+    lib.orc_ctr_key.argtypes = [u64, u64]
+    lib.orc_u01.restype = f64
+    lib.orc_u01.argtypes = [u64]
+    for name in ("orc_objective_seq", "orc_objective_tree"):
+        fn = getattr(lib, name)
+        fn.restype = f64
+        fn.argtypes = [C.c_int, pd, sz]
+    for name in ("orc_std_err_serial", "orc_std_err_tree", "orc_block_tree_sum", "orc_tiled_sum"):
+        fn = getattr(lib, name)
+        fn.restype = f64
+        fn.argtypes = [pd, sz]
+    lib.orc_de_serial.restype = Status
+    lib.orc_de_serial.argtypes = [C.c_int, C.c_int, C.c_int, pd, sz, C.POINTER(XorShift),
+                                  f64, f64, f64, sz, sz, sz, C.POINTER(EvalLog)]
+    lib.orc_de_sync_init.argtypes = [C.POINTER(DESync), pd]
+    lib.orc_de_sync_step.argtypes = [C.POINTER(DESync)]
+    lib.orc_de_sync_step_omp.argtypes = [C.POINTER(DESync), C.c_int]
+    return lib
+
+
+OBJ = {"rosenbrock": 0, "sphere": 1, "styblinski_tang": 2, "rastrigin": 3}
+
+
+class DESyncRun:
+    """Owns the numpy buffers of one synchronous-DE oracle run."""
+
+    def __init__(self, lib, obj, pop, D, x0, *, minimize=True, strategy=1, n_shards=1,
+                 CR=0.9, F=0.8, eps=0.0, max_iter=1000, best_val_no_change=50,
+                 seed=12374563468, trace=False):
+        self.lib = lib
+        self.pop, self.D = pop, D
+        self.bufs = [np.zeros((pop, D)), np.zeros((pop, D))]
+        self.scores = np.zeros(pop)
+        self.trace = np.zeros((pop, 5), dtype=np.uint64) if trace else None
+        s = DESync()
+        s.obj, s.minimize, s.strategy = OBJ[obj] if isinstance(obj, str) else obj, int(minimize), strategy
+        s.pop, s.D, s.n_shards = pop, D, n_shards
+        s.CR, s.F, s.eps = CR, F, eps
+        s.max_iter, s.best_val_no_change, s.seed = max_iter, best_val_no_change, seed
+        s.cur, s.nxt, s.scores = _ptr(self.bufs[0]), _ptr(self.bufs[1]), _ptr(self.scores)
+        s.trace = self.trace.ctypes.data_as(pu) if trace else None
+        self.s = s
+        self.x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        lib.orc_de_sync_init(C.byref(s), _ptr(self.x0))
+
+    def step(self, n=1, threads=0):
+        for _ in range(n):
+            if threads:
+                self.lib.orc_de_sync_step_omp(C.byref(self.s), threads)
+            else:
+                self.lib.orc_de_sync_step(C.byref(self.s))
+
+    @property
+    def population(self):
+        addr = C.addressof(self.s.cur.contents)
+        for b in self.bufs:
+            if b.ctypes.data == addr:
+                return b
+        raise RuntimeError("cur pointer lost")
+
+    @property
+    def best_x(self):
+        return self.population[self.s.best_id].copy()

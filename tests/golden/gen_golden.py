@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Regenerate tests/golden/*.json by running the UNMODIFIED reference.
+
+The reference is compiled from /root/reference by `make -C oracle ref` into
+oracle/_ref/ref_driver (git-ignored; the reference sources are never copied).
+This script only works where /root/reference exists (the build container); the
+JSON files it writes are committed and are what the tests read everywhere else.
+
+Doubles are stored as C99 hexfloat strings (bit-exact); u64 as decimal strings.
+"""
+import json
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+DRIVER = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+
+
+def run(*args):
+    out = subprocess.check_output([DRIVER, *map(str, args)], text=True)
+    return json.loads(out)
+
+
+def write(name, obj):
+    path = os.path.join(HERE, name)
+    with open(path, "w") as fh:
+        json.dump(obj, fh, separators=(",", ":"))
+        fh.write("\n")
+    print(f"wrote {name}: {os.path.getsize(path)} bytes")
+
+
+def main():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
+    if not os.path.exists(DRIVER):
+        sys.exit("reference driver not built (is /root/reference present?)")
+
+    # G1 — RNG streams
+    write("rng.json", run("rng", 1024))
+
+    # G2 — config C1 and relatives: full minimize() runs with default stops
+    g2 = {
+        "c1_random_pop40_x0_5_7": run("de", "random", 2, 40, 1000, 10e-4, 50, "5,7", 0),
+        "random_pop50_x0_5_7": run("de", "random", 2, 50, 1000, 10e-4, 50, "5,7", 0),
+        "example_best_pop50_x0_2_7": run("de", "best", 2, 50, 1000, 10e-4, 50, "2,7", 0),
+        "readme_objective_pop40": run("de-readme", 40),
+    }
+    write("de_c1.json", g2)
+
+    # G3 — per-evaluation traces, 5 generations, early stop disabled (eps=0)
+    g3 = {}
+    for strat in ("random", "best"):
+        g3[f"{strat}_pop8_D4"] = run("de", strat, 4, 8, 5, 0, 1000, "2.5", 2)
+        g3[f"{strat}_pop40_D2"] = run("de", strat, 2, 40, 5, 0, 1000, "5,7", 2)
+        g3[f"{strat}_pop64_D16"] = run("de", strat, 16, 64, 5, 0, 1000, "4.096", 1)
+        g3[f"{strat}_pop256_D128"] = run("de", strat, 128, 256, 5, 0, 1000, "4.096", 1)
+    write("de_trace.json", g3)
+
+    more = os.path.join(HERE, "gen_golden_more.py")
+    if os.path.exists(more):
+        import runpy
+        runpy.run_path(more, init_globals={"run": run, "write": write})["main"]()
+
+
+if __name__ == "__main__":
+    main()
