@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: candidate-evals/s of Differential Evolution on
+Rosenbrock-128D, fp64 (BASELINE.json metric; workload = configs[1], pop=65536 per GPU).
+
+A "step" is one turn of the DE loop (best scan + stop tests + one generation of
+mutation/crossover/evaluation/selection over the whole population) on synthetic
+input: x0_i = 4.096, CR=0.9, F=0.8, strategy random, early stops disabled.
+
+    python bench.py --gpus N --steps K --warmup W
+(N>1: launched by torch.distributed.run, one rank per GPU, weak scaling: every
+GPU owns 65536 agents.) Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+D = 128
+POP_PER_GPU = 65536
+BYTES_PER_CANDIDATE = 5 * D * 8 + 16  # 4 row reads + 1 row write + score r/w
+HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def cpu_baseline():
+    """Reference DE (unmodified nlsolver.h, built into oracle/_ref) timed on this host's
+    cores; falls back to the oracle port when the reference binary is absent."""
+    drv = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    gens = 24
+    if os.path.exists(drv):
+        out = subprocess.check_output([drv, "bench-de", str(D), str(POP_PER_GPU), str(gens)],
+                                      text=True)
+        r = json.loads(out)
+        return {"value": r["candidate_evals_per_s"], "unit": "candidate-evals/s", "cores": 1,
+                "kind": "reference",
+                "sample": f"reference DE<random> Rosenbrock-{D}D pop={POP_PER_GPU}, "
+                          f"{gens} generations ({r['fcalls']} evals, {r['seconds']:.1f} s), "
+                          "1 thread (library is single-threaded by design)"}
+    from tests import _oracle as O
+    lib = O.load()
+    threads = os.cpu_count() or 1
+    run = O.DESyncRun(lib, "rosenbrock", POP_PER_GPU, D, np.full(D, 4.096), eps=0.0,
+                      max_iter=10**9, best_val_no_change=10**9)
+    t0 = time.perf_counter()
+    run.step(gens, threads=threads)
+    dt = time.perf_counter() - t0
+    return {"value": POP_PER_GPU * gens / dt, "unit": "candidate-evals/s", "cores": threads,
+            "kind": "port",
+            "sample": f"oracle sync DE Rosenbrock-{D}D pop={POP_PER_GPU}, {gens} generations, "
+                      f"OpenMP {threads} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--pop-per-gpu", type=int, default=POP_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import nlsolver_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with "
+                         "torch.distributed.run --nproc-per-node N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    pop_local = args.pop_per_gpu
+    pop = pop_local * world
+    common = dict(minimize=True, strategy=nlsolver_amd.DE_RANDOM, CR=0.9, F=0.8, eps=0.0,
+                  max_iter=10**12, best_val_no_change=10**12, seed=12374563468,
+                  device=local_rank)
+    x0 = np.full(D, 4.096)
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if distributed:
+        from nlsolver_amd.dist import ShardedDE
+        drv = ShardedDE(dist, lambda lo, n, stream: nlsolver_amd.DEEngine(
+            "rosenbrock", pop, D, shard_lo=lo, shard_n=n, stream=stream, **common),
+            pop, D, device)
+        eng = drv.engine
+        stepper = drv.step
+    else:
+        eng = nlsolver_amd.DEEngine("rosenbrock", pop, D, **common)
+        stepper = eng.step
+    eng.init(x0)
+    stepper(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    stepper(args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    st = eng.status()
+    assert st.iteration == args.warmup + args.steps, (st.iteration, args.warmup + args.steps)
+
+    out = None
+    if rank == 0:
+        # dominant kernel: de_generation_kernel, timed alone with hipEvents on its stream
+        launches = max(args.steps, 20)
+        kern_ms = eng.time_generation_kernel(launches) / launches
+        achieved = BYTES_PER_CANDIDATE * pop_local / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "candidate-evals/sec (pop x iters/s) Rosenbrock-128D DE",
+            "value": pop * args.steps / dt,
+            "unit": "candidate-evals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"Rosenbrock-{D}D DE strategy=random CR=0.9 F=0.8, "
+                                   f"pop={pop_local} per GPU (BASELINE configs[1]), "
+                                   "one step = best scan + stop tests + one generation",
+                       "global_pop": pop, "dim": D,
+                       "parallelism": f"population-sharded x{world} (island donors, "
+                                      "one all-gather of the best record per generation)"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "de_generation_kernel",
+                         "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": BYTES_PER_CANDIDATE * pop_local},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+    eng.close()
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,157 @@
+/* include/nlsg_c_api.h — C-ABI of the MI355X-native nlsolver iteration engine.
+ *
+ * Drop-in boundary for the hot path of JSzitas/nlsolver. The
+ * reference has no FFI layer: its boundary is the C++ template API
+ * `Solver<Callable,[RNG,]T,...>(f,[gen,]params...).minimize(std::vector<T>&)`
+ * (nlsolver.h:2390-2410 DE, 2522-2591 PSO, 2110-2165 NelderMead, 3181-3196
+ * BFGS, 3443-3465 LevenbergMarquardt). The header-only host API in
+ * include/nlsolver_mi/nlsolver.h keeps that surface and forwards the
+ * population/batch loops to the entry points declared here; each entry point
+ * names the reference loop it replaces.
+ *
+ * Conventions
+ *  - plain C: pointers, sizes, POD structs; no C++/torch types.
+ *  - every function returns an nlsg_err (0 = ok) and never throws; the text of
+ *    the last error on the calling thread is nlsg_last_error().
+ *  - `*_host` pointers are host memory borrowed for the duration of the call;
+ *    `*_dev` pointers are device memory on the engine's device. Buffers an
+ *    engine allocates are owned by the engine and freed by *_destroy().
+ *  - one engine handle per host thread; calls on one handle are serialised by
+ *    the caller (the reference's solver objects are not thread-safe either,
+ *    nlsolver.h:2104/2189, 3436/3541).
+ *  - work is enqueued on the engine's HIP stream (cfg.stream, or a private
+ *    stream when NULL) and is asynchronous unless the function says it syncs.
+ */
+#ifndef NLSG_C_API_H_
+#define NLSG_C_API_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NLSG_ABI_VERSION 1
+
+typedef enum {
+  NLSG_OK = 0,
+  NLSG_ERR_INVALID_ARG = 1,  /* bad pointer / size / enum                     */
+  NLSG_ERR_UNSUPPORTED = 2,  /* valid request the device path does not cover  */
+  NLSG_ERR_NO_DEVICE = 3,    /* no usable gfx950 device                       */
+  NLSG_ERR_HIP = 4,          /* a HIP runtime call failed                     */
+  NLSG_ERR_OOM = 5,          /* device allocation failed                      */
+  NLSG_ERR_STATE = 6         /* call order violated (e.g. step before init)   */
+} nlsg_err;
+
+/* Built-in device objectives (the reference calls an arbitrary host functor in
+ * the inner loop, nlsolver.h:2463; a device kernel cannot). */
+typedef enum {
+  NLSG_OBJ_ROSENBROCK = 0,      /* example.cpp:41-48, N-D chain                */
+  NLSG_OBJ_SPHERE = 1,          /* test_functions.h:52-57                      */
+  NLSG_OBJ_STYBLINSKI_TANG = 2, /* test_functions.h:249-260                    */
+  NLSG_OBJ_RASTRIGIN = 3        /* test_functions.h:69-78                      */
+} nlsg_objective;
+
+/* enum RecombinationStrategy { best, random } — nlsolver.h:2377 (same order). */
+typedef enum { NLSG_DE_BEST = 0, NLSG_DE_RANDOM = 1 } nlsg_de_strategy;
+
+const char *nlsg_last_error(void);
+int nlsg_abi_version(void);
+/* Number of visible HIP devices whose arch is gfx950 (0 if none / no runtime). */
+int nlsg_device_count(void);
+
+/* solver_status<T> (nlsolver.h:2054-2097) plus engine bookkeeping. */
+typedef struct {
+  double f_value;               /* best objective (sign as the solver minimises) */
+  uint64_t iteration;           /* completed generations / iterations            */
+  uint64_t function_calls_used;
+  uint64_t gradient_evals_used;
+  uint64_t hessian_evals_used;
+  uint64_t best_index;          /* global row index of the best agent            */
+  uint64_t val_no_change;       /* nlsolver.h:2439 counter                        */
+  double std_err;               /* last std_err(scores) (NaN if not evaluated)   */
+  int32_t done;                 /* a stop test of nlsolver.h:2441-2443 fired     */
+  int32_t reserved;
+} nlsg_status;
+
+/* ========================================================================== */
+/* Differential Evolution — replaces DE::solve (nlsolver.h:2414-2476) and its */
+/* helpers init_agents/generate_indices/propose_new_agent (2302-2375).         */
+/* ========================================================================== */
+typedef struct nlsg_de nlsg_de; /* opaque engine handle */
+
+typedef struct {
+  uint32_t struct_size; /* sizeof(nlsg_de_config), for ABI evolution          */
+  int32_t device;       /* HIP device ordinal                                  */
+  void *stream;         /* hipStream_t to enqueue on; NULL = private stream    */
+  int32_t objective;    /* nlsg_objective                                      */
+  int32_t minimize;     /* 1 = minimize(), 0 = maximize() (nlsolver.h:2404-10) */
+  int32_t strategy;     /* nlsg_de_strategy                                    */
+  int32_t trace;        /* 1 = keep (r1,r2,r3,jrand,accept) of the last gen    */
+  uint64_t pop;         /* GLOBAL population size (ctor arg pop_size, :2393)   */
+  uint64_t dim;         /* x.size()                                            */
+  uint64_t shard_lo;    /* first global agent owned by this engine             */
+  uint64_t shard_n;     /* agents owned (== pop on one GPU); donors are drawn  */
+                        /* inside the shard (island model)      */
+  double CR, F, eps;    /* crossover_prob, differential_weight, eps (:2391-92) */
+  uint64_t max_iter;    /* :2393                                               */
+  uint64_t best_val_no_change; /* :2394                                        */
+  uint64_t seed;        /* key of the counter-based generator                  */
+} nlsg_de_config;
+
+int nlsg_de_create(const nlsg_de_config *cfg, nlsg_de **out);
+int nlsg_de_destroy(nlsg_de *e);
+
+/* init_agents + initial scoring (nlsolver.h:2315-2323, 2423-2425):
+ * agents[a][i] = (u - 0.5) * x0[i]; scores[a] = +-f(agents[a]). Asynchronous. */
+int nlsg_de_init(nlsg_de *e, const double *x0_host);
+
+/* Enqueue `turns` turns of the reference's while(true) loop (2429-2475): best
+ * scan + stop tests, then one generation (mutation, crossover, evaluation,
+ * selection) unless a stop test fired. Once `done` is set further turns are
+ * no-ops on device. Asynchronous; no host synchronisation. */
+int nlsg_de_step(nlsg_de *e, uint64_t turns);
+
+/* Full solve(): init, turns until done, x_inout <- best agent (2441-2447).
+ * Synchronises. `poll_every` turns are enqueued between host checks of the
+ * device stop flag (0 = engine default). */
+int nlsg_de_minimize(nlsg_de *e, double *x_inout_host, uint64_t poll_every,
+                     nlsg_status *out);
+
+/* Synchronise the stream and read the device-resident solver state. */
+int nlsg_de_status(nlsg_de *e, nlsg_status *out);
+/* Best agent (x has dim entries), its score and global index. Synchronises. */
+int nlsg_de_best(nlsg_de *e, double *x_host, double *f, uint64_t *index);
+/* Parity-test access: current population shard (shard_n*dim, row-major),
+ * scores (shard_n) and the last generation's trace (shard_n*5 u64:
+ * r1,r2,r3,jrand,accept; requires cfg.trace). NULL pointers are skipped. */
+int nlsg_de_download(nlsg_de *e, double *pop_host, double *scores_host,
+                     uint64_t *trace_host);
+/* Replace the current shard population and scores (tests, checkpoint/resume). */
+int nlsg_de_upload(nlsg_de *e, const double *pop_host, const double *scores_host);
+
+/* Measurement aid for bench.py: launches ONLY the generation kernel `launches`
+ * times back to back on the engine's stream (buffers ping-pong, solver state is
+ * restored afterwards) bracketed by two hipEvents; returns total milliseconds. */
+int nlsg_de_time_generation_kernel(nlsg_de *e, uint32_t launches, float *ms_total);
+/* Same bracket around `turns` full turns (scan + generation). */
+int nlsg_de_time_turns(nlsg_de *e, uint64_t turns, float *ms_total);
+
+/* ---- multi-GPU exchange (one small record per rank per generation) -------- */
+/* A turn on a sharded population is split so the host can run ONE collective
+ * between the two halves (RCCL all-gather through torch.distributed):
+ *   nlsg_de_turn_begin  : local best scan -> record in `send_dev`
+ *   <all-gather of record_doubles() doubles per rank into `gathered_dev`>
+ *   nlsg_de_turn_end    : global best (lowest f, incumbent keeps ties, then
+ *                         lowest global index), stop tests, generation.
+ * Record layout (doubles): [f_best, idx_best(as u64 bits), sum_scores, m2, valid,
+ *                           x_best[0..dim)]. */
+uint64_t nlsg_de_record_doubles(const nlsg_de *e);
+int nlsg_de_turn_begin(nlsg_de *e, double *send_dev);
+int nlsg_de_turn_end(nlsg_de *e, const double *gathered_dev, int32_t world);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NLSG_C_API_H_ */

@@ -1,0 +1,11 @@
+"""nlsolver_amd — MI355X-native iteration engine behind the nlsolver API surface.
+
+Layout:
+    csrc/                 HIP kernels for gfx950 + the extern "C" boundary
+    libnlsolver_hip.so    built in-tree by `make -C nlsolver_amd/csrc`
+    _capi.py              ctypes binding of include/nlsg_c_api.h
+    de.py                 DE / DESolver: mirror of nlsolver::DE (nlsolver.h:2379-2477)
+    dist.py               population sharding across ranks (torch.distributed / RCCL)
+"""
+from ._capi import DE_BEST, DE_RANDOM, NlsgError  # noqa: F401
+from .de import DE, DEEngine, DESolver  # noqa: F401

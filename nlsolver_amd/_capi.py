@@ -1,0 +1,89 @@
+"""ctypes binding of libnlsolver_hip.so (include/nlsg_c_api.h).
+
+The library is the product's only compute path. There is no CPU fallback: if
+the shared object is missing or no gfx950 device is visible, calls raise.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libnlsolver_hip.so")
+
+u64, i32, f64 = C.c_uint64, C.c_int32, C.c_double
+pd = C.POINTER(C.c_double)
+pu = C.POINTER(C.c_uint64)
+
+OBJECTIVES = {"rosenbrock": 0, "sphere": 1, "styblinski_tang": 2, "rastrigin": 3}
+DE_BEST, DE_RANDOM = 0, 1  # enum RecombinationStrategy { best, random }, nlsolver.h:2377
+
+
+class NlsgError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"nlsg error {code}: {msg}")
+        self.code = code
+
+
+class Status(C.Structure):
+    """nlsg_status == solver_status<T> (nlsolver.h:2054-2097) + engine fields."""
+    _fields_ = [("f_value", f64), ("iteration", u64), ("function_calls_used", u64),
+                ("gradient_evals_used", u64), ("hessian_evals_used", u64),
+                ("best_index", u64), ("val_no_change", u64), ("std_err", f64),
+                ("done", i32), ("reserved", i32)]
+
+    def get_summary(self):
+        # tuple order of solver_status::get_summary, nlsolver.h:2079-2083
+        return (self.function_calls_used, self.iteration, self.f_value,
+                self.gradient_evals_used, self.hessian_evals_used)
+
+
+class DEConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("device", i32), ("stream", C.c_void_p),
+                ("objective", i32), ("minimize", i32), ("strategy", i32), ("trace", i32),
+                ("pop", u64), ("dim", u64), ("shard_lo", u64), ("shard_n", u64),
+                ("CR", f64), ("F", f64), ("eps", f64),
+                ("max_iter", u64), ("best_val_no_change", u64), ("seed", u64)]
+
+
+# every symbol include/nlsg_c_api.h declares: name -> (restype, argtypes)
+_H = C.c_void_p
+SYMBOLS = {
+    "nlsg_last_error": (C.c_char_p, []),
+    "nlsg_abi_version": (C.c_int, []),
+    "nlsg_device_count": (C.c_int, []),
+    "nlsg_de_create": (C.c_int, [C.POINTER(DEConfig), C.POINTER(_H)]),
+    "nlsg_de_destroy": (C.c_int, [_H]),
+    "nlsg_de_init": (C.c_int, [_H, pd]),
+    "nlsg_de_step": (C.c_int, [_H, u64]),
+    "nlsg_de_minimize": (C.c_int, [_H, pd, u64, C.POINTER(Status)]),
+    "nlsg_de_status": (C.c_int, [_H, C.POINTER(Status)]),
+    "nlsg_de_best": (C.c_int, [_H, pd, pd, pu]),
+    "nlsg_de_download": (C.c_int, [_H, pd, pd, pu]),
+    "nlsg_de_upload": (C.c_int, [_H, pd, pd]),
+    "nlsg_de_time_generation_kernel": (C.c_int, [_H, C.c_uint32, C.POINTER(C.c_float)]),
+    "nlsg_de_time_turns": (C.c_int, [_H, u64, C.POINTER(C.c_float)]),
+    "nlsg_de_record_doubles": (u64, [_H]),
+    "nlsg_de_turn_begin": (C.c_int, [_H, C.c_void_p]),
+    "nlsg_de_turn_end": (C.c_int, [_H, C.c_void_p, i32]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libnlsolver_hip.so (built by __graft_entry__.build() / csrc/Makefile)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NlsgError(-1, f"{LIB_PATH} is missing: build it with "
+                                "`make -C nlsolver_amd/csrc` (no CPU fallback exists)")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise NlsgError(rc, lib().nlsg_last_error().decode(errors="replace"))

@@ -1,0 +1,415 @@
+// nlsolver_amd/csrc/nlsg_de.hip — host side of the DE engine + its C-ABI
+// (include/nlsg_c_api.h). Owns the device buffers and the HIP stream; enqueues
+// the kernels of nlsg_de_kernels.h. No CPU fallback: every entry point either
+// runs on a gfx950 device or returns an error.
+#include <new>
+#include <vector>
+
+#include "nlsg_de_kernels.h"
+
+using namespace nlsg;
+
+struct nlsg_de {
+  nlsg_de_config cfg;
+  DeParams p;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  double *x0_dev = nullptr;
+  TilePartial *part = nullptr;
+  DeLocal *loc = nullptr;
+  double *rec = nullptr;  // local record (single-GPU finaliser input)
+  uint32_t ntiles = 0;
+  int chunks = 0;
+  bool initialised = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+
+int check_device(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return fail(NLSG_ERR_NO_DEVICE, "no HIP device visible");
+  if (device < 0 || device >= n)
+    return fail(NLSG_ERR_INVALID_ARG, "device %d out of range (0..%d)", device, n - 1);
+  hipDeviceProp_t prop;
+  NLSG_HIP(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(NLSG_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only",
+                device, prop.gcnArchName);
+  return NLSG_OK;
+}
+
+template <typename K>
+struct Dispatch;  // OBJ x CHUNKS dispatch of a kernel family
+
+#define NLSG_FOR_CHUNKS(OBJ, chunks, CALL) \
+  switch (chunks) {                        \
+    case 1: CALL(OBJ, 1); break;           \
+    case 2: CALL(OBJ, 2); break;           \
+    case 4: CALL(OBJ, 4); break;           \
+    case 8: CALL(OBJ, 8); break;           \
+    default: break;                        \
+  }
+#define NLSG_FOR_OBJ(obj, chunks, CALL)                                              \
+  switch (obj) {                                                                     \
+    case NLSG_OBJ_ROSENBROCK: NLSG_FOR_CHUNKS(NLSG_OBJ_ROSENBROCK, chunks, CALL); break; \
+    case NLSG_OBJ_SPHERE: NLSG_FOR_CHUNKS(NLSG_OBJ_SPHERE, chunks, CALL); break;     \
+    case NLSG_OBJ_STYBLINSKI_TANG:                                                   \
+      NLSG_FOR_CHUNKS(NLSG_OBJ_STYBLINSKI_TANG, chunks, CALL);                       \
+      break;                                                                         \
+    case NLSG_OBJ_RASTRIGIN: NLSG_FOR_CHUNKS(NLSG_OBJ_RASTRIGIN, chunks, CALL); break; \
+    default: break;                                                                  \
+  }
+
+void launch_init(nlsg_de *e) {
+  const dim3 grid(static_cast<unsigned>((e->p.shard_n + 3) / 4)), block(256);
+#define CALL(OBJ, C) \
+  hipLaunchKernelGGL((de_init_kernel<OBJ, C>), grid, block, 0, e->stream, e->p, e->x0_dev)
+  NLSG_FOR_OBJ(e->cfg.objective, e->chunks, CALL)
+#undef CALL
+}
+
+void launch_generation(nlsg_de *e, int par_override, uint64_t gen_override) {
+  const dim3 grid(static_cast<unsigned>((e->p.shard_n + 3) / 4)), block(256);
+#define CALL(OBJ, C)                                                                   \
+  hipLaunchKernelGGL((de_generation_kernel<OBJ, C>), grid, block, 0, e->stream, e->p, \
+                     par_override, gen_override)
+  NLSG_FOR_OBJ(e->cfg.objective, e->chunks, CALL)
+#undef CALL
+}
+
+// local scan: tile partials -> DeLocal (+ second pass when std_err can decide)
+void launch_local_scan(nlsg_de *e) {
+  hipLaunchKernelGGL(de_scan_partial_kernel, dim3(e->ntiles), dim3(256), 0, e->stream, e->p,
+                     e->part);
+  hipLaunchKernelGGL(de_scan_local_kernel, dim3(1), dim3(256), 0, e->stream, e->p, e->part,
+                     e->ntiles, e->loc);
+  if (e->cfg.eps > 0) {
+    hipLaunchKernelGGL(de_var_partial_kernel, dim3(e->ntiles), dim3(256), 0, e->stream, e->p,
+                       e->part, &e->loc->mean);
+    hipLaunchKernelGGL(de_var_local_kernel, dim3(1), dim3(256), 0, e->stream, e->p, e->part,
+                       e->ntiles, e->loc);
+  }
+}
+
+void launch_turn_single(nlsg_de *e) {
+  launch_local_scan(e);
+  hipLaunchKernelGGL(de_pack_record_kernel, dim3(1), dim3(256), 0, e->stream, e->p, e->loc,
+                     e->rec);
+  hipLaunchKernelGGL(de_finalize_kernel, dim3(1), dim3(256), 0, e->stream, e->p, e->rec, 1,
+                     static_cast<uint64_t>(kRecHeader) + e->p.D);
+  launch_generation(e, -1, 0);
+}
+
+int read_state(nlsg_de *e, DeState *host) {
+  hipLaunchKernelGGL(de_settle_kernel, dim3(1), dim3(1), 0, e->stream, e->p);
+  NLSG_HIP(hipMemcpyAsync(host, e->p.state, sizeof(DeState), hipMemcpyDeviceToHost, e->stream));
+  NLSG_HIP(hipStreamSynchronize(e->stream));
+  NLSG_HIP(hipGetLastError());
+  return NLSG_OK;
+}
+
+void fill_status(const DeState &s, nlsg_status *out) {
+  out->f_value = s.best_f;
+  out->iteration = s.iter;
+  out->function_calls_used = s.fcalls;
+  out->gradient_evals_used = 0;
+  out->hessian_evals_used = 0;
+  out->best_index = s.best_id;
+  out->val_no_change = s.val_no_change;
+  out->std_err = s.std_err;
+  out->done = s.done;
+  out->reserved = 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *nlsg_last_error(void) { return err_buf(); }
+int nlsg_abi_version(void) { return NLSG_ABI_VERSION; }
+
+int nlsg_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  int ok = 0;
+  for (int d = 0; d < n; d++) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, d) == hipSuccess &&
+        std::strncmp(prop.gcnArchName, "gfx950", 6) == 0)
+      ok++;
+  }
+  return ok;
+}
+
+int nlsg_de_create(const nlsg_de_config *cfg, nlsg_de **out) {
+  if (!cfg || !out) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  *out = nullptr;
+  if (cfg->struct_size != sizeof(nlsg_de_config))
+    return fail(NLSG_ERR_INVALID_ARG, "nlsg_de_config size mismatch (%u vs %zu)",
+                cfg->struct_size, sizeof(nlsg_de_config));
+  if (cfg->dim < 1) return fail(NLSG_ERR_INVALID_ARG, "dim must be >= 1");
+  if (cfg->dim > 1024)
+    return fail(NLSG_ERR_UNSUPPORTED, "dim %llu > 1024 is not covered by the device path",
+                (unsigned long long)cfg->dim);
+  if (cfg->objective < 0 || cfg->objective > NLSG_OBJ_RASTRIGIN)
+    return fail(NLSG_ERR_INVALID_ARG, "unknown objective %d", cfg->objective);
+  if (cfg->strategy != NLSG_DE_BEST && cfg->strategy != NLSG_DE_RANDOM)
+    return fail(NLSG_ERR_INVALID_ARG, "unknown strategy %d", cfg->strategy);
+  if (cfg->shard_n < 4 || cfg->shard_lo + cfg->shard_n > cfg->pop)
+    return fail(NLSG_ERR_INVALID_ARG,
+                "shard [%llu,+%llu) invalid for pop %llu (a shard needs >= 4 agents: three "
+                "distinct donors besides the target, nlsolver.h:2331-2355)",
+                (unsigned long long)cfg->shard_lo, (unsigned long long)cfg->shard_n,
+                (unsigned long long)cfg->pop);
+  if (cfg->shard_n > (1ull << 32))
+    return fail(NLSG_ERR_UNSUPPORTED, "shard_n > 2^32 agents per engine");
+  int rc = check_device(cfg->device);
+  if (rc) return rc;
+  NLSG_HIP(hipSetDevice(cfg->device));
+
+  nlsg_de *e = new (std::nothrow) nlsg_de();
+  if (!e) return fail(NLSG_ERR_OOM, "host allocation failed");
+  e->cfg = *cfg;
+  const uint64_t D = cfg->dim, n = cfg->shard_n;
+  e->chunks = D <= 128 ? 1 : D <= 256 ? 2 : D <= 512 ? 4 : 8;
+  e->ntiles = static_cast<uint32_t>((n + kTile - 1) / kTile);
+  if (cfg->stream) {
+    e->stream = static_cast<hipStream_t>(cfg->stream);
+  } else {
+    hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (he != hipSuccess) {
+      delete e;
+      return fail(NLSG_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(he));
+    }
+    e->own_stream = true;
+  }
+  DeParams &p = e->p;
+  std::memset(&p, 0, sizeof p);
+  auto alloc = [&](void **ptr, size_t bytes) { return hipMalloc(ptr, bytes ? bytes : 8); };
+  hipError_t he = hipSuccess;
+  const size_t rows = n * D * sizeof(double);
+  if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&p.buf[0]), rows);
+  if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&p.buf[1]), rows);
+  if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&p.scores), n * sizeof(double));
+  if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&p.best_x), D * sizeof(double));
+  if (he == hipSuccess && cfg->trace)
+    he = alloc(reinterpret_cast<void **>(&p.trace), n * kTraceWords * sizeof(uint64_t));
+  if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&p.state), sizeof(DeState));
+  if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&e->x0_dev), D * sizeof(double));
+  if (he == hipSuccess)
+    he = alloc(reinterpret_cast<void **>(&e->part), e->ntiles * sizeof(TilePartial));
+  if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&e->loc), sizeof(DeLocal));
+  if (he == hipSuccess)
+    he = alloc(reinterpret_cast<void **>(&e->rec), (kRecHeader + D) * sizeof(double));
+  if (he == hipSuccess) he = hipEventCreate(&e->ev0);
+  if (he == hipSuccess) he = hipEventCreate(&e->ev1);
+  if (he != hipSuccess) {
+    nlsg_de_destroy(e);
+    return fail(he == hipErrorOutOfMemory ? NLSG_ERR_OOM : NLSG_ERR_HIP,
+                "device allocation failed: %s", hipGetErrorString(he));
+  }
+  p.pop = cfg->pop;
+  p.D = D;
+  p.shard_lo = cfg->shard_lo;
+  p.shard_n = n;
+  p.CR = cfg->CR;
+  p.F = cfg->F;
+  p.eps = cfg->eps;
+  p.fmul = cfg->minimize ? 1.0 : -1.0;  // f_multiplier, nlsolver.h:2418
+  p.max_iter = cfg->max_iter;
+  p.best_val_no_change = cfg->best_val_no_change;
+  p.seed = cfg->seed;
+  p.strategy = cfg->strategy;
+  p.vec = (D % 2 == 0) ? 1 : 0;
+  *out = e;
+  return NLSG_OK;
+}
+
+int nlsg_de_destroy(nlsg_de *e) {
+  if (!e) return NLSG_OK;
+  hipSetDevice(e->cfg.device);
+  if (e->stream) hipStreamSynchronize(e->stream);
+  hipFree(e->p.buf[0]);
+  hipFree(e->p.buf[1]);
+  hipFree(e->p.scores);
+  hipFree(e->p.best_x);
+  hipFree(e->p.trace);
+  hipFree(e->p.state);
+  hipFree(e->x0_dev);
+  hipFree(e->part);
+  hipFree(e->loc);
+  hipFree(e->rec);
+  if (e->ev0) hipEventDestroy(e->ev0);
+  if (e->ev1) hipEventDestroy(e->ev1);
+  if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
+  delete e;
+  return NLSG_OK;
+}
+
+int nlsg_de_init(nlsg_de *e, const double *x0_host) {
+  if (!e || !x0_host) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  NLSG_HIP(hipSetDevice(e->cfg.device));
+  NLSG_HIP(hipMemcpyAsync(e->x0_dev, x0_host, e->p.D * sizeof(double), hipMemcpyHostToDevice,
+                          e->stream));
+  // the host buffer is borrowed for this call only
+  NLSG_HIP(hipStreamSynchronize(e->stream));
+  hipLaunchKernelGGL(de_reset_state_kernel, dim3(1), dim3(1), 0, e->stream, e->p);
+  launch_init(e);
+  NLSG_HIP(hipGetLastError());
+  e->initialised = true;
+  return NLSG_OK;
+}
+
+int nlsg_de_step(nlsg_de *e, uint64_t turns) {
+  if (!e) return fail(NLSG_ERR_INVALID_ARG, "null engine");
+  if (!e->initialised) return fail(NLSG_ERR_STATE, "nlsg_de_init has not been called");
+  if (e->cfg.shard_n != e->cfg.pop)
+    return fail(NLSG_ERR_STATE,
+                "sharded engine: use nlsg_de_turn_begin / nlsg_de_turn_end around the exchange");
+  NLSG_HIP(hipSetDevice(e->cfg.device));
+  for (uint64_t t = 0; t < turns; t++) launch_turn_single(e);
+  NLSG_HIP(hipGetLastError());
+  return NLSG_OK;
+}
+
+int nlsg_de_status(nlsg_de *e, nlsg_status *out) {
+  if (!e || !out) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  if (!e->initialised) return fail(NLSG_ERR_STATE, "nlsg_de_init has not been called");
+  NLSG_HIP(hipSetDevice(e->cfg.device));
+  DeState s;
+  int rc = read_state(e, &s);
+  if (rc) return rc;
+  fill_status(s, out);
+  return NLSG_OK;
+}
+
+int nlsg_de_best(nlsg_de *e, double *x_host, double *f, uint64_t *index) {
+  if (!e) return fail(NLSG_ERR_INVALID_ARG, "null engine");
+  if (!e->initialised) return fail(NLSG_ERR_STATE, "nlsg_de_init has not been called");
+  NLSG_HIP(hipSetDevice(e->cfg.device));
+  DeState s;
+  int rc = read_state(e, &s);
+  if (rc) return rc;
+  if (x_host)
+    NLSG_HIP(hipMemcpy(x_host, e->p.best_x, e->p.D * sizeof(double), hipMemcpyDeviceToHost));
+  if (f) *f = s.best_f;
+  if (index) *index = s.best_id;
+  return NLSG_OK;
+}
+
+int nlsg_de_download(nlsg_de *e, double *pop_host, double *scores_host, uint64_t *trace_host) {
+  if (!e) return fail(NLSG_ERR_INVALID_ARG, "null engine");
+  if (!e->initialised) return fail(NLSG_ERR_STATE, "nlsg_de_init has not been called");
+  NLSG_HIP(hipSetDevice(e->cfg.device));
+  DeState s;
+  int rc = read_state(e, &s);
+  if (rc) return rc;
+  const uint64_t n = e->p.shard_n, D = e->p.D;
+  if (pop_host)
+    NLSG_HIP(hipMemcpy(pop_host, e->p.buf[s.parity], n * D * sizeof(double),
+                       hipMemcpyDeviceToHost));
+  if (scores_host)
+    NLSG_HIP(hipMemcpy(scores_host, e->p.scores, n * sizeof(double), hipMemcpyDeviceToHost));
+  if (trace_host) {
+    if (!e->p.trace) return fail(NLSG_ERR_STATE, "engine was created without cfg.trace");
+    NLSG_HIP(hipMemcpy(trace_host, e->p.trace, n * kTraceWords * sizeof(uint64_t),
+                       hipMemcpyDeviceToHost));
+  }
+  return NLSG_OK;
+}
+
+int nlsg_de_upload(nlsg_de *e, const double *pop_host, const double *scores_host) {
+  if (!e || !pop_host || !scores_host) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  if (!e->initialised) return fail(NLSG_ERR_STATE, "nlsg_de_init has not been called");
+  NLSG_HIP(hipSetDevice(e->cfg.device));
+  DeState s;
+  int rc = read_state(e, &s);
+  if (rc) return rc;
+  const uint64_t n = e->p.shard_n, D = e->p.D;
+  NLSG_HIP(hipMemcpy(e->p.buf[s.parity], pop_host, n * D * sizeof(double), hipMemcpyHostToDevice));
+  NLSG_HIP(hipMemcpy(e->p.scores, scores_host, n * sizeof(double), hipMemcpyHostToDevice));
+  return NLSG_OK;
+}
+
+int nlsg_de_minimize(nlsg_de *e, double *x_inout_host, uint64_t poll_every, nlsg_status *out) {
+  if (!e || !x_inout_host) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  int rc = nlsg_de_init(e, x_inout_host);
+  if (rc) return rc;
+  if (poll_every == 0) poll_every = 32;
+  DeState s;
+  for (;;) {
+    rc = nlsg_de_step(e, poll_every);
+    if (rc) return rc;
+    rc = read_state(e, &s);
+    if (rc) return rc;
+    if (s.done) break;
+  }
+  // x = agents[best_id] (nlsolver.h:2444)
+  NLSG_HIP(hipMemcpy(x_inout_host, e->p.best_x, e->p.D * sizeof(double), hipMemcpyDeviceToHost));
+  if (out) fill_status(s, out);
+  return NLSG_OK;
+}
+
+int nlsg_de_time_generation_kernel(nlsg_de *e, uint32_t launches, float *ms_total) {
+  if (!e || !ms_total) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  if (!e->initialised) return fail(NLSG_ERR_STATE, "nlsg_de_init has not been called");
+  NLSG_HIP(hipSetDevice(e->cfg.device));
+  DeState s;
+  int rc = read_state(e, &s);
+  if (rc) return rc;
+  NLSG_HIP(hipEventRecord(e->ev0, e->stream));
+  for (uint32_t k = 0; k < launches; k++)
+    launch_generation(e, (s.parity + static_cast<int>(k)) & 1, s.iter + 1 + k);
+  NLSG_HIP(hipEventRecord(e->ev1, e->stream));
+  NLSG_HIP(hipEventSynchronize(e->ev1));
+  NLSG_HIP(hipGetLastError());
+  NLSG_HIP(hipEventElapsedTime(ms_total, e->ev0, e->ev1));
+  // The population advanced `launches` generations without best scans; the
+  // engine must be re-initialised before it is used for a solve again.
+  e->initialised = false;
+  return NLSG_OK;
+}
+
+int nlsg_de_time_turns(nlsg_de *e, uint64_t turns, float *ms_total) {
+  if (!e || !ms_total) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  if (!e->initialised) return fail(NLSG_ERR_STATE, "nlsg_de_init has not been called");
+  if (e->cfg.shard_n != e->cfg.pop) return fail(NLSG_ERR_STATE, "sharded engine");
+  NLSG_HIP(hipSetDevice(e->cfg.device));
+  NLSG_HIP(hipEventRecord(e->ev0, e->stream));
+  for (uint64_t t = 0; t < turns; t++) launch_turn_single(e);
+  NLSG_HIP(hipEventRecord(e->ev1, e->stream));
+  NLSG_HIP(hipEventSynchronize(e->ev1));
+  NLSG_HIP(hipGetLastError());
+  NLSG_HIP(hipEventElapsedTime(ms_total, e->ev0, e->ev1));
+  return NLSG_OK;
+}
+
+uint64_t nlsg_de_record_doubles(const nlsg_de *e) {
+  return e ? static_cast<uint64_t>(kRecHeader) + e->p.D : 0;
+}
+
+int nlsg_de_turn_begin(nlsg_de *e, double *send_dev) {
+  if (!e || !send_dev) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  if (!e->initialised) return fail(NLSG_ERR_STATE, "nlsg_de_init has not been called");
+  NLSG_HIP(hipSetDevice(e->cfg.device));
+  launch_local_scan(e);
+  hipLaunchKernelGGL(de_pack_record_kernel, dim3(1), dim3(256), 0, e->stream, e->p, e->loc,
+                     send_dev);
+  NLSG_HIP(hipGetLastError());
+  return NLSG_OK;
+}
+
+int nlsg_de_turn_end(nlsg_de *e, const double *gathered_dev, int32_t world) {
+  if (!e || !gathered_dev || world < 1) return fail(NLSG_ERR_INVALID_ARG, "bad argument");
+  if (!e->initialised) return fail(NLSG_ERR_STATE, "nlsg_de_init has not been called");
+  NLSG_HIP(hipSetDevice(e->cfg.device));
+  hipLaunchKernelGGL(de_finalize_kernel, dim3(1), dim3(256), 0, e->stream, e->p, gathered_dev,
+                     world, static_cast<uint64_t>(kRecHeader) + e->p.D);
+  launch_generation(e, -1, 0);
+  NLSG_HIP(hipGetLastError());
+  return NLSG_OK;
+}
+
+}  // extern "C"

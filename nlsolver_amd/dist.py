@@ -1,0 +1,55 @@
+"""Population sharding across the GPUs of one node.
+
+One process per GPU. Rank r owns the contiguous rows [r*pop/G, (r+1)*pop/G) of the
+population (island model: donors are drawn inside the shard, the RNG is keyed by
+the GLOBAL agent id). Per generation ONE collective: an all-gather of each rank's
+best record (D+5 doubles) over RCCL (`torch.distributed`, backend "nccl"); every
+rank then runs the same deterministic finaliser on the gathered records, so the
+solver state (best, counters, stop flag) is identical on all ranks without a
+second exchange.
+
+torch is plumbing here (device buffers for the records, the stream, the
+collective); the kernels are launched through the C-ABI on torch's current stream.
+"""
+import numpy as np
+
+
+def shard_bounds(pop, world, rank):
+    """Contiguous equal split; pop must divide evenly (keeps every shard's tile tree equal)."""
+    if pop % world:
+        raise ValueError(f"population {pop} is not divisible by world size {world}")
+    n = pop // world
+    return rank * n, n
+
+
+class ShardedDE:
+    """Drives one DE shard per rank; `engine_factory(shard_lo, shard_n, stream)` builds the
+    rank's engine (nlsolver_amd.DEEngine on GPUs; tests substitute a CPU stand-in)."""
+
+    def __init__(self, dist, engine_factory, pop, dim, device):
+        import torch
+        self.torch, self.dist = torch, dist
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self.lo, self.n = shard_bounds(pop, self.world, self.rank)
+        self.device = device
+        stream = None
+        if device.type == "cuda":
+            stream = torch.cuda.current_stream(device).cuda_stream
+        self.engine = engine_factory(self.lo, self.n, stream)
+        rec = self.engine.record_doubles()
+        assert rec == dim + 5
+        self.send = torch.zeros(rec, dtype=torch.float64, device=device)
+        self.gathered = torch.zeros(self.world * rec, dtype=torch.float64, device=device)
+
+    def init(self, x0):
+        self.engine.init(np.ascontiguousarray(x0, dtype=np.float64))
+
+    def turn(self):
+        """One turn of the reference loop on the sharded population."""
+        self.engine.turn_begin(self.send.data_ptr())
+        self.dist.all_gather_into_tensor(self.gathered, self.send)
+        self.engine.turn_end(self.gathered.data_ptr(), self.world)
+
+    def step(self, turns=1):
+        for _ in range(turns):
+            self.turn()

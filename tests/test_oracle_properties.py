@@ -1,0 +1,67 @@
+"""CPU checks of the synchronous restatement itself (no GPU):
+tree objective vs reference arithmetic (1e-12), reduction trees, convergence
+of the synchronous algorithm to the reference's results on config C1."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests import _oracle as O
+
+
+@pytest.mark.parametrize("obj", ["rosenbrock", "sphere", "styblinski_tang", "rastrigin"])
+@pytest.mark.parametrize("D", [1, 2, 3, 5, 64, 127, 128, 129, 256, 1000, 1024])
+def test_tree_objective_within_1e12_of_sequential(oracle, obj, D):
+    rng = np.random.default_rng(D)
+    for _ in range(20):
+        x = rng.uniform(-2.048, 2.048, D)
+        seq = oracle.orc_objective_seq(O.OBJ[obj], x.ctypes.data_as(O.pd), D)
+        tree = oracle.orc_objective_tree(O.OBJ[obj], x.ctypes.data_as(O.pd), D)
+        assert abs(tree - seq) <= 1e-12 * max(1.0, abs(seq))  # north_star tolerance
+    if D == 2:  # a single term: the tree is exact
+        assert tree == seq
+
+
+@pytest.mark.parametrize("n", [2, 3, 255, 256, 257, 1024, 1025, 4096, 65536 + 7])
+def test_std_err_tree_close_to_reference_formula(oracle, n):
+    x = np.random.default_rng(n).normal(50, 10, n)
+    ser = oracle.orc_std_err_serial(x.ctypes.data_as(O.pd), n)
+    tree = oracle.orc_std_err_tree(x.ctypes.data_as(O.pd), n)
+    assert abs(ser - tree) <= 1e-12 * ser
+    assert abs(ser - np.std(x, ddof=1)) <= 1e-12 * ser
+
+
+def test_sync_de_reaches_reference_quality_on_c1(oracle, golden):
+    """Config C1 (Rosenbrock-2D, pop=40, x0={5,7}): the synchronous counter-RNG
+    algorithm lands where the reference lands (its own tests accept 0.05)."""
+    ref = golden("de_c1.json")["c1_random_pop40_x0_5_7"]
+    run = O.DESyncRun(oracle, "rosenbrock", 40, 2, [5, 7], eps=10e-4)
+    for _ in range(2000):
+        run.step()
+        if run.s.done:
+            break
+    assert run.s.done
+    x = run.best_x
+    assert np.all(np.abs(x - 1.0) <= 0.05)
+    assert run.scores[run.s.best_id] < 1e-3
+    # same order of magnitude of work as the reference (1840 calls / 45 iterations)
+    assert 0.3 * ref["iters"] <= run.s.iter <= 3 * ref["iters"]
+    assert run.s.fcalls == 40 * (run.s.iter + 1)
+
+
+def test_sync_de_island_shards_keep_donors_local(oracle):
+    run = O.DESyncRun(oracle, "rosenbrock", 64, 8, [4.096] * 8, n_shards=4, trace=True)
+    run.step()
+    tr = run.trace
+    for a in range(64):
+        lo = (a // 16) * 16
+        r = tr[a, :3]
+        assert np.all((r >= lo) & (r < lo + 16)) and len(set(r.tolist()) | {a}) == 4
+
+
+def test_omp_variant_is_bit_identical(oracle):
+    a = O.DESyncRun(oracle, "rosenbrock", 512, 128, [4.096] * 128)
+    b = O.DESyncRun(oracle, "rosenbrock", 512, 128, [4.096] * 128)
+    a.step(3)
+    b.step(3, threads=4)
+    assert np.array_equal(a.population, b.population) and np.array_equal(a.scores, b.scores)
