@@ -32,7 +32,7 @@ def cpu_baseline():
     """Reference DE (unmodified nlsolver.h, built into oracle/_ref) timed on this host's
     cores; falls back to the oracle port when the reference binary is absent."""
     drv = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
-    gens = 24
+    gens = 200
     if os.path.exists(drv):
         out = subprocess.check_output([drv, "bench-de", str(D), str(POP_PER_GPU), str(gens)],
                                       text=True)
