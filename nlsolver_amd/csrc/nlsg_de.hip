@@ -2,6 +2,8 @@
 // (include/nlsg_c_api.h). Owns the device buffers and the HIP stream; enqueues
 // the kernels of nlsg_de_kernels.h. No CPU fallback: every entry point either
 // runs on a gfx950 device or returns an error.
+#include <algorithm>
+#include <cstdlib>
 #include <new>
 #include <vector>
 
@@ -15,10 +17,9 @@ struct nlsg_de {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   double *x0_dev = nullptr;
-  TilePartial *part = nullptr;
+  double *zero_dev = nullptr;
   DeLocal *loc = nullptr;
   double *rec = nullptr;  // local record (single-GPU finaliser input)
-  uint32_t ntiles = 0;
   int chunks = 0;
   bool initialised = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -64,41 +65,55 @@ struct Dispatch;  // OBJ x CHUNKS dispatch of a kernel family
 
 void launch_init(nlsg_de *e) {
   const dim3 grid(static_cast<unsigned>((e->p.shard_n + 3) / 4)), block(256);
-#define CALL(OBJ, C) \
-  hipLaunchKernelGGL((de_init_kernel<OBJ, C>), grid, block, 0, e->stream, e->p, e->x0_dev)
+#define CALL(OBJ, C)                                                                          \
+  if (e->p.vec)                                                                               \
+    hipLaunchKernelGGL((de_init_kernel<OBJ, C, true>), grid, block, 0, e->stream, e->p,       \
+                       e->x0_dev);                                                            \
+  else                                                                                        \
+    hipLaunchKernelGGL((de_init_kernel<OBJ, C, false>), grid, block, 0, e->stream, e->p,      \
+                       e->x0_dev)
   NLSG_FOR_OBJ(e->cfg.objective, e->chunks, CALL)
 #undef CALL
 }
 
 void launch_generation(nlsg_de *e, int par_override, uint64_t gen_override) {
   const dim3 grid(static_cast<unsigned>((e->p.shard_n + 3) / 4)), block(256);
-#define CALL(OBJ, C)                                                                   \
-  hipLaunchKernelGGL((de_generation_kernel<OBJ, C>), grid, block, 0, e->stream, e->p, \
-                     par_override, gen_override)
+#define CALL(OBJ, C)                                                                          \
+  if (e->p.vec)                                                                               \
+    hipLaunchKernelGGL((de_generation_kernel<OBJ, C, true>), grid, block, 0, e->stream, e->p, \
+                       par_override, gen_override);                                           \
+  else                                                                                        \
+    hipLaunchKernelGGL((de_generation_kernel<OBJ, C, false>), grid, block, 0, e->stream,      \
+                       e->p, par_override, gen_override)
   NLSG_FOR_OBJ(e->cfg.objective, e->chunks, CALL)
 #undef CALL
 }
 
-// local scan: tile partials -> DeLocal (+ second pass when std_err can decide)
-void launch_local_scan(nlsg_de *e) {
-  hipLaunchKernelGGL(de_scan_partial_kernel, dim3(e->ntiles), dim3(256), 0, e->stream, e->p,
-                     e->part);
-  hipLaunchKernelGGL(de_scan_local_kernel, dim3(1), dim3(256), 0, e->stream, e->p, e->part,
-                     e->ntiles, e->loc);
+// head of a turn when std_err can decide (eps > 0) or the population is sharded:
+// shard summary (best with the incumbent rule, two-pass sum / M2) -> record
+void launch_local_summary(nlsg_de *e, double *rec_dev) {
+  hipLaunchKernelGGL(de_scan_partial_kernel, dim3(e->p.ntiles), dim3(256), 0, e->stream, e->p);
+  hipLaunchKernelGGL(de_local_kernel, dim3(1), dim3(256), 0, e->stream, e->p, e->loc);
   if (e->cfg.eps > 0) {
-    hipLaunchKernelGGL(de_var_partial_kernel, dim3(e->ntiles), dim3(256), 0, e->stream, e->p,
-                       e->part, &e->loc->mean);
-    hipLaunchKernelGGL(de_var_local_kernel, dim3(1), dim3(256), 0, e->stream, e->p, e->part,
-                       e->ntiles, e->loc);
+    hipLaunchKernelGGL(de_var_partial_kernel, dim3(e->p.ntiles), dim3(256), 0, e->stream, e->p,
+                       &e->loc->mean);
+    hipLaunchKernelGGL(de_var_local_kernel, dim3(1), dim3(256), 0, e->stream, e->p, e->loc);
   }
+  hipLaunchKernelGGL(de_pack_record_kernel, dim3(1), dim3(256), 0, e->stream, e->p, e->loc,
+                     rec_dev);
 }
 
 void launch_turn_single(nlsg_de *e) {
-  launch_local_scan(e);
-  hipLaunchKernelGGL(de_pack_record_kernel, dim3(1), dim3(256), 0, e->stream, e->p, e->loc,
-                     e->rec);
-  hipLaunchKernelGGL(de_finalize_kernel, dim3(1), dim3(256), 0, e->stream, e->p, e->rec, 1,
-                     static_cast<uint64_t>(kRecHeader) + e->p.D);
+  if (e->cfg.eps > 0) {
+    launch_local_summary(e, e->rec);
+    hipLaunchKernelGGL(de_finalize_kernel, dim3(1), dim3(256), 0, e->stream, e->p, e->rec, 1,
+                       static_cast<uint64_t>(kRecHeader) + e->p.D);
+  } else {
+    // std_err < eps (nlsolver.h:2443) is false for every value std_err can take
+    // when eps <= 0 or NaN: the head of the turn is two small launches
+    hipLaunchKernelGGL(de_scan_partial_kernel, dim3(e->p.ntiles), dim3(256), 0, e->stream, e->p);
+    hipLaunchKernelGGL(de_head_kernel, dim3(1), dim3(256), 0, e->stream, e->p);
+  }
   launch_generation(e, -1, 0);
 }
 
@@ -174,7 +189,6 @@ int nlsg_de_create(const nlsg_de_config *cfg, nlsg_de **out) {
   e->cfg = *cfg;
   const uint64_t D = cfg->dim, n = cfg->shard_n;
   e->chunks = D <= 128 ? 1 : D <= 256 ? 2 : D <= 512 ? 4 : 8;
-  e->ntiles = static_cast<uint32_t>((n + kTile - 1) / kTile);
   if (cfg->stream) {
     e->stream = static_cast<hipStream_t>(cfg->stream);
   } else {
@@ -197,9 +211,13 @@ int nlsg_de_create(const nlsg_de_config *cfg, nlsg_de **out) {
   if (he == hipSuccess && cfg->trace)
     he = alloc(reinterpret_cast<void **>(&p.trace), n * kTraceWords * sizeof(uint64_t));
   if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&p.state), sizeof(DeState));
-  if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&e->x0_dev), D * sizeof(double));
+  p.ntiles = static_cast<uint32_t>((n + kTile - 1) / kTile);
   if (he == hipSuccess)
-    he = alloc(reinterpret_cast<void **>(&e->part), e->ntiles * sizeof(TilePartial));
+    he = alloc(reinterpret_cast<void **>(&p.part), p.ntiles * sizeof(TilePartial));
+  if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&e->zero_dev), 16);
+  if (he == hipSuccess) he = hipMemset(e->zero_dev, 0, 16);
+  p.zero = e->zero_dev;
+  if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&e->x0_dev), D * sizeof(double));
   if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&e->loc), sizeof(DeLocal));
   if (he == hipSuccess)
     he = alloc(reinterpret_cast<void **>(&e->rec), (kRecHeader + D) * sizeof(double));
@@ -237,8 +255,9 @@ int nlsg_de_destroy(nlsg_de *e) {
   hipFree(e->p.best_x);
   hipFree(e->p.trace);
   hipFree(e->p.state);
+  hipFree(e->p.part);
   hipFree(e->x0_dev);
-  hipFree(e->part);
+  hipFree(e->zero_dev);
   hipFree(e->loc);
   hipFree(e->rec);
   if (e->ev0) hipEventDestroy(e->ev0);
@@ -394,9 +413,7 @@ int nlsg_de_turn_begin(nlsg_de *e, double *send_dev) {
   if (!e || !send_dev) return fail(NLSG_ERR_INVALID_ARG, "null argument");
   if (!e->initialised) return fail(NLSG_ERR_STATE, "nlsg_de_init has not been called");
   NLSG_HIP(hipSetDevice(e->cfg.device));
-  launch_local_scan(e);
-  hipLaunchKernelGGL(de_pack_record_kernel, dim3(1), dim3(256), 0, e->stream, e->p, e->loc,
-                     send_dev);
+  launch_local_summary(e, send_dev);
   NLSG_HIP(hipGetLastError());
   return NLSG_OK;
 }

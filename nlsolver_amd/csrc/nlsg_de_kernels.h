@@ -2,24 +2,29 @@
 //
 // Replaces the loops of DE::solve (nlsolver.h:2414-2476):
 //   de_init_kernel        init_agents + initial scoring      (2315-2323, 2423-2425)
-//   de_scan_partial/final best scan, no-change counter, stop (2429-2447) + std_err (2037-2052)
 //   de_generation_kernel  generate_indices + propose_new_agent + f() + selection (2449-2472)
+//   de_scan_partial_kernel + de_head_kernel
+//                         best scan, no-change counter, stop tests (2429-2447)
+//   de_var_* kernels      second pass of std_err (2037-2052), only when eps > 0 can decide
 //
 // Data layout in HBM: population row-major [shard_n][D] fp64, two buffers
 // (synchronous generation: donors are read from `cur`, survivors written to
 // `nxt`); scores [shard_n] fp64 updated in place by the owning wave.
 // Mapping: one wave64 per agent; lane l holds elements c*128 + 2l, +1 of each
 // 128-element chunk c, so every wave-level load/store is one contiguous 1 KiB
-// burst (global_load_dwordx4 / global_store_dwordx4) when D is even.
+// burst (global_load_dwordx4 / global_store_dwordx4) when D is even. One agent
+// per wave and 4 agents per 256-thread block, dispatched dynamically: measured
+// 10-13 % faster at pop = 2^20 than persistent grid-stride waves (same device,
+// same run), which lose to load imbalance between CUs (DESIGN.md §DE kernel).
 #pragma once
 
 #include "nlsg_common.h"
 
 namespace nlsg {
 
-constexpr int kDeMaxTries = 64;      // bounded donor rejection loop
-constexpr int kTile = 1024;          // reduction tile
-constexpr int kTraceWords = 5;       // r1, r2, r3, jrand, accept
+constexpr int kDeMaxTries = 64;       // bounded donor rejection loop
+constexpr int kTile = 1024;           // reduction tile
+constexpr int kTraceWords = 5;        // r1, r2, r3, jrand, accept
 
 // Device-resident solver state (one per engine).
 struct DeState {
@@ -35,12 +40,25 @@ struct DeState {
   int32_t pad;
 };
 
+// Per tile of kTile scores: block-tree sum, minimum and first index of it,
+// block-tree sum of squared deviations (second pass).
+struct TilePartial {
+  double sum;
+  double minv;
+  uint64_t mini;  // shard-local index (~0 if the tile holds only NaN)
+  double m2;
+};
+
 struct DeParams {
   double *buf[2];      // population ping-pong
   double *scores;      // [shard_n]
   double *best_x;      // [D] row of the incumbent best (valid after a scan)
   uint64_t *trace;     // [shard_n*5] or nullptr
   DeState *state;
+  TilePartial *part;   // [ntiles] written by de_scan_partial_kernel
+  const double *zero;  // 16 bytes of zeros: source for lanes past the row end
+  uint32_t ntiles;
+  uint32_t pad0;
   uint64_t pop, D, shard_lo, shard_n;
   double CR, F, eps, fmul;
   uint64_t max_iter, best_val_no_change, seed;
@@ -49,32 +67,38 @@ struct DeParams {
 };
 
 // ---- row access ------------------------------------------------------------
-template <int CHUNKS>
-__device__ inline void load_row(const double *__restrict__ row, uint64_t D, int vec,
-                                double (&v)[CHUNKS][2]) {
+// Branch-free and select-free on purpose: a load guarded by a runtime condition
+// makes hipcc branch around it and drain vmcnt before the next one, and a select
+// on the loaded value forces the wait to the load site; both serialise the row
+// gathers. Lanes past the end of the row read 16 bytes of zeros (`zero`) instead,
+// so all loads of an agent are issued back to back and waited for at first use.
+// VEC = rows are 16-byte aligned (D even).
+template <int CHUNKS, bool VEC>
+__device__ inline void load_row(const double *__restrict__ row, uint64_t D,
+                                const double *__restrict__ zero, double (&v)[CHUNKS][2]) {
   const int lane = lane_id();
 #pragma unroll
   for (int c = 0; c < CHUNKS; c++) {
     const uint64_t e0 = static_cast<uint64_t>(c) * 128 + 2 * static_cast<uint64_t>(lane);
-    if (vec) {
-      double2 t = make_double2(0.0, 0.0);
-      if (e0 < D) t = *reinterpret_cast<const double2 *>(row + e0);
+    if (VEC) {
+      const double *src = (e0 < D) ? row + e0 : zero;  // D even: e0 + 1 < D as well
+      const double2 t = *reinterpret_cast<const double2 *>(src);
       v[c][0] = t.x;
       v[c][1] = t.y;
     } else {
-      v[c][0] = (e0 < D) ? row[e0] : 0.0;
-      v[c][1] = (e0 + 1 < D) ? row[e0 + 1] : 0.0;
+      v[c][0] = *((e0 < D) ? row + e0 : zero);
+      v[c][1] = *((e0 + 1 < D) ? row + e0 + 1 : zero);
     }
   }
 }
-template <int CHUNKS>
-__device__ inline void store_row(double *__restrict__ row, uint64_t D, int vec,
+template <int CHUNKS, bool VEC>
+__device__ inline void store_row(double *__restrict__ row, uint64_t D,
                                  const double (&v)[CHUNKS][2]) {
   const int lane = lane_id();
 #pragma unroll
   for (int c = 0; c < CHUNKS; c++) {
     const uint64_t e0 = static_cast<uint64_t>(c) * 128 + 2 * static_cast<uint64_t>(lane);
-    if (vec) {
+    if (VEC) {
       if (e0 < D) *reinterpret_cast<double2 *>(row + e0) = make_double2(v[c][0], v[c][1]);
     } else {
       if (e0 < D) row[e0] = v[c][0];
@@ -83,8 +107,35 @@ __device__ inline void store_row(double *__restrict__ row, uint64_t D, int vec,
   }
 }
 
+// lower value wins; equal values keep the lower index; NaN never wins
+__device__ inline void argmin_combine(double &v, uint64_t &i, double ov, uint64_t oi) {
+  if (ov < v || (ov == v && oi < i)) {
+    v = ov;
+    i = oi;
+  }
+}
+
+// wave- then block-level argmin; thread 0 returns the block result
+__device__ inline void block_argmin_256(double &bv, uint64_t &bi, double *mv, uint64_t *mi) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const double ov = __shfl_xor(bv, off, 64);
+    const uint64_t oi = __shfl_xor(bi, off, 64);
+    argmin_combine(bv, bi, ov, oi);
+  }
+  const int wid = static_cast<int>(threadIdx.x) >> 6;
+  __syncthreads();
+  if (lane_id() == 0) {
+    mv[wid] = bv;
+    mi[wid] = bi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+    for (int w = 1; w < 4; w++) argmin_combine(bv, bi, mv[w], mi[w]);
+}
+
 // ---- generation 0 ----------------------------------------------------------
-template <int OBJ, int CHUNKS>
+template <int OBJ, int CHUNKS, bool VEC>
 __global__ __launch_bounds__(256) void de_init_kernel(DeParams p, const double *__restrict__ x0) {
   const uint64_t a = static_cast<uint64_t>(blockIdx.x) * 4 +
                      __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
@@ -102,7 +153,7 @@ __global__ __launch_bounds__(256) void de_init_kernel(DeParams p, const double *
       xv[c][k] = (e < p.D) ? (u01(ctr_key(ka, e)) - 0.5) * x0[e] : 0.0;
     }
   }
-  store_row<CHUNKS>(p.buf[0] + a * p.D, p.D, p.vec, xv);
+  store_row<CHUNKS, VEC>(p.buf[0] + a * p.D, p.D, xv);
   const double f = p.fmul * wave_objective<OBJ, CHUNKS>(xv, p.D);  // :2423-2425
   if (lane == 0) p.scores[a] = f;
 }
@@ -121,7 +172,7 @@ __global__ void de_reset_state_kernel(DeParams p) {
 }
 
 // ---- one generation ----------------------------------------------------------
-template <int OBJ, int CHUNKS>
+template <int OBJ, int CHUNKS, bool VEC>
 __global__ __launch_bounds__(256) void de_generation_kernel(DeParams p, int par_override,
                                                           uint64_t gen_override) {
   // par_override >= 0: timing mode (nlsg_de_time_generation_kernel) — buffer
@@ -137,70 +188,60 @@ __global__ __launch_bounds__(256) void de_generation_kernel(DeParams p, int par_
   const double *__restrict__ cur = p.buf[par];
   double *__restrict__ nxt = p.buf[par ^ 1];
   const uint64_t D = p.D;
-  const uint64_t ga = p.shard_lo + a;  // global agent id keys the RNG
+  const uint64_t ga = p.shard_lo + a;  // the global agent id keys the RNG
   const uint64_t ka = ctr_key(ctr_key(p.seed, generation), ga);
 
   // generate_indices (nlsolver.h:2331-2355): three distinct donors != fixed,
   // by rejection, drawn inside this engine's shard. Wave-uniform (scalar) code.
   const uint64_t fixed = (p.strategy == NLSG_DE_RANDOM) ? ga : st->best_id;  // :2451-2457
-  uint64_t r[3];
+  uint64_t r0 = ~0ull, r1 = ~0ull, r2 = ~0ull;
   int have = 0;
   for (int k = 0; k < kDeMaxTries && have < 3; k++) {
     const uint64_t cand = p.shard_lo + clamp_index(u01(ctr_key(ka, D + 1 + k)), p.shard_n);
-    bool used = (cand == fixed);
-    for (int j = 0; j < 3; j++) used |= (j < have && r[j] == cand);
+    const bool used = (cand == fixed) || (have > 0 && cand == r0) || (have > 1 && cand == r1);
     if (!used) {
-      if (have == 0) r[0] = cand;
-      else if (have == 1) r[1] = cand;
-      else r[2] = cand;
+      if (have == 0) r0 = cand;
+      else if (have == 1) r1 = cand;
+      else r2 = cand;
       have++;
     }
   }
   for (uint64_t cand = p.shard_lo; have < 3; cand++) {  // fallback: lowest unused
-    bool used = (cand == fixed);
-    for (int j = 0; j < 3; j++) used |= (j < have && r[j] == cand);
+    const bool used = (cand == fixed) || (have > 0 && cand == r0) || (have > 1 && cand == r1);
     if (!used) {
-      if (have == 0) r[0] = cand;
-      else if (have == 1) r[1] = cand;
-      else r[2] = cand;
+      if (have == 0) r0 = cand;
+      else if (have == 1) r1 = cand;
+      else r2 = cand;
       have++;
     }
   }
   const uint64_t jrand = clamp_index(u01(ctr_key(ka, D)), D);  // :2364
 
-  // rows: own (selection survivor), base (non-crossed coordinates), 3 donors
-  double own[CHUNKS][2], d1[CHUNKS][2], d2[CHUNKS][2], d3[CHUNKS][2];
-  load_row<CHUNKS>(cur + a * D, D, p.vec, own);
-  load_row<CHUNKS>(cur + (r[0] - p.shard_lo) * D, D, p.vec, d1);
-  load_row<CHUNKS>(cur + (r[1] - p.shard_lo) * D, D, p.vec, d2);
-  load_row<CHUNKS>(cur + (r[2] - p.shard_lo) * D, D, p.vec, d3);
+  // rows: own (selection survivor), keep (non-crossed coordinates: own row for
+  // strategy random, the row of best_id for strategy best, :2451-2457), 3 donors.
+  // All loads are issued back to back; the first wait is at first use.
+  double own[CHUNKS][2], keep[CHUNKS][2], d1[CHUNKS][2], d2[CHUNKS][2], d3[CHUNKS][2];
+  load_row<CHUNKS, VEC>(cur + a * D, D, p.zero, own);
+  load_row<CHUNKS, VEC>(cur + (r0 - p.shard_lo) * D, D, p.zero, d1);
+  load_row<CHUNKS, VEC>(cur + (r1 - p.shard_lo) * D, D, p.zero, d2);
+  load_row<CHUNKS, VEC>(cur + (r2 - p.shard_lo) * D, D, p.zero, d3);
+  // strategy best: the row of best_id (L2-resident). Strategy random needs no
+  // fifth row; its load is still issued (so the instruction stream does not
+  // depend on the strategy) but every lane reads the 16 zero bytes.
+  const bool rnd = p.strategy == NLSG_DE_RANDOM;
+  load_row<CHUNKS, VEC>(p.best_x, rnd ? 0 : D, p.zero, keep);
   const double old_score = p.scores[a];
 
   // propose_new_agent (nlsolver.h:2357-2375)
   double trial[CHUNKS][2];
-  if (p.strategy == NLSG_DE_RANDOM) {
 #pragma unroll
-    for (int c = 0; c < CHUNKS; c++) {
+  for (int c = 0; c < CHUNKS; c++) {
 #pragma unroll
-      for (int k = 0; k < 2; k++) {
-        const uint64_t e = static_cast<uint64_t>(c) * 128 + 2 * static_cast<uint64_t>(lane) + k;
-        const double u = u01(ctr_key(ka, e));
-        const double mut = d1[c][k] + p.F * (d2[c][k] - d3[c][k]);
-        trial[c][k] = (u < p.CR || e == jrand) ? mut : own[c][k];
-      }
-    }
-  } else {
-    double base[CHUNKS][2];
-    load_row<CHUNKS>(p.best_x, D, p.vec, base);  // row of best_id (L2-resident)
-#pragma unroll
-    for (int c = 0; c < CHUNKS; c++) {
-#pragma unroll
-      for (int k = 0; k < 2; k++) {
-        const uint64_t e = static_cast<uint64_t>(c) * 128 + 2 * static_cast<uint64_t>(lane) + k;
-        const double u = u01(ctr_key(ka, e));
-        const double mut = d1[c][k] + p.F * (d2[c][k] - d3[c][k]);
-        trial[c][k] = (u < p.CR || e == jrand) ? mut : base[c][k];
-      }
+    for (int k = 0; k < 2; k++) {
+      const uint64_t e = static_cast<uint64_t>(c) * 128 + 2 * static_cast<uint64_t>(lane) + k;
+      const double u = u01(ctr_key(ka, e));
+      const double mut = d1[c][k] + p.F * (d2[c][k] - d3[c][k]);
+      trial[c][k] = (u < p.CR || e == jrand) ? mut : (rnd ? own[c][k] : keep[c][k]);
     }
   }
   // (elements >= D are 0 in every loaded row, hence 0 in the trial as well)
@@ -208,81 +249,134 @@ __global__ __launch_bounds__(256) void de_generation_kernel(DeParams p, int par_
   const bool accept = score < old_score;                                 // :2466 (NaN -> keep)
   double *out = nxt + a * D;
   if (accept) {
-    store_row<CHUNKS>(out, D, p.vec, trial);
+    store_row<CHUNKS, VEC>(out, D, trial);
     if (lane == 0) p.scores[a] = score;
   } else {
-    store_row<CHUNKS>(out, D, p.vec, own);
+    store_row<CHUNKS, VEC>(out, D, own);
   }
   if (p.trace != nullptr && lane == 0) {
     uint64_t *t = p.trace + a * kTraceWords;
-    t[0] = r[0];
-    t[1] = r[1];
-    t[2] = r[2];
+    t[0] = r0;
+    t[1] = r1;
+    t[2] = r2;
     t[3] = jrand;
     t[4] = accept ? 1u : 0u;
   }
 }
 
-// ---- best scan + std_err + stop tests ------------------------------------------
-// Per tile of 1024 scores: block-tree sum, min value and first index of it.
-struct TilePartial {
-  double sum;
-  double minv;
-  uint64_t mini;  // shard-local index
-  double m2;      // sum of squared deviations from the mean (second pass)
-};
-
-__device__ inline void argmin_combine(double &v, uint64_t &i, double ov, uint64_t oi) {
-  // lower value wins; equal values keep the lower index; NaN never wins
-  if (ov < v || (ov == v && oi < i)) {
-    v = ov;
-    i = oi;
+// ---- best scan + stop tests -------------------------------------------------
+// Applies the iter++ of the generation that ran since the previous scan.
+__device__ inline void apply_pending(DeState *st, const DeParams &p) {
+  if (st->pending) {
+    st->iter += 1;
+    st->fcalls += p.pop;
+    st->parity ^= 1;
+    st->pending = 0;
   }
 }
 
-__global__ __launch_bounds__(256) void de_scan_partial_kernel(DeParams p, TilePartial *part) {
+// First level of the best scan (and of std_err's first pass): one block per
+// tile of kTile scores.
+__global__ __launch_bounds__(256) void de_scan_partial_kernel(DeParams p) {
   __shared__ double red[4];
   __shared__ double mv[4];
   __shared__ uint64_t mi[4];
-  const DeState *st = p.state;
-  if (st->done) return;
+  if (p.state->done) return;
   const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kTile;
-  const uint64_t n = p.shard_n;
   double acc = 0.0;
   double bv = __builtin_inf();
   uint64_t bi = ~0ull;
-  for (uint64_t i = base + threadIdx.x; i < base + kTile && i < n; i += 256) {
-    const double s = p.scores[i];
-    acc = acc + s;
-    argmin_combine(bv, bi, s, i);
+  for (uint64_t i = base + threadIdx.x; i < base + kTile && i < p.shard_n; i += 256) {
+    const double sc = p.scores[i];
+    acc = acc + sc;
+    argmin_combine(bv, bi, sc, i);
   }
   const double total = block_tree_256(acc, red);
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    const double ov = __shfl_xor(bv, off, 64);
-    const uint64_t oi = __shfl_xor(bi, off, 64);
-    argmin_combine(bv, bi, ov, oi);
-  }
-  const int wid = static_cast<int>(threadIdx.x) >> 6;
-  if (lane_id() == 0) {
-    mv[wid] = bv;
-    mi[wid] = bi;
-  }
-  __syncthreads();
+  block_argmin_256(bv, bi, mv, mi);
   if (threadIdx.x == 0) {
-    for (int w = 1; w < 4; w++) argmin_combine(bv, bi, mv[w], mi[w]);
-    part[blockIdx.x].sum = total;
-    part[blockIdx.x].minv = bv;
-    part[blockIdx.x].mini = bi;
+    p.part[blockIdx.x].sum = total;
+    p.part[blockIdx.x].minv = bv;
+    p.part[blockIdx.x].mini = bi;
   }
 }
 
-// Second pass of std_err (nlsolver.h:2046-2049) with the mean of pass one.
-__global__ __launch_bounds__(256) void de_var_partial_kernel(DeParams p, TilePartial *part,
-                                                           const double *mean_ptr) {
-  __shared__ double red[4];
-  const DeState *st = p.state;
+// Shard minimum with the reference's tie rule (strict '<' scan starting from the
+// incumbent, nlsolver.h:2432-2437): the incumbent survives when nobody in the
+// shard is strictly better. Returns (score, GLOBAL index, owned) in thread 0.
+__device__ inline void shard_best(const DeParams &p, const DeState *st, double *mv, uint64_t *mi,
+                                  double &bv, uint64_t &gi, bool &mine) {
+  bv = __builtin_inf();
+  uint64_t bi = ~0ull;
+  for (uint32_t j = threadIdx.x; j < p.ntiles; j += 256)
+    argmin_combine(bv, bi, p.part[j].minv, p.part[j].mini);
+  block_argmin_256(bv, bi, mv, mi);
+  gi = 0;
+  mine = false;
+  if (threadIdx.x == 0) {
+    const uint64_t inc = st->best_id;
+    gi = (bi == ~0ull) ? inc : p.shard_lo + bi;
+    if (inc >= p.shard_lo && inc < p.shard_lo + p.shard_n) {
+      const double inc_score = p.scores[inc - p.shard_lo];
+      if (!(bv < inc_score)) {
+        gi = inc;
+        bv = inc_score;
+      }
+    }
+    mine = gi >= p.shard_lo && gi < p.shard_lo + p.shard_n;
+  }
+}
+
+// Counters and stop tests shared by the two finalisers (thread 0 only).
+__device__ inline void finish_turn(DeState *st, const DeParams &p, uint64_t bi, double bv,
+                                   bool have_best, double se) {
+  // not_updated <=> best_id did not move: the strict '<' scan (:2431-2437) can
+  // never return to the incumbent once it has left it.
+  const bool not_updated = (bi == st->best_id);
+  st->val_no_change = not_updated ? st->val_no_change + 1 : 0;  // :2439
+  st->best_id = bi;
+  if (have_best) st->best_f = bv;
+  st->std_err = se;
+  if (st->iter >= p.max_iter || st->val_no_change >= p.best_val_no_change ||
+      (p.eps > 0 && se < p.eps)) {  // :2441-2443
+    st->done = 1;
+  } else {
+    st->pending = 1;  // the generation enqueued right after this kernel will run
+  }
+}
+
+// One-GPU, eps <= 0 (std_err cannot decide): the whole head of a turn in one
+// single-block launch.
+__global__ __launch_bounds__(256) void de_head_kernel(DeParams p) {
+  __shared__ double mv[4];
+  __shared__ uint64_t mi[4];
+  __shared__ uint64_t s_row;
+  __shared__ int s_have;
+  __shared__ int s_par;
+  DeState *st = p.state;
   if (st->done) return;
+  if (threadIdx.x == 0) apply_pending(st, p);
+  __syncthreads();
+  double bv;
+  uint64_t gi;
+  bool mine;
+  shard_best(p, st, mv, mi, bv, gi, mine);
+  if (threadIdx.x == 0) {
+    s_par = st->parity;
+    finish_turn(st, p, gi, bv, mine, __builtin_nan(""));
+    s_row = gi - p.shard_lo;
+    s_have = mine ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_have) return;
+  const double *row = p.buf[s_par] + s_row * p.D;  // x = agents[best_id], :2444
+  for (uint64_t d = threadIdx.x; d < p.D; d += 256) p.best_x[d] = row[d];
+}
+
+// ---- std_err (eps > 0) and the sharded path ------------------------------------
+// Second pass of std_err (nlsolver.h:2046-2049) with the mean of pass one.
+__global__ __launch_bounds__(256) void de_var_partial_kernel(DeParams p, const double *mean_ptr) {
+  __shared__ double red[4];
+  if (p.state->done) return;
   const double mean = *mean_ptr;
   const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kTile;
   double acc = 0.0;
@@ -291,80 +385,53 @@ __global__ __launch_bounds__(256) void de_var_partial_kernel(DeParams p, TilePar
     acc = acc + d * d;
   }
   const double total = block_tree_256(acc, red);
-  if (threadIdx.x == 0) part[blockIdx.x].m2 = total;
+  if (threadIdx.x == 0) p.part[blockIdx.x].m2 = total;
 }
 
-// Local (per-shard) summary produced by the scan; consumed by the finaliser
-// directly (one GPU) or exchanged between ranks (record).
+// Per-shard summary; consumed by the finaliser directly (one GPU) or exchanged
+// between ranks (record).
 struct DeLocal {
-  double sum;      // tiled sum of the shard's scores
-  double mean;     // sum / shard_n
-  double minv;     // shard minimum
-  uint64_t mini;   // GLOBAL index of its first occurrence (incumbent keeps ties)
-  double m2;       // tiled sum of squared deviations from `mean`
+  double sum;     // tiled sum of the shard's scores (eps > 0 only)
+  double mean;    // sum / shard_n
+  double minv;    // shard minimum (incumbent keeps ties)
+  uint64_t mini;  // GLOBAL index
+  double m2;      // tiled sum of squared deviations from `mean`
+  double valid;   // 1.0 when `mini` is owned by this shard
 };
 
-// Single block. phase 0: applies the pending iter++ of the previous generation,
-// reduces the tile partials to (sum, min, argmin) and the local mean.
-__global__ __launch_bounds__(256) void de_scan_local_kernel(DeParams p, const TilePartial *part,
-                                                          uint32_t ntiles, DeLocal *loc) {
+__global__ __launch_bounds__(256) void de_local_kernel(DeParams p, DeLocal *loc) {
   __shared__ double red[4];
   __shared__ double mv[4];
   __shared__ uint64_t mi[4];
   DeState *st = p.state;
   if (st->done) return;
-  double acc = 0.0;
-  double bv = __builtin_inf();
-  uint64_t bi = ~0ull;
-  for (uint32_t j = threadIdx.x; j < ntiles; j += 256) {
-    acc = acc + part[j].sum;
-    argmin_combine(bv, bi, part[j].minv, part[j].mini);
-  }
-  const double total = block_tree_256(acc, red);
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    const double ov = __shfl_xor(bv, off, 64);
-    const uint64_t oi = __shfl_xor(bi, off, 64);
-    argmin_combine(bv, bi, ov, oi);
-  }
-  const int wid = static_cast<int>(threadIdx.x) >> 6;
-  if (lane_id() == 0) {
-    mv[wid] = bv;
-    mi[wid] = bi;
-  }
+  if (threadIdx.x == 0) apply_pending(st, p);
   __syncthreads();
+  double bv;
+  uint64_t gi;
+  bool mine;
+  shard_best(p, st, mv, mi, bv, gi, mine);
+  double total = 0.0;
+  if (p.eps > 0) {
+    double acc = 0.0;
+    for (uint32_t j = threadIdx.x; j < p.ntiles; j += 256) acc = acc + p.part[j].sum;
+    total = block_tree_256(acc, red);
+  }
   if (threadIdx.x == 0) {
-    for (int w = 1; w < 4; w++) argmin_combine(bv, bi, mv[w], mi[w]);
-    if (st->pending) {  // the generation enqueued before this scan has run
-      st->iter += 1;
-      st->fcalls += p.pop;
-      st->parity ^= 1;
-      st->pending = 0;
-    }
-    // incumbent keeps ties (strict '<' scan starting from best_id, :2432-2437)
-    uint64_t gi = (bi == ~0ull) ? st->best_id : p.shard_lo + bi;
-    const uint64_t inc = st->best_id;
-    if (inc >= p.shard_lo && inc < p.shard_lo + p.shard_n) {
-      const double inc_score = p.scores[inc - p.shard_lo];
-      if (!(bv < inc_score)) {  // nobody is strictly better than the incumbent
-        gi = inc;
-        bv = inc_score;
-      }
-    }
     loc->sum = total;
     loc->mean = total / static_cast<double>(p.shard_n);  // :2044
     loc->minv = bv;
     loc->mini = gi;
     loc->m2 = 0.0;
+    loc->valid = mine ? 1.0 : 0.0;
   }
 }
 
-__global__ __launch_bounds__(256) void de_var_local_kernel(DeParams p, const TilePartial *part,
-                                                         uint32_t ntiles, DeLocal *loc) {
+__global__ __launch_bounds__(256) void de_var_local_kernel(DeParams p, DeLocal *loc) {
   __shared__ double red[4];
   if (p.state->done) return;
   double acc = 0.0;
-  for (uint32_t j = threadIdx.x; j < ntiles; j += 256) acc = acc + part[j].m2;
+  for (uint32_t j = threadIdx.x; j < p.ntiles; j += 256) acc = acc + p.part[j].m2;
   const double total = block_tree_256(acc, red);
   if (threadIdx.x == 0) loc->m2 = total;
 }
@@ -380,21 +447,21 @@ __global__ __launch_bounds__(256) void de_pack_record_kernel(DeParams p, const D
   const DeState *st = p.state;
   if (st->done) return;
   const uint64_t gi = loc->mini;
-  const bool mine = gi >= p.shard_lo && gi < p.shard_lo + p.shard_n;
+  const bool mine = loc->valid == 1.0;
   if (threadIdx.x == 0) {
     rec[0] = loc->minv;
     rec[1] = __longlong_as_double(static_cast<long long>(gi));
     rec[2] = loc->sum;
     rec[3] = loc->m2;
-    rec[4] = mine ? 1.0 : 0.0;
+    rec[4] = loc->valid;
   }
   const double *row = p.buf[st->parity] + (mine ? (gi - p.shard_lo) : 0) * p.D;
   for (uint64_t d = threadIdx.x; d < p.D; d += 256) rec[kRecHeader + d] = mine ? row[d] : 0.0;
 }
 
-// Finaliser: picks the global best among `world` records (world == 1: the
-// local record), applies the no-change counter and the stop tests
-// (nlsolver.h:2439-2447), refreshes best_x. Single block.
+// Finaliser over `world` records (world == 1: the local record): global best
+// (lower value; on ties the incumbent, then the lower global index), counters,
+// stop tests (nlsolver.h:2439-2447), best_x. Single block.
 __global__ __launch_bounds__(256) void de_finalize_kernel(DeParams p, const double *recs,
                                                         int32_t world, uint64_t rec_stride) {
   __shared__ int s_win;
@@ -410,7 +477,6 @@ __global__ __launch_bounds__(256) void de_finalize_kernel(DeParams p, const doub
       if (rec[4] != 1.0) continue;
       const double v = rec[0];
       const uint64_t i = static_cast<uint64_t>(__double_as_longlong(rec[1]));
-      // lower value wins; on ties the incumbent wins, then the lower index
       const bool better =
           win < 0 || v < bv || (v == bv && bi != inc && (i == inc || i < bi));
       if (better) {
@@ -419,12 +485,6 @@ __global__ __launch_bounds__(256) void de_finalize_kernel(DeParams p, const doub
         win = r;
       }
     }
-    // not_updated <=> best_id did not move: the strict '<' scan (:2431-2437) can
-    // never return to the incumbent once it has left it.
-    const bool not_updated = (bi == inc);
-    st->val_no_change = not_updated ? st->val_no_change + 1 : 0;  // :2439
-    st->best_id = bi;
-    if (win >= 0) st->best_f = bv;
     // std_err over the global scores (only when it can decide: eps > 0)
     double se = __builtin_nan("");
     if (p.eps > 0) {
@@ -446,13 +506,7 @@ __global__ __launch_bounds__(256) void de_finalize_kernel(DeParams p, const doub
       }
       se = sqrt(m2 / static_cast<double>(p.pop - 1));  // :2050-2051
     }
-    st->std_err = se;
-    if (st->iter >= p.max_iter || st->val_no_change >= p.best_val_no_change ||
-        (p.eps > 0 && se < p.eps)) {  // :2441-2443
-      st->done = 1;
-    } else {
-      st->pending = 1;  // the generation enqueued right after this kernel will run
-    }
+    finish_turn(st, p, bi, bv, win >= 0, se);
     s_win = win;
   }
   __syncthreads();
@@ -462,14 +516,6 @@ __global__ __launch_bounds__(256) void de_finalize_kernel(DeParams p, const doub
 }
 
 // Applies a pending iter++ without scanning (used before reading the state).
-__global__ void de_settle_kernel(DeParams p) {
-  DeState *st = p.state;
-  if (st->pending) {
-    st->iter += 1;
-    st->fcalls += p.pop;
-    st->parity ^= 1;
-    st->pending = 0;
-  }
-}
+__global__ void de_settle_kernel(DeParams p) { apply_pending(p.state, p); }
 
 }  // namespace nlsg
