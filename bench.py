@@ -80,9 +80,11 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    distributed = world > 1
+    # NLSG_BENCH_FORCE_DIST=1 exercises the sharded/RCCL path with a single rank (self-test)
+    distributed = world > 1 or os.environ.get("NLSG_BENCH_FORCE_DIST") == "1"
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     pop_local = args.pop_per_gpu

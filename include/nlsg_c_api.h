@@ -84,7 +84,8 @@ typedef struct nlsg_de nlsg_de; /* opaque engine handle */
 typedef struct {
   uint32_t struct_size; /* sizeof(nlsg_de_config), for ABI evolution          */
   int32_t device;       /* HIP device ordinal                                  */
-  void *stream;         /* hipStream_t to enqueue on; NULL = private stream    */
+  void *stream;         /* hipStream_t to enqueue on; NULL = private stream.   */
+                        /* For the null stream pass hipStreamLegacy ((void*)1) */
   int32_t objective;    /* nlsg_objective                                      */
   int32_t minimize;     /* 1 = minimize(), 0 = maximize() (nlsolver.h:2404-10) */
   int32_t strategy;     /* nlsg_de_strategy                                    */

@@ -39,7 +39,9 @@ class DEEngine:
         cfg = DEConfig()
         cfg.struct_size = C.sizeof(DEConfig)
         cfg.device = device
-        cfg.stream = stream
+        # None: the engine creates a private stream. An integer is a hipStream_t handle;
+        # 0 is torch's default (null) stream, spelled hipStreamLegacy = 1 for the C-ABI.
+        cfg.stream = None if stream is None else (stream or 1)
         cfg.objective = _capi.OBJECTIVES[objective] if isinstance(objective, str) else objective
         cfg.minimize = int(bool(minimize))
         cfg.strategy = strategy

@@ -115,6 +115,14 @@ typedef struct {
 } orc_de_sync;
 
 void orc_de_sync_init(orc_de_sync *s, const double *x0); /* generation 0 */
+/* The turn in the pieces the sharded (multi-GPU) path executes: per-shard record
+ * -> [all-gather] -> apply (global best, counters, stop tests) -> per-shard
+ * generation -> commit. orc_de_sync_step is exactly this with all shards local. */
+#define ORC_DE_REC_HEADER 5
+void orc_de_shard_record(const orc_de_sync *s, size_t lo, size_t n, double *rec);
+int orc_de_apply_records(orc_de_sync *s, const double *recs, int world, double *best_x);
+void orc_de_shard_generation(orc_de_sync *s, size_t lo, size_t n, int threads);
+void orc_de_commit(orc_de_sync *s);
 /* One reference loop turn: best scan + stop tests (nlsolver.h:2429-2447), then
  * if not done one synchronous generation (2449-2472) and iter++. */
 void orc_de_sync_step(orc_de_sync *s);

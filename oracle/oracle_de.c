@@ -131,20 +131,6 @@ void orc_de_sync_init(orc_de_sync *s, const double *x0) {
   s->std_err = NAN;
 }
 
-/* Best scan with the reference's tie rule (nlsolver.h:2432-2437): the result
- * is the incumbent when its score equals the minimum, otherwise the first
- * index holding the minimum; NaN is never "less". */
-static int best_scan(const double *scores, size_t pop, uint64_t *best_id) {
-  int not_updated = 1;
-  for (size_t i = 0; i < pop; i++) {
-    if (scores[i] < scores[*best_id]) {
-      *best_id = i;
-      not_updated = 0;
-    }
-  }
-  return not_updated;
-}
-
 static void sync_agent(const orc_de_sync *s, uint64_t kg, size_t a, double *trial) {
   const size_t D = s->D, pop = s->pop;
   const size_t shard_n = pop / s->n_shards;
@@ -188,23 +174,121 @@ static void sync_agent(const orc_de_sync *s, uint64_t kg, size_t a, double *tria
   }
 }
 
-static int sync_prologue(orc_de_sync *s) {
+/* ---- the turn head, in the record form the multi-GPU path exchanges ---------
+ * Record of one shard (ORC_DE_REC_HEADER + D doubles):
+ *   [minv, mini (u64 bits), sum, m2, valid, x_best[0..D)]
+ * One shard (n_shards == 1) degenerates to the reference's scan + two-pass
+ * std_err; several shards merge (n, sum, M2) per shard in rank order. */
+static uint64_t dbl_bits(double d) {
+  uint64_t u;
+  memcpy(&u, &d, 8);
+  return u;
+}
+static double bits_dbl(uint64_t u) {
+  double d;
+  memcpy(&d, &u, 8);
+  return d;
+}
+
+void orc_de_shard_record(const orc_de_sync *s, size_t lo, size_t n, double *rec) {
+  const double *sc = s->scores + lo;
+  /* first index of the shard minimum; NaN is never "less" */
+  double bv = INFINITY;
+  size_t bi = (size_t)-1;
+  for (size_t i = 0; i < n; i++)
+    if (sc[i] < bv || (sc[i] == bv && bi == (size_t)-1)) {
+      bv = sc[i];
+      bi = i;
+    }
+  uint64_t gi = (bi == (size_t)-1) ? s->best_id : lo + bi;
+  const uint64_t inc = s->best_id;
+  if (inc >= lo && inc < lo + n) { /* the incumbent keeps ties (:2432-2437) */
+    const double inc_score = s->scores[inc];
+    if (!(bv < inc_score)) {
+      gi = inc;
+      bv = inc_score;
+    }
+  }
+  const int mine = gi >= lo && gi < lo + n;
+  double sum = 0.0, m2 = 0.0;
+  if (s->eps > 0) {
+    sum = orc_tiled_sum(sc, n);
+    m2 = orc_tiled_sumsq_dev(sc, n, sum / (double)n);
+  }
+  rec[0] = bv;
+  rec[1] = bits_dbl(gi);
+  rec[2] = sum;
+  rec[3] = m2;
+  rec[4] = mine ? 1.0 : 0.0;
+  for (size_t d = 0; d < s->D; d++) rec[ORC_DE_REC_HEADER + d] = mine ? s->cur[gi * s->D + d] : 0.0;
+}
+
+int orc_de_apply_records(orc_de_sync *s, const double *recs, int world, double *best_x) {
   if (s->done) return 1;
-  const int not_updated = best_scan(s->scores, s->pop, &s->best_id);
-  s->val_no_change = (uint64_t)not_updated * (s->val_no_change + 1); /* :2439 */
+  const size_t stride = ORC_DE_REC_HEADER + s->D;
+  const uint64_t inc = s->best_id;
+  int win = -1;
+  double bv = INFINITY;
+  uint64_t bi = inc;
+  for (int r = 0; r < world; r++) {
+    const double *rec = recs + (size_t)r * stride;
+    if (rec[4] != 1.0) continue;
+    const double v = rec[0];
+    const uint64_t i = dbl_bits(rec[1]);
+    /* lower value wins; on ties the incumbent, then the lower global index */
+    const int better = win < 0 || v < bv || (v == bv && bi != inc && (i == inc || i < bi));
+    if (better) {
+      bv = v;
+      bi = i;
+      win = r;
+    }
+  }
+  const int not_updated = (bi == inc);
+  s->val_no_change = not_updated ? s->val_no_change + 1 : 0; /* :2439 */
+  s->best_id = bi;
+  if (win >= 0 && best_x) memcpy(best_x, recs + (size_t)win * stride + ORC_DE_REC_HEADER, s->D * sizeof(double));
   /* std_err is only evaluated when it can decide something (eps > 0): for
    * eps <= 0 or NaN the test `std_err < eps` (:2443) is false for every value
    * std_err can take (>= 0 or NaN). */
-  if (s->eps > 0) s->std_err = orc_std_err_tree(s->scores, s->pop);
+  double se = NAN;
+  if (s->eps > 0) {
+    const double n_r = (double)(s->pop / (size_t)world);
+    double tot = 0.0;
+    for (int r = 0; r < world; r++) tot = tot + recs[(size_t)r * stride + 2];
+    const double gmean = tot / (double)s->pop;
+    double m2 = 0.0;
+    for (int r = 0; r < world; r++) {
+      const double *rec = recs + (size_t)r * stride;
+      double term = rec[3];
+      if (world > 1) {
+        const double dm = rec[2] / n_r - gmean;
+        term = term + n_r * (dm * dm);
+      }
+      m2 = m2 + term;
+    }
+    se = sqrt(m2 / (double)(s->pop - 1)); /* :2050-2051 */
+  }
+  s->std_err = se;
   if (s->iter >= s->max_iter || s->val_no_change >= s->best_val_no_change ||
-      (s->eps > 0 && s->std_err < s->eps)) { /* :2441-2443 */
+      (s->eps > 0 && se < s->eps)) { /* :2441-2443 */
     s->done = 1;
     return 1;
   }
   return 0;
 }
 
-static void sync_epilogue(orc_de_sync *s) {
+void orc_de_shard_generation(orc_de_sync *s, size_t lo, size_t n, int threads) {
+  const uint64_t kg = orc_ctr_key(s->seed, s->iter + 1);
+#pragma omp parallel num_threads(threads > 0 ? threads : 1)
+  {
+    double *trial = (double *)malloc(s->D * sizeof(double));
+#pragma omp for schedule(static)
+    for (long a = (long)lo; a < (long)(lo + n); a++) sync_agent(s, kg, (size_t)a, trial);
+    free(trial);
+  }
+}
+
+void orc_de_commit(orc_de_sync *s) {
   double *t = s->cur;
   s->cur = s->nxt;
   s->nxt = t;
@@ -212,24 +296,19 @@ static void sync_epilogue(orc_de_sync *s) {
   s->iter++;
 }
 
-void orc_de_sync_step(orc_de_sync *s) {
-  if (sync_prologue(s)) return;
-  const uint64_t kg = orc_ctr_key(s->seed, s->iter + 1);
-  double *trial = (double *)malloc(s->D * sizeof(double));
-  for (size_t a = 0; a < s->pop; a++) sync_agent(s, kg, a, trial);
-  free(trial);
-  sync_epilogue(s);
+static void sync_step(orc_de_sync *s, int threads) {
+  if (s->done) return;
+  const int world = (int)s->n_shards;
+  const size_t shard_n = s->pop / s->n_shards;
+  const size_t stride = ORC_DE_REC_HEADER + s->D;
+  double *recs = (double *)malloc((size_t)world * stride * sizeof(double));
+  for (int r = 0; r < world; r++) orc_de_shard_record(s, (size_t)r * shard_n, shard_n, recs + (size_t)r * stride);
+  const int done = orc_de_apply_records(s, recs, world, NULL);
+  free(recs);
+  if (done) return;
+  orc_de_shard_generation(s, 0, s->pop, threads);
+  orc_de_commit(s);
 }
 
-void orc_de_sync_step_omp(orc_de_sync *s, int threads) {
-  if (sync_prologue(s)) return;
-  const uint64_t kg = orc_ctr_key(s->seed, s->iter + 1);
-#pragma omp parallel num_threads(threads)
-  {
-    double *trial = (double *)malloc(s->D * sizeof(double));
-#pragma omp for schedule(static)
-    for (long a = 0; a < (long)s->pop; a++) sync_agent(s, kg, (size_t)a, trial);
-    free(trial);
-  }
-  sync_epilogue(s);
-}
+void orc_de_sync_step(orc_de_sync *s) { sync_step(s, 1); }
+void orc_de_sync_step_omp(orc_de_sync *s, int threads) { sync_step(s, threads); }

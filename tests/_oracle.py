@@ -75,6 +75,11 @@ def load():
     lib.orc_de_sync_init.argtypes = [C.POINTER(DESync), pd]
     lib.orc_de_sync_step.argtypes = [C.POINTER(DESync)]
     lib.orc_de_sync_step_omp.argtypes = [C.POINTER(DESync), C.c_int]
+    lib.orc_de_shard_record.argtypes = [C.POINTER(DESync), sz, sz, pd]
+    lib.orc_de_apply_records.restype = C.c_int
+    lib.orc_de_apply_records.argtypes = [C.POINTER(DESync), pd, C.c_int, pd]
+    lib.orc_de_shard_generation.argtypes = [C.POINTER(DESync), sz, sz, C.c_int]
+    lib.orc_de_commit.argtypes = [C.POINTER(DESync)]
     return lib
 
 
@@ -121,3 +126,55 @@ class DESyncRun:
     @property
     def best_x(self):
         return self.population[self.s.best_id].copy()
+
+
+class OracleShardEngine:
+    """CPU stand-in with the DEEngine interface used by nlsolver_amd.dist.ShardedDE
+    (record_doubles / init / turn_begin / turn_end on host tensors). It owns a full-size
+    oracle state but only ever computes the rows of its own shard — exactly what one
+    rank does; used by the gloo tests to exercise the host-side exchange logic."""
+
+    def __init__(self, lib, obj, pop, D, lo, n, **kw):
+        self.lib, self.lo, self.n, self.D, self.pop = lib, lo, n, D, pop
+        self.kw = dict(kw, n_shards=pop // n)
+        self.obj = obj
+        self.run = None
+
+    def record_doubles(self):
+        return self.D + 5
+
+    def init(self, x0):
+        self.run = DESyncRun(self.lib, self.obj, self.pop, self.D, x0, **self.kw)
+        # forget every row this rank does not own
+        mask = np.ones(self.pop, bool)
+        mask[self.lo:self.lo + self.n] = False
+        self.run.population[mask] = np.nan
+        self.run.scores[mask] = np.nan
+
+    def turn_begin(self, send_ptr):
+        rec = np.ctypeslib.as_array(C.cast(send_ptr, pd), (self.D + 5,))
+        if not self.run.s.done:
+            self.lib.orc_de_shard_record(C.byref(self.run.s), self.lo, self.n, _ptr(rec))
+
+    def turn_end(self, gathered_ptr, world):
+        s = self.run.s
+        if s.done:
+            return
+        best_x = np.zeros(self.D)
+        done = self.lib.orc_de_apply_records(C.byref(s), C.cast(gathered_ptr, pd), world, _ptr(best_x))
+        if done:
+            self.best_x_cache = best_x
+            return
+        # strategy best reads the row of best_id: install the exchanged copy
+        keep = None
+        if not (self.lo <= s.best_id < self.lo + self.n):
+            keep = self.run.population[s.best_id].copy()
+            self.run.population[s.best_id] = best_x
+        self.lib.orc_de_shard_generation(C.byref(s), self.lo, self.n, 1)
+        if keep is not None:
+            self.run.population[s.best_id] = keep
+        self.lib.orc_de_commit(C.byref(s))
+
+    def shard(self):
+        return (self.run.population[self.lo:self.lo + self.n].copy(),
+                self.run.scores[self.lo:self.lo + self.n].copy())

@@ -1,0 +1,53 @@
+// tests/cpp/header_device.cpp — the drop-in header with a DEVICE objective:
+// same user code as against the reference, the objective type is
+// nlsolver::device::Rosenbrock<double>, the population loops run on the GPU
+// through libnlsolver_hip.so (dlopen; $NLSG_LIBRARY). No CPU fallback.
+//   header_device <best|random> <D> <pop> <max_iter> <eps> <no_change> <x0>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "nlsolver_mi/nlsolver.h"
+
+using nlsolver::DE;
+using nlsolver::rng::xorshift;
+using DEStrat = nlsolver::RecombinationStrategy;
+using Objective = nlsolver::device::Rosenbrock<double>;
+
+template <DEStrat S>
+static int run(size_t D, size_t pop, size_t max_iter, double eps, size_t no_change, double x0) {
+  Objective f;
+  xorshift<double> gen;
+  std::vector<double> x(D, x0);
+  try {
+    auto solver = DE<Objective, xorshift<double>, double, S>(f, gen, 0.9, 0.8, eps, pop, max_iter,
+                                                             no_change);
+    auto res = solver.minimize(x);
+    auto [fcalls, iters, fv, g, h] = res.get_summary();
+    (void)g;
+    (void)h;
+    std::printf("{\"fcalls\":%zu,\"iters\":%zu,\"f\":\"%a\",\"f_host\":\"%a\",\"x\":[", fcalls,
+                iters, fv, f(x));
+    for (size_t i = 0; i < D; i++) std::printf("%s\"%a\"", i ? "," : "", x[i]);
+    const double a = gen(), b = gen();
+    std::printf("],\"rng_after\":[\"%a\",\"%a\"]}\n", a, b);
+  } catch (const nlsolver::device_error &e) {
+    std::printf("{\"device_error\":\"%s\"}\n", e.what());
+    return 3;
+  }
+  return 0;
+}
+
+int main(int argc, char **argv) {
+  if (argc < 8) {
+    std::fprintf(stderr, "usage: header_device <best|random> D pop max_iter eps no_change x0\n");
+    return 2;
+  }
+  const size_t D = std::strtoull(argv[2], nullptr, 10), pop = std::strtoull(argv[3], nullptr, 10);
+  const size_t max_iter = std::strtoull(argv[4], nullptr, 10);
+  const double eps = std::strtod(argv[5], nullptr);
+  const size_t no_change = std::strtoull(argv[6], nullptr, 10);
+  const double x0 = std::strtod(argv[7], nullptr);
+  if (!std::strcmp(argv[1], "best")) return run<DEStrat::best>(D, pop, max_iter, eps, no_change, x0);
+  return run<DEStrat::random>(D, pop, max_iter, eps, no_change, x0);
+}

@@ -185,3 +185,47 @@ def test_north_star_size_properties(eng_mod, oracle):
     # the reported best is the first minimum
     assert bf == S.min() or bf <= S.min()
     # spot-check against the oracle on one generation of a slice is covered at pop=65536
+
+
+@pytest.mark.parametrize("kw", [dict(strategy=1, eps=0.0, best_val_no_change=1000),
+                                dict(strategy=0, eps=0.0, best_val_no_change=1000),
+                                dict(strategy=1, eps=5000.0, best_val_no_change=1000),
+                                dict(strategy=0, eps=0.0, best_val_no_change=2)])
+@pytest.mark.parametrize("pop,D,shards", [(64, 16, 2), (4096, 128, 4), (2048, 130, 2)])
+def test_sharded_path_on_one_gpu_bit_exact(eng_mod, oracle, kw, pop, D, shards):
+    """The multi-GPU code path (turn_begin -> gathered records -> turn_end) with all
+    shards on one device: the records are concatenated where RCCL's all-gather would
+    put them. Must equal the restatement with n_shards shards (island donors)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    n = pop // shards
+    x0 = x0_for(D)
+    turns = 8
+    ref = O.DESyncRun(oracle, "rosenbrock", pop, D, x0, n_shards=shards, **kw)
+    ref.step(turns)
+    engs = [eng_mod.DEEngine("rosenbrock", pop, D, shard_lo=r * n, shard_n=n, stream=stream, **kw)
+            for r in range(shards)]
+    rec = engs[0].record_doubles()
+    assert rec == D + 5
+    gathered = torch.zeros(shards * rec, dtype=torch.float64, device=dev)
+    for e in engs:
+        e.init(x0)
+    for _ in range(turns):
+        for r, e in enumerate(engs):
+            e.turn_begin(gathered[r * rec:(r + 1) * rec].data_ptr())
+        for e in engs:
+            e.turn_end(gathered.data_ptr(), shards)
+    for r, e in enumerate(engs):
+        P, S = e.download()
+        assert np.array_equal(P, ref.population[r * n:(r + 1) * n]), f"shard {r} population"
+        assert np.array_equal(S, ref.scores[r * n:(r + 1) * n]), f"shard {r} scores"
+        st = e.status()
+        assert (st.best_index, st.iteration, st.val_no_change, st.function_calls_used, st.done) == \
+            (ref.s.best_id, ref.s.iter, ref.s.val_no_change, ref.s.fcalls, ref.s.done)
+        if kw["eps"] > 0:
+            assert st.std_err == ref.s.std_err
+        bx, bf, bi = e.best()
+        assert bi == ref.s.best_id and bf == ref.scores[bi]
+        assert np.array_equal(bx, ref.population[bi])
+        e.close()

@@ -1,0 +1,70 @@
+"""N>1 path on CPU: world_size-2 gloo processes drive nlsolver_amd.dist.ShardedDE
+(the product's host-side sharding/exchange logic) over a CPU stand-in engine built on
+the oracle. The result must equal the single-process restatement with n_shards=2."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from nlsolver_amd.dist import ShardedDE, shard_bounds
+from tests import _oracle as O
+
+
+def test_shard_bounds():
+    assert [shard_bounds(64, 4, r) for r in range(4)] == [(0, 16), (16, 16), (32, 16), (48, 16)]
+    with pytest.raises(ValueError):
+        shard_bounds(10, 4, 0)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, cfg, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lib = O.load()
+    pop, D, turns, kw = cfg["pop"], cfg["D"], cfg["turns"], cfg["kw"]
+    drv = ShardedDE(dist, lambda lo, n, stream: O.OracleShardEngine(lib, "rosenbrock", pop, D, lo, n, **kw),
+                    pop, D, torch.device("cpu"))
+    drv.init(np.full(D, 4.096))
+    drv.step(turns)
+    P, S = drv.engine.shard()
+    s = drv.engine.run.s
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), P=P, S=S,
+             state=np.array([s.best_id, s.iter, s.val_no_change, s.fcalls, s.done], dtype=np.int64),
+             std_err=np.array([s.std_err]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kw", [dict(strategy=1, eps=0.0, best_val_no_change=1000),
+                                dict(strategy=0, eps=0.0, best_val_no_change=1000),
+                                dict(strategy=1, eps=5000.0, best_val_no_change=1000),
+                                dict(strategy=0, eps=0.0, best_val_no_change=2)])
+def test_world2_gloo_matches_single_process_oracle(tmp_path, oracle, kw):
+    world, pop, D, turns = 2, 64, 16, 12
+    cfg = dict(pop=pop, D=D, turns=turns, kw=kw)
+    mp.start_processes(_worker, args=(world, _free_port(), cfg, str(tmp_path)), nprocs=world,
+                       join=True, start_method="fork")
+    ref = O.DESyncRun(oracle, "rosenbrock", pop, D, np.full(D, 4.096), n_shards=world, **kw)
+    ref.step(turns)
+    n = pop // world
+    for r in range(world):
+        got = np.load(tmp_path / f"rank{r}.npz")
+        assert np.array_equal(got["P"], ref.population[r * n:(r + 1) * n]), f"rank {r} population"
+        assert np.array_equal(got["S"], ref.scores[r * n:(r + 1) * n]), f"rank {r} scores"
+        # every rank holds the same solver state after the same finaliser
+        assert got["state"].tolist() == [ref.s.best_id, ref.s.iter, ref.s.val_no_change,
+                                         ref.s.fcalls, ref.s.done]
+        if kw["eps"] > 0:
+            assert got["std_err"][0] == ref.s.std_err
+    if kw.get("eps", 0) > 0 or kw.get("best_val_no_change", 1000) < 10:
+        assert ref.s.done == 1 and ref.s.iter < turns  # the stop test really fired mid-run

@@ -1,0 +1,90 @@
+"""The drop-in C++ header (include/nlsolver_mi/nlsolver.h), driven from user-style
+C++ programs in tests/cpp/ (built with g++ -std=c++17)."""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import _oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "tests", "cpp", "bin")
+LIB = os.path.join(ROOT, "nlsolver_amd", "libnlsolver_hip.so")
+
+
+@pytest.fixture(scope="module")
+def built():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp")])
+    return BIN
+
+
+def hx(v):
+    return float.fromhex(v)
+
+
+def test_config_c1_through_header_matches_reference_bit_exact(built, golden):
+    out = json.loads(subprocess.check_output([os.path.join(built, "header_c1")], text=True))
+    gold = golden("de_c1.json")
+    for name in ("c1_random_pop40_x0_5_7", "random_pop50_x0_5_7", "example_best_pop50_x0_2_7"):
+        g, o = gold[name], out[name]
+        assert (o["fcalls"], o["iters"]) == (g["fcalls"], g["iters"]), name
+        assert hx(o["f"]) == hx(g["f"]) and [hx(v) for v in o["x"]] == [hx(v) for v in g["x"]]
+        # the caller's generator advanced exactly as under the reference
+        assert [hx(v) for v in o["rng_after"]] == [hx(v) for v in g["rng_after"]]
+        assert o["grad"] == 0 and o["hess"] == 0
+    g, o = gold["readme_objective_pop40"], out["readme_objective_pop40"]
+    assert (o["fcalls"], o["iters"], hx(o["f"])) == (g["fcalls"], g["iters"], hx(g["f"]))
+    assert [hx(v) for v in o["x"]] == [hx(v) for v in g["x"]]
+    # lambda / const-ref functors ran and converged
+    assert abs(hx(out["lambda"]["x"][0]) - 1) < 0.05 and abs(hx(out["lambda"]["x"][1])) < 0.05
+    assert hx(out["const_ref_sphere"]["f"]) < 1e-3
+
+
+def test_device_objective_has_no_cpu_fallback(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    exe = os.path.join(built, "header_device")
+    args = [exe, "random", "2", "40", "100", "1e-3", "50", "5"]
+    r = subprocess.run(args, env=dict(os.environ, NLSG_LIBRARY=LIB), capture_output=True, text=True)
+    assert r.returncode == 3 and "no HIP device" in r.stdout
+    r = subprocess.run(args, env=dict(os.environ, NLSG_LIBRARY="/nonexistent/lib.so"),
+                       capture_output=True, text=True)
+    assert r.returncode == 3 and "no CPU fallback" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("strategy,D,pop,max_iter,eps,no_change,x0", [
+    ("random", 2, 40, 1000, 10e-4, 50, 5.0),
+    ("best", 2, 50, 1000, 10e-4, 50, 3.0),
+    ("random", 128, 4096, 25, 0.0, 1000, 4.096),
+    ("best", 130, 512, 10, 0.0, 1000, 2.0),
+])
+def test_device_objective_through_header_matches_oracle(built, oracle, strategy, D, pop, max_iter,
+                                                        eps, no_change, x0):
+    out = subprocess.check_output(
+        [os.path.join(built, "header_device"), strategy, str(D), str(pop), str(max_iter),
+         repr(eps), str(no_change), repr(x0)], env=dict(os.environ, NLSG_LIBRARY=LIB), text=True)
+    o = json.loads(out)
+    assert "device_error" not in o, o
+    # the header keys the device RNG with two draws of the caller's generator
+    xs = O.XorShift()
+    oracle.orc_xorshift_init(C.byref(xs))
+    half = [min(int(oracle.orc_xorshift_next(C.byref(xs)) * 2.0**32), 2**32 - 1) for _ in range(2)]
+    seed = (half[0] << 32) | half[1]
+    ref = O.DESyncRun(oracle, "rosenbrock", pop, D, [x0] * D, strategy=1 if strategy == "random" else 0,
+                      eps=eps, max_iter=max_iter, best_val_no_change=no_change, seed=seed)
+    while not ref.s.done:
+        ref.step()
+    assert (o["fcalls"], o["iters"]) == (ref.s.fcalls, ref.s.iter)
+    assert hx(o["f"]) == ref.scores[ref.s.best_id]
+    assert np.array_equal(np.array([hx(v) for v in o["x"]]), ref.best_x)
+    after = [oracle.orc_xorshift_next(C.byref(xs)) for _ in range(2)]
+    assert [hx(v) for v in o["rng_after"]] == after  # generator advanced by exactly two draws
+    # host evaluation of the tagged objective agrees with the device value (1e-12)
+    assert abs(hx(o["f_host"]) - hx(o["f"])) <= 1e-12 * max(1.0, abs(hx(o["f"])))
+    if D == 2:
+        assert np.all(np.abs(ref.best_x - 1.0) <= 0.05)  # the reference's own pass criterion
