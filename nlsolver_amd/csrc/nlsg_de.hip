@@ -93,12 +93,15 @@ void launch_generation(nlsg_de *e, int par_override, uint64_t gen_override) {
 // shard summary (best with the incumbent rule, two-pass sum / M2) -> record
 void launch_local_summary(nlsg_de *e, double *rec_dev) {
   hipLaunchKernelGGL(de_scan_partial_kernel, dim3(e->p.ntiles), dim3(256), 0, e->stream, e->p);
-  hipLaunchKernelGGL(de_local_kernel, dim3(1), dim3(256), 0, e->stream, e->p, e->loc);
-  if (e->cfg.eps > 0) {
-    hipLaunchKernelGGL(de_var_partial_kernel, dim3(e->p.ntiles), dim3(256), 0, e->stream, e->p,
-                       &e->loc->mean);
-    hipLaunchKernelGGL(de_var_local_kernel, dim3(1), dim3(256), 0, e->stream, e->p, e->loc);
+  if (!(e->cfg.eps > 0)) {  // no second std_err pass: scan summary and record in one launch
+    hipLaunchKernelGGL(de_local_kernel, dim3(1), dim3(256), 0, e->stream, e->p, e->loc, rec_dev);
+    return;
   }
+  hipLaunchKernelGGL(de_local_kernel, dim3(1), dim3(256), 0, e->stream, e->p, e->loc,
+                     static_cast<double *>(nullptr));
+  hipLaunchKernelGGL(de_var_partial_kernel, dim3(e->p.ntiles), dim3(256), 0, e->stream, e->p,
+                     &e->loc->mean);
+  hipLaunchKernelGGL(de_var_local_kernel, dim3(1), dim3(256), 0, e->stream, e->p, e->loc);
   hipLaunchKernelGGL(de_pack_record_kernel, dim3(1), dim3(256), 0, e->stream, e->p, e->loc,
                      rec_dev);
 }

@@ -25,6 +25,7 @@ namespace nlsg {
 constexpr int kDeMaxTries = 64;       // bounded donor rejection loop
 constexpr int kTile = 1024;           // reduction tile
 constexpr int kTraceWords = 5;        // r1, r2, r3, jrand, accept
+constexpr int kRecHeader = 5;         // exchange record header (see de_pack_record_kernel)
 
 // Device-resident solver state (one per engine).
 struct DeState {
@@ -399,10 +400,14 @@ struct DeLocal {
   double valid;   // 1.0 when `mini` is owned by this shard
 };
 
-__global__ __launch_bounds__(256) void de_local_kernel(DeParams p, DeLocal *loc) {
+// `rec` != nullptr (only when eps <= 0, i.e. no second std_err pass is needed):
+// the exchange record is packed by this launch as well.
+__global__ __launch_bounds__(256) void de_local_kernel(DeParams p, DeLocal *loc, double *rec) {
   __shared__ double red[4];
   __shared__ double mv[4];
   __shared__ uint64_t mi[4];
+  __shared__ uint64_t s_gi;
+  __shared__ int s_mine, s_par;
   DeState *st = p.state;
   if (st->done) return;
   if (threadIdx.x == 0) apply_pending(st, p);
@@ -424,7 +429,22 @@ __global__ __launch_bounds__(256) void de_local_kernel(DeParams p, DeLocal *loc)
     loc->mini = gi;
     loc->m2 = 0.0;
     loc->valid = mine ? 1.0 : 0.0;
+    if (rec != nullptr) {
+      rec[0] = bv;
+      rec[1] = __longlong_as_double(static_cast<long long>(gi));
+      rec[2] = total;
+      rec[3] = 0.0;
+      rec[4] = mine ? 1.0 : 0.0;
+    }
+    s_gi = gi;
+    s_mine = mine ? 1 : 0;
+    s_par = st->parity;
   }
+  if (rec == nullptr) return;
+  __syncthreads();
+  const double *row = p.buf[s_par] + (s_mine ? (s_gi - p.shard_lo) : 0) * p.D;
+  for (uint64_t d = threadIdx.x; d < p.D; d += 256)
+    rec[kRecHeader + d] = s_mine ? row[d] : 0.0;
 }
 
 __global__ __launch_bounds__(256) void de_var_local_kernel(DeParams p, DeLocal *loc) {
@@ -440,7 +460,6 @@ __global__ __launch_bounds__(256) void de_var_local_kernel(DeParams p, DeLocal *
 //   [minv, mini(bits), sum, m2, valid, x_best[0..D)]
 // `valid` is 1 when the record's row belongs to the sending shard (it is 0 only
 // for a shard whose scores are all NaN and that does not own the incumbent).
-constexpr int kRecHeader = 5;
 
 __global__ __launch_bounds__(256) void de_pack_record_kernel(DeParams p, const DeLocal *loc,
                                                            double *rec) {
