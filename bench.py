@@ -56,6 +56,25 @@ def cpu_baseline():
                       f"OpenMP {threads} threads"}
 
 
+def pmc_traffic(pop_local):
+    """HBM bytes per launch of de_generation_kernel from the committed rocprofv3 PMC passes
+    (profiles/r01/de_pmc_summary.json; separate FETCH_SIZE / WRITE_SIZE runs of this script),
+    corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE counts half of wide coalesced
+    reads on gfx950 (calibrated on de_scan_partial_kernel's known 8 B/agent), WRITE_SIZE exact;
+    both in KiB. None when no profile exists for this population size."""
+    path = os.path.join(ROOT, "profiles", "r01", "de_pmc_summary.json")
+    tag = {65536: "c2b", 1048576: "nsb"}.get(pop_local)
+    if tag is None or not os.path.exists(path):
+        return None
+    prof = json.load(open(path)).get(tag, {})
+    pick = lambda ctr: next((v["mean_KiB"] for k, v in prof.get(ctr, {}).items()
+                             if "de_generation_kernel" in k), None)
+    fetch, write = pick("FETCH_SIZE"), pick("WRITE_SIZE")
+    if fetch is None or write is None:
+        return None
+    return (2.0 * fetch + write) * 1024.0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,7 +163,8 @@ def main():
                        "parallelism": f"population-sharded x{world} (island donors, "
                                       "one all-gather of the best record per generation)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic(pop_local),
                          "kernel": "de_generation_kernel",
                          "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": BYTES_PER_CANDIDATE * pop_local},
