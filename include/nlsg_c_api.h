@@ -152,6 +152,60 @@ uint64_t nlsg_de_record_doubles(const nlsg_de *e);
 int nlsg_de_turn_begin(nlsg_de *e, double *send_dev);
 int nlsg_de_turn_end(nlsg_de *e, const double *gathered_dev, int32_t world);
 
+/* ========================================================================== */
+/* Particle Swarm Optimisation — replaces PSO::solve (nlsolver.h:2593-2624),   */
+/* init_solver_state (2626-2657), update_velocities (2658-2677),               */
+/* update_positions (2678-2700), threshold_positions (2701-2715) and            */
+/* update_best_positions (2716-2741).                                           */
+/* Accelerated is the parity target; Vanilla runs the intended pbest/gbest      */
+/* update (the reference's has a zero cognitive term and an out-of-bounds       */
+/* read). Best sentinels are +inf (B8), the no-change counter is  */
+/* driven by "an update happened" (B9). See DESIGN.md.                          */
+/* ========================================================================== */
+typedef struct nlsg_pso nlsg_pso;
+
+/* enum PSOType { Vanilla, Accelerated } — nlsolver.h:2496 (same order). */
+typedef enum { NLSG_PSO_VANILLA = 0, NLSG_PSO_ACCELERATED = 1 } nlsg_pso_type;
+
+typedef struct {
+  uint32_t struct_size;
+  int32_t device;
+  void *stream;          /* as nlsg_de_config.stream                              */
+  int32_t objective;     /* nlsg_objective                                        */
+  int32_t minimize;      /* 1 = minimize(), 0 = maximize()                        */
+  int32_t type;          /* nlsg_pso_type                                         */
+  int32_t bounded;       /* 1 = (x, lower, upper) overloads: threshold_positions  */
+                         /* 0 = minimize(x): bounds only seed the initial swarm   */
+  uint64_t n_particles;  /* GLOBAL swarm size (ctor arg, nlsolver.h:2525)         */
+  uint64_t dim;
+  uint64_t shard_lo, shard_n; /* particles owned by this engine                   */
+  double inertia, cognitive, social, eps; /* ctor args :2523-2526                 */
+  uint64_t max_iter, best_val_no_change;
+  uint64_t seed;
+} nlsg_pso_config;
+
+int nlsg_pso_create(const nlsg_pso_config *cfg, nlsg_pso **out);
+int nlsg_pso_destroy(nlsg_pso *e);
+/* init_solver_state + the first update_best_positions' evaluations (2626-2657, 2595). */
+int nlsg_pso_init(nlsg_pso *e, const double *lower_host, const double *upper_host);
+/* `turns` turns of: best update of the last evaluation + stop tests (2599-2605), then
+ * velocity/position update, thresholding and evaluation (2606-2621). Asynchronous. */
+int nlsg_pso_step(nlsg_pso *e, uint64_t turns);
+/* Whole solve(): init with the given bounds, turns until done, x_out <- swarm best. */
+int nlsg_pso_minimize(nlsg_pso *e, double *x_out_host, const double *lower_host,
+                      const double *upper_host, uint64_t poll_every, nlsg_status *out);
+int nlsg_pso_status(nlsg_pso *e, nlsg_status *out);
+int nlsg_pso_best(nlsg_pso *e, double *x_host, double *f, uint64_t *index);
+/* Parity-test access (shard): positions, velocities (Vanilla), personal-best values,
+ * values of the last evaluation. NULL pointers are skipped. */
+int nlsg_pso_download(nlsg_pso *e, double *pos_host, double *vel_host, double *pbest_val_host,
+                      double *cur_val_host);
+int nlsg_pso_time_move_kernel(nlsg_pso *e, uint32_t launches, float *ms_total);
+/* sharded turn, as nlsg_de_turn_begin / nlsg_de_turn_end */
+uint64_t nlsg_pso_record_doubles(const nlsg_pso *e);
+int nlsg_pso_turn_begin(nlsg_pso *e, double *send_dev);
+int nlsg_pso_turn_end(nlsg_pso *e, const double *gathered_dev, int32_t world);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,6 +44,17 @@ class DEConfig(C.Structure):
                 ("max_iter", u64), ("best_val_no_change", u64), ("seed", u64)]
 
 
+PSO_VANILLA, PSO_ACCELERATED = 0, 1  # enum PSOType { Vanilla, Accelerated }, nlsolver.h:2496
+
+
+class PSOConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("device", i32), ("stream", C.c_void_p),
+                ("objective", i32), ("minimize", i32), ("type", i32), ("bounded", i32),
+                ("n_particles", u64), ("dim", u64), ("shard_lo", u64), ("shard_n", u64),
+                ("inertia", f64), ("cognitive", f64), ("social", f64), ("eps", f64),
+                ("max_iter", u64), ("best_val_no_change", u64), ("seed", u64)]
+
+
 # every symbol include/nlsg_c_api.h declares: name -> (restype, argtypes)
 _H = C.c_void_p
 SYMBOLS = {
@@ -64,6 +75,18 @@ SYMBOLS = {
     "nlsg_de_record_doubles": (u64, [_H]),
     "nlsg_de_turn_begin": (C.c_int, [_H, C.c_void_p]),
     "nlsg_de_turn_end": (C.c_int, [_H, C.c_void_p, i32]),
+    "nlsg_pso_create": (C.c_int, [C.POINTER(PSOConfig), C.POINTER(_H)]),
+    "nlsg_pso_destroy": (C.c_int, [_H]),
+    "nlsg_pso_init": (C.c_int, [_H, pd, pd]),
+    "nlsg_pso_step": (C.c_int, [_H, u64]),
+    "nlsg_pso_minimize": (C.c_int, [_H, pd, pd, pd, u64, C.POINTER(Status)]),
+    "nlsg_pso_status": (C.c_int, [_H, C.POINTER(Status)]),
+    "nlsg_pso_best": (C.c_int, [_H, pd, pd, pu]),
+    "nlsg_pso_download": (C.c_int, [_H, pd, pd, pd, pd]),
+    "nlsg_pso_time_move_kernel": (C.c_int, [_H, C.c_uint32, C.POINTER(C.c_float)]),
+    "nlsg_pso_record_doubles": (u64, [_H]),
+    "nlsg_pso_turn_begin": (C.c_int, [_H, C.c_void_p]),
+    "nlsg_pso_turn_end": (C.c_int, [_H, C.c_void_p, i32]),
 }
 
 _lib = None

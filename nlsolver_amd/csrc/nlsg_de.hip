@@ -18,7 +18,7 @@ struct nlsg_de {
   bool own_stream = false;
   double *x0_dev = nullptr;
   double *zero_dev = nullptr;
-  DeLocal *loc = nullptr;
+  ShardLocal *loc = nullptr;
   double *rec = nullptr;  // local record (single-GPU finaliser input)
   int chunks = 0;
   bool initialised = false;
@@ -221,7 +221,7 @@ int nlsg_de_create(const nlsg_de_config *cfg, nlsg_de **out) {
   if (he == hipSuccess) he = hipMemset(e->zero_dev, 0, 16);
   p.zero = e->zero_dev;
   if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&e->x0_dev), D * sizeof(double));
-  if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&e->loc), sizeof(DeLocal));
+  if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&e->loc), sizeof(ShardLocal));
   if (he == hipSuccess)
     he = alloc(reinterpret_cast<void **>(&e->rec), (kRecHeader + D) * sizeof(double));
   if (he == hipSuccess) he = hipEventCreate(&e->ev0);

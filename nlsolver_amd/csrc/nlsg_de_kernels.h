@@ -23,9 +23,7 @@
 namespace nlsg {
 
 constexpr int kDeMaxTries = 64;       // bounded donor rejection loop
-constexpr int kTile = 1024;           // reduction tile
 constexpr int kTraceWords = 5;        // r1, r2, r3, jrand, accept
-constexpr int kRecHeader = 5;         // exchange record header (see de_pack_record_kernel)
 
 // Device-resident solver state (one per engine).
 struct DeState {
@@ -39,15 +37,6 @@ struct DeState {
   int32_t parity;          // population buffer holding the current generation
   int32_t pending;         // a generation ran since the last scan (iter++ due)
   int32_t pad;
-};
-
-// Per tile of kTile scores: block-tree sum, minimum and first index of it,
-// block-tree sum of squared deviations (second pass).
-struct TilePartial {
-  double sum;
-  double minv;
-  uint64_t mini;  // shard-local index (~0 if the tile holds only NaN)
-  double m2;
 };
 
 struct DeParams {
@@ -66,74 +55,6 @@ struct DeParams {
   int32_t strategy;
   int32_t vec;         // rows are 16-byte aligned (D even)
 };
-
-// ---- row access ------------------------------------------------------------
-// Branch-free and select-free on purpose: a load guarded by a runtime condition
-// makes hipcc branch around it and drain vmcnt before the next one, and a select
-// on the loaded value forces the wait to the load site; both serialise the row
-// gathers. Lanes past the end of the row read 16 bytes of zeros (`zero`) instead,
-// so all loads of an agent are issued back to back and waited for at first use.
-// VEC = rows are 16-byte aligned (D even).
-template <int CHUNKS, bool VEC>
-__device__ inline void load_row(const double *__restrict__ row, uint64_t D,
-                                const double *__restrict__ zero, double (&v)[CHUNKS][2]) {
-  const int lane = lane_id();
-#pragma unroll
-  for (int c = 0; c < CHUNKS; c++) {
-    const uint64_t e0 = static_cast<uint64_t>(c) * 128 + 2 * static_cast<uint64_t>(lane);
-    if (VEC) {
-      const double *src = (e0 < D) ? row + e0 : zero;  // D even: e0 + 1 < D as well
-      const double2 t = *reinterpret_cast<const double2 *>(src);
-      v[c][0] = t.x;
-      v[c][1] = t.y;
-    } else {
-      v[c][0] = *((e0 < D) ? row + e0 : zero);
-      v[c][1] = *((e0 + 1 < D) ? row + e0 + 1 : zero);
-    }
-  }
-}
-template <int CHUNKS, bool VEC>
-__device__ inline void store_row(double *__restrict__ row, uint64_t D,
-                                 const double (&v)[CHUNKS][2]) {
-  const int lane = lane_id();
-#pragma unroll
-  for (int c = 0; c < CHUNKS; c++) {
-    const uint64_t e0 = static_cast<uint64_t>(c) * 128 + 2 * static_cast<uint64_t>(lane);
-    if (VEC) {
-      if (e0 < D) *reinterpret_cast<double2 *>(row + e0) = make_double2(v[c][0], v[c][1]);
-    } else {
-      if (e0 < D) row[e0] = v[c][0];
-      if (e0 + 1 < D) row[e0 + 1] = v[c][1];
-    }
-  }
-}
-
-// lower value wins; equal values keep the lower index; NaN never wins
-__device__ inline void argmin_combine(double &v, uint64_t &i, double ov, uint64_t oi) {
-  if (ov < v || (ov == v && oi < i)) {
-    v = ov;
-    i = oi;
-  }
-}
-
-// wave- then block-level argmin; thread 0 returns the block result
-__device__ inline void block_argmin_256(double &bv, uint64_t &bi, double *mv, uint64_t *mi) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    const double ov = __shfl_xor(bv, off, 64);
-    const uint64_t oi = __shfl_xor(bi, off, 64);
-    argmin_combine(bv, bi, ov, oi);
-  }
-  const int wid = static_cast<int>(threadIdx.x) >> 6;
-  __syncthreads();
-  if (lane_id() == 0) {
-    mv[wid] = bv;
-    mi[wid] = bi;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0)
-    for (int w = 1; w < 4; w++) argmin_combine(bv, bi, mv[w], mi[w]);
-}
 
 // ---- generation 0 ----------------------------------------------------------
 template <int OBJ, int CHUNKS, bool VEC>
@@ -389,20 +310,9 @@ __global__ __launch_bounds__(256) void de_var_partial_kernel(DeParams p, const d
   if (threadIdx.x == 0) p.part[blockIdx.x].m2 = total;
 }
 
-// Per-shard summary; consumed by the finaliser directly (one GPU) or exchanged
-// between ranks (record).
-struct DeLocal {
-  double sum;     // tiled sum of the shard's scores (eps > 0 only)
-  double mean;    // sum / shard_n
-  double minv;    // shard minimum (incumbent keeps ties)
-  uint64_t mini;  // GLOBAL index
-  double m2;      // tiled sum of squared deviations from `mean`
-  double valid;   // 1.0 when `mini` is owned by this shard
-};
-
 // `rec` != nullptr (only when eps <= 0, i.e. no second std_err pass is needed):
 // the exchange record is packed by this launch as well.
-__global__ __launch_bounds__(256) void de_local_kernel(DeParams p, DeLocal *loc, double *rec) {
+__global__ __launch_bounds__(256) void de_local_kernel(DeParams p, ShardLocal *loc, double *rec) {
   __shared__ double red[4];
   __shared__ double mv[4];
   __shared__ uint64_t mi[4];
@@ -447,7 +357,7 @@ __global__ __launch_bounds__(256) void de_local_kernel(DeParams p, DeLocal *loc,
     rec[kRecHeader + d] = s_mine ? row[d] : 0.0;
 }
 
-__global__ __launch_bounds__(256) void de_var_local_kernel(DeParams p, DeLocal *loc) {
+__global__ __launch_bounds__(256) void de_var_local_kernel(DeParams p, ShardLocal *loc) {
   __shared__ double red[4];
   if (p.state->done) return;
   double acc = 0.0;
@@ -461,7 +371,7 @@ __global__ __launch_bounds__(256) void de_var_local_kernel(DeParams p, DeLocal *
 // `valid` is 1 when the record's row belongs to the sending shard (it is 0 only
 // for a shard whose scores are all NaN and that does not own the incumbent).
 
-__global__ __launch_bounds__(256) void de_pack_record_kernel(DeParams p, const DeLocal *loc,
+__global__ __launch_bounds__(256) void de_pack_record_kernel(DeParams p, const ShardLocal *loc,
                                                            double *rec) {
   const DeState *st = p.state;
   if (st->done) return;

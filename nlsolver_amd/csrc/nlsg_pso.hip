@@ -1,0 +1,401 @@
+// nlsolver_amd/csrc/nlsg_pso.hip — host side of the PSO engine + its C-ABI
+// (include/nlsg_c_api.h). Same structure as nlsg_de.hip. No CPU fallback.
+#include <algorithm>
+#include <cmath>
+#include <new>
+#include <vector>
+
+#include "nlsg_pso_kernels.h"
+
+using namespace nlsg;
+
+struct nlsg_pso {
+  nlsg_pso_config cfg;
+  PsoParams p;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  double *lower_dev = nullptr, *upper_dev = nullptr, *zero_dev = nullptr, *tab_dev = nullptr;
+  ShardLocal *loc = nullptr;
+  double *rec = nullptr;
+  int chunks = 0;
+  bool initialised = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+
+int pso_check_device(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return fail(NLSG_ERR_NO_DEVICE, "no HIP device visible");
+  if (device < 0 || device >= n)
+    return fail(NLSG_ERR_INVALID_ARG, "device %d out of range (0..%d)", device, n - 1);
+  hipDeviceProp_t prop;
+  NLSG_HIP(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(NLSG_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only",
+                device, prop.gcnArchName);
+  return NLSG_OK;
+}
+
+#define PSO_FOR_CHUNKS(OBJ, chunks, CALL) \
+  switch (chunks) {                       \
+    case 1: CALL(OBJ, 1); break;          \
+    case 2: CALL(OBJ, 2); break;          \
+    case 4: CALL(OBJ, 4); break;          \
+    case 8: CALL(OBJ, 8); break;          \
+    default: break;                       \
+  }
+#define PSO_FOR_OBJ(obj, chunks, CALL)                                                  \
+  switch (obj) {                                                                        \
+    case NLSG_OBJ_ROSENBROCK: PSO_FOR_CHUNKS(NLSG_OBJ_ROSENBROCK, chunks, CALL); break; \
+    case NLSG_OBJ_SPHERE: PSO_FOR_CHUNKS(NLSG_OBJ_SPHERE, chunks, CALL); break;         \
+    case NLSG_OBJ_STYBLINSKI_TANG:                                                      \
+      PSO_FOR_CHUNKS(NLSG_OBJ_STYBLINSKI_TANG, chunks, CALL);                           \
+      break;                                                                            \
+    case NLSG_OBJ_RASTRIGIN: PSO_FOR_CHUNKS(NLSG_OBJ_RASTRIGIN, chunks, CALL); break;   \
+    default: break;                                                                     \
+  }
+
+void launch_init(nlsg_pso *e) {
+  const dim3 grid(static_cast<unsigned>((e->p.shard_n + 3) / 4)), block(256);
+  const bool vec = e->p.D % 2 == 0;
+#define CALL(OBJ, C)                                                                        \
+  if (vec)                                                                                  \
+    hipLaunchKernelGGL((pso_init_kernel<OBJ, C, true>), grid, block, 0, e->stream, e->p);   \
+  else                                                                                      \
+    hipLaunchKernelGGL((pso_init_kernel<OBJ, C, false>), grid, block, 0, e->stream, e->p)
+  PSO_FOR_OBJ(e->cfg.objective, e->chunks, CALL)
+#undef CALL
+}
+
+void launch_move(nlsg_pso *e, int timing, uint64_t iter_ovr) {
+  const dim3 grid(static_cast<unsigned>((e->p.shard_n + 3) / 4)), block(256);
+  const bool vec = e->p.D % 2 == 0;
+  const bool accel = e->cfg.type == NLSG_PSO_ACCELERATED;
+#define CALL(OBJ, C)                                                                          \
+  if (vec && accel)                                                                           \
+    hipLaunchKernelGGL((pso_move_kernel<OBJ, C, true, NLSG_PSO_ACCELERATED>), grid, block, 0, \
+                       e->stream, e->p, timing, iter_ovr);                                    \
+  else if (vec)                                                                               \
+    hipLaunchKernelGGL((pso_move_kernel<OBJ, C, true, NLSG_PSO_VANILLA>), grid, block, 0,     \
+                       e->stream, e->p, timing, iter_ovr);                                    \
+  else if (accel)                                                                             \
+    hipLaunchKernelGGL((pso_move_kernel<OBJ, C, false, NLSG_PSO_ACCELERATED>), grid, block,   \
+                       0, e->stream, e->p, timing, iter_ovr);                                 \
+  else                                                                                        \
+    hipLaunchKernelGGL((pso_move_kernel<OBJ, C, false, NLSG_PSO_VANILLA>), grid, block, 0,    \
+                       e->stream, e->p, timing, iter_ovr)
+  PSO_FOR_OBJ(e->cfg.objective, e->chunks, CALL)
+#undef CALL
+}
+
+void launch_local_summary(nlsg_pso *e, double *rec_dev) {
+  hipLaunchKernelGGL(pso_scan_partial_kernel, dim3(e->p.ntiles), dim3(256), 0, e->stream, e->p);
+  if (!(e->cfg.eps > 0)) {
+    hipLaunchKernelGGL(pso_local_kernel, dim3(1), dim3(256), 0, e->stream, e->p, e->loc, rec_dev);
+    return;
+  }
+  hipLaunchKernelGGL(pso_local_kernel, dim3(1), dim3(256), 0, e->stream, e->p, e->loc,
+                     static_cast<double *>(nullptr));
+  hipLaunchKernelGGL(pso_var_partial_kernel, dim3(e->p.ntiles), dim3(256), 0, e->stream, e->p,
+                     &e->loc->mean);
+  hipLaunchKernelGGL(pso_var_local_kernel, dim3(1), dim3(256), 0, e->stream, e->p, e->loc);
+  hipLaunchKernelGGL(pso_pack_record_kernel, dim3(1), dim3(256), 0, e->stream, e->p, e->loc,
+                     rec_dev);
+}
+
+void launch_turn_single(nlsg_pso *e) {
+  if (e->cfg.eps > 0) {
+    launch_local_summary(e, e->rec);
+    hipLaunchKernelGGL(pso_finalize_kernel, dim3(1), dim3(256), 0, e->stream, e->p, e->rec, 1,
+                       static_cast<uint64_t>(kRecHeader) + e->p.D);
+  } else {
+    hipLaunchKernelGGL(pso_scan_partial_kernel, dim3(e->p.ntiles), dim3(256), 0, e->stream, e->p);
+    hipLaunchKernelGGL(pso_head_kernel, dim3(1), dim3(256), 0, e->stream, e->p);
+  }
+  launch_move(e, 0, 0);
+}
+
+int read_state(nlsg_pso *e, PsoState *host) {
+  hipLaunchKernelGGL(pso_settle_kernel, dim3(1), dim3(1), 0, e->stream, e->p);
+  NLSG_HIP(hipMemcpyAsync(host, e->p.state, sizeof(PsoState), hipMemcpyDeviceToHost, e->stream));
+  NLSG_HIP(hipStreamSynchronize(e->stream));
+  NLSG_HIP(hipGetLastError());
+  return NLSG_OK;
+}
+
+void fill_status(const PsoState &s, nlsg_status *out) {
+  out->f_value = s.gbest_val;
+  out->iteration = s.iter;
+  out->function_calls_used = s.fevals;
+  out->gradient_evals_used = 0;
+  out->hessian_evals_used = 0;
+  out->best_index = s.gbest_idx;
+  out->val_no_change = s.val_no_change;
+  out->std_err = s.std_err;
+  out->done = s.done;
+  out->reserved = 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nlsg_pso_create(const nlsg_pso_config *cfg, nlsg_pso **out) {
+  if (!cfg || !out) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  *out = nullptr;
+  if (cfg->struct_size != sizeof(nlsg_pso_config))
+    return fail(NLSG_ERR_INVALID_ARG, "nlsg_pso_config size mismatch (%u vs %zu)",
+                cfg->struct_size, sizeof(nlsg_pso_config));
+  if (cfg->dim < 1) return fail(NLSG_ERR_INVALID_ARG, "dim must be >= 1");
+  if (cfg->dim > 1024)
+    return fail(NLSG_ERR_UNSUPPORTED, "dim %llu > 1024 is not covered by the device path",
+                (unsigned long long)cfg->dim);
+  if (cfg->objective < 0 || cfg->objective > NLSG_OBJ_RASTRIGIN)
+    return fail(NLSG_ERR_INVALID_ARG, "unknown objective %d", cfg->objective);
+  if (cfg->type != NLSG_PSO_VANILLA && cfg->type != NLSG_PSO_ACCELERATED)
+    return fail(NLSG_ERR_INVALID_ARG, "unknown PSO type %d", cfg->type);
+  if (cfg->shard_n < 1 || cfg->shard_lo + cfg->shard_n > cfg->n_particles)
+    return fail(NLSG_ERR_INVALID_ARG, "shard [%llu,+%llu) invalid for %llu particles",
+                (unsigned long long)cfg->shard_lo, (unsigned long long)cfg->shard_n,
+                (unsigned long long)cfg->n_particles);
+  if (cfg->shard_n > (1ull << 32))
+    return fail(NLSG_ERR_UNSUPPORTED, "shard_n > 2^32 particles per engine");
+  int rc = pso_check_device(cfg->device);
+  if (rc) return rc;
+  NLSG_HIP(hipSetDevice(cfg->device));
+
+  nlsg_pso *e = new (std::nothrow) nlsg_pso();
+  if (!e) return fail(NLSG_ERR_OOM, "host allocation failed");
+  e->cfg = *cfg;
+  const uint64_t D = cfg->dim, n = cfg->shard_n;
+  e->chunks = D <= 128 ? 1 : D <= 256 ? 2 : D <= 512 ? 4 : 8;
+  if (cfg->stream) {
+    e->stream = static_cast<hipStream_t>(cfg->stream);
+  } else {
+    hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (he != hipSuccess) {
+      delete e;
+      return fail(NLSG_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(he));
+    }
+    e->own_stream = true;
+  }
+  PsoParams &p = e->p;
+  std::memset(&p, 0, sizeof p);
+  auto alloc = [&](void **ptr, size_t bytes) { return hipMalloc(ptr, bytes ? bytes : 8); };
+  const bool vanilla = cfg->type == NLSG_PSO_VANILLA;
+  const size_t rows = n * D * sizeof(double);
+  hipError_t he = hipSuccess;
+  if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&p.pos), rows);
+  if (he == hipSuccess && vanilla) he = alloc(reinterpret_cast<void **>(&p.vel), rows);
+  if (he == hipSuccess && vanilla) he = alloc(reinterpret_cast<void **>(&p.pbest_pos), rows);
+  if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&p.pbest_val), n * sizeof(double));
+  if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&p.cur_val), n * sizeof(double));
+  if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&p.gbest_x), D * sizeof(double));
+  if (he == hipSuccess) he = hipMemset(p.gbest_x, 0, D * sizeof(double));
+  if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&e->lower_dev), D * sizeof(double));
+  if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&e->upper_dev), D * sizeof(double));
+  if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&e->zero_dev), 16);
+  if (he == hipSuccess) he = hipMemset(e->zero_dev, 0, 16);
+  if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&p.state), sizeof(PsoState));
+  p.ntiles = static_cast<uint32_t>((n + kTile - 1) / kTile);
+  if (he == hipSuccess)
+    he = alloc(reinterpret_cast<void **>(&p.part), p.ntiles * sizeof(TilePartial));
+  if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&e->loc), sizeof(ShardLocal));
+  if (he == hipSuccess)
+    he = alloc(reinterpret_cast<void **>(&e->rec), (kRecHeader + D) * sizeof(double));
+  // inertia schedule pow(inertia, iter) (:2613) computed with the host libm, as the
+  // reference does, so the device uses bit-identical values
+  p.tab_len = std::min<uint64_t>(cfg->max_iter + 1, 1u << 16);
+  std::vector<double> tab(p.tab_len);
+  for (uint64_t k = 0; k < p.tab_len; k++) tab[k] = std::pow(cfg->inertia, static_cast<double>(k));
+  if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&e->tab_dev), p.tab_len * sizeof(double));
+  if (he == hipSuccess)
+    he = hipMemcpy(e->tab_dev, tab.data(), p.tab_len * sizeof(double), hipMemcpyHostToDevice);
+  if (he == hipSuccess) he = hipEventCreate(&e->ev0);
+  if (he == hipSuccess) he = hipEventCreate(&e->ev1);
+  if (he != hipSuccess) {
+    nlsg_pso_destroy(e);
+    return fail(he == hipErrorOutOfMemory ? NLSG_ERR_OOM : NLSG_ERR_HIP,
+                "device allocation failed: %s", hipGetErrorString(he));
+  }
+  p.lower = e->lower_dev;
+  p.upper = e->upper_dev;
+  p.zero = e->zero_dev;
+  p.inertia_tab = e->tab_dev;
+  p.n = cfg->n_particles;
+  p.D = D;
+  p.shard_lo = cfg->shard_lo;
+  p.shard_n = n;
+  p.inertia = cfg->inertia;
+  p.cog = cfg->cognitive;
+  p.soc = cfg->social;
+  p.eps = cfg->eps;
+  p.fmul = cfg->minimize ? 1.0 : -1.0;
+  p.max_iter = cfg->max_iter;
+  p.best_val_no_change = cfg->best_val_no_change;
+  p.seed = cfg->seed;
+  p.type = cfg->type;
+  p.bounded = cfg->bounded ? 1 : 0;
+  *out = e;
+  return NLSG_OK;
+}
+
+int nlsg_pso_destroy(nlsg_pso *e) {
+  if (!e) return NLSG_OK;
+  hipSetDevice(e->cfg.device);
+  if (e->stream) hipStreamSynchronize(e->stream);
+  hipFree(e->p.pos);
+  hipFree(e->p.vel);
+  hipFree(e->p.pbest_pos);
+  hipFree(e->p.pbest_val);
+  hipFree(e->p.cur_val);
+  hipFree(e->p.gbest_x);
+  hipFree(e->p.state);
+  hipFree(e->p.part);
+  hipFree(e->lower_dev);
+  hipFree(e->upper_dev);
+  hipFree(e->zero_dev);
+  hipFree(e->tab_dev);
+  hipFree(e->loc);
+  hipFree(e->rec);
+  if (e->ev0) hipEventDestroy(e->ev0);
+  if (e->ev1) hipEventDestroy(e->ev1);
+  if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
+  delete e;
+  return NLSG_OK;
+}
+
+int nlsg_pso_init(nlsg_pso *e, const double *lower_host, const double *upper_host) {
+  if (!e || !lower_host || !upper_host) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  NLSG_HIP(hipSetDevice(e->cfg.device));
+  const size_t bytes = e->p.D * sizeof(double);
+  NLSG_HIP(hipMemcpyAsync(e->lower_dev, lower_host, bytes, hipMemcpyHostToDevice, e->stream));
+  NLSG_HIP(hipMemcpyAsync(e->upper_dev, upper_host, bytes, hipMemcpyHostToDevice, e->stream));
+  NLSG_HIP(hipStreamSynchronize(e->stream));  // host buffers are borrowed for this call only
+  hipLaunchKernelGGL(pso_reset_state_kernel, dim3(1), dim3(1), 0, e->stream, e->p);
+  launch_init(e);
+  NLSG_HIP(hipGetLastError());
+  e->initialised = true;
+  return NLSG_OK;
+}
+
+int nlsg_pso_step(nlsg_pso *e, uint64_t turns) {
+  if (!e) return fail(NLSG_ERR_INVALID_ARG, "null engine");
+  if (!e->initialised) return fail(NLSG_ERR_STATE, "nlsg_pso_init has not been called");
+  if (e->cfg.shard_n != e->cfg.n_particles)
+    return fail(NLSG_ERR_STATE,
+                "sharded engine: use nlsg_pso_turn_begin / nlsg_pso_turn_end around the exchange");
+  NLSG_HIP(hipSetDevice(e->cfg.device));
+  for (uint64_t t = 0; t < turns; t++) launch_turn_single(e);
+  NLSG_HIP(hipGetLastError());
+  return NLSG_OK;
+}
+
+int nlsg_pso_status(nlsg_pso *e, nlsg_status *out) {
+  if (!e || !out) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  if (!e->initialised) return fail(NLSG_ERR_STATE, "nlsg_pso_init has not been called");
+  NLSG_HIP(hipSetDevice(e->cfg.device));
+  PsoState s;
+  int rc = read_state(e, &s);
+  if (rc) return rc;
+  fill_status(s, out);
+  return NLSG_OK;
+}
+
+int nlsg_pso_best(nlsg_pso *e, double *x_host, double *f, uint64_t *index) {
+  if (!e) return fail(NLSG_ERR_INVALID_ARG, "null engine");
+  if (!e->initialised) return fail(NLSG_ERR_STATE, "nlsg_pso_init has not been called");
+  NLSG_HIP(hipSetDevice(e->cfg.device));
+  PsoState s;
+  int rc = read_state(e, &s);
+  if (rc) return rc;
+  if (x_host)
+    NLSG_HIP(hipMemcpy(x_host, e->p.gbest_x, e->p.D * sizeof(double), hipMemcpyDeviceToHost));
+  if (f) *f = s.gbest_val;
+  if (index) *index = s.gbest_idx;
+  return NLSG_OK;
+}
+
+int nlsg_pso_download(nlsg_pso *e, double *pos_host, double *vel_host, double *pbest_val_host,
+                      double *cur_val_host) {
+  if (!e) return fail(NLSG_ERR_INVALID_ARG, "null engine");
+  if (!e->initialised) return fail(NLSG_ERR_STATE, "nlsg_pso_init has not been called");
+  NLSG_HIP(hipSetDevice(e->cfg.device));
+  NLSG_HIP(hipStreamSynchronize(e->stream));
+  const uint64_t n = e->p.shard_n, D = e->p.D;
+  if (pos_host) NLSG_HIP(hipMemcpy(pos_host, e->p.pos, n * D * sizeof(double), hipMemcpyDeviceToHost));
+  if (vel_host) {
+    if (!e->p.vel) return fail(NLSG_ERR_STATE, "velocities exist only for Vanilla PSO");
+    NLSG_HIP(hipMemcpy(vel_host, e->p.vel, n * D * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  if (pbest_val_host)
+    NLSG_HIP(hipMemcpy(pbest_val_host, e->p.pbest_val, n * sizeof(double), hipMemcpyDeviceToHost));
+  if (cur_val_host)
+    NLSG_HIP(hipMemcpy(cur_val_host, e->p.cur_val, n * sizeof(double), hipMemcpyDeviceToHost));
+  return NLSG_OK;
+}
+
+int nlsg_pso_minimize(nlsg_pso *e, double *x_out_host, const double *lower_host,
+                      const double *upper_host, uint64_t poll_every, nlsg_status *out) {
+  if (!e || !x_out_host) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  int rc = nlsg_pso_init(e, lower_host, upper_host);
+  if (rc) return rc;
+  if (poll_every == 0) poll_every = 32;
+  PsoState s;
+  for (;;) {
+    rc = nlsg_pso_step(e, poll_every);
+    if (rc) return rc;
+    rc = read_state(e, &s);
+    if (rc) return rc;
+    if (s.done) break;
+  }
+  // x = swarm_best_position (nlsolver.h:2601)
+  NLSG_HIP(hipMemcpy(x_out_host, e->p.gbest_x, e->p.D * sizeof(double), hipMemcpyDeviceToHost));
+  if (out) fill_status(s, out);
+  return NLSG_OK;
+}
+
+int nlsg_pso_time_move_kernel(nlsg_pso *e, uint32_t launches, float *ms_total) {
+  if (!e || !ms_total) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  if (!e->initialised) return fail(NLSG_ERR_STATE, "nlsg_pso_init has not been called");
+  NLSG_HIP(hipSetDevice(e->cfg.device));
+  PsoState s;
+  int rc = read_state(e, &s);
+  if (rc) return rc;
+  NLSG_HIP(hipEventRecord(e->ev0, e->stream));
+  for (uint32_t k = 0; k < launches; k++) launch_move(e, 1, s.iter + k);
+  NLSG_HIP(hipEventRecord(e->ev1, e->stream));
+  NLSG_HIP(hipEventSynchronize(e->ev1));
+  NLSG_HIP(hipGetLastError());
+  NLSG_HIP(hipEventElapsedTime(ms_total, e->ev0, e->ev1));
+  e->initialised = false;  // the swarm moved without best bookkeeping: re-init before solving
+  return NLSG_OK;
+}
+
+uint64_t nlsg_pso_record_doubles(const nlsg_pso *e) {
+  return e ? static_cast<uint64_t>(kRecHeader) + e->p.D : 0;
+}
+
+int nlsg_pso_turn_begin(nlsg_pso *e, double *send_dev) {
+  if (!e || !send_dev) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  if (!e->initialised) return fail(NLSG_ERR_STATE, "nlsg_pso_init has not been called");
+  NLSG_HIP(hipSetDevice(e->cfg.device));
+  launch_local_summary(e, send_dev);
+  NLSG_HIP(hipGetLastError());
+  return NLSG_OK;
+}
+
+int nlsg_pso_turn_end(nlsg_pso *e, const double *gathered_dev, int32_t world) {
+  if (!e || !gathered_dev || world < 1) return fail(NLSG_ERR_INVALID_ARG, "bad argument");
+  if (!e->initialised) return fail(NLSG_ERR_STATE, "nlsg_pso_init has not been called");
+  NLSG_HIP(hipSetDevice(e->cfg.device));
+  hipLaunchKernelGGL(pso_finalize_kernel, dim3(1), dim3(256), 0, e->stream, e->p, gathered_dev,
+                     world, static_cast<uint64_t>(kRecHeader) + e->p.D);
+  launch_move(e, 0, 0);
+  NLSG_HIP(hipGetLastError());
+  return NLSG_OK;
+}
+
+}  // extern "C"

@@ -49,6 +49,11 @@ uint64_t orc_mix64(uint64_t z);
 uint64_t orc_ctr_key(uint64_t parent, uint64_t index); /* mix(parent+G*(index+1)) */
 double orc_u01(uint64_t bits); /* (double)bits * 2^-64, cf. nlsolver.h:1358 */
 
+/* Deterministic log / cos (no libm): shared definition of the transcendental
+ * arithmetic of the synchronous restatements and the HIP kernels. */
+double orc_log(double x);
+double orc_cos(double y);
+
 /* ------------------------------------------------------------ objectives --- */
 enum {
   ORC_OBJ_ROSENBROCK = 0,      /* example.cpp:41-48 generalised to N-D chain  */
@@ -129,6 +134,41 @@ void orc_de_sync_step(orc_de_sync *s);
 /* Multi-threaded variant of the generation (OpenMP over agents); identical
  * results. Used only for the CPU baseline timing. */
 void orc_de_sync_step_omp(orc_de_sync *s, int threads);
+
+/* -------------------------------------------------------------------- PSO --- */
+/* PSO::solve and helpers (nlsolver.h:2479-2742), literal (incl. the sentinels B8,
+ * the best_index rule B9 and, for Vanilla, B7). type 0 = Vanilla, 1 = Accelerated. */
+orc_status orc_pso_serial(int obj, int minimize, int type, int bounded, double *x, size_t D,
+                          const double *lower, const double *upper, orc_xorshift *gen,
+                          double inertia, double cog, double soc, size_t n, size_t max_iter,
+                          size_t best_val_no_change, double eps, orc_eval_log *log);
+
+/* Synchronous restatement. Deviations from the literal algorithm, each documented in
+ * counter RNG; +inf best sentinels (B8); val_no_change driven by
+ * update_happened (B9); Vanilla uses the intended pbest/gbest terms (B7); log/cos
+ * are orc_log/orc_cos. */
+typedef struct {
+  int obj, minimize, type, bounded;
+  size_t n, D, n_shards;
+  double inertia0, cog, soc, eps;
+  size_t max_iter, best_val_no_change;
+  uint64_t seed;
+  const double *lower, *upper; /* D each (init range; thresholds when bounded) */
+  double *pos, *vel, *pbest_pos; /* n*D; vel/pbest_pos only for Vanilla */
+  double *pbest_val, *cur_val;   /* n */
+  double *gbest_x;               /* D */
+  double gbest_val;
+  uint64_t gbest_idx;
+  uint64_t iter, val_no_change, fevals;
+  int done;
+  double std_err, inertia;
+} orc_pso_sync;
+void orc_pso_sync_init(orc_pso_sync *s);
+void orc_pso_sync_step(orc_pso_sync *s, int threads);
+void orc_pso_shard_record(const orc_pso_sync *s, size_t lo, size_t n, double *rec);
+int orc_pso_apply_records(orc_pso_sync *s, const double *recs, int world);
+void orc_pso_shard_move(orc_pso_sync *s, size_t lo, size_t n, int threads);
+void orc_pso_commit(orc_pso_sync *s);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,97 @@
+/* oracle/oracle_math.c — TEST INFRASTRUCTURE, NOT PRODUCT CODE (see oracle.h).
+ *
+ * Deterministic log / cos built from +,-,*,/ only (no libm), so that the
+ * synchronous restatements and the HIP kernels — which carry their own copy of
+ * the same algorithms in nlsolver_amd/csrc/nlsg_math.h — agree bit for bit.
+ * Accuracy ~1 ulp; the serial restatements keep libm, like the reference
+ * (rnorm, nlsolver.h:2479-2485).
+ *
+ * Algorithms: classic argument reduction + minimax kernels (Sun fdlibm
+ * e_log.c / k_cos.c / k_sin.c coefficient sets, public since 1993).
+ */
+#include <math.h>
+#include <string.h>
+
+#include "oracle.h"
+
+static uint64_t bits_of(double d) {
+  uint64_t u;
+  memcpy(&u, &d, 8);
+  return u;
+}
+static double from_bits(uint64_t u) {
+  double d;
+  memcpy(&d, &u, 8);
+  return d;
+}
+
+/* natural logarithm for finite x >= 0 (x == 0 -> -inf, x < 0 or NaN -> NaN) */
+double orc_log(double x) {
+  static const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                      Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+                      Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+                      Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                      Lg7 = 1.479819860511658591e-01;
+  if (x != x || x < 0.0) return NAN;
+  if (x == 0.0) return -INFINITY;
+  if (x == INFINITY) return x;
+  int k = 0;
+  uint64_t u = bits_of(x);
+  if ((u >> 52) == 0) { /* subnormal: scale up by 2^54 */
+    x = x * 0x1p54;
+    u = bits_of(x);
+    k -= 54;
+  }
+  /* x = 2^k * m with m in [sqrt(1/2), sqrt(2)) */
+  uint32_t hx = (uint32_t)(u >> 32);
+  hx += 0x3ff00000u - 0x3fe6a09eu;
+  k += (int)(hx >> 20) - 0x3ff;
+  hx = (hx & 0x000fffffu) + 0x3fe6a09eu;
+  const double m = from_bits(((uint64_t)hx << 32) | (u & 0xffffffffull));
+  const double f = m - 1.0;
+  const double hfsq = 0.5 * f * f;
+  const double s = f / (2.0 + f);
+  const double z = s * s;
+  const double w = z * z;
+  const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+  const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+  const double R = t2 + t1;
+  const double dk = (double)k;
+  return s * (hfsq + R) + dk * ln2_lo - hfsq + f + dk * ln2_hi;
+}
+
+static double kernel_cos(double x) { /* |x| <= pi/4 */
+  static const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                      C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                      C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+  const double z = x * x;
+  const double r = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+  const double hz = 0.5 * z;
+  const double w = 1.0 - hz;
+  return w + (((1.0 - w) - hz) + z * r);
+}
+static double kernel_sin(double x) { /* |x| <= pi/4 */
+  static const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                      S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                      S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+  const double z = x * x;
+  const double v = z * x;
+  const double r = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+  return x + v * (S1 + z * r);
+}
+
+/* cosine for |y| <= 64 (two-term Cody-Waite reduction by pi/2); NaN outside */
+double orc_cos(double y) {
+  static const double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00,
+                      pio2_1t = 6.07710050650619224932e-11;
+  if (!(y >= -64.0 && y <= 64.0)) return NAN;
+  const double fn = floor(y * invpio2 + 0.5);
+  const double r = (y - fn * pio2_1) - fn * pio2_1t;
+  const int q = (int)((long long)fn & 3);
+  switch (q) {
+    case 0: return kernel_cos(r);
+    case 1: return -kernel_sin(r);
+    case 2: return -kernel_cos(r);
+    default: return kernel_sin(r);
+  }
+}

@@ -42,6 +42,18 @@ class DESync(C.Structure):
                 ("done", C.c_int), ("std_err", f64), ("trace", pu)]
 
 
+class PSOSync(C.Structure):
+    _fields_ = [("obj", C.c_int), ("minimize", C.c_int), ("type", C.c_int), ("bounded", C.c_int),
+                ("n", sz), ("D", sz), ("n_shards", sz),
+                ("inertia0", f64), ("cog", f64), ("soc", f64), ("eps", f64),
+                ("max_iter", sz), ("best_val_no_change", sz), ("seed", u64),
+                ("lower", pd), ("upper", pd),
+                ("pos", pd), ("vel", pd), ("pbest_pos", pd), ("pbest_val", pd), ("cur_val", pd),
+                ("gbest_x", pd), ("gbest_val", f64), ("gbest_idx", u64),
+                ("iter", u64), ("val_no_change", u64), ("fevals", u64),
+                ("done", C.c_int), ("std_err", f64), ("inertia", f64)]
+
+
 def _ptr(a):
     return a.ctypes.data_as(pd)
 
@@ -80,6 +92,21 @@ def load():
     lib.orc_de_apply_records.argtypes = [C.POINTER(DESync), pd, C.c_int, pd]
     lib.orc_de_shard_generation.argtypes = [C.POINTER(DESync), sz, sz, C.c_int]
     lib.orc_de_commit.argtypes = [C.POINTER(DESync)]
+    for name in ("orc_log", "orc_cos"):
+        fn = getattr(lib, name)
+        fn.restype = f64
+        fn.argtypes = [f64]
+    lib.orc_pso_serial.restype = Status
+    lib.orc_pso_serial.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, pd, sz, pd, pd,
+                                   C.POINTER(XorShift), f64, f64, f64, sz, sz, sz, f64,
+                                   C.POINTER(EvalLog)]
+    lib.orc_pso_sync_init.argtypes = [C.POINTER(PSOSync)]
+    lib.orc_pso_sync_step.argtypes = [C.POINTER(PSOSync), C.c_int]
+    lib.orc_pso_shard_record.argtypes = [C.POINTER(PSOSync), sz, sz, pd]
+    lib.orc_pso_apply_records.restype = C.c_int
+    lib.orc_pso_apply_records.argtypes = [C.POINTER(PSOSync), pd, C.c_int]
+    lib.orc_pso_shard_move.argtypes = [C.POINTER(PSOSync), sz, sz, C.c_int]
+    lib.orc_pso_commit.argtypes = [C.POINTER(PSOSync)]
     return lib
 
 
@@ -178,3 +205,38 @@ class OracleShardEngine:
     def shard(self):
         return (self.run.population[self.lo:self.lo + self.n].copy(),
                 self.run.scores[self.lo:self.lo + self.n].copy())
+
+
+PSO_VANILLA, PSO_ACCELERATED = 0, 1
+
+
+class PSOSyncRun:
+    """Owns the numpy buffers of one synchronous-PSO oracle run."""
+
+    def __init__(self, lib, obj, n, D, lower, upper, *, type=PSO_ACCELERATED, bounded=False,
+                 minimize=True, n_shards=1, inertia=0.8, cog=1.8, soc=1.8, eps=0.0, max_iter=5000,
+                 best_val_no_change=50, seed=12374563468):
+        self.lib, self.n, self.D = lib, n, D
+        self.lower = np.ascontiguousarray(np.broadcast_to(lower, (D,)), dtype=np.float64)
+        self.upper = np.ascontiguousarray(np.broadcast_to(upper, (D,)), dtype=np.float64)
+        self.pos = np.zeros((n, D))
+        self.vel = np.zeros((n, D))
+        self.pbest_pos = np.zeros((n, D))
+        self.pbest_val = np.zeros(n)
+        self.cur_val = np.zeros(n)
+        self.gbest_x = np.zeros(D)
+        s = PSOSync()
+        s.obj = OBJ[obj] if isinstance(obj, str) else obj
+        s.minimize, s.type, s.bounded = int(minimize), type, int(bounded)
+        s.n, s.D, s.n_shards = n, D, n_shards
+        s.inertia0, s.cog, s.soc, s.eps = inertia, cog, soc, eps
+        s.max_iter, s.best_val_no_change, s.seed = max_iter, best_val_no_change, seed
+        s.lower, s.upper = _ptr(self.lower), _ptr(self.upper)
+        s.pos, s.vel, s.pbest_pos = _ptr(self.pos), _ptr(self.vel), _ptr(self.pbest_pos)
+        s.pbest_val, s.cur_val, s.gbest_x = _ptr(self.pbest_val), _ptr(self.cur_val), _ptr(self.gbest_x)
+        self.s = s
+        lib.orc_pso_sync_init(C.byref(s))
+
+    def step(self, n=1, threads=1):
+        for _ in range(n):
+            self.lib.orc_pso_sync_step(C.byref(self.s), threads)

@@ -1,0 +1,18 @@
+"""Second part of gen_golden.py (PSO / NelderMead / BFGS / LM / tinyqr goldens).
+Executed by gen_golden.py with `run` and `write` injected."""
+
+
+def main():
+    # G4 — PSO (nlsolver.h:2496-2742). Vanilla is only pinned where it is defined
+    # behaviour (particles <= D).
+    g4 = {
+        "accel_2d_x0_3_3": run("pso", "accelerated", 2, 10, 50, 0, 1000, "3,3", 2),
+        "accel_256d_64p": run("pso", "accelerated", 256, 64, 5, 0, 1000, "0.3", 1),
+        "accel_8d_bounded": run("pso", "accelerated", 8, 16, 20, 0, 1000, "2.0", 1, 1, -1.5, 1.5),
+        "accel_2d_default_stops": run("pso", "accelerated", 2, 10, 5000, 10e-4, 50, "3,3", 0),
+        "accel_2d_other_coefs": run("pso", "accelerated", 2, 12, 30, 0, 1000, "3,3", 1, 0, 0, 0,
+                                    0.7, 1.5, 1.2),
+        "vanilla_16d_10p": run("pso", "vanilla", 16, 10, 20, 0, 1000, "2.0", 1),
+        "vanilla_16d_10p_bounded": run("pso", "vanilla", 16, 10, 20, 0, 1000, "2.0", 1, 1, -1.0, 3.0),
+    }
+    write("pso.json", g4)

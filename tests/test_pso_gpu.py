@@ -1,0 +1,140 @@
+"""Parity tests: the HIP PSO path (through the C-ABI) vs the oracle's synchronous
+restatement. Bit-exact positions, velocities, personal bests, swarm best, counters."""
+import numpy as np
+import pytest
+
+from tests import _oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mod():
+    import torch
+    assert torch.cuda.is_available()
+    import nlsolver_amd
+    return nlsolver_amd
+
+
+def check_state(eng, ref, tag):
+    pos, vel, pbest, cur = eng.download()
+    assert np.array_equal(pos, ref.pos), f"{tag}: positions"
+    assert np.array_equal(cur, ref.cur_val), f"{tag}: values of the last evaluation"
+    assert np.array_equal(pbest, ref.pbest_val), f"{tag}: personal-best values"
+    if vel is not None:
+        assert np.array_equal(vel, ref.vel), f"{tag}: velocities"
+    st = eng.status()
+    assert (st.iteration, st.function_calls_used, st.val_no_change, st.done) == \
+        (ref.s.iter, ref.s.fevals, ref.s.val_no_change, ref.s.done), tag
+    if ref.s.fevals:
+        assert st.f_value == ref.s.gbest_val and st.best_index == ref.s.gbest_idx, tag
+
+
+@pytest.mark.parametrize("n,D", [(10, 2), (64, 256), (37, 130), (16, 5), (1030, 128), (8, 1024)])
+@pytest.mark.parametrize("type_", [O.PSO_ACCELERATED, O.PSO_VANILLA])
+@pytest.mark.parametrize("bounded", [False, True])
+def test_pso_turns_bit_exact(mod, oracle, n, D, type_, bounded):
+    lo = -2.048 * (1 + 0.001 * np.arange(D))
+    hi = 2.048 * (1 + 0.002 * np.arange(D))
+    kw = dict(type=type_, bounded=bounded, eps=0.0, max_iter=1000, best_val_no_change=1000)
+    ref = O.PSOSyncRun(oracle, "rosenbrock", n, D, lo, hi, **kw)
+    with mod.PSOEngine("rosenbrock", n, D, **kw) as eng:
+        eng.init(lo, hi)
+        check_state(eng, ref, "init")
+        for t in range(5):
+            eng.step(1)
+            ref.step(1)
+            check_state(eng, ref, f"turn {t}")
+        bx, bf, bi = eng.best()
+        assert np.array_equal(bx, ref.gbest_x) and bf == ref.s.gbest_val and bi == ref.s.gbest_idx
+
+
+@pytest.mark.parametrize("kw", [dict(eps=10e-4), dict(eps=0.0, max_iter=9),
+                                dict(eps=0.0, best_val_no_change=3), dict(eps=50.0)])
+@pytest.mark.parametrize("type_", [O.PSO_ACCELERATED, O.PSO_VANILLA])
+def test_pso_full_minimize_matches_oracle_to_the_stop(mod, oracle, kw, type_):
+    args = dict(eps=10e-4, max_iter=300, best_val_no_change=50, type=type_)
+    args.update(kw)
+    ref = O.PSOSyncRun(oracle, "rosenbrock", 10, 2, -3.0, 3.0, **args)
+    while not ref.s.done:
+        ref.step()
+    x = np.zeros(2)
+    with mod.PSOEngine("rosenbrock", 10, 2, **args) as eng:
+        st = eng.minimize(x, -3.0, 3.0, poll_every=7)
+    assert st.done == 1
+    assert (st.iteration, st.function_calls_used) == (ref.s.iter, ref.s.fevals)
+    assert st.f_value == ref.s.gbest_val and np.array_equal(x, ref.gbest_x)
+    if args["eps"] > 0:
+        assert st.std_err == ref.s.std_err
+
+
+def test_pso_maximize_and_other_objectives(mod, oracle):
+    for obj, mini in (("sphere", False), ("styblinski_tang", True)):
+        kw = dict(type=O.PSO_ACCELERATED, minimize=mini, eps=0.0, max_iter=100, best_val_no_change=1000)
+        ref = O.PSOSyncRun(oracle, obj, 48, 20, -2.0, 3.0, **kw)
+        ref.step(6)
+        with mod.PSOEngine(obj, 48, 20, **kw) as eng:
+            eng.init(-2.0, 3.0)
+            eng.step(6)
+            check_state(eng, ref, obj)
+
+
+def test_pso_class_mirror_reaches_reference_quality(mod, golden):
+    """PSO(f, gen, ...) with the reference's defaults through the class mirror: Accelerated
+    PSO on Rosenbrock-2D from x0=(3,3) lands near the reference's result quality."""
+    ref = golden("pso.json")["accel_2d_x0_3_3"]
+    x = np.array([3.0, 3.0])
+    st = mod.PSO("rosenbrock", None, 0.8, 1.8, 1.8, 10, 50, 1000, 0.0,
+                 type=mod.PSO_ACCELERATED).minimize(x)
+    fcalls, iters, f, g, h = st.get_summary()
+    assert (fcalls, iters) == (ref["fcalls"], ref["iters"]) == (510, 50)
+    assert f < 0.5 and np.all(np.abs(x - 1.0) < 0.8)
+
+
+@pytest.mark.parametrize("type_", [O.PSO_ACCELERATED, O.PSO_VANILLA])
+@pytest.mark.parametrize("eps", [0.0, 200.0])
+def test_pso_sharded_path_on_one_gpu_bit_exact(mod, oracle, type_, eps):
+    import torch
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    n, D, shards, turns = 4096, 256, 4, 6
+    kw = dict(type=type_, eps=eps, max_iter=1000, best_val_no_change=1000)
+    ref = O.PSOSyncRun(oracle, "rosenbrock", n, D, -2.048, 2.048, n_shards=shards, **kw)
+    ref.step(turns)
+    m = n // shards
+    engs = [mod.PSOEngine("rosenbrock", n, D, shard_lo=r * m, shard_n=m, stream=stream, **kw)
+            for r in range(shards)]
+    rec = engs[0].record_doubles()
+    gathered = torch.zeros(shards * rec, dtype=torch.float64, device=dev)
+    for e in engs:
+        e.init(-2.048, 2.048)
+    for _ in range(turns):
+        for r, e in enumerate(engs):
+            e.turn_begin(gathered[r * rec:(r + 1) * rec].data_ptr())
+        for e in engs:
+            e.turn_end(gathered.data_ptr(), shards)
+    for r, e in enumerate(engs):
+        pos, vel, pbest, cur = e.download()
+        sl = slice(r * m, (r + 1) * m)
+        assert np.array_equal(pos, ref.pos[sl]) and np.array_equal(pbest, ref.pbest_val[sl])
+        st = e.status()
+        assert (st.iteration, st.function_calls_used, st.val_no_change, st.done, st.best_index) == \
+            (ref.s.iter, ref.s.fevals, ref.s.val_no_change, ref.s.done, ref.s.gbest_idx)
+        assert st.f_value == ref.s.gbest_val
+        if eps > 0:
+            assert st.std_err == ref.s.std_err
+        bx, _, _ = e.best()
+        assert np.array_equal(bx, ref.gbest_x)
+        e.close()
+
+
+def test_pso_config5_shard_size_properties(mod, oracle):
+    """BASELINE config 5's per-GPU shard: 131072 particles x D=256 (2^20 / 8 GPUs)."""
+    n, D = 131072, 256
+    kw = dict(type=O.PSO_ACCELERATED, eps=0.0, max_iter=1000, best_val_no_change=1000)
+    ref = O.PSOSyncRun(oracle, "rosenbrock", n, D, -2.048, 2.048, **kw)
+    ref.step(2, threads=8)
+    with mod.PSOEngine("rosenbrock", n, D, **kw) as eng:
+        eng.init(-2.048, 2.048)
+        eng.step(2)
+        check_state(eng, ref, "config5 shard")
