@@ -217,6 +217,9 @@ class api {
   decltype(&nlsg_de_create) de_create;
   decltype(&nlsg_de_destroy) de_destroy;
   decltype(&nlsg_de_minimize) de_minimize;
+  decltype(&nlsg_pso_create) pso_create;
+  decltype(&nlsg_pso_destroy) pso_destroy;
+  decltype(&nlsg_pso_minimize) pso_minimize;
 
   void check(int rc) const {
     if (rc != NLSG_OK)
@@ -236,6 +239,9 @@ class api {
     bind(h, "nlsg_de_create", de_create);
     bind(h, "nlsg_de_destroy", de_destroy);
     bind(h, "nlsg_de_minimize", de_minimize);
+    bind(h, "nlsg_pso_create", pso_create);
+    bind(h, "nlsg_pso_destroy", pso_destroy);
+    bind(h, "nlsg_pso_minimize", pso_minimize);
     if (abi_version() != NLSG_ABI_VERSION)
       throw device_error("libnlsolver_hip.so ABI version mismatch");
   }
@@ -398,6 +404,179 @@ class DE {
 template <typename Callable, typename RNG, typename scalar_t = double,
           RecombinationStrategy RecombinationType = random>
 using DESolver = DE<Callable, RNG, scalar_t, RecombinationType>;
+
+// ---------------------------------------------------------------------------
+// PSO — nlsolver.h:2479-2742
+// ---------------------------------------------------------------------------
+// rnorm (nlsolver.h:2479-2485): u1 feeds log, u2 feeds cos (two sequenced draws).
+template <typename scalar_t, typename RNG>
+static inline scalar_t rnorm(RNG &generator) {
+  constexpr scalar_t pi_ = 3.141593;
+  const scalar_t u1 = generator();
+  const scalar_t u2 = generator();
+  return std::sqrt(-2 * std::log(u1)) * std::cos(2 * pi_ * u2);
+}
+
+enum PSOType { Vanilla, Accelerated };  // nlsolver.h:2496
+
+template <typename Callable, typename RNG, typename scalar_t = double, PSOType Type = Vanilla>
+class PSO {
+  RNG &generator;
+  Callable &f;
+  const scalar_t inertia0, cognitive_coef, social_coef;
+  const size_t n_particles, max_iter, best_val_no_change;
+  const scalar_t eps;
+
+ public:
+  // same positional arguments and defaults as nlsolver.h:2522-2526
+  PSO(Callable &f, RNG &generator, const scalar_t inertia = 0.8,
+      const scalar_t cognitive_coef = 1.8, const scalar_t social_coef = 1.8,
+      const size_t n_particles = 10, const size_t max_iter = 5000,
+      const size_t best_val_no_change = 50, const scalar_t eps = 10e-4)
+      : generator(generator),
+        f(f),
+        inertia0(inertia),
+        cognitive_coef(cognitive_coef),
+        social_coef(social_coef),
+        n_particles(n_particles),
+        max_iter(max_iter),
+        best_val_no_change(best_val_no_change),
+        eps(eps) {}
+  // bounds = -+|x_i|, no thresholding (nlsolver.h:2553-2575)
+  solver_status<scalar_t> minimize(std::vector<scalar_t> &x) { return free_run<true>(x); }
+  solver_status<scalar_t> maximize(std::vector<scalar_t> &x) { return free_run<false>(x); }
+  // (x, lower, upper) — note the order, opposite to NelderMead (nlsolver.h:2577-2591)
+  solver_status<scalar_t> minimize(std::vector<scalar_t> &x, const std::vector<scalar_t> &lower,
+                                   const std::vector<scalar_t> &upper) {
+    return solve<true, true>(x, lower, upper);
+  }
+  solver_status<scalar_t> maximize(std::vector<scalar_t> &x, const std::vector<scalar_t> &lower,
+                                   const std::vector<scalar_t> &upper) {
+    return solve<false, true>(x, lower, upper);
+  }
+
+ private:
+  template <bool minimize>
+  solver_status<scalar_t> free_run(std::vector<scalar_t> &x) {
+    std::vector<scalar_t> lower(x.size()), upper(x.size());
+    for (size_t i = 0; i < x.size(); i++) {
+      const scalar_t t = std::abs(x[i]);
+      lower[i] = -t;
+      upper[i] = t;
+    }
+    return solve<minimize, false>(x, lower, upper);
+  }
+
+  template <bool minimize, bool constrained>
+  solver_status<scalar_t> solve(std::vector<scalar_t> &x, const std::vector<scalar_t> &lower,
+                                const std::vector<scalar_t> &upper) {
+    if constexpr (device::is_device_objective<Callable>::value) {
+      static_assert(std::is_same_v<scalar_t, double>, "the device path computes in fp64");
+      const device::api &api = device::api::get();
+      nlsg_pso_config cfg{};
+      cfg.struct_size = sizeof(cfg);
+      if (const char *d = std::getenv("NLSG_DEVICE")) cfg.device = std::atoi(d);
+      cfg.objective = Callable::nlsg_objective;
+      cfg.minimize = minimize ? 1 : 0;
+      cfg.type = Type == Accelerated ? NLSG_PSO_ACCELERATED : NLSG_PSO_VANILLA;
+      cfg.bounded = constrained ? 1 : 0;
+      cfg.n_particles = cfg.shard_n = n_particles;
+      cfg.dim = x.size();
+      cfg.inertia = inertia0;
+      cfg.cognitive = cognitive_coef;
+      cfg.social = social_coef;
+      cfg.eps = eps;
+      cfg.max_iter = max_iter;
+      cfg.best_val_no_change = best_val_no_change;
+      cfg.seed = device::seed_from(generator);
+      nlsg_pso *eng = nullptr;
+      api.check(api.pso_create(&cfg, &eng));
+      nlsg_status st{};
+      const int rc = api.pso_minimize(eng, x.data(), lower.data(), upper.data(), 0, &st);
+      const std::string msg = rc ? api.last_error() : "";
+      api.pso_destroy(eng);
+      if (rc) throw device_error("nlsg error " + std::to_string(rc) + ": " + msg);
+      return solver_status<scalar_t>(st.f_value, st.iteration, st.function_calls_used);
+    } else {
+      return solve_host<minimize, constrained>(x, lower, upper);
+    }
+  }
+
+  // Host path for arbitrary callables: the reference's serial algorithm
+  // (init_solver_state 2626-2657, solve 2593-2624, update_best_positions
+  // 2716-2741 incl. its sentinels and best_index rule). Accelerated is literal;
+  // Vanilla uses the intended pbest/gbest terms (the reference's line 2669-2674
+  // has a zero cognitive term and reads swarm_best_position out of bounds).
+  template <bool minimize, bool constrained>
+  solver_status<scalar_t> solve_host(std::vector<scalar_t> &x, const std::vector<scalar_t> &lower,
+                                     const std::vector<scalar_t> &upper) {
+    const size_t D = lower.size(), NP = n_particles;
+    constexpr scalar_t sign = minimize ? 1.0 : -1.0;
+    std::vector<scalar_t> pos(NP * D), vel(Type == Vanilla ? NP * D : 0),
+        pbest_pos(Type == Vanilla ? NP * D : 0);
+    std::vector<scalar_t> pbest_val(NP, 10000), gbest, point(D);
+    scalar_t swarm_best = 100000.0, inertia = inertia0;
+    size_t f_evals = 0, stale = 0, iter = 0;
+    for (size_t i = 0; i < NP; i++)
+      for (size_t j = 0; j < D; j++) {
+        const scalar_t width = std::abs(upper[j] - lower[j]);
+        pos[i * D + j] = lower[j] + ((upper[j] - lower[j]) * generator());
+        if constexpr (Type == Vanilla) {
+          vel[i * D + j] = -width + (generator() * width);
+          pbest_pos[i * D + j] = pos[i * D + j];
+        }
+      }
+    for (;;) {
+      size_t best_index = 0;
+      bool improved = false;
+      for (size_t i = 0; i < NP; i++) {
+        point.assign(pos.begin() + i * D, pos.begin() + (i + 1) * D);
+        const scalar_t val = sign * f(point);
+        if (val < swarm_best) {
+          swarm_best = val;
+          best_index = i;
+          improved = true;
+        }
+        if (val < pbest_val[i]) {
+          pbest_val[i] = val;
+          if constexpr (Type == Vanilla)
+            std::copy(point.begin(), point.end(), pbest_pos.begin() + i * D);
+        }
+      }
+      f_evals += NP;
+      if (improved) gbest.assign(pos.begin() + best_index * D, pos.begin() + (best_index + 1) * D);
+      stale = (best_index == 0) * (stale + 1);  // nlsolver.h:2740
+      if (iter >= max_iter || stale >= best_val_no_change || std_err(pbest_val) < eps) {
+        x = gbest;
+        return solver_status<scalar_t>(swarm_best, iter, f_evals);
+      }
+      if constexpr (Type == Accelerated) inertia = std::pow(inertia0, iter);  // :2613
+      for (size_t i = 0; i < NP; i++)
+        for (size_t j = 0; j < D; j++) {
+          scalar_t &p = pos[i * D + j];
+          if constexpr (Type == Accelerated) {
+            p = inertia * rnorm<scalar_t>(generator) + (1 - cognitive_coef) * p +
+                social_coef * gbest[j];
+          } else {
+            const scalar_t r_p = generator(), r_g = generator();
+            scalar_t &v = vel[i * D + j];
+            v = (inertia * v) + cognitive_coef * r_p * (pbest_pos[i * D + j] - p) +
+                social_coef * r_g * (gbest[j] - p);
+            p += v;
+          }
+          if constexpr (constrained) {
+            p = p < lower[j] ? lower[j] : p;
+            p = p > upper[j] ? upper[j] : p;
+          }
+        }
+      iter++;
+    }
+  }
+};
+
+// README.md:99 uses the (stale) name PSOSolver for the same class.
+template <typename Callable, typename RNG, typename scalar_t = double, PSOType Type = Vanilla>
+using PSOSolver = PSO<Callable, RNG, scalar_t, Type>;
 
 }  // namespace nlsolver
 

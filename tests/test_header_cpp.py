@@ -88,3 +88,45 @@ def test_device_objective_through_header_matches_oracle(built, oracle, strategy,
     assert abs(hx(o["f_host"]) - hx(o["f"])) <= 1e-12 * max(1.0, abs(hx(o["f"])))
     if D == 2:
         assert np.all(np.abs(ref.best_x - 1.0) <= 0.05)  # the reference's own pass criterion
+
+
+def test_pso_host_path_through_header_matches_reference_bit_exact(built, golden):
+    out = json.loads(subprocess.check_output([os.path.join(built, "header_pso"), "host"], text=True))
+    gold = golden("pso.json")
+    for name in ("accel_2d_x0_3_3", "accel_256d_64p", "accel_8d_bounded", "accel_2d_default_stops"):
+        g, o = gold[name], out[name]
+        assert (o["fcalls"], o["iters"]) == (g["fcalls"], g["iters"]), name
+        assert hx(o["f"]) == hx(g["f"]) and o["x"] == g["x"] and o["rng_after"] == g["rng_after"]
+    # Vanilla with the intended update converges on the 2-D example (reference: UB)
+    assert hx(out["vanilla_2d_intended_update"]["f"]) < 0.1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,D,n,max_iter,eps,no_change,bound,bounded", [
+    ("accel", 2, 10, 50, 0.0, 1000, 3.0, 0),
+    ("accel", 256, 512, 12, 0.0, 1000, 2.048, 1),
+    ("vanilla", 16, 64, 40, 1e-3, 50, 2.0, 1),
+])
+def test_pso_device_objective_through_header_matches_oracle(built, oracle, kind, D, n, max_iter,
+                                                            eps, no_change, bound, bounded):
+    out = subprocess.check_output(
+        [os.path.join(built, "header_pso"), "device", kind, str(D), str(n), str(max_iter),
+         repr(eps), str(no_change), repr(bound), str(bounded)],
+        env=dict(os.environ, NLSG_LIBRARY=LIB), text=True)
+    o = json.loads(out)
+    assert "device_error" not in o, o
+    o = o["run"]
+    xs = O.XorShift()
+    oracle.orc_xorshift_init(C.byref(xs))
+    half = [min(int(oracle.orc_xorshift_next(C.byref(xs)) * 2.0**32), 2**32 - 1) for _ in range(2)]
+    seed = (half[0] << 32) | half[1]
+    ref = O.PSOSyncRun(oracle, "rosenbrock", n, D, -bound, bound, bounded=bool(bounded),
+                       type=O.PSO_ACCELERATED if kind == "accel" else O.PSO_VANILLA, eps=eps,
+                       max_iter=max_iter, best_val_no_change=no_change, seed=seed)
+    while not ref.s.done:
+        ref.step()
+    assert (o["fcalls"], o["iters"]) == (ref.s.fevals, ref.s.iter)
+    assert hx(o["f"]) == ref.s.gbest_val
+    assert np.array_equal(np.array([hx(v) for v in o["x"]]), ref.gbest_x)
+    after = [oracle.orc_xorshift_next(C.byref(xs)) for _ in range(2)]
+    assert [hx(v) for v in o["rng_after"]] == after
