@@ -170,6 +170,26 @@ int orc_pso_apply_records(orc_pso_sync *s, const double *recs, int world);
 void orc_pso_shard_move(orc_pso_sync *s, size_t lo, size_t n, int threads);
 void orc_pso_commit(orc_pso_sync *s);
 
+/* ------------------------------------------------------------------- BFGS --- */
+/* The convex quadratic of SURVEY.md §8c G6 (diag + rank-1):
+ *   f(x) = 1/2 sum d_i x_i^2 + 1/2 c (sum x)^2 - sum b_i x_i. */
+typedef struct {
+  const double *d, *b; /* n each */
+  double c;
+} orc_quad;
+typedef struct {
+  uint64_t f_calls, g_calls;
+  double *f_log; /* optional: every objective value in call order */
+  size_t f_cap, f_count;
+} orc_bfgs_counters;
+/* BFGS::solve<true> (nlsolver.h:3196-3285) with more_thuente_search (1527-1891) and
+ * update_inverse_hessian (3130-3168). tree = 0: the reference's sequential sums;
+ * tree = 1: the HIP kernel's lane tree. */
+orc_status orc_bfgs_quad(const orc_quad *q, double *x, size_t n, size_t max_iter, double grad_eps,
+                         double alpha, int tree, orc_bfgs_counters *cnt);
+void orc_update_inverse_hessian(double *H, const double *s, const double *y, double *t, double rho,
+                                size_t n, int tree);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,8 +54,38 @@ class PSOSync(C.Structure):
                 ("done", C.c_int), ("std_err", f64), ("inertia", f64)]
 
 
+class Quad(C.Structure):
+    _fields_ = [("d", pd), ("b", pd), ("c", f64)]
+
+
+class BfgsCounters(C.Structure):
+    _fields_ = [("f_calls", u64), ("g_calls", u64), ("f_log", pd), ("f_cap", sz), ("f_count", sz)]
+
+
 def _ptr(a):
     return a.ctypes.data_as(pd)
+
+
+def quad_problem(n, c=0.01):
+    """The G6 quadratic's parameters: d_i = 1 + 9 i/(n-1), b_i = sin(0.1 i)."""
+    import math
+    d = np.array([1.0 + 9.0 * i / (n - 1) if n > 1 else 1.0 for i in range(n)])
+    b = np.array([math.sin(0.1 * i) for i in range(n)])
+    return d, b, c
+
+
+def bfgs_quad(lib, x0, *, max_iter=100, grad_eps=5e-3, alpha=1.0, tree=0, log=False, c=0.01):
+    """Run the oracle's BFGS on the G6 quadratic; returns (status, x, f_log)."""
+    x = np.ascontiguousarray(x0, dtype=np.float64).copy()
+    n = x.size
+    d, b, c = quad_problem(n, c)
+    q = Quad(_ptr(d), _ptr(b), c)
+    cnt = BfgsCounters()
+    flog = np.zeros(22 * (max_iter + 1) + 4) if log else None
+    if log:
+        cnt.f_log, cnt.f_cap = _ptr(flog), flog.size
+    st = lib.orc_bfgs_quad(C.byref(q), _ptr(x), n, max_iter, grad_eps, alpha, tree, C.byref(cnt))
+    return st, x, (flog[:cnt.f_count] if log else None)
 
 
 def load():
@@ -107,6 +137,10 @@ def load():
     lib.orc_pso_apply_records.argtypes = [C.POINTER(PSOSync), pd, C.c_int]
     lib.orc_pso_shard_move.argtypes = [C.POINTER(PSOSync), sz, sz, C.c_int]
     lib.orc_pso_commit.argtypes = [C.POINTER(PSOSync)]
+    lib.orc_bfgs_quad.restype = Status
+    lib.orc_bfgs_quad.argtypes = [C.POINTER(Quad), pd, sz, sz, f64, f64, C.c_int,
+                                  C.POINTER(BfgsCounters)]
+    lib.orc_update_inverse_hessian.argtypes = [pd, pd, pd, pd, f64, sz, C.c_int]
     return lib
 
 

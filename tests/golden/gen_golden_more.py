@@ -16,3 +16,18 @@ def main():
         "vanilla_16d_10p_bounded": run("pso", "vanilla", 16, 10, 20, 0, 1000, "2.0", 1, 1, -1.0, 3.0),
     }
     write("pso.json", g4)
+
+    # G6 — BFGS + More-Thuente on the diag+rank-1 quadratic (nlsolver.h:3169-3286,
+    # 1527-1891), analytic gradient functor; every objective value is recorded.
+    # args: n max_iter grad_eps alpha x0 x0_step trace
+    g6 = {
+        "n8": run("bfgs", 8, 100, 1e-10, 1, 1, 0, 1),
+        "n64": run("bfgs", 64, 100, 1e-10, 1, 1, 0, 1),
+        "n1024": run("bfgs", 1024, 100, 1e-10, 1, 1, 0, 1),
+        "n64_default_stop": run("bfgs", 64, 100, 5e-3, 1, 1, 0, 1),
+        "n100_ragged_start": run("bfgs", 100, 100, 1e-10, 1, 0.5, 0.03, 1),
+        "n130_alpha_half": run("bfgs", 130, 100, 1e-10, 0.5, -2, 0.01, 1),
+        "n256_max_iter_5": run("bfgs", 256, 5, 0.0, 1, 1, 0, 1),
+        "hess_update_3x3": run("hess-update"),
+    }
+    write("bfgs.json", g6)
