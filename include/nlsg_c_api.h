@@ -206,6 +206,55 @@ uint64_t nlsg_pso_record_doubles(const nlsg_pso *e);
 int nlsg_pso_turn_begin(nlsg_pso *e, double *send_dev);
 int nlsg_pso_turn_end(nlsg_pso *e, const double *gathered_dev, int32_t world);
 
+/* ========================================================================== */
+/* Batched BFGS — replaces BFGS::solve (nlsolver.h:3196-3285), the More-Thuente */
+/* search it calls (cvsrch/cstep 1527-1793, more_thuente_search 1880-1891) and  */
+/* update_inverse_hessian (3130-3168), for `batch` independent starts of one    */
+/* objective (the reference solves one start per minimize() call).              */
+/* ========================================================================== */
+typedef struct nlsg_bfgs nlsg_bfgs;
+
+/* Objectives with an analytic gradient functor on device. */
+typedef enum {
+  /* f(x) = 1/2 sum d_i x_i^2 + 1/2 c (sum x)^2 - sum b_i x_i   */
+  NLSG_OBJ_QUAD_DIAG_RANK1 = 16
+} nlsg_grad_objective;
+
+typedef struct {
+  uint32_t struct_size;
+  int32_t device;
+  void *stream;
+  int32_t objective;   /* nlsg_grad_objective                                    */
+  int32_t reserved;
+  uint64_t batch;      /* independent problems                                    */
+  uint64_t dim;        /* x.size() of each problem (<= 1024)                      */
+  uint64_t max_iter;   /* ctor args of nlsolver.h:3181-3185                       */
+  double grad_eps, alpha;
+  double quad_c;       /* rank-1 weight of NLSG_OBJ_QUAD_DIAG_RANK1               */
+} nlsg_bfgs_config;
+
+/* diag_host / lin_host: d[dim], b[dim] of the objective (copied). */
+int nlsg_bfgs_create(const nlsg_bfgs_config *cfg, const double *diag_host,
+                     const double *lin_host, nlsg_bfgs **out);
+int nlsg_bfgs_destroy(nlsg_bfgs *e);
+/* x0_host: batch*dim start points (row-major). H = I, g = grad(x0) (3212, 3234). */
+int nlsg_bfgs_init(nlsg_bfgs *e, const double *x0_host);
+/* `iters` turns of the while(true) loop of 3238-3284 for every unfinished problem:
+ * stop tests, direction, reset guard, More-Thuente search, s/y/rho, rank-2 update. */
+int nlsg_bfgs_step(nlsg_bfgs *e, uint64_t iters);
+/* Number of problems whose stop test has not fired yet. Synchronises. */
+int nlsg_bfgs_unfinished(nlsg_bfgs *e, uint64_t *count);
+/* x (batch*dim) and per-problem status (batch). Synchronises. NULLs are skipped.
+ * status.f_value is f(x) evaluated when the stop test fired (3243). */
+int nlsg_bfgs_download(nlsg_bfgs *e, double *x_host, nlsg_status *status_host);
+/* Parity-test access: gradient (batch*dim) and inverse Hessian (batch*dim*dim) */
+int nlsg_bfgs_download_state(nlsg_bfgs *e, double *g_host, double *h_host);
+/* init + steps until every problem is done + download. */
+int nlsg_bfgs_minimize(nlsg_bfgs *e, double *x_inout_host, nlsg_status *status_host);
+/* hipEvent bracket around `iters` turns: total ms and the share spent in the two
+ * kernels that stream the inverse Hessians (t = H y; rank-2 update + next direction). */
+int nlsg_bfgs_time_steps(nlsg_bfgs *e, uint64_t iters, float *ms_total, float *ms_hessian);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,6 +55,15 @@ class PSOConfig(C.Structure):
                 ("max_iter", u64), ("best_val_no_change", u64), ("seed", u64)]
 
 
+OBJ_QUAD_DIAG_RANK1 = 16
+
+
+class BFGSConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("device", i32), ("stream", C.c_void_p),
+                ("objective", i32), ("reserved", i32), ("batch", u64), ("dim", u64),
+                ("max_iter", u64), ("grad_eps", f64), ("alpha", f64), ("quad_c", f64)]
+
+
 # every symbol include/nlsg_c_api.h declares: name -> (restype, argtypes)
 _H = C.c_void_p
 SYMBOLS = {
@@ -87,6 +96,15 @@ SYMBOLS = {
     "nlsg_pso_record_doubles": (u64, [_H]),
     "nlsg_pso_turn_begin": (C.c_int, [_H, C.c_void_p]),
     "nlsg_pso_turn_end": (C.c_int, [_H, C.c_void_p, i32]),
+    "nlsg_bfgs_create": (C.c_int, [C.POINTER(BFGSConfig), pd, pd, C.POINTER(_H)]),
+    "nlsg_bfgs_destroy": (C.c_int, [_H]),
+    "nlsg_bfgs_init": (C.c_int, [_H, pd]),
+    "nlsg_bfgs_step": (C.c_int, [_H, u64]),
+    "nlsg_bfgs_unfinished": (C.c_int, [_H, pu]),
+    "nlsg_bfgs_download": (C.c_int, [_H, pd, C.POINTER(Status)]),
+    "nlsg_bfgs_download_state": (C.c_int, [_H, pd, pd]),
+    "nlsg_bfgs_minimize": (C.c_int, [_H, pd, C.POINTER(Status)]),
+    "nlsg_bfgs_time_steps": (C.c_int, [_H, u64, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
 }
 
 _lib = None

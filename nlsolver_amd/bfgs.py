@@ -1,0 +1,124 @@
+"""Host-side mirror of the reference's BFGS class for device objectives, batched.
+
+Reference interface (nlsolver.h:3169-3196):
+    BFGS<Callable, scalar_t, Grad>(f, g = fin_diff, max_iter = 100, grad_eps = 5e-3, alpha = 1)
+    solver_status minimize(std::vector<T>& x)          (one start per call)
+Here `f` is a device objective with an analytic gradient (QuadDiagRank1); minimize() accepts one
+start (n,) or a batch of independent starts (batch, n) — BASELINE config 3 — solved in lock step
+on the GPU, and returns one status per start.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import BFGSConfig, Status, check, lib
+
+
+class QuadDiagRank1:
+    """f(x) = 1/2 sum d_i x_i^2 + 1/2 c (sum x)^2 - sum b_i x_i with its analytic gradient."""
+    nlsg_objective = _capi.OBJ_QUAD_DIAG_RANK1
+
+    def __init__(self, d, b, c):
+        self.d = np.ascontiguousarray(d, dtype=np.float64)
+        self.b = np.ascontiguousarray(b, dtype=np.float64)
+        self.c = float(c)
+        assert self.d.shape == self.b.shape and self.d.ndim == 1
+
+    def __call__(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        return 0.5 * np.sum(self.d * x * x) + 0.5 * self.c * np.sum(x) ** 2 - np.sum(self.b * x)
+
+
+class BFGSEngine:
+    def __init__(self, objective, batch, *, max_iter=100, grad_eps=5e-3, alpha=1.0, device=0,
+                 stream=None):
+        cfg = BFGSConfig()
+        cfg.struct_size = C.sizeof(BFGSConfig)
+        cfg.device = device
+        cfg.stream = None if stream is None else (stream or 1)
+        cfg.objective = objective.nlsg_objective
+        cfg.batch, cfg.dim = batch, objective.d.size
+        cfg.max_iter, cfg.grad_eps, cfg.alpha, cfg.quad_c = max_iter, grad_eps, alpha, objective.c
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        check(lib().nlsg_bfgs_create(C.byref(cfg), objective.d.ctypes.data_as(_capi.pd),
+                                     objective.b.ctypes.data_as(_capi.pd), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().nlsg_bfgs_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _x(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        assert x.shape == (self.cfg.batch, self.cfg.dim)
+        return x
+
+    def init(self, x0):
+        check(lib().nlsg_bfgs_init(self._h, self._x(x0).ctypes.data_as(_capi.pd)))
+
+    def step(self, iters=1):
+        check(lib().nlsg_bfgs_step(self._h, iters))
+
+    def unfinished(self):
+        c = C.c_uint64()
+        check(lib().nlsg_bfgs_unfinished(self._h, C.byref(c)))
+        return c.value
+
+    def download(self):
+        B, n = self.cfg.batch, self.cfg.dim
+        x = np.empty((B, n))
+        st = (Status * B)()
+        check(lib().nlsg_bfgs_download(self._h, x.ctypes.data_as(_capi.pd), st))
+        return x, list(st)
+
+    def download_state(self, hessian=True):
+        B, n = self.cfg.batch, self.cfg.dim
+        g = np.empty((B, n))
+        H = np.empty((B, n, n)) if hessian else None
+        check(lib().nlsg_bfgs_download_state(self._h, g.ctypes.data_as(_capi.pd),
+                                             H.ctypes.data_as(_capi.pd) if hessian else None))
+        return g, H
+
+    def minimize(self, x):
+        x = self._x(x)
+        st = (Status * self.cfg.batch)()
+        check(lib().nlsg_bfgs_minimize(self._h, x.ctypes.data_as(_capi.pd), st))
+        return x, list(st)
+
+    def time_steps(self, iters):
+        total, hess = C.c_float(), C.c_float()
+        check(lib().nlsg_bfgs_time_steps(self._h, iters, C.byref(total), C.byref(hess)))
+        return total.value, hess.value
+
+
+class BFGS:
+    """Drop-in for nlsolver::BFGS on a device objective; x may be (n,) or (batch, n)."""
+
+    def __init__(self, f, g=None, max_iter=100, grad_eps=5e-3, alpha=1.0, *, device=0):
+        if g is not None:
+            raise TypeError("device objectives carry their analytic gradient; pass g=None")
+        self.f = f
+        self.args = dict(max_iter=max_iter, grad_eps=grad_eps, alpha=alpha, device=device)
+
+    def minimize(self, x):
+        if not isinstance(x, np.ndarray) or x.dtype != np.float64 or x.ndim not in (1, 2):
+            raise TypeError("x must be a float64 numpy array of shape (n,) or (batch, n); "
+                            "it is updated in place")
+        xb = x.reshape(1, -1) if x.ndim == 1 else x
+        with BFGSEngine(self.f, xb.shape[0], **self.args) as eng:
+            out, st = eng.minimize(xb)
+        xb[...] = out
+        return st[0] if x.ndim == 1 else st
+
+    def maximize(self, x):  # nlsolver.h:3199 static_assert(minimize, ...)
+        raise NotImplementedError("BFGS currently only supports minimization (nlsolver.h:3199)")

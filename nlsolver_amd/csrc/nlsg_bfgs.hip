@@ -1,0 +1,290 @@
+// nlsolver_amd/csrc/nlsg_bfgs.hip — host side of the batched BFGS engine + C-ABI.
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include "nlsg_bfgs_kernels.h"
+
+using namespace nlsg;
+
+struct nlsg_bfgs {
+  nlsg_bfgs_config cfg;
+  BfgsParams p;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  double *qd_dev = nullptr, *qb_dev = nullptr, *zero_dev = nullptr;
+  unsigned long long *count_dev = nullptr;
+  int chunks = 0;
+  bool vec = false, initialised = false;
+  uint32_t bpp = 0;  // blocks per problem in the H-streaming kernels
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+};
+
+namespace {
+
+#define BFGS_DISPATCH(KERNEL, grid, ...)                                                         \
+  do {                                                                                           \
+    const dim3 g_(grid), b_(256);                                                                \
+    switch (e->chunks * 2 + (e->vec ? 1 : 0)) {                                                  \
+      case 2: hipLaunchKernelGGL((KERNEL<1, false>), g_, b_, 0, e->stream, __VA_ARGS__); break;  \
+      case 3: hipLaunchKernelGGL((KERNEL<1, true>), g_, b_, 0, e->stream, __VA_ARGS__); break;   \
+      case 4: hipLaunchKernelGGL((KERNEL<2, false>), g_, b_, 0, e->stream, __VA_ARGS__); break;  \
+      case 5: hipLaunchKernelGGL((KERNEL<2, true>), g_, b_, 0, e->stream, __VA_ARGS__); break;   \
+      case 8: hipLaunchKernelGGL((KERNEL<4, false>), g_, b_, 0, e->stream, __VA_ARGS__); break;  \
+      case 9: hipLaunchKernelGGL((KERNEL<4, true>), g_, b_, 0, e->stream, __VA_ARGS__); break;   \
+      case 16: hipLaunchKernelGGL((KERNEL<8, false>), g_, b_, 0, e->stream, __VA_ARGS__); break; \
+      case 17: hipLaunchKernelGGL((KERNEL<8, true>), g_, b_, 0, e->stream, __VA_ARGS__); break;  \
+      default: break;                                                                            \
+    }                                                                                            \
+  } while (0)
+
+void launch_iteration(nlsg_bfgs *e, bool timed) {
+  const unsigned wave_grid = static_cast<unsigned>((e->p.batch + 3) / 4);
+  const unsigned row_grid = static_cast<unsigned>(e->p.batch * e->bpp);
+  BFGS_DISPATCH(bfgs_search_kernel, wave_grid, e->p);
+  if (timed) hipEventRecord(e->ev2, e->stream);
+  BFGS_DISPATCH(bfgs_hy_kernel, row_grid, e->p, e->bpp);
+  BFGS_DISPATCH(bfgs_update_kernel, row_grid, e->p, e->bpp);
+  if (timed) hipEventRecord(e->ev3, e->stream);
+}
+
+int bfgs_check_device(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return fail(NLSG_ERR_NO_DEVICE, "no HIP device visible");
+  if (device < 0 || device >= n)
+    return fail(NLSG_ERR_INVALID_ARG, "device %d out of range (0..%d)", device, n - 1);
+  hipDeviceProp_t prop;
+  NLSG_HIP(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(NLSG_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only",
+                device, prop.gcnArchName);
+  return NLSG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nlsg_bfgs_create(const nlsg_bfgs_config *cfg, const double *diag_host, const double *lin_host,
+                     nlsg_bfgs **out) {
+  if (!cfg || !out || !diag_host || !lin_host) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  *out = nullptr;
+  if (cfg->struct_size != sizeof(nlsg_bfgs_config))
+    return fail(NLSG_ERR_INVALID_ARG, "nlsg_bfgs_config size mismatch (%u vs %zu)",
+                cfg->struct_size, sizeof(nlsg_bfgs_config));
+  if (cfg->objective != NLSG_OBJ_QUAD_DIAG_RANK1)
+    return fail(NLSG_ERR_INVALID_ARG, "unknown objective %d", cfg->objective);
+  if (cfg->dim < 1 || cfg->batch < 1) return fail(NLSG_ERR_INVALID_ARG, "dim and batch must be >= 1");
+  if (cfg->dim > 1024)
+    return fail(NLSG_ERR_UNSUPPORTED, "dim %llu > 1024 is not covered by the device path",
+                (unsigned long long)cfg->dim);
+  int rc = bfgs_check_device(cfg->device);
+  if (rc) return rc;
+  NLSG_HIP(hipSetDevice(cfg->device));
+  nlsg_bfgs *e = new (std::nothrow) nlsg_bfgs();
+  if (!e) return fail(NLSG_ERR_OOM, "host allocation failed");
+  e->cfg = *cfg;
+  const uint64_t n = cfg->dim, B = cfg->batch;
+  e->chunks = n <= 128 ? 1 : n <= 256 ? 2 : n <= 512 ? 4 : 8;
+  e->vec = n % 2 == 0;
+  e->bpp = static_cast<uint32_t>((n + 4 * kBfgsRowsPerWave - 1) / (4 * kBfgsRowsPerWave));
+  if (B * e->bpp > 0x7fffffffull) {
+    delete e;
+    return fail(NLSG_ERR_UNSUPPORTED, "batch * dim too large for one launch grid");
+  }
+  if (cfg->stream) {
+    e->stream = static_cast<hipStream_t>(cfg->stream);
+  } else {
+    hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (he != hipSuccess) {
+      delete e;
+      return fail(NLSG_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(he));
+    }
+    e->own_stream = true;
+  }
+  BfgsParams &p = e->p;
+  std::memset(&p, 0, sizeof p);
+  auto alloc = [&](void **ptr, size_t bytes) { return hipMalloc(ptr, bytes ? bytes : 8); };
+  hipError_t he = hipSuccess;
+  const size_t vec_bytes = B * n * sizeof(double);
+  if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&p.H), B * n * n * sizeof(double));
+  if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&p.x), vec_bytes);
+  if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&p.g), vec_bytes);
+  if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&p.dir), vec_bytes);
+  if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&p.s), vec_bytes);
+  if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&p.y), vec_bytes);
+  if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&p.t), vec_bytes);
+  if (he == hipSuccess) he = hipMemset(p.dir, 0, vec_bytes);
+  if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&p.prob), B * sizeof(BfgsProblem));
+  if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&e->qd_dev), n * sizeof(double));
+  if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&e->qb_dev), n * sizeof(double));
+  if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&e->zero_dev), 16);
+  if (he == hipSuccess) he = hipMemset(e->zero_dev, 0, 16);
+  if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&e->count_dev), 8);
+  if (he == hipSuccess)
+    he = hipMemcpy(e->qd_dev, diag_host, n * sizeof(double), hipMemcpyHostToDevice);
+  if (he == hipSuccess)
+    he = hipMemcpy(e->qb_dev, lin_host, n * sizeof(double), hipMemcpyHostToDevice);
+  if (he == hipSuccess) he = hipEventCreate(&e->ev0);
+  if (he == hipSuccess) he = hipEventCreate(&e->ev1);
+  if (he == hipSuccess) he = hipEventCreate(&e->ev2);
+  if (he == hipSuccess) he = hipEventCreate(&e->ev3);
+  if (he != hipSuccess) {
+    nlsg_bfgs_destroy(e);
+    return fail(he == hipErrorOutOfMemory ? NLSG_ERR_OOM : NLSG_ERR_HIP,
+                "device allocation failed: %s", hipGetErrorString(he));
+  }
+  p.qd = e->qd_dev;
+  p.qb = e->qb_dev;
+  p.zero = e->zero_dev;
+  p.batch = B;
+  p.n = n;
+  p.max_iter = cfg->max_iter;
+  p.grad_eps = cfg->grad_eps;
+  p.alpha = cfg->alpha;
+  p.qc = cfg->quad_c;
+  *out = e;
+  return NLSG_OK;
+}
+
+int nlsg_bfgs_destroy(nlsg_bfgs *e) {
+  if (!e) return NLSG_OK;
+  hipSetDevice(e->cfg.device);
+  if (e->stream) hipStreamSynchronize(e->stream);
+  hipFree(e->p.H);
+  hipFree(e->p.x);
+  hipFree(e->p.g);
+  hipFree(e->p.dir);
+  hipFree(e->p.s);
+  hipFree(e->p.y);
+  hipFree(e->p.t);
+  hipFree(e->p.prob);
+  hipFree(e->qd_dev);
+  hipFree(e->qb_dev);
+  hipFree(e->zero_dev);
+  hipFree(e->count_dev);
+  for (hipEvent_t ev : {e->ev0, e->ev1, e->ev2, e->ev3})
+    if (ev) hipEventDestroy(ev);
+  if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
+  delete e;
+  return NLSG_OK;
+}
+
+int nlsg_bfgs_init(nlsg_bfgs *e, const double *x0_host) {
+  if (!e || !x0_host) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  NLSG_HIP(hipSetDevice(e->cfg.device));
+  NLSG_HIP(hipMemcpyAsync(e->p.x, x0_host, e->p.batch * e->p.n * sizeof(double),
+                          hipMemcpyHostToDevice, e->stream));
+  NLSG_HIP(hipStreamSynchronize(e->stream));
+  BFGS_DISPATCH(bfgs_init_kernel, static_cast<unsigned>((e->p.batch + 3) / 4), e->p);
+  NLSG_HIP(hipGetLastError());
+  e->initialised = true;
+  return NLSG_OK;
+}
+
+int nlsg_bfgs_step(nlsg_bfgs *e, uint64_t iters) {
+  if (!e) return fail(NLSG_ERR_INVALID_ARG, "null engine");
+  if (!e->initialised) return fail(NLSG_ERR_STATE, "nlsg_bfgs_init has not been called");
+  NLSG_HIP(hipSetDevice(e->cfg.device));
+  for (uint64_t k = 0; k < iters; k++) launch_iteration(e, false);
+  NLSG_HIP(hipGetLastError());
+  return NLSG_OK;
+}
+
+int nlsg_bfgs_unfinished(nlsg_bfgs *e, uint64_t *count) {
+  if (!e || !count) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  if (!e->initialised) return fail(NLSG_ERR_STATE, "nlsg_bfgs_init has not been called");
+  NLSG_HIP(hipSetDevice(e->cfg.device));
+  NLSG_HIP(hipMemsetAsync(e->count_dev, 0, 8, e->stream));
+  hipLaunchKernelGGL(bfgs_count_unfinished_kernel,
+                     dim3(static_cast<unsigned>((e->p.batch + 255) / 256)), dim3(256), 0, e->stream,
+                     e->p, e->count_dev);
+  unsigned long long c = 0;
+  NLSG_HIP(hipMemcpyAsync(&c, e->count_dev, 8, hipMemcpyDeviceToHost, e->stream));
+  NLSG_HIP(hipStreamSynchronize(e->stream));
+  *count = c;
+  return NLSG_OK;
+}
+
+int nlsg_bfgs_download(nlsg_bfgs *e, double *x_host, nlsg_status *status_host) {
+  if (!e) return fail(NLSG_ERR_INVALID_ARG, "null engine");
+  if (!e->initialised) return fail(NLSG_ERR_STATE, "nlsg_bfgs_init has not been called");
+  NLSG_HIP(hipSetDevice(e->cfg.device));
+  NLSG_HIP(hipStreamSynchronize(e->stream));
+  const uint64_t B = e->p.batch, n = e->p.n;
+  if (x_host) NLSG_HIP(hipMemcpy(x_host, e->p.x, B * n * sizeof(double), hipMemcpyDeviceToHost));
+  if (status_host) {
+    std::vector<BfgsProblem> pr(B);
+    NLSG_HIP(hipMemcpy(pr.data(), e->p.prob, B * sizeof(BfgsProblem), hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < B; i++) {
+      nlsg_status &st = status_host[i];
+      st.f_value = pr[i].fval;
+      st.iteration = pr[i].iter;
+      st.function_calls_used = pr[i].fcalls;
+      st.gradient_evals_used = pr[i].gcalls;
+      st.hessian_evals_used = 0;
+      st.best_index = i;
+      st.val_no_change = 0;
+      st.std_err = pr[i].cur_norm;  // gradient norm at the last iterate
+      st.done = pr[i].done;
+      st.reserved = 0;
+    }
+  }
+  return NLSG_OK;
+}
+
+int nlsg_bfgs_download_state(nlsg_bfgs *e, double *g_host, double *h_host) {
+  if (!e) return fail(NLSG_ERR_INVALID_ARG, "null engine");
+  if (!e->initialised) return fail(NLSG_ERR_STATE, "nlsg_bfgs_init has not been called");
+  NLSG_HIP(hipSetDevice(e->cfg.device));
+  NLSG_HIP(hipStreamSynchronize(e->stream));
+  const uint64_t B = e->p.batch, n = e->p.n;
+  if (g_host) NLSG_HIP(hipMemcpy(g_host, e->p.g, B * n * sizeof(double), hipMemcpyDeviceToHost));
+  if (h_host)
+    NLSG_HIP(hipMemcpy(h_host, e->p.H, B * n * n * sizeof(double), hipMemcpyDeviceToHost));
+  return NLSG_OK;
+}
+
+int nlsg_bfgs_minimize(nlsg_bfgs *e, double *x_inout_host, nlsg_status *status_host) {
+  if (!e || !x_inout_host) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  int rc = nlsg_bfgs_init(e, x_inout_host);
+  if (rc) return rc;
+  // every problem stops after at most max_iter + 1 turns (the last one only fires the stop test)
+  uint64_t left = e->cfg.max_iter + 1;
+  for (;;) {
+    const uint64_t chunk = std::min<uint64_t>(left ? left : 1, 8);
+    rc = nlsg_bfgs_step(e, chunk);
+    if (rc) return rc;
+    left = left > chunk ? left - chunk : 0;
+    uint64_t open = 0;
+    rc = nlsg_bfgs_unfinished(e, &open);
+    if (rc) return rc;
+    if (open == 0) break;
+  }
+  return nlsg_bfgs_download(e, x_inout_host, status_host);
+}
+
+int nlsg_bfgs_time_steps(nlsg_bfgs *e, uint64_t iters, float *ms_total, float *ms_hessian) {
+  if (!e || !ms_total) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  if (!e->initialised) return fail(NLSG_ERR_STATE, "nlsg_bfgs_init has not been called");
+  NLSG_HIP(hipSetDevice(e->cfg.device));
+  float hess = 0.f;
+  NLSG_HIP(hipEventRecord(e->ev0, e->stream));
+  for (uint64_t k = 0; k < iters; k++) {
+    // one timed iteration per sync: the two inner events are reused
+    launch_iteration(e, true);
+    NLSG_HIP(hipEventSynchronize(e->ev3));
+    float ms = 0.f;
+    NLSG_HIP(hipEventElapsedTime(&ms, e->ev2, e->ev3));
+    hess += ms;
+  }
+  NLSG_HIP(hipEventRecord(e->ev1, e->stream));
+  NLSG_HIP(hipEventSynchronize(e->ev1));
+  NLSG_HIP(hipGetLastError());
+  NLSG_HIP(hipEventElapsedTime(ms_total, e->ev0, e->ev1));
+  if (ms_hessian) *ms_hessian = hess;
+  return NLSG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,502 @@
+// nlsolver_amd/csrc/nlsg_bfgs_kernels.h — gfx950 kernels of the batched BFGS engine.
+//
+// Replaces (nlsolver.h): BFGS::solve 3196-3285, update_inverse_hessian 3130-3168,
+// cvsrch 1673-1793, cstep 1527-1671, math::dot / norm 58-99.
+//
+// Data layout: inverse Hessians [batch][n][n] fp64 row-major (8 MiB per problem at
+// n = 1024, 32 GiB for batch = 4096); vectors [batch][n]. All problems advance in
+// lock step, one launch per phase:
+//   bfgs_search_kernel   one wave per problem: stop tests, reset guard, the whole
+//                        More-Thuente search (<= 20 f+g evaluations), s, x, g, y, rho
+//   bfgs_hy_kernel       t = H y            (reads H once)            — HBM bound
+//   bfgs_update_kernel   H -= rho (s t^T + t s^T + denom s s^T) fused with the next
+//                        direction d = -H' g (reads H, writes H)      — HBM bound
+// A freshly reset H (identity, 3212 / 3253-3260) is never materialised: a per-problem
+// flag makes the two streaming kernels treat H as I (no read).
+// Every reduction is the lane tree of DESIGN.md (element e -> lane (e%128)/2, in-lane
+// sequential, 64-lane xor butterfly), mirrored by oracle/oracle_bfgs.c (tree = 1).
+#pragma once
+
+#include "nlsg_common.h"
+
+namespace nlsg {
+
+struct BfgsProblem {  // per-problem scalars
+  double prev_norm, cur_norm, rho, fval;
+  uint64_t iter, fcalls, gcalls;
+  int32_t done, identity;
+};
+
+struct BfgsParams {
+  double *H;                  // [batch][n][n]
+  double *x, *g, *dir, *s, *y, *t;  // [batch][n]
+  BfgsProblem *prob;          // [batch]
+  const double *qd, *qb;      // objective parameters d, b [n]
+  const double *zero;
+  uint64_t batch, n, max_iter;
+  double grad_eps, alpha, qc;
+};
+
+// ---- wave-level vector helpers (vectors replicated in every lane layout) --------
+template <int CHUNKS>
+__device__ inline double wave_dot(const double (&a)[CHUNKS][2], const double (&b)[CHUNKS][2]) {
+  double acc = 0.0;
+#pragma unroll
+  for (int c = 0; c < CHUNKS; c++) {
+    acc = acc + a[c][0] * b[c][0];
+    acc = acc + a[c][1] * b[c][1];
+  }
+  return wave_sum(acc);
+}
+template <int CHUNKS>
+__device__ inline double wave_total(const double (&a)[CHUNKS][2]) {
+  double acc = 0.0;
+#pragma unroll
+  for (int c = 0; c < CHUNKS; c++) {
+    acc = acc + a[c][0];
+    acc = acc + a[c][1];
+  }
+  return wave_sum(acc);
+}
+
+// The G6 quadratic and its gradient (operation order of oracle_bfgs.c quad_f / quad_g).
+template <int CHUNKS>
+__device__ inline double quad_f(const double (&x)[CHUNKS][2], const double (&d)[CHUNKS][2],
+                                const double (&b)[CHUNKS][2], double c) {
+  double aq = 0.0, al = 0.0;
+#pragma unroll
+  for (int k = 0; k < CHUNKS; k++) {
+    aq = aq + d[k][0] * x[k][0] * x[k][0];
+    aq = aq + d[k][1] * x[k][1] * x[k][1];
+    al = al + b[k][0] * x[k][0];
+    al = al + b[k][1] * x[k][1];
+  }
+  const double qq = wave_sum(aq);
+  const double sx = wave_total<CHUNKS>(x);
+  const double lin = wave_sum(al);
+  return 0.5 * qq + 0.5 * c * (sx * sx) - lin;
+}
+template <int CHUNKS>
+__device__ inline void quad_g(const double (&x)[CHUNKS][2], const double (&d)[CHUNKS][2],
+                              const double (&b)[CHUNKS][2], double c, uint64_t n,
+                              double (&g)[CHUNKS][2]) {
+  const double sx = wave_total<CHUNKS>(x);
+  const int lane = lane_id();
+#pragma unroll
+  for (int k = 0; k < CHUNKS; k++) {
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const uint64_t e = static_cast<uint64_t>(k) * 128 + 2 * static_cast<uint64_t>(lane) + h;
+      const double v = d[k][h] * x[k][h] + c * sx - b[k][h];
+      g[k][h] = (e < n) ? v : 0.0;  // lanes past n hold zeros in every vector
+    }
+  }
+}
+
+// ---- More-Thuente (scalar code, identical in every lane) -------------------------
+__device__ inline double mt_max_abs3(double x, double y, double z) {
+  return fmax(fabs(x), fmax(fabs(y), fabs(z)));
+}
+__device__ inline double mt_min(double a, double b) { return b < a ? b : a; }
+__device__ inline double mt_max(double a, double b) { return a < b ? b : a; }
+__device__ inline double mt_clamp(double v, double lo, double hi) {
+  return v < lo ? lo : (hi < v ? hi : v);
+}
+
+// cstep, nlsolver.h:1527-1671
+__device__ inline int mt_cstep(double &stx, double &fx, double &dx, double &sty, double &fy,
+                               double &dy, double &stp, double fp, double dp, int &brackt,
+                               double stpmin, double stpmax, int &info) {
+  info = 0;
+  int bound;
+  if ((brackt & ((stp <= mt_min(stx, sty)) || (stp >= mt_max(stx, sty)))) ||
+      (dx * (stp - stx) >= 0.0) || (stpmax < stpmin))
+    return -1;
+  const double sgnd = dp * (dx / fabs(dx));
+  double stpf = 0, stpc, stpq;
+  if (fp > fx) {
+    info = 1;
+    bound = 1;
+    const double theta = 3. * (fx - fp) / (stp - stx) + dx + dp;
+    const double s = mt_max_abs3(theta, dx, dp);
+    double gamma = s * sqrt((theta / s) * (theta / s) - (dx / s) * (dp / s));
+    if (stp < stx) gamma = -gamma;
+    const double p = (gamma - dx) + theta;
+    const double q = ((gamma - dx) + gamma) + dp;
+    const double r = p / q;
+    stpc = stx + r * (stp - stx);
+    stpq = stx + ((dx / ((fx - fp) / (stp - stx) + dx)) / 2.) * (stp - stx);
+    if (fabs(stpc - stx) < fabs(stpq - stx))
+      stpf = stpc;
+    else
+      stpf = stpc + (stpq - stpc) / 2;
+    brackt = 1;
+  } else if (sgnd < 0.0) {
+    info = 2;
+    bound = 0;
+    const double theta = 3 * (fx - fp) / (stp - stx) + dx + dp;
+    const double s = mt_max_abs3(theta, dx, dp);
+    double gamma = s * sqrt((theta / s) * (theta / s) - (dx / s) * (dp / s));
+    if (stp > stx) gamma = -gamma;
+    const double p = (gamma - dp) + theta;
+    const double q = ((gamma - dp) + gamma) + dx;
+    const double r = p / q;
+    stpc = stp + r * (stx - stp);
+    stpq = stp + (dp / (dp - dx)) * (stx - stp);
+    if (fabs(stpc - stp) > fabs(stpq - stp))
+      stpf = stpc;
+    else
+      stpf = stpq;
+    brackt = 1;
+  } else if (fabs(dp) < fabs(dx)) {
+    info = 3;
+    bound = 1;
+    const double theta = 3 * (fx - fp) / (stp - stx) + dx + dp;
+    const double s = mt_max_abs3(theta, dx, dp);
+    double gamma = s * sqrt(mt_max(0., (theta / s) * (theta / s) - (dx / s) * (dp / s)));
+    if (stp > stx) gamma = -gamma;
+    const double p = (gamma - dp) + theta;
+    const double q = (gamma + (dx - dp)) + gamma;
+    const double r = p / q;
+    if ((r < 0.0) & (gamma != 0.0))
+      stpc = stp + r * (stx - stp);
+    else if (stp > stx)
+      stpc = stpmax;
+    else
+      stpc = stpmin;
+    stpq = stp + (dp / (dp - dx)) * (stx - stp);
+    if (brackt)
+      stpf = (fabs(stp - stpc) < fabs(stp - stpq)) ? stpc : stpq;
+    else
+      stpf = (fabs(stp - stpc) > fabs(stp - stpq)) ? stpc : stpq;
+  } else {
+    info = 4;
+    bound = 0;
+    if (brackt) {
+      const double theta = 3 * (fp - fy) / (sty - stp) + dy + dp;
+      const double s = mt_max_abs3(theta, dy, dp);
+      double gamma = s * sqrt((theta / s) * (theta / s) - (dy / s) * (dp / s));
+      if (stp > sty) gamma = -gamma;
+      const double p = (gamma - dp) + theta;
+      const double q = ((gamma - dp) + gamma) + dy;
+      const double r = p / q;
+      stpc = stp + r * (sty - stp);
+      stpf = stpc;
+    } else if (stp > stx) {
+      stpf = stpmax;
+    } else {
+      stpf = stpmin;
+    }
+  }
+  if (fp > fx) {
+    sty = stp;
+    fy = fp;
+    dy = dp;
+  } else {
+    if (sgnd < 0.0) {
+      sty = stx;
+      fy = fx;
+      dy = dx;
+    }
+    stx = stp;
+    fx = fp;
+    dx = dp;
+  }
+  stpf = mt_clamp(stpf, stpmin, stpmax);
+  stp = stpf;
+  if (brackt & bound) {
+    if (sty > stx)
+      stp = mt_min(stx + 0.66 * (sty - stx), stp);
+    else
+      stp = mt_max(stx + 0.66 * (sty - stx), stp);
+  }
+  return 0;
+}
+
+template <int CHUNKS, bool VEC>
+__device__ inline void load_vec(const double *p, uint64_t n, const double *zero,
+                                double (&v)[CHUNKS][2]) {
+  load_row<CHUNKS, VEC>(p, n, zero, v);
+}
+
+// One wave per problem: everything of an iteration except the two H passes.
+template <int CHUNKS, bool VEC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void
+bfgs_search_kernel(BfgsParams p) {
+  const uint64_t pid = static_cast<uint64_t>(blockIdx.x) * 4 +
+                       __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+  if (pid >= p.batch) return;
+  BfgsProblem *pr = p.prob + pid;
+  if (pr->done) return;
+  const int lane = lane_id();
+  const uint64_t n = p.n;
+  double x[CHUNKS][2], g[CHUNKS][2], dir[CHUNKS][2], qd[CHUNKS][2], qb[CHUNKS][2];
+  load_vec<CHUNKS, VEC>(p.x + pid * n, n, p.zero, x);
+  load_vec<CHUNKS, VEC>(p.g + pid * n, n, p.zero, g);
+  load_vec<CHUNKS, VEC>(p.dir + pid * n, n, p.zero, dir);
+  load_vec<CHUNKS, VEC>(p.qd, n, p.zero, qd);
+  load_vec<CHUNKS, VEC>(p.qb, n, p.zero, qb);
+  uint64_t iter = pr->iter, fcalls = pr->fcalls, gcalls = pr->gcalls;
+  double prev_norm = pr->prev_norm, cur_norm = pr->cur_norm;
+
+  // stop tests, nlsolver.h:3239-3246
+  if (iter >= p.max_iter || cur_norm < p.grad_eps || fabs(cur_norm - prev_norm) < p.grad_eps ||
+      isinf(cur_norm)) {
+    const double fv = quad_f<CHUNKS>(x, qd, qb, p.qc);
+    if (lane == 0) {
+      pr->fval = fv;
+      pr->fcalls = fcalls + 1;
+      pr->done = 1;
+    }
+    return;
+  }
+  // direction: d = -H g, computed by the previous update pass (or -g while H = I)
+  // H in memory is valid after the previous update pass; only the very first
+  // iteration (H = I, :3212) and the reset guard below use the identity shortcut
+  int identity = (iter == 0) ? 1 : 0;
+  if (identity) {
+#pragma unroll
+    for (int c = 0; c < CHUNKS; c++) {
+      dir[c][0] = -g[c][0];
+      dir[c][1] = -g[c][1];
+    }
+  }
+  const double phi = wave_dot<CHUNKS>(g, dir);
+  if ((phi > 0) || isnan(phi) || cur_norm > prev_norm) {  // reset guard, :3253-3260
+    identity = 1;
+#pragma unroll
+    for (int c = 0; c < CHUNKS; c++) {
+      dir[c][0] = -g[c][0];
+      dir[c][1] = -g[c][1];
+    }
+  }
+  double pg[CHUNKS][2];
+#pragma unroll
+  for (int c = 0; c < CHUNKS; c++) {
+    pg[c][0] = g[c][0];
+    pg[c][1] = g[c][1];
+  }
+  // more_thuente_search (1880-1891) -> cvsrch (1673-1793)
+  const double f0 = quad_f<CHUNKS>(x, qd, qb, p.qc);
+  fcalls++;
+  double stp = p.alpha;
+  {
+    int info = 0, infoc = 1;
+    const double xtol = 1e-15, ftol = 1e-4, gtol = 1e-2, stpmin = 1e-15, stpmax = 1e15, xtrapf = 4;
+    const int maxfev = 20;
+    int nfev = 0;
+    const double dginit = wave_dot<CHUNKS>(g, dir);
+    if (!(dginit >= 0.0)) {
+      int brackt = 0, stage1 = 1;
+      const double finit = f0, dgtest = ftol * dginit;
+      double width = stpmax - stpmin, width1 = 2 * width;
+      double stx = 0.0, fx = finit, dgx = dginit, sty = 0.0, fy = finit, dgy = dginit;
+      double stmin, stmax;
+      for (;;) {
+        if (brackt) {
+          stmin = mt_min(stx, sty);
+          stmax = mt_max(stx, sty);
+        } else {
+          stmin = stx;
+          stmax = stp + xtrapf * (stp - stx);
+        }
+        stp = mt_clamp(stp, stpmin, stpmax);
+        if ((brackt && ((stp <= stmin) || (stp >= stmax))) || (nfev >= maxfev - 1) ||
+            (infoc == 0) || (brackt && ((stmax - stmin) <= (xtol * stmax))))
+          stp = stx;
+        double tmp[CHUNKS][2];
+#pragma unroll
+        for (int c = 0; c < CHUNKS; c++) {
+          tmp[c][0] = x[c][0] + stp * dir[c][0];
+          tmp[c][1] = x[c][1] + stp * dir[c][1];
+        }
+        const double fcur = quad_f<CHUNKS>(tmp, qd, qb, p.qc);
+        fcalls++;
+        quad_g<CHUNKS>(tmp, qd, qb, p.qc, n, g);
+        gcalls++;
+        nfev++;
+        const double dg = wave_dot<CHUNKS>(g, dir);
+        const double ftest1 = finit + stp * dgtest;
+        if ((brackt & ((stp <= stmin) | (stp >= stmax))) | (infoc == 0)) info = 6;
+        if ((stp == stpmax) & (fcur <= ftest1) & (dg <= dgtest)) info = 5;
+        if ((stp == stpmin) & ((fcur > ftest1) | (dg >= dgtest))) info = 4;
+        if (nfev >= maxfev) info = 3;
+        if (brackt & (stmax - stmin <= xtol * stmax)) info = 2;
+        if ((fcur <= ftest1) & (fabs(dg) <= gtol * (-dginit))) info = 1;
+        if (info != 0) break;
+        if (stage1 & (fcur <= ftest1) & (dg >= mt_min(ftol, gtol) * dginit)) stage1 = 0;
+        if (stage1 & (fcur <= fx) & (fcur > ftest1)) {
+          const double fm = fcur - stp * dgtest;
+          double fxm = fx - stx * dgtest, fym = fy - sty * dgtest;
+          const double dgm = dg - dgtest;
+          double dgxm = dgx - dgtest, dgym = dgy - dgtest;
+          mt_cstep(stx, fxm, dgxm, sty, fym, dgym, stp, fm, dgm, brackt, stmin, stmax, infoc);
+          fx = fxm + stx * dgtest;
+          fy = fym + sty * dgtest;
+          dgx = dgxm + dgtest;
+          dgy = dgym + dgtest;
+        } else {
+          mt_cstep(stx, fx, dgx, sty, fy, dgy, stp, fcur, dg, brackt, stmin, stmax, infoc);
+        }
+        if (brackt) {
+          if (fabs(sty - stx) >= 0.66 * width1) stp = stx + 0.5 * (sty - stx);
+          width1 = width;
+          width = fabs(sty - stx);
+        }
+      }
+    }
+  }
+  // s = rate d; x += s; g = grad(x); norms; y; rho  (3266-3278)
+  double s[CHUNKS][2], y[CHUNKS][2];
+#pragma unroll
+  for (int c = 0; c < CHUNKS; c++) {
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      s[c][h] = dir[c][h] * stp;
+      x[c][h] = x[c][h] + s[c][h];
+    }
+  }
+  quad_g<CHUNKS>(x, qd, qb, p.qc, n, g);
+  gcalls++;
+  prev_norm = cur_norm;
+  cur_norm = sqrt(wave_dot<CHUNKS>(g, g));
+#pragma unroll
+  for (int c = 0; c < CHUNKS; c++) {
+    y[c][0] = g[c][0] - pg[c][0];
+    y[c][1] = g[c][1] - pg[c][1];
+  }
+  double rho = wave_dot<CHUNKS>(y, s);
+  rho = 1 / rho;
+  store_row<CHUNKS, VEC>(p.x + pid * n, n, x);
+  store_row<CHUNKS, VEC>(p.g + pid * n, n, g);
+  store_row<CHUNKS, VEC>(p.s + pid * n, n, s);
+  store_row<CHUNKS, VEC>(p.y + pid * n, n, y);
+  if (lane == 0) {
+    pr->prev_norm = prev_norm;
+    pr->cur_norm = cur_norm;
+    pr->rho = rho;
+    pr->iter = iter + 1;
+    pr->fcalls = fcalls;
+    pr->gcalls = gcalls;
+    pr->identity = identity;
+  }
+}
+
+// g = grad(x0), norms as at nlsolver.h:3234-3237
+template <int CHUNKS, bool VEC>
+__global__ __launch_bounds__(256) void bfgs_init_kernel(BfgsParams p) {
+  const uint64_t pid = static_cast<uint64_t>(blockIdx.x) * 4 +
+                       __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+  if (pid >= p.batch) return;
+  const uint64_t n = p.n;
+  double x[CHUNKS][2], g[CHUNKS][2], qd[CHUNKS][2], qb[CHUNKS][2];
+  load_vec<CHUNKS, VEC>(p.x + pid * n, n, p.zero, x);
+  load_vec<CHUNKS, VEC>(p.qd, n, p.zero, qd);
+  load_vec<CHUNKS, VEC>(p.qb, n, p.zero, qb);
+  quad_g<CHUNKS>(x, qd, qb, p.qc, n, g);
+  store_row<CHUNKS, VEC>(p.g + pid * n, n, g);
+  if (lane_id() == 0) {
+    BfgsProblem *pr = p.prob + pid;
+    pr->prev_norm = 1e9;
+    pr->cur_norm = 1e8;
+    pr->rho = 0.0;
+    pr->fval = 0.0;
+    pr->iter = 0;
+    pr->fcalls = 0;
+    pr->gcalls = 1;
+    pr->done = 0;
+    pr->identity = 1;
+  }
+}
+
+constexpr int kBfgsRowsPerWave = 8;  // rows a wave streams per launch (vector kept in regs)
+
+// t = H y (first loop of update_inverse_hessian, 3139-3142). Block = 4 waves = 32 rows.
+template <int CHUNKS, bool VEC>
+__global__ __launch_bounds__(256) void bfgs_hy_kernel(BfgsParams p, uint32_t blocks_per_problem) {
+  const uint64_t pid = blockIdx.x / blocks_per_problem;
+  const BfgsProblem *pr = p.prob + pid;
+  if (pr->done) return;
+  const uint64_t n = p.n;
+  const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+  const uint64_t row0 =
+      (static_cast<uint64_t>(blockIdx.x % blocks_per_problem) * 4 + wid) * kBfgsRowsPerWave;
+  if (row0 >= n) return;
+  const int lane = lane_id();
+  double y[CHUNKS][2];
+  load_vec<CHUNKS, VEC>(p.y + pid * n, n, p.zero, y);
+  double *t = p.t + pid * n;
+  if (pr->identity) {  // H = I: t = y exactly, nothing to stream
+    for (int r = 0; r < kBfgsRowsPerWave; r++) {
+      const uint64_t j = row0 + r;
+      if (j < n && lane == 0) t[j] = p.y[pid * n + j];
+    }
+    return;
+  }
+  const double *Hp = p.H + pid * n * n;
+#pragma unroll 2
+  for (int r = 0; r < kBfgsRowsPerWave; r++) {
+    const uint64_t j = row0 + r;
+    if (j >= n) break;
+    double h[CHUNKS][2];
+    load_row<CHUNKS, VEC>(Hp + j * n, n, p.zero, h);
+    const double v = wave_dot<CHUNKS>(y, h);  // dot(grad_diff, H row), :3140
+    if (lane == 0) t[j] = v;
+  }
+}
+
+// rank-2 update (3151-3164) fused with the next direction d = -H' g (3248-3251)
+template <int CHUNKS, bool VEC>
+__global__ __launch_bounds__(256) void bfgs_update_kernel(BfgsParams p,
+                                                        uint32_t blocks_per_problem) {
+  const uint64_t pid = blockIdx.x / blocks_per_problem;
+  const BfgsProblem *pr = p.prob + pid;
+  if (pr->done) return;
+  const uint64_t n = p.n;
+  const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+  const uint64_t row0 =
+      (static_cast<uint64_t>(blockIdx.x % blocks_per_problem) * 4 + wid) * kBfgsRowsPerWave;
+  if (row0 >= n) return;
+  const int lane = lane_id();
+  double s[CHUNKS][2], t[CHUNKS][2], y[CHUNKS][2], g[CHUNKS][2];
+  load_vec<CHUNKS, VEC>(p.s + pid * n, n, p.zero, s);
+  load_vec<CHUNKS, VEC>(p.t + pid * n, n, p.zero, t);
+  load_vec<CHUNKS, VEC>(p.y + pid * n, n, p.zero, y);
+  load_vec<CHUNKS, VEC>(p.g + pid * n, n, p.zero, g);
+  const double rho = pr->rho;
+  double denom = wave_dot<CHUNKS>(y, t);  // :3143-3145
+  denom = (denom * rho) + 1.0;
+  const bool identity = pr->identity != 0;
+  double *Hp = p.H + pid * n * n;
+  double *dir = p.dir + pid * n;
+#pragma unroll 2
+  for (int r = 0; r < kBfgsRowsPerWave; r++) {
+    const uint64_t j = row0 + r;
+    if (j >= n) break;
+    double h[CHUNKS][2];
+    // H = I is never materialised: identity rows are synthesised
+    load_row<CHUNKS, VEC>(Hp + j * n, identity ? 0 : n, p.zero, h);
+    const double sj = p.s[pid * n + j], tj = p.t[pid * n + j];
+#pragma unroll
+    for (int c = 0; c < CHUNKS; c++) {
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const uint64_t i = static_cast<uint64_t>(c) * 128 + 2 * static_cast<uint64_t>(lane) + k;
+        const double hij = identity ? (i == j ? 1.0 : 0.0) : h[c][k];
+        const double v =
+            hij - rho * (s[c][k] * tj + t[c][k] * sj + denom * s[c][k] * sj);  // :3156-3163
+        h[c][k] = (i < n) ? v : 0.0;
+      }
+    }
+    store_row<CHUNKS, VEC>(Hp + j * n, n, h);
+    const double dj = -wave_dot<CHUNKS>(h, g);  // :3249-3250 with the updated row
+    if (lane == 0) dir[j] = dj;
+  }
+}
+
+__global__ void bfgs_count_unfinished_kernel(BfgsParams p, unsigned long long *count) {
+  const uint64_t pid = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (pid < p.batch && !p.prob[pid].done) atomicAdd(count, 1ull);
+}
+
+}  // namespace nlsg
