@@ -75,6 +75,54 @@ def pmc_traffic(pop_local):
     return (2.0 * fetch + write) * 1024.0
 
 
+def main_bfgs(args):
+    """BASELINE configs[2]: BFGS on the convex quadratic, dim=1024, batch=4096 independent
+    starts on one GPU. One step = one BFGS iteration of every problem (stop tests, direction,
+    More-Thuente search, rank-2 inverse-Hessian update). Replicas only across GPUs (problems
+    are independent, no collective)."""
+    import math
+
+    import torch
+
+    import nlsolver_amd
+    n = 1024
+    batch = 4096 if args.pop_per_gpu == POP_PER_GPU else args.pop_per_gpu
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    d = np.array([1.0 + 9.0 * i / (n - 1) for i in range(n)])
+    b = np.array([math.sin(0.1 * i) for i in range(n)])
+    rng = np.random.default_rng(12374563468 % 2**32)
+    x0 = 1.0 + 0.5 * (rng.random((batch, n)) - 0.5)
+    steps, warm = min(args.steps, 40), min(args.warmup, 4)
+    eng = nlsolver_amd.BFGSEngine(nlsolver_amd.QuadDiagRank1(d, b, 0.01), batch,
+                                  max_iter=10**9, grad_eps=0.0, alpha=1.0, device=local_rank)
+    eng.init(x0)
+    eng.step(warm)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.step(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    open_ = eng.unfinished()
+    total_ms, hess_ms = eng.time_steps(4)
+    hess_ms /= 4
+    bytes_per_iter = 3 * n * n * 8 * batch  # read H (t = H y) + read & write H (update)
+    achieved = bytes_per_iter / (hess_ms * 1e-3) / 1e9
+    print(json.dumps({
+        "metric": "BFGS iterations x problems / s (quadratic dim=1024)",
+        "value": batch * steps / dt, "unit": "iteration-problems/s", "n_gpus": 1, "steps": steps,
+        "warmup": warm, "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"BFGS + More-Thuente, convex quadratic dim={n}, batch={batch} "
+                               "independent starts (BASELINE configs[2])",
+                   "unfinished_problems": open_},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "bfgs_hy_kernel + bfgs_update_kernel", "kernel_ms": hess_ms,
+                     "algorithmic_bytes_per_launch": bytes_per_iter}}))
+    eng.close()
+
+
 def main_pso(args):
     """BASELINE configs[4]: PSO swarm = 2^20 particles x D=256 sharded over 8 GPUs ->
     131072 particles per GPU (weak scaling). One step = best update + stop tests + one
@@ -167,10 +215,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--pop-per-gpu", type=int, default=POP_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["de", "pso-accel", "pso-vanilla"], default="de",
+    ap.add_argument("--workload", choices=["de", "pso-accel", "pso-vanilla", "bfgs"], default="de",
                     help="de = the headline benchmark (BASELINE metric); pso-* = config 5's "
                          "per-GPU shard (secondary, same JSON shape)")
     args = ap.parse_args()
+    if args.workload == "bfgs":
+        return main_bfgs(args)
     if args.workload != "de":
         return main_pso(args)
 
