@@ -21,14 +21,17 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include <iostream>
+#include <limits>
 #include <stdexcept>
 #include <string>
 #include <tuple>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "../nlsg_c_api.h"
@@ -199,6 +202,32 @@ struct Rastrigin {  // test_functions.h:69-78
   }
 };
 
+// Objectives with an analytic gradient on the device (batched BFGS):
+// f(x) = 1/2 sum d_i x_i^2 + 1/2 c (sum x)^2 - sum b_i x_i  (SURVEY.md §8c G6).
+template <typename T = double>
+struct QuadDiagRank1 {
+  static constexpr int nlsg_grad_objective = NLSG_OBJ_QUAD_DIAG_RANK1;
+  std::vector<T> d, b;
+  T c;
+  QuadDiagRank1(std::vector<T> d, std::vector<T> b, T c) : d(std::move(d)), b(std::move(b)), c(c) {}
+  T operator()(const std::vector<T> &x) const {
+    T q = 0, sx = 0, lin = 0;
+    for (size_t i = 0; i < x.size(); i++) {
+      q += d[i] * x[i] * x[i];
+      sx += x[i];
+      lin += b[i] * x[i];
+    }
+    return 0.5 * q + 0.5 * c * (sx * sx) - lin;
+  }
+};
+// Grad tag for device objectives: their gradient is evaluated by the kernels.
+struct analytic_grad {};
+
+template <typename C, typename = void>
+struct has_grad_objective : std::false_type {};
+template <typename C>
+struct has_grad_objective<C, std::void_t<decltype(C::nlsg_grad_objective)>> : std::true_type {};
+
 template <typename C, typename = void>
 struct is_device_objective : std::false_type {};
 template <typename C>
@@ -220,6 +249,9 @@ class api {
   decltype(&nlsg_pso_create) pso_create;
   decltype(&nlsg_pso_destroy) pso_destroy;
   decltype(&nlsg_pso_minimize) pso_minimize;
+  decltype(&nlsg_bfgs_create) bfgs_create;
+  decltype(&nlsg_bfgs_destroy) bfgs_destroy;
+  decltype(&nlsg_bfgs_minimize) bfgs_minimize;
 
   void check(int rc) const {
     if (rc != NLSG_OK)
@@ -242,6 +274,9 @@ class api {
     bind(h, "nlsg_pso_create", pso_create);
     bind(h, "nlsg_pso_destroy", pso_destroy);
     bind(h, "nlsg_pso_minimize", pso_minimize);
+    bind(h, "nlsg_bfgs_create", bfgs_create);
+    bind(h, "nlsg_bfgs_destroy", bfgs_destroy);
+    bind(h, "nlsg_bfgs_minimize", bfgs_minimize);
     if (abi_version() != NLSG_ABI_VERSION)
       throw device_error("libnlsolver_hip.so ABI version mismatch");
   }
@@ -577,6 +612,339 @@ class PSO {
 // README.md:99 uses the (stale) name PSOSolver for the same class.
 template <typename Callable, typename RNG, typename scalar_t = double, PSOType Type = Vanilla>
 using PSOSolver = PSO<Callable, RNG, scalar_t, Type>;
+
+// ---------------------------------------------------------------------------
+// finite differences + line search + BFGS — nlsolver.h:1383-1412, 1519-1891, 3130-3286
+// ---------------------------------------------------------------------------
+namespace finite_difference {
+// central differences of accuracy 1 (4 evaluations per dimension), the only order the
+// default Grad functor uses (nlsolver.h:1385-1412 with accuracy = 1, 2852-2853)
+template <typename Callable, typename scalar_t>
+void finite_difference_gradient(Callable &f, std::vector<scalar_t> &x, std::vector<scalar_t> &grad) {
+  constexpr scalar_t eps = std::numeric_limits<scalar_t>::epsilon() * 10e7;
+  constexpr scalar_t coeff[4] = {1, -8, 8, -1}, shift[4] = {-2, -1, 1, 2};
+  constexpr scalar_t dd = 12 * eps;
+  std::fill(grad.begin(), grad.end(), 0.0);
+  for (size_t d = 0; d < x.size(); d++) {
+    for (int k = 0; k < 4; k++) {
+      const scalar_t keep = x[d];
+      x[d] += shift[k] * eps;
+      grad[d] += coeff[k] * f(x);
+      x[d] = keep;
+    }
+    grad[d] /= dd;
+  }
+}
+}  // namespace finite_difference
+
+template <typename Callable, typename scalar_t>
+struct fin_diff {  // nlsolver.h:2848-2855
+  void operator()(Callable &f, std::vector<scalar_t> &x, std::vector<scalar_t> &gradient) {
+    finite_difference::finite_difference_gradient<Callable, scalar_t>(f, x, gradient);
+  }
+};
+
+namespace math {
+template <typename T>
+inline T dot(const T *x, const T *y, int n) {  // nlsolver.h:58-67
+  T s = 0;
+  for (int i = 0; i < n; i++) s += x[i] * y[i];
+  return s;
+}
+template <typename T>
+inline T norm(const T *x, int n) {  // nlsolver.h:91-99
+  T s = 0;
+  for (int i = 0; i < n; i++) s += x[i] * x[i];
+  return std::sqrt(s);
+}
+}  // namespace math
+
+namespace linesearch {
+// More-Thuente safeguarded step (nlsolver.h:1527-1671). Interval end points and the
+// trial are updated in place; `info` reports the case (0 = rejected input).
+template <typename T>
+struct mt_interval {
+  T stx, fx, dx, sty, fy, dy;
+  bool brackt;
+};
+template <typename T>
+static int cstep(mt_interval<T> &iv, T &stp, const T fp, const T dp, const T stpmin, const T stpmax,
+                 int &info) {
+  info = 0;
+  T &stx = iv.stx, &fx = iv.fx, &dx = iv.dx, &sty = iv.sty, &fy = iv.fy, &dy = iv.dy;
+  bool &brackt = iv.brackt;
+  bool bound;
+  if ((brackt & ((stp <= std::min<T>(stx, sty)) || (stp >= std::max<T>(stx, sty)))) ||
+      (dx * (stp - stx) >= 0.0) || (stpmax < stpmin))
+    return -1;
+  const T sgnd = dp * (dx / std::fabs(dx));
+  auto cubic = [](T theta, T a, T b) {
+    const T s = std::max(std::fabs(theta), std::max(std::fabs(a), std::fabs(b)));
+    return std::make_pair(s, (theta / s) * (theta / s) - (a / s) * (b / s));
+  };
+  T stpf = 0, stpc, stpq;
+  if (fp > fx) {
+    info = 1;
+    bound = true;
+    const T theta = 3. * (fx - fp) / (stp - stx) + dx + dp;
+    auto [s, rad] = cubic(theta, dx, dp);
+    T gamma = s * std::sqrt(rad);
+    if (stp < stx) gamma = -gamma;
+    const T r = ((gamma - dx) + theta) / (((gamma - dx) + gamma) + dp);
+    stpc = stx + r * (stp - stx);
+    stpq = stx + ((dx / ((fx - fp) / (stp - stx) + dx)) / 2.) * (stp - stx);
+    stpf = std::fabs(stpc - stx) < std::fabs(stpq - stx) ? stpc : stpc + (stpq - stpc) / 2;
+    brackt = true;
+  } else if (sgnd < 0.0) {
+    info = 2;
+    bound = false;
+    const T theta = 3 * (fx - fp) / (stp - stx) + dx + dp;
+    auto [s, rad] = cubic(theta, dx, dp);
+    T gamma = s * std::sqrt(rad);
+    if (stp > stx) gamma = -gamma;
+    const T r = ((gamma - dp) + theta) / (((gamma - dp) + gamma) + dx);
+    stpc = stp + r * (stx - stp);
+    stpq = stp + (dp / (dp - dx)) * (stx - stp);
+    stpf = std::fabs(stpc - stp) > std::fabs(stpq - stp) ? stpc : stpq;
+    brackt = true;
+  } else if (std::fabs(dp) < std::fabs(dx)) {
+    info = 3;
+    bound = true;
+    const T theta = 3 * (fx - fp) / (stp - stx) + dx + dp;
+    auto [s, rad] = cubic(theta, dx, dp);
+    T gamma = s * std::sqrt(std::max<T>(static_cast<T>(0.), rad));
+    if (stp > stx) gamma = -gamma;
+    const T r = ((gamma - dp) + theta) / ((gamma + (dx - dp)) + gamma);
+    if ((r < 0.0) & (gamma != 0.0))
+      stpc = stp + r * (stx - stp);
+    else
+      stpc = stp > stx ? stpmax : stpmin;
+    stpq = stp + (dp / (dp - dx)) * (stx - stp);
+    const bool closer_c = std::fabs(stp - stpc) < std::fabs(stp - stpq);
+    const bool farther_c = std::fabs(stp - stpc) > std::fabs(stp - stpq);
+    stpf = brackt ? (closer_c ? stpc : stpq) : (farther_c ? stpc : stpq);
+  } else {
+    info = 4;
+    bound = false;
+    if (brackt) {
+      const T theta = 3 * (fp - fy) / (sty - stp) + dy + dp;
+      auto [s, rad] = cubic(theta, dy, dp);
+      T gamma = s * std::sqrt(rad);
+      if (stp > sty) gamma = -gamma;
+      const T r = ((gamma - dp) + theta) / (((gamma - dp) + gamma) + dy);
+      stpf = stp + r * (sty - stp);
+    } else {
+      stpf = stp > stx ? stpmax : stpmin;
+    }
+  }
+  if (fp > fx) {
+    sty = stp;
+    fy = fp;
+    dy = dp;
+  } else {
+    if (sgnd < 0.0) {
+      sty = stx;
+      fy = fx;
+      dy = dx;
+    }
+    stx = stp;
+    fx = fp;
+    dx = dp;
+  }
+  stp = std::clamp(stpf, stpmin, stpmax);
+  if (brackt & bound) {
+    const T lim = stx + static_cast<T>(0.66) * (sty - stx);
+    stp = sty > stx ? std::min<T>(lim, stp) : std::max<T>(lim, stp);
+  }
+  return 0;
+}
+
+// cvsrch + more_thuente_search (nlsolver.h:1673-1793, 1880-1891): evaluates f(x) first,
+// then up to 20 trial points; `gradient` ends as the gradient at the last trial.
+template <typename Callable, typename Grad, typename T = double>
+T more_thuente_search(Callable &f, std::vector<T> &x, std::vector<T> &gradient,
+                      const std::vector<T> &dir, std::vector<T> &trial, T alpha, Grad g) {
+  const T finit = f(x);
+  T stp = alpha;
+  constexpr T xtol = 1e-15, ftol = 1e-4, gtol = 1e-2, stpmin = 1e-15, stpmax = 1e15, xtrapf = 4;
+  constexpr int maxfev = 20;
+  const int n = static_cast<int>(x.size());
+  const T dginit = math::dot(gradient.data(), dir.data(), n);
+  if (dginit >= 0.0) return stp;
+  int info = 0, infoc = 1, nfev = 0;
+  bool stage1 = true;
+  const T dgtest = ftol * dginit;
+  T width = stpmax - stpmin, width1 = 2 * width;
+  mt_interval<T> iv{0.0, finit, dginit, 0.0, finit, dginit, false};
+  for (;;) {
+    T stmin, stmax;
+    if (iv.brackt) {
+      stmin = std::min<T>(iv.stx, iv.sty);
+      stmax = std::max<T>(iv.stx, iv.sty);
+    } else {
+      stmin = iv.stx;
+      stmax = stp + xtrapf * (stp - iv.stx);
+    }
+    stp = std::clamp(stp, stpmin, stpmax);
+    if ((iv.brackt && ((stp <= stmin) || (stp >= stmax))) || (nfev >= maxfev - 1) ||
+        (infoc == 0) || (iv.brackt && ((stmax - stmin) <= (xtol * stmax))))
+      stp = iv.stx;
+    for (size_t i = 0; i < x.size(); i++) trial[i] = x[i] + stp * dir[i];
+    const T fcur = f(trial);
+    g(trial, gradient);
+    nfev++;
+    const T dg = math::dot(gradient.data(), dir.data(), n);
+    const T ftest1 = finit + stp * dgtest;
+    if ((iv.brackt & ((stp <= stmin) | (stp >= stmax))) | (infoc == 0)) info = 6;
+    if ((stp == stpmax) & (fcur <= ftest1) & (dg <= dgtest)) info = 5;
+    if ((stp == stpmin) & ((fcur > ftest1) | (dg >= dgtest))) info = 4;
+    if (nfev >= maxfev) info = 3;
+    if (iv.brackt & (stmax - stmin <= xtol * stmax)) info = 2;
+    if ((fcur <= ftest1) & (std::fabs(dg) <= gtol * (-dginit))) info = 1;
+    if (info != 0) return stp;
+    if (stage1 & (fcur <= ftest1) & (dg >= std::min<T>(ftol, gtol) * dginit)) stage1 = false;
+    if (stage1 & (fcur <= iv.fx) & (fcur > ftest1)) {
+      mt_interval<T> m{iv.stx, iv.fx - iv.stx * dgtest, iv.dx - dgtest,
+                       iv.sty, iv.fy - iv.sty * dgtest, iv.dy - dgtest, iv.brackt};
+      cstep(m, stp, fcur - stp * dgtest, dg - dgtest, stmin, stmax, infoc);
+      iv = {m.stx, m.fx + m.stx * dgtest, m.dx + dgtest, m.sty, m.fy + m.sty * dgtest,
+            m.dy + dgtest, m.brackt};
+    } else {
+      cstep(iv, stp, fcur, dg, stmin, stmax, infoc);
+    }
+    if (iv.brackt) {
+      if (std::fabs(iv.sty - iv.stx) >= 0.66 * width1) stp = iv.stx + 0.5 * (iv.sty - iv.stx);
+      width1 = width;
+      width = std::fabs(iv.sty - iv.stx);
+    }
+  }
+}
+}  // namespace linesearch
+
+template <typename Callable, typename scalar_t = double,
+          typename Grad = std::conditional_t<device::has_grad_objective<Callable>::value,
+                                             device::analytic_grad, fin_diff<Callable, scalar_t>>>
+class BFGS {
+  Callable &f;
+  Grad g;
+  const size_t max_iter;
+  const scalar_t grad_eps, alpha;
+
+ public:
+  // same positional arguments and defaults as nlsolver.h:3181-3185
+  explicit BFGS(Callable &f, Grad g = Grad(), const size_t max_iter = 100,
+                const scalar_t grad_eps = 5e-3, const scalar_t alpha = 1)
+      : f(f), g(g), max_iter(max_iter), grad_eps(grad_eps), alpha(alpha) {}
+  solver_status<scalar_t> minimize(std::vector<scalar_t> &x) {
+    if constexpr (device::has_grad_objective<Callable>::value) {
+      std::vector<std::vector<scalar_t>> one{x};
+      auto st = minimize_batch(one);
+      x = one[0];
+      return st[0];
+    } else {
+      return solve_host(x);
+    }
+  }
+  solver_status<scalar_t> maximize(std::vector<scalar_t> &) {
+    static_assert(sizeof(Callable) == 0, "BFGS currently only supports minimization");  // :3199
+    return solver_status<scalar_t>(0, 0, 0);
+  }
+  // Extension (BASELINE config 3): `xs.size()` independent starts solved in lock step on
+  // the GPU; the reference solves one start per minimize() call.
+  std::vector<solver_status<scalar_t>> minimize_batch(std::vector<std::vector<scalar_t>> &xs) {
+    static_assert(device::has_grad_objective<Callable>::value,
+                  "minimize_batch needs a device objective with an analytic gradient");
+    static_assert(std::is_same_v<scalar_t, double>, "the device path computes in fp64");
+    const device::api &api = device::api::get();
+    const size_t B = xs.size(), n = B ? xs[0].size() : 0;
+    nlsg_bfgs_config cfg{};
+    cfg.struct_size = sizeof(cfg);
+    if (const char *d = std::getenv("NLSG_DEVICE")) cfg.device = std::atoi(d);
+    cfg.objective = Callable::nlsg_grad_objective;
+    cfg.batch = B;
+    cfg.dim = n;
+    cfg.max_iter = max_iter;
+    cfg.grad_eps = grad_eps;
+    cfg.alpha = alpha;
+    cfg.quad_c = f.c;
+    nlsg_bfgs *eng = nullptr;
+    api.check(api.bfgs_create(&cfg, f.d.data(), f.b.data(), &eng));
+    std::vector<scalar_t> flat(B * n);
+    for (size_t p = 0; p < B; p++) std::copy(xs[p].begin(), xs[p].end(), flat.begin() + p * n);
+    std::vector<nlsg_status> st(B);
+    const int rc = api.bfgs_minimize(eng, flat.data(), st.data());
+    const std::string msg = rc ? api.last_error() : "";
+    api.bfgs_destroy(eng);
+    if (rc) throw device_error("nlsg error " + std::to_string(rc) + ": " + msg);
+    std::vector<solver_status<scalar_t>> out;
+    for (size_t p = 0; p < B; p++) {
+      std::copy(flat.begin() + p * n, flat.begin() + (p + 1) * n, xs[p].begin());
+      out.emplace_back(st[p].f_value, st[p].iteration, st[p].function_calls_used,
+                       st[p].gradient_evals_used);
+    }
+    return out;
+  }
+
+ private:
+  // Host path for arbitrary callables: BFGS::solve (nlsolver.h:3196-3285) incl. the
+  // literal rank-2 update of update_inverse_hessian (3130-3168).
+  solver_status<scalar_t> solve_host(std::vector<scalar_t> &x) {
+    const size_t n = x.size();
+    const int ni = static_cast<int>(n);
+    std::vector<scalar_t> H(n * n, 0.0), dir(n, 0.0), grad(n, 0.0), prev_grad(n, 0.0), y(n, 0.0),
+        s(n, 0.0), trial(n, 0.0), t(n);
+    for (size_t i = 0; i < n; i++) H[i + i * n] = 1.0;
+    size_t iter = 0, f_calls = 0, g_calls = 0;
+    auto f_counted = [&](std::vector<scalar_t> &at) {
+      f_calls++;
+      return f(at);
+    };
+    auto g_counted = [&](std::vector<scalar_t> &at, std::vector<scalar_t> &out) {
+      g_calls++;
+      if constexpr (std::is_same_v<Grad, fin_diff<Callable, scalar_t>>) {
+        fin_diff<decltype(f_counted), scalar_t>()(f_counted, at, out);  // counts f calls too
+      } else {
+        g(f, at, out);
+      }
+    };
+    g_counted(x, grad);
+    scalar_t prev_norm = 1e9, cur_norm = 1e8;
+    for (;;) {
+      if (iter >= max_iter || cur_norm < grad_eps || std::abs(cur_norm - prev_norm) < grad_eps ||
+          std::isinf(cur_norm)) {
+        const scalar_t f_final = f_counted(x);  // sequenced before f_calls is read
+        return solver_status<scalar_t>(f_final, iter, f_calls, g_calls);
+      }
+      for (size_t j = 0; j < n; j++) dir[j] = -math::dot(H.data() + j * n, grad.data(), ni);
+      const scalar_t phi = math::dot(grad.data(), dir.data(), ni);
+      if ((phi > 0) || std::isnan(phi) || cur_norm > prev_norm) {
+        std::fill(H.begin(), H.end(), 0.0);
+        for (size_t i = 0; i < n; i++) {
+          H[i + i * n] = 1.0;
+          dir[i] = -grad[i];
+        }
+      }
+      prev_grad = grad;
+      const scalar_t rate =
+          linesearch::more_thuente_search(f_counted, x, grad, dir, trial, alpha, g_counted);
+      for (size_t i = 0; i < n; i++) s[i] = dir[i] * rate;
+      for (size_t i = 0; i < n; i++) x[i] += s[i];
+      g_counted(x, grad);
+      prev_norm = cur_norm;
+      cur_norm = math::norm(grad.data(), ni);
+      for (size_t i = 0; i < n; i++) y[i] = grad[i] - prev_grad[i];
+      scalar_t rho = math::dot(y.data(), s.data(), ni);
+      rho = 1 / rho;
+      for (size_t i = 0; i < n; i++) t[i] = math::dot(y.data(), H.data() + i * n, ni);
+      scalar_t denom = math::dot(y.data(), t.data(), ni);
+      denom = (denom * rho) + 1.0;
+      for (size_t j = 0; j < n; j++)
+        for (size_t i = 0; i < n; i++)
+          H[j * n + i] = H[j * n + i] - rho * (s[i] * t[j] + t[i] * s[j] + denom * s[i] * s[j]);
+      iter++;
+    }
+  }
+};
 
 }  // namespace nlsolver
 

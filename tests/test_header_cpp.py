@@ -130,3 +130,41 @@ def test_pso_device_objective_through_header_matches_oracle(built, oracle, kind,
     assert np.array_equal(np.array([hx(v) for v in o["x"]]), ref.gbest_x)
     after = [oracle.orc_xorshift_next(C.byref(xs)) for _ in range(2)]
     assert [hx(v) for v in o["rng_after"]] == after
+
+
+@pytest.mark.parametrize("name", ["n8", "n64", "n1024", "n64_default_stop", "n100_ragged_start",
+                                  "n130_alpha_half", "n256_max_iter_5"])
+def test_bfgs_host_path_through_header_matches_reference_bit_exact(built, golden, name):
+    g = golden("bfgs.json")[name]
+    out = subprocess.check_output(
+        [os.path.join(built, "header_bfgs"), "host", str(g["n"]), str(g["max_iter"]),
+         repr(hx(g["grad_eps"])), repr(hx(g["alpha"])), repr(hx(g["x0"])), repr(hx(g["x0_step"]))],
+        text=True)
+    o = json.loads(out)
+    assert (o["fcalls"], o["iters"], o["gcalls"]) == (g["fcalls"], g["iters"], g["gcalls"])
+    assert o["f"] == g["f"] and o["x"][:8] == g["x_head"]
+
+
+def test_bfgs_default_finite_difference_gradient_runs(built):
+    o = json.loads(subprocess.check_output([os.path.join(built, "header_bfgs"), "findiff"], text=True))
+    x = [hx(v) for v in o["x"]]
+    assert abs(x[0] - 1) < 0.05 and abs(x[1] - 1) < 0.05  # example.cpp's BFGS on Rosenbrock
+    assert o["fcalls"] > 4 * o["gcalls"]  # fin_diff counts its 4 evaluations per dimension
+
+
+@pytest.mark.gpu
+def test_bfgs_device_batch_through_header_matches_oracle(built, oracle):
+    n, B, max_iter, grad_eps, alpha = 96, 5, 60, 1e-8, 1.0
+    out = subprocess.check_output(
+        [os.path.join(built, "header_bfgs"), "device", str(n), str(B), str(max_iter),
+         repr(grad_eps), repr(alpha)], env=dict(os.environ, NLSG_LIBRARY=LIB), text=True)
+    res = json.loads(out)
+    assert isinstance(res, list) and len(res) == B, res
+    import math
+    for p, o in enumerate(res):
+        x0 = np.array([1.0 + 0.01 * p * math.cos(0.3 * i) for i in range(n)])
+        ref, xr, _ = O.bfgs_quad(oracle, x0, max_iter=max_iter, grad_eps=grad_eps, alpha=alpha, tree=1)
+        assert (o["fcalls"], o["iters"], o["gcalls"]) == \
+            (ref.function_calls_used, ref.iteration, ref.gradient_evals_used)
+        assert hx(o["f"]) == ref.f_value
+        assert np.array_equal(np.array([hx(v) for v in o["x"]]), xr)
