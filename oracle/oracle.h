@@ -190,6 +190,24 @@ orc_status orc_bfgs_quad(const orc_quad *q, double *x, size_t n, size_t max_iter
 void orc_update_inverse_hessian(double *H, const double *s, const double *y, double *t, double rho,
                                 size_t n, int tree);
 
+/* --------------------------------------------------------------------- LM --- */
+double orc_exp(double x);  /* deterministic (no libm), shared with the HIP kernels */
+double orc_tanh(double x);
+void orc_cholesky(double *A, size_t n);                        /* nlsolver.h:251-269 */
+void orc_update_with_hessian(double *update, double *hess, const double *grad, size_t n); /* :310-330 */
+void orc_qr_decomposition(const double *X, size_t n, size_t p, double tol, double *Q, double *R);
+void orc_tinyqr_lm(const double *X, const double *y, size_t n, size_t p, double *beta);
+void orc_lm_make_tanh_problem(uint64_t seed, uint64_t problem, size_t m, size_t n, double *A,
+                              double *y, double *theta0);
+typedef struct {
+  int kind; /* 0: r_i = y_i - p0 exp(p1 t_i) (n = 2); 1: r_i = y_i - tanh(sum_j A_ij theta_j) */
+  size_t m, n;
+  const double *A, *y, *t;
+} orc_nlls;
+orc_status orc_lm_solve(const orc_nlls *q, double *x, double *lambda, double up, double down,
+                        size_t max_iter, double f_delta, int solver, int order, double *f_log,
+                        size_t f_cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,8 +62,33 @@ class BfgsCounters(C.Structure):
     _fields_ = [("f_calls", u64), ("g_calls", u64), ("f_log", pd), ("f_cap", sz), ("f_count", sz)]
 
 
+class Nlls(C.Structure):
+    _fields_ = [("kind", C.c_int), ("m", sz), ("n", sz), ("A", pd), ("y", pd), ("t", pd)]
+
+
 def _ptr(a):
     return a.ctypes.data_as(pd)
+
+
+def tanh_problem(lib, seed, problem, m, n):
+    A, y, th0 = np.zeros((m, n)), np.zeros(m), np.zeros(n)
+    lib.orc_lm_make_tanh_problem(seed, problem, m, n, _ptr(A), _ptr(y), _ptr(th0))
+    return A, y, th0
+
+
+def lm_solve(lib, A, y, x0, *, kind=1, t=None, lam=10.0, up=10.0, down=10.0, max_iter=100,
+             f_delta=1e-12, solver=0, order=0):
+    """Oracle LM on one problem; returns (status, x, final lambda, f_log)."""
+    x = np.ascontiguousarray(x0, dtype=np.float64).copy()
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    A = np.ascontiguousarray(A, dtype=np.float64) if A is not None else np.zeros(1)
+    tt = np.ascontiguousarray(t, dtype=np.float64) if t is not None else np.zeros(1)
+    q = Nlls(kind, y.size, x.size, _ptr(A), _ptr(y), _ptr(tt))
+    lam_c = C.c_double(lam)
+    flog = np.zeros(max_iter + 2)
+    st = lib.orc_lm_solve(C.byref(q), _ptr(x), C.cast(C.byref(lam_c), pd), up, down, max_iter,
+                          f_delta, solver, order, _ptr(flog), flog.size)
+    return st, x, lam_c.value, flog[:st.function_calls_used]
 
 
 def quad_problem(n, c=0.01):
@@ -141,6 +166,17 @@ def load():
     lib.orc_bfgs_quad.argtypes = [C.POINTER(Quad), pd, sz, sz, f64, f64, C.c_int,
                                   C.POINTER(BfgsCounters)]
     lib.orc_update_inverse_hessian.argtypes = [pd, pd, pd, pd, f64, sz, C.c_int]
+    for name in ("orc_exp", "orc_tanh"):
+        fn = getattr(lib, name)
+        fn.restype = f64
+        fn.argtypes = [f64]
+    lib.orc_cholesky.argtypes = [pd, sz]
+    lib.orc_update_with_hessian.argtypes = [pd, pd, pd, sz]
+    lib.orc_qr_decomposition.argtypes = [pd, sz, sz, f64, pd, pd]
+    lib.orc_tinyqr_lm.argtypes = [pd, pd, sz, sz, pd]
+    lib.orc_lm_make_tanh_problem.argtypes = [u64, u64, sz, sz, pd, pd, pd]
+    lib.orc_lm_solve.restype = Status
+    lib.orc_lm_solve.argtypes = [C.POINTER(Nlls), pd, pd, f64, f64, sz, f64, C.c_int, C.c_int, pd, sz]
     return lib
 
 

@@ -31,3 +31,22 @@ def main():
         "hess_update_3x3": run("hess-update"),
     }
     write("bfgs.json", g6)
+
+    # G8/G9 — LevenbergMarquardt (nlsolver.h:3428-3545) with Gauss-Newton functors, its
+    # Cholesky solve (251-330) and tinyqr (291-310, 437-470).
+    seed = 12374563468
+    g8 = {
+        "exp_default": run("lm-exp"),
+        "exp_lambda1_5iters": run("lm-exp", 1, 5, 0),
+        # lm-tanh seed problem m n lambda max_iter f_delta
+        "tanh_m16_n4": run("lm-tanh", seed, 0, 16, 4, 10, 20, 0),
+        "tanh_m64_n8_p3": run("lm-tanh", seed, 3, 64, 8, 10, 20, 0),
+        "tanh_m128_n64": run("lm-tanh", seed, 1, 128, 64, 10, 12, 0),
+        "tanh_m512_n64": run("lm-tanh", seed, 0, 512, 64, 10, 20, 0),
+        "tanh_m512_n64_default_stop": run("lm-tanh", seed, 5, 512, 64, 10, 100, 1e-12),
+        "tinyqr_example": run("tinyqr-example"),
+        "linalg_n4": run("linalg", 4, 1, 0.5),
+        "linalg_n16": run("linalg", 16, 2, 10),
+        "linalg_n64": run("linalg", 64, 3, 10),
+    }
+    write("lm.json", g8)
