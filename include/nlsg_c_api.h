@@ -255,6 +255,47 @@ int nlsg_bfgs_minimize(nlsg_bfgs *e, double *x_inout_host, nlsg_status *status_h
  * kernels that stream the inverse Hessians (t = H y; rank-2 update + next direction). */
 int nlsg_bfgs_time_steps(nlsg_bfgs *e, uint64_t iters, float *ms_total, float *ms_hessian);
 
+/* ========================================================================== */
+/* Batched Levenberg-Marquardt NLLS — replaces LevenbergMarquardt::solve        */
+/* (nlsolver.h:3465-3544) driven with Gauss-Newton functors (f = sum r^2,       */
+/* Grad = 2 J^T r, Hess = 2 J^T J), math::get_update_with_hessian (251-330) and */
+/* — solver = QR — tinyqr::lm on the damped matrix (tinyqr.h:253-310, 437-470), */
+/* for `batch` independent problems of one residual model.                      */
+/* ========================================================================== */
+typedef struct nlsg_lm nlsg_lm;
+
+typedef enum {
+  /* r_i(theta) = y_i - tanh(sum_j A_ij theta_j)   */
+  NLSG_OBJ_TANH_REGRESSION = 32
+} nlsg_nlls_objective;
+typedef enum { NLSG_LM_CHOLESKY = 0, NLSG_LM_QR = 1 } nlsg_lm_solver;
+
+typedef struct {
+  uint32_t struct_size;
+  int32_t device;
+  void *stream;
+  int32_t objective;      /* nlsg_nlls_objective                                     */
+  int32_t solver;         /* nlsg_lm_solver                                          */
+  uint64_t batch;         /* independent problems                                    */
+  uint64_t m;             /* residuals per problem                                   */
+  uint64_t n;             /* parameters per problem (<= 64)                          */
+  double lambda, up, down; /* ctor args lambda, upward_mult, downward_mult (:3443-45) */
+  uint64_t max_iter;      /* :3446                                                   */
+  double f_delta;         /* :3447                                                   */
+} nlsg_lm_config;
+
+int nlsg_lm_create(const nlsg_lm_config *cfg, nlsg_lm **out);
+int nlsg_lm_destroy(nlsg_lm *e);
+/* design matrices A [batch][m][n] row-major and targets y [batch][m] (copied to HBM) */
+int nlsg_lm_set_data(nlsg_lm *e, const double *a_host, const double *y_host);
+/* Whole solve() of every problem in one launch: theta [batch][n] in/out, one status per
+ * problem (f, iterations, f/grad/hess evaluation counts), final damping per problem
+ * (the reference keeps lambda as a mutable member, :3436/3541). NULLs are skipped. */
+int nlsg_lm_minimize(nlsg_lm *e, double *theta_inout_host, nlsg_status *status_host,
+                     double *lambda_out_host);
+/* Same launch bracketed by hipEvents (theta restored from theta0 each time). */
+int nlsg_lm_time_solve(nlsg_lm *e, const double *theta0_host, uint32_t repeats, float *ms_total);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,6 +64,16 @@ class BFGSConfig(C.Structure):
                 ("max_iter", u64), ("grad_eps", f64), ("alpha", f64), ("quad_c", f64)]
 
 
+OBJ_TANH_REGRESSION = 32
+LM_CHOLESKY, LM_QR = 0, 1
+
+
+class LMConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("device", i32), ("stream", C.c_void_p),
+                ("objective", i32), ("solver", i32), ("batch", u64), ("m", u64), ("n", u64),
+                ("lambda_", f64), ("up", f64), ("down", f64), ("max_iter", u64), ("f_delta", f64)]
+
+
 # every symbol include/nlsg_c_api.h declares: name -> (restype, argtypes)
 _H = C.c_void_p
 SYMBOLS = {
@@ -105,6 +115,11 @@ SYMBOLS = {
     "nlsg_bfgs_download_state": (C.c_int, [_H, pd, pd]),
     "nlsg_bfgs_minimize": (C.c_int, [_H, pd, C.POINTER(Status)]),
     "nlsg_bfgs_time_steps": (C.c_int, [_H, u64, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "nlsg_lm_create": (C.c_int, [C.POINTER(LMConfig), C.POINTER(_H)]),
+    "nlsg_lm_destroy": (C.c_int, [_H]),
+    "nlsg_lm_set_data": (C.c_int, [_H, pd, pd]),
+    "nlsg_lm_minimize": (C.c_int, [_H, pd, C.POINTER(Status), pd]),
+    "nlsg_lm_time_solve": (C.c_int, [_H, pd, C.c_uint32, C.POINTER(C.c_float)]),
 }
 
 _lib = None

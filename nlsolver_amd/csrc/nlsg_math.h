@@ -81,4 +81,30 @@ __device__ inline double det_cos(double y) {
   return q == 0 ? c : q == 1 ? -s : q == 2 ? -c : s;
 }
 
+// exp / tanh for the NLLS residual models (same algorithms as oracle_lm.c orc_exp/orc_tanh)
+__device__ inline double det_exp(double x) {
+  constexpr double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
+                   invln2 = 1.44269504088896338700e+00, P1 = 1.66666666666666019037e-01,
+                   P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+                   P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+  if (x != x) return x;
+  if (x > 709.0) return __builtin_inf();
+  if (x < -708.0) return 0.0;
+  const int k = static_cast<int>(invln2 * x + (x < 0 ? -0.5 : 0.5));
+  const double hi = x - static_cast<double>(k) * ln2HI, lo = static_cast<double>(k) * ln2LO;
+  const double r = hi - lo;
+  const double t = r * r;
+  const double c = r - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+  const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+  return y * __longlong_as_double(static_cast<long long>(static_cast<uint64_t>(1023 + k) << 52));
+}
+__device__ inline double det_tanh(double x) {
+  if (x != x) return x;
+  const double ax = fabs(x);
+  if (ax > 22.0) return x < 0 ? -1.0 : 1.0;
+  const double e = det_exp(2.0 * ax);
+  const double t = 1.0 - 2.0 / (e + 1.0);
+  return x < 0 ? -t : t;
+}
+
 }  // namespace nlsg

@@ -1,0 +1,102 @@
+"""Host-side mirror of the reference's LevenbergMarquardt class, batched, for NLLS models
+whose Gauss-Newton functors live on the device.
+
+Reference interface (nlsolver.h:3428-3463):
+    LevenbergMarquardt<Callable, scalar_t, Grad, Hess>(f, lambda = 10, upward_mult = 10,
+        downward_mult = 10, max_iter = 100, f_delta = 1e-12, g, h).minimize(x)
+Here `f` is a TanhRegression model (f = sum r^2, Grad = 2 J^T r, Hess = 2 J^T J evaluated by the
+kernels); minimize() takes one start (n,) or a batch (batch, n) — BASELINE config 4.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import LMConfig, Status, check, lib
+
+
+class TanhRegression:
+    """r_i(theta) = y_i - tanh(sum_j A_ij theta_j); A: (batch, m, n), y: (batch, m)."""
+    nlsg_nlls_objective = _capi.OBJ_TANH_REGRESSION
+
+    def __init__(self, A, y):
+        self.A = np.ascontiguousarray(A, dtype=np.float64)
+        self.y = np.ascontiguousarray(y, dtype=np.float64)
+        if self.A.ndim == 2:
+            self.A, self.y = self.A[None], self.y[None]
+        assert self.A.ndim == 3 and self.y.shape == self.A.shape[:2]
+
+    def __call__(self, theta, problem=0):
+        r = self.y[problem] - np.tanh(self.A[problem] @ np.asarray(theta, dtype=np.float64))
+        return float(r @ r)
+
+
+class LMEngine:
+    def __init__(self, model, *, lam=10.0, up=10.0, down=10.0, max_iter=100, f_delta=1e-12,
+                 solver=_capi.LM_CHOLESKY, device=0, stream=None):
+        B, m, n = model.A.shape
+        cfg = LMConfig()
+        cfg.struct_size = C.sizeof(LMConfig)
+        cfg.device = device
+        cfg.stream = None if stream is None else (stream or 1)
+        cfg.objective, cfg.solver = model.nlsg_nlls_objective, solver
+        cfg.batch, cfg.m, cfg.n = B, m, n
+        cfg.lambda_, cfg.up, cfg.down, cfg.max_iter, cfg.f_delta = lam, up, down, max_iter, f_delta
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        check(lib().nlsg_lm_create(C.byref(cfg), C.byref(self._h)))
+        check(lib().nlsg_lm_set_data(self._h, model.A.ctypes.data_as(_capi.pd),
+                                     model.y.ctypes.data_as(_capi.pd)))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().nlsg_lm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def minimize(self, theta):
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        assert theta.shape == (self.cfg.batch, self.cfg.n)
+        st = (Status * self.cfg.batch)()
+        lam = np.empty(self.cfg.batch)
+        check(lib().nlsg_lm_minimize(self._h, theta.ctypes.data_as(_capi.pd), st,
+                                     lam.ctypes.data_as(_capi.pd)))
+        return theta, list(st), lam
+
+    def time_solve(self, theta0, repeats=1):
+        theta0 = np.ascontiguousarray(theta0, dtype=np.float64)
+        ms = C.c_float()
+        check(lib().nlsg_lm_time_solve(self._h, theta0.ctypes.data_as(_capi.pd), repeats, C.byref(ms)))
+        return ms.value
+
+
+class LevenbergMarquardt:
+    """Drop-in for nlsolver::LevenbergMarquardt on a device NLLS model; x: (n,) or (batch, n)."""
+
+    def __init__(self, f, lam=10.0, upward_mult=10.0, downward_mult=10.0, max_iter=100,
+                 f_delta=1e-12, g=None, h=None, *, solver=_capi.LM_CHOLESKY, device=0):
+        if g is not None or h is not None:
+            raise TypeError("device NLLS models carry their Gauss-Newton functors; pass g=h=None")
+        self.f = f
+        self.args = dict(lam=lam, up=upward_mult, down=downward_mult, max_iter=max_iter,
+                         f_delta=f_delta, solver=solver, device=device)
+
+    def minimize(self, x):
+        if not isinstance(x, np.ndarray) or x.dtype != np.float64 or x.ndim not in (1, 2):
+            raise TypeError("x must be a float64 numpy array of shape (n,) or (batch, n)")
+        xb = x.reshape(1, -1) if x.ndim == 1 else x
+        with LMEngine(self.f, **self.args) as eng:
+            out, st, lam = eng.minimize(xb)
+        xb[...] = out
+        self.lambdas = lam  # the reference keeps lambda as a member across calls (:3436)
+        return st[0] if x.ndim == 1 else st
+
+    def maximize(self, x):  # nlsolver.h:3468 static_assert(minimize, ...)
+        raise NotImplementedError("LevenbergMarquardt currently only supports minimization")

@@ -71,10 +71,15 @@ static void forwardsolve(double *update, const double *L, const double *b, size_
     update[i] = (b[i] - sum) / L[i + i * n];
   }
 }
-static void backsolve_t(const double *U, double *b, size_t n) { /* :270-281 */
+/* order = 1 adds the terms of each inner sum from j = n-1 down to i+1: the order in which
+ * the solution components become available, which lets the kernel sweep columns in parallel */
+static void backsolve_t(const double *U, double *b, size_t n, int order) { /* :270-281 */
   for (int i = (int)n - 1; i >= 0; --i) {
     double sum = 0.0;
-    for (size_t j = (size_t)i + 1; j < n; ++j) sum += U[j * n + (size_t)i] * b[j];
+    if (order == 0)
+      for (size_t j = (size_t)i + 1; j < n; ++j) sum += U[j * n + (size_t)i] * b[j];
+    else
+      for (size_t j = n; j-- > (size_t)i + 1;) sum += U[j * n + (size_t)i] * b[j];
     b[i] = (b[i] - sum) / U[(size_t)i * n + (size_t)i];
   }
 }
@@ -84,14 +89,18 @@ static int is_diagonal(const double *A, size_t n) { /* :295-307 (positive off-di
       if (i != j && A[i * n + j] > 2.220446049250313e-16 * 1e12) return 0;
   return 1;
 }
-void orc_update_with_hessian(double *update, double *hess, const double *grad, size_t n) {
+void orc_update_with_hessian_order(double *update, double *hess, const double *grad, size_t n,
+                                   int order) {
   if (is_diagonal(hess, n)) { /* :310-330 */
     for (size_t i = 0; i < n; i++) update[i] = grad[i] / hess[i * n + i];
     return;
   }
   orc_cholesky(hess, n);
   forwardsolve(update, hess, grad, n);
-  backsolve_t(hess, update, n);
+  backsolve_t(hess, update, n, order);
+}
+void orc_update_with_hessian(double *update, double *hess, const double *grad, size_t n) {
+  orc_update_with_hessian_order(update, hess, grad, n, 0);
 }
 
 /* ---- tinyqr ------------------------------------------------------------------ */
@@ -281,7 +290,7 @@ orc_status orc_lm_solve(const orc_nlls *q, double *x, double *lambda, double up,
     if (iter >= max_iter || delta < f_delta || isnan(prev)) break; /* :3520-3527 */
     for (size_t i = 0; i < n; i++) H[i * n + i] += *lambda;          /* :3529-3531 */
     if (solver == 0) {
-      orc_update_with_hessian(upd, H, g, n);
+      orc_update_with_hessian_order(upd, H, g, n, order);
     } else {
       for (size_t i = 0; i < n; i++) /* column-major copy of the row-major damped matrix */
         for (size_t j = 0; j < n; j++) Xc[j * n + i] = H[i * n + j];

@@ -1,0 +1,75 @@
+"""Parity tests: batched HIP Levenberg-Marquardt (J^T J on fp64 MFMA + Cholesky in LDS) vs
+oracle_lm.c in the kernel's operation order (order=1): bit-exact parameters, objective
+values, damping, counters. Against the reference run (golden, sequential sums, libm tanh):
+objective within tolerance while above the rounding floor."""
+import numpy as np
+import pytest
+
+from tests import _oracle as O
+
+pytestmark = pytest.mark.gpu
+SEED = 12374563468
+
+
+@pytest.fixture(scope="module")
+def mod():
+    import torch
+    assert torch.cuda.is_available()
+    import nlsolver_amd
+    return nlsolver_amd
+
+
+def problems(oracle, first, batch, m, n):
+    A, y, t0 = np.zeros((batch, m, n)), np.zeros((batch, m)), np.zeros((batch, n))
+    for b in range(batch):
+        A[b], y[b], t0[b] = O.tanh_problem(oracle, SEED, first + b, m, n)
+    return A, y, t0
+
+
+@pytest.mark.parametrize("m,n,batch", [(16, 4, 5), (64, 8, 6), (100, 33, 4), (128, 64, 6),
+                                       (512, 64, 8), (70, 1, 3)])
+@pytest.mark.parametrize("kw", [dict(lam=10.0, max_iter=20, f_delta=0.0),
+                                dict(lam=10.0, max_iter=100, f_delta=1e-12),
+                                dict(lam=0.5, up=4.0, down=3.0, max_iter=6, f_delta=0.0)])
+def test_lm_batch_bit_exact_vs_kernel_order_oracle(mod, oracle, m, n, batch, kw):
+    A, y, t0 = problems(oracle, 0, batch, m, n)
+    with mod.LMEngine(mod.TanhRegression(A, y), **kw) as eng:
+        th, st, lam = eng.minimize(t0.copy())
+    for b in range(batch):
+        ref, xr, lam_r, flog = O.lm_solve(oracle, A[b], y[b], t0[b], order=1, **kw)
+        assert (st[b].iteration, st[b].function_calls_used, st[b].gradient_evals_used,
+                st[b].hessian_evals_used) == (ref.iteration, ref.function_calls_used,
+                                              ref.gradient_evals_used, ref.hessian_evals_used), b
+        assert st[b].f_value == ref.f_value, f"problem {b}"
+        assert np.array_equal(th[b], xr), f"problem {b}"
+        assert lam[b] == lam_r
+
+
+def test_lm_matches_reference_run_within_tolerance(mod, oracle, golden):
+    """Device result vs the reference LM class itself (golden f_vals) on its own problems."""
+    g = golden("lm.json")["tanh_m512_n64"]
+    A, y, t0 = O.tanh_problem(oracle, SEED, 0, 512, 64)
+    ref = np.array([float.fromhex(v) for v in g["f_vals"]])
+    # the device reports the final objective; replay iteration by iteration through max_iter
+    for k in (1, 2, 3, 5, 8):
+        st = mod.LevenbergMarquardt(mod.TanhRegression(A, y), 10.0, 10.0, 10.0, k, 0.0).minimize(
+            t0.copy())
+        assert st.iteration == k
+        if ref[k] > 1e-10:
+            assert abs(st.f_value - ref[k]) <= 1e-9 * ref[k]
+        else:
+            assert st.f_value < 1e-9
+    assert float.fromhex(g["f"]) < 1e-20
+
+
+def test_lm_config4_shape_sample(mod, oracle):
+    """BASELINE config 4's shape (m=512, n=64) with a reduced batch, 20 iterations."""
+    batch = 32
+    A, y, t0 = problems(oracle, 100, batch, 512, 64)
+    kw = dict(lam=10.0, max_iter=20, f_delta=0.0)
+    with mod.LMEngine(mod.TanhRegression(A, y), **kw) as eng:
+        th, st, lam = eng.minimize(t0.copy())
+    for b in range(0, batch, 5):
+        ref, xr, lam_r, _ = O.lm_solve(oracle, A[b], y[b], t0[b], order=1, **kw)
+        assert st[b].f_value == ref.f_value and np.array_equal(th[b], xr)
+    assert all(s.iteration == 20 and s.f_value < 1e-20 for s in st)
