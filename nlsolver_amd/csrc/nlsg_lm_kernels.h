@@ -81,21 +81,36 @@ __device__ inline double lm_evaluate(const LmParams &p, LmShared &sh, uint64_t p
       a[k] = *reinterpret_cast<const double2 *>(in ? Ap + i * kLmN + 2 * lp : p.zero);
       yv[k] = *(in ? yp + i : p.zero);
     }
+    // z = A theta for the wave's 16 rows: one 32-lane butterfly per load instruction
+    double z[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      z[k] = a[k].x * th0 + a[k].y * th1;
+#pragma unroll
+      for (int off = 16; off >= 1; off >>= 1) z[k] = z[k] + __shfl_xor(z[k], off, 64);
+    }
+    // tanh / residual / weight ONCE per row: lane lp < 8 of each half takes row k = lp
+    // (instead of all 32 lanes of the half repeating the same transcendental 8 times)
+    double zsel = z[0], ysel = yv[0];
+#pragma unroll
+    for (int k = 1; k < 8; k++) {
+      zsel = (lp == k) ? z[k] : zsel;
+      ysel = (lp == k) ? yv[k] : ysel;
+    }
+    const double tsel = det_tanh(zsel);
+    const double rsel = ysel - tsel;
+    const double wsel = 1 - tsel * tsel;
+    if (lp < 8) sh.r[2 * (8 * w + lp) + half] = rsel;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
       const int rb = 2 * (8 * w + k) + half;
-      double z = a[k].x * th0 + a[k].y * th1;
-#pragma unroll
-      for (int off = 16; off >= 1; off >>= 1) z = z + __shfl_xor(z, off, 64);
-      const double t = det_tanh(z);
-      const double r = yv[k] - t;
-      const double wgt = 1 - t * t;
+      const double r = __shfl(rsel, 32 * half + k, 64);
+      const double wgt = __shfl(wsel, 32 * half + k, 64);
       facc = facc + r * r;
       double2 jv;
       jv.x = -(wgt * a[k].x);
       jv.y = -(wgt * a[k].y);
       *reinterpret_cast<double2 *>(&sh.J[rb * kLmJStride + 2 * lp]) = jv;
-      if (lp == 0) sh.r[rb] = r;
     }
     __syncthreads();
     // ---- J^T J on the matrix cores, J^T r on the VALU (same A operand)
@@ -134,58 +149,54 @@ __device__ inline double lm_evaluate(const LmParams &p, LmShared &sh, uint64_t p
   return f;
 }
 
-// get_update_with_hessian (nlsolver.h:310-330) on the n x n leading block of sh.H
-__device__ inline void lm_solve_cholesky(LmShared &sh, int n) {
-  const int t = threadIdx.x;
+// get_update_with_hessian (nlsolver.h:310-330) on the n x n leading block of sh.H.
+// Runs in ONE wave (lane = matrix row, n <= 64): no workgroup barriers inside; values
+// cross lanes through LDS (a wave's DS instructions execute in order) or a lane broadcast.
+__device__ inline void lm_solve_cholesky_wave(LmShared &sh, int n) {
+  const int t = lane_id();
+  const bool row = t < n;
   // is_diagonal (:295-307): any off-diagonal above eps * 1e12 (positive values only)
-  if (t == 0) sh.flag = 0;
-  __syncthreads();
   bool off = false;
-  for (int e = t; e < n * n; e += 256) {
-    const int i = e / n, j = e % n;
-    if (i != j && sh.H[i * kLmHStride + j] > 2.220446049250313e-16 * 1e12) off = true;
-  }
-  if (off) sh.flag = 1;
-  __syncthreads();
-  if (!sh.flag) {
-    if (t < n) sh.upd[t] = sh.g[t] / sh.H[t * kLmHStride + t];
-    __syncthreads();
+  if (row)
+    for (int j = 0; j < n; j++)
+      off = off || (j != t && sh.H[t * kLmHStride + j] > 2.220446049250313e-16 * 1e12);
+  if (__ballot(off) == 0ull) {
+    if (row) sh.upd[t] = sh.g[t] / sh.H[t * kLmHStride + t];
     return;
   }
-  // cholesky (:251-269), column by column; each element's sum runs over k in order
+  // cholesky (:251-269), column by column; every element's sum runs over k in order
+  double *Ht = &sh.H[t * kLmHStride];
   for (int j = 0; j < n; j++) {
-    if (t == j) {
-      double sum = 0;
-      for (int k = 0; k < j; k++) sum += sh.H[j * kLmHStride + k] * sh.H[j * kLmHStride + k];
-      sh.H[j * kLmHStride + j] = sqrt(sh.H[j * kLmHStride + j] - sum);
+    const double *Hj = &sh.H[j * kLmHStride];
+    double sum = 0;
+    if (row && t >= j) {
+#pragma unroll 8
+      for (int k = 0; k < j; k++) sum += Ht[k] * Hj[k];
     }
-    __syncthreads();
-    if (t > j && t < n) {
-      double sum = 0;
-      for (int k = 0; k < j; k++) sum += sh.H[t * kLmHStride + k] * sh.H[j * kLmHStride + k];
-      sh.H[t * kLmHStride + j] =
-          (1.0 / sh.H[j * kLmHStride + j] * (sh.H[t * kLmHStride + j] - sum));
-    }
-    __syncthreads();
+    // diagonal first (lane j: sum = sum_k L[j][k]^2), then the column below it
+    double d = 0.0;
+    if (t == j) d = sqrt(Ht[j] - sum);
+    d = __shfl(d, j, 64);
+    if (t == j) Ht[j] = d;
+    if (row && t > j) Ht[j] = (1.0 / d * (Ht[j] - sum));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
   // forwardsolve_inplace (:282-294): column sweep, each row's sum grows in j order
-  if (t < n) sh.sum[t] = 0.0;
-  __syncthreads();
+  double sum = 0.0, u = 0.0;
   for (int j = 0; j < n; j++) {
-    if (t == j) sh.upd[j] = (sh.g[j] - sh.sum[j]) / sh.H[j + j * kLmHStride];
-    __syncthreads();
-    if (t > j && t < n) sh.sum[t] += sh.H[t * kLmHStride + j] * sh.upd[j];
-    __syncthreads();
+    if (t == j) u = (sh.g[j] - sum) / Ht[j];
+    const double uj = __shfl(u, j, 64);
+    if (row && t > j) sum += Ht[j] * uj;
   }
   // backsolve_inplace_t (:270-281) with the inner sums taken from j = n-1 down to i+1
-  if (t < n) sh.sum[t] = 0.0;
-  __syncthreads();
+  sum = 0.0;
   for (int j = n - 1; j >= 0; j--) {
-    if (t == j) sh.upd[j] = (sh.upd[j] - sh.sum[j]) / sh.H[j * kLmHStride + j];
-    __syncthreads();
-    if (t < j) sh.sum[t] += sh.H[j * kLmHStride + t] * sh.upd[j];
-    __syncthreads();
+    if (t == j) u = (u - sum) / Ht[j];
+    const double uj = __shfl(u, j, 64);
+    if (row && t < j) sum += sh.H[j * kLmHStride + t] * uj;
   }
+  if (row) sh.upd[t] = u;
 }
 
 __global__ __launch_bounds__(256) void lm_solve_kernel(LmParams p) {
@@ -205,8 +216,10 @@ __global__ __launch_bounds__(256) void lm_solve_kernel(LmParams p) {
     if (iter >= p.max_iter || delta < p.f_delta || isnan(prev)) break;  // :3520-3527
     if (t < n) sh.H[t * kLmHStride + t] += lambda;                      // :3529-3531
     __syncthreads();
-    lm_solve_cholesky(sh, n);
-    if (t < n) sh.theta[t] = sh.theta[t] - sh.upd[t];  // always accepted, :3534
+    if (t < 64) {  // wave 0 solves the damped system and applies the step
+      lm_solve_cholesky_wave(sh, n);
+      if (t < n) sh.theta[t] = sh.theta[t] - sh.upd[t];  // always accepted, :3534
+    }
     __syncthreads();
     prev = cur;
     cur = lm_evaluate(p, sh, pid);
