@@ -208,6 +208,19 @@ orc_status orc_lm_solve(const orc_nlls *q, double *x, double *lambda, double up,
                         size_t max_iter, double f_delta, int solver, int order, double *f_log,
                         size_t f_cap);
 
+/* --------------------------------------------------------------------- NM --- */
+/* NelderMead::solve (nlsolver.h:2166-2299) and the minimize/maximize wrappers with
+ * restarts (2127-2163). *eps is the solver's mutable member (B2). order: 0 reference
+ * arithmetic, 1 kernel trees for the objective and std_err. */
+orc_status orc_nm_solve(int obj, int minimize, int bound, double *x, size_t n, const double *upper,
+                        const double *lower, double step, double alpha, double gamma, double rho,
+                        double sigma, double *eps, size_t max_iter, size_t no_change_best_tol,
+                        int order, orc_eval_log *log);
+orc_status orc_nm_run(int obj, int minimize, int bound, double *x, size_t n, const double *upper,
+                      const double *lower, double step, double alpha, double gamma, double rho,
+                      double sigma, double *eps, size_t max_iter, size_t no_change_best_tol,
+                      size_t restarts, int order, orc_eval_log *log);
+
 #ifdef __cplusplus
 }
 #endif

@@ -175,6 +175,9 @@ def load():
     lib.orc_qr_decomposition.argtypes = [pd, sz, sz, f64, pd, pd]
     lib.orc_tinyqr_lm.argtypes = [pd, pd, sz, sz, pd]
     lib.orc_lm_make_tanh_problem.argtypes = [u64, u64, sz, sz, pd, pd, pd]
+    lib.orc_nm_run.restype = Status
+    lib.orc_nm_run.argtypes = [C.c_int, C.c_int, C.c_int, pd, sz, pd, pd, f64, f64, f64, f64, f64,
+                               pd, sz, sz, sz, C.c_int, C.POINTER(EvalLog)]
     lib.orc_lm_solve.restype = Status
     lib.orc_lm_solve.argtypes = [C.POINTER(Nlls), pd, pd, f64, f64, sz, f64, C.c_int, C.c_int, pd, sz]
     return lib
@@ -310,3 +313,23 @@ class PSOSyncRun:
     def step(self, n=1, threads=1):
         for _ in range(n):
             self.lib.orc_pso_sync_step(C.byref(self.s), threads)
+
+
+def nm_run(lib, x0, *, obj="rosenbrock", minimize=True, upper=None, lower=None, step=-1.0,
+           alpha=1.0, gamma=2.0, rho=0.5, sigma=0.5, eps=1e-6, max_iter=500, no_change=20,
+           restarts=0, order=0, log_cap=0):
+    """Oracle NelderMead minimize()/maximize(); returns (status, x, eps_after, log or None)."""
+    x = np.ascontiguousarray(x0, dtype=np.float64).copy()
+    n = x.size
+    bound = upper is not None
+    up = np.ascontiguousarray(np.broadcast_to(upper if bound else 0.0, (n,)), dtype=np.float64)
+    lo = np.ascontiguousarray(np.broadcast_to(lower if bound else 0.0, (n,)), dtype=np.float64)
+    eps_c = C.c_double(eps)
+    lg, lx, lf = None, None, None
+    if log_cap:
+        lx, lf = np.zeros((log_cap, n)), np.zeros(log_cap)
+        lg = EvalLog(_ptr(lx), _ptr(lf), log_cap, 0, n)
+    st = lib.orc_nm_run(OBJ[obj], int(minimize), int(bound), _ptr(x), n, _ptr(up), _ptr(lo), step,
+                        alpha, gamma, rho, sigma, C.cast(C.byref(eps_c), pd), max_iter, no_change,
+                        restarts, order, C.byref(lg) if lg else None)
+    return st, x, eps_c.value, ((lx[:lg.count], lf[:lg.count]) if lg else None)

@@ -50,3 +50,20 @@ def main():
         "linalg_n64": run("linalg", 64, 3, 10),
     }
     write("lm.json", g8)
+
+    # G5 — NelderMead (nlsolver.h:2099-2300) on Rosenbrock-ND. Even D only: the reference's
+    # simplex ctor writes one element past an n-vector, which for odd n lands on
+    # the allocator's chunk header and aborts the process (observed for D = 3).
+    # args: D step max_iter eps no_change restarts x0 x0_step bounded upper lower minimize trace
+    g5 = {
+        "example_2d": run("nm", 2, -1, 500, 1e-6, 20, 0, 2, 5, 0, 0, 0, 1, 1),
+        "d4_200iters": run("nm", 4, -1, 200, 0, 1000, 0, 0.5, 0, 0, 0, 0, 1, 1),
+        "d4_fixed_step": run("nm", 4, 0.75, 120, 0, 1000, 0, -1.2, 0.3, 0, 0, 0, 1, 1),
+        "d16_bounded": run("nm", 16, -1, 300, 0, 1000, 0, 0.5, 0.05, 1, 1.5, -1.0, 1, 0),
+        "d8_restarts": run("nm", 8, -1, 150, 1e-6, 20, 2, 0.5, 0.1, 0, 0, 0, 1, 0),
+        "d6_maximize_bounded": run("nm", 6, -1, 100, 0, 1000, 0, 0.3, 0.2, 1, 2.0, -2.0, 0, 1),
+        "d128_2000iters": run("nm", 128, -1, 2000, 0, 100000, 0, 0.5, 0, 0, 0, 0, 1, 0),
+        "d130_ragged": run("nm", 130, -1, 600, 0, 100000, 0, 0.4, 0.001, 0, 0, 0, 1, 0),
+        "simplex_init_1234": run("simplex-init"),
+    }
+    write("nm.json", g5)
