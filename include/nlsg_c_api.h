@@ -296,6 +296,38 @@ int nlsg_lm_minimize(nlsg_lm *e, double *theta_inout_host, nlsg_status *status_h
 /* Same launch bracketed by hipEvents (theta restored from theta0 each time). */
 int nlsg_lm_time_solve(nlsg_lm *e, const double *theta0_host, uint32_t repeats, float *ms_total);
 
+/* ========================================================================== */
+/* Batched Nelder-Mead — replaces NelderMead::solve (nlsolver.h:2166-2299), the  */
+/* simplex helpers (simplex ctor 1905-1950, update_centroid 1965-1984,           */
+/* simplex_transform 1986-2007, shrink 2009-2035, max_abs_vec 1894-1904) and the */
+/* minimize/maximize wrappers with restarts (2127-2163), for `batch` independent */
+/* starts (one simplex per workgroup).                                           */
+/* ========================================================================== */
+typedef struct nlsg_nm nlsg_nm;
+
+typedef struct {
+  uint32_t struct_size;
+  int32_t device;
+  void *stream;
+  int32_t objective;   /* nlsg_objective                                          */
+  int32_t minimize;    /* 1 = minimize(), 0 = maximize()                           */
+  int32_t bounded;     /* 1 = the (x, upper, lower) overloads (2136, 2155)         */
+  int32_t reserved;
+  uint64_t batch;
+  uint64_t dim;        /* <= 128 (the simplex lives in LDS)                        */
+  double step, alpha, gamma, rho, sigma, eps; /* ctor args, nlsolver.h:2110-2113   */
+  uint64_t max_iter, no_change_best_tol, restarts; /* :2114-2115                   */
+} nlsg_nm_config;
+
+int nlsg_nm_create(const nlsg_nm_config *cfg, nlsg_nm **out);
+int nlsg_nm_destroy(nlsg_nm *e);
+/* x [batch][dim] in/out; upper/lower [dim] (shared by the batch; NULL when unbounded; note
+ * the reference's argument order: upper first). One status per start; eps_out receives each
+ * solver's mutated tolerance (nlsolver.h:2189). NULLs are skipped. Synchronises. */
+int nlsg_nm_minimize(nlsg_nm *e, double *x_inout_host, const double *upper_host,
+                     const double *lower_host, nlsg_status *status_host, double *eps_out_host);
+int nlsg_nm_time_solve(nlsg_nm *e, const double *x0_host, uint32_t repeats, float *ms_total);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,6 +8,7 @@ Layout:
     pso.py                PSO / PSOSolver: mirror of nlsolver::PSO (nlsolver.h:2498-2742)
     bfgs.py               BFGS (batched starts): mirror of nlsolver::BFGS (nlsolver.h:3169-3286)
     lm.py                 LevenbergMarquardt (batched NLLS): mirror of nlsolver.h:3428-3545
+    nm.py                 NelderMead (batched starts): mirror of nlsolver.h:2099-2300
     dist.py               population sharding across ranks (torch.distributed / RCCL)
 """
 from ._capi import DE_BEST, DE_RANDOM, PSO_ACCELERATED, PSO_VANILLA, NlsgError  # noqa: F401
@@ -15,3 +16,4 @@ from .de import DE, DEEngine, DESolver  # noqa: F401
 from .pso import PSO, PSOEngine, PSOSolver  # noqa: F401
 from .bfgs import BFGS, BFGSEngine, QuadDiagRank1  # noqa: F401
 from .lm import LevenbergMarquardt, LMEngine, TanhRegression  # noqa: F401
+from .nm import NelderMead, NMEngine  # noqa: F401

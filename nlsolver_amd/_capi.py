@@ -74,6 +74,14 @@ class LMConfig(C.Structure):
                 ("lambda_", f64), ("up", f64), ("down", f64), ("max_iter", u64), ("f_delta", f64)]
 
 
+class NMConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("device", i32), ("stream", C.c_void_p),
+                ("objective", i32), ("minimize", i32), ("bounded", i32), ("reserved", i32),
+                ("batch", u64), ("dim", u64),
+                ("step", f64), ("alpha", f64), ("gamma", f64), ("rho", f64), ("sigma", f64),
+                ("eps", f64), ("max_iter", u64), ("no_change_best_tol", u64), ("restarts", u64)]
+
+
 # every symbol include/nlsg_c_api.h declares: name -> (restype, argtypes)
 _H = C.c_void_p
 SYMBOLS = {
@@ -120,6 +128,10 @@ SYMBOLS = {
     "nlsg_lm_set_data": (C.c_int, [_H, pd, pd]),
     "nlsg_lm_minimize": (C.c_int, [_H, pd, C.POINTER(Status), pd]),
     "nlsg_lm_time_solve": (C.c_int, [_H, pd, C.c_uint32, C.POINTER(C.c_float)]),
+    "nlsg_nm_create": (C.c_int, [C.POINTER(NMConfig), C.POINTER(_H)]),
+    "nlsg_nm_destroy": (C.c_int, [_H]),
+    "nlsg_nm_minimize": (C.c_int, [_H, pd, pd, pd, C.POINTER(Status), pd]),
+    "nlsg_nm_time_solve": (C.c_int, [_H, pd, C.c_uint32, C.POINTER(C.c_float)]),
 }
 
 _lib = None

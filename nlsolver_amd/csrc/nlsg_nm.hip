@@ -1,0 +1,206 @@
+// nlsolver_amd/csrc/nlsg_nm.hip — host side of the batched Nelder-Mead engine + C-ABI.
+#include <new>
+#include <vector>
+
+#include "nlsg_nm_kernels.h"
+
+using namespace nlsg;
+
+struct nlsg_nm {
+  nlsg_nm_config cfg;
+  NmParams p;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  double *upper_dev = nullptr, *lower_dev = nullptr;
+  size_t lds = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+int nm_check_device(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return fail(NLSG_ERR_NO_DEVICE, "no HIP device visible");
+  if (device < 0 || device >= n)
+    return fail(NLSG_ERR_INVALID_ARG, "device %d out of range (0..%d)", device, n - 1);
+  hipDeviceProp_t prop;
+  NLSG_HIP(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(NLSG_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only",
+                device, prop.gcnArchName);
+  return NLSG_OK;
+}
+
+template <int OBJ>
+hipError_t prepare(size_t lds) {
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(nm_solve_kernel<OBJ>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+}
+
+void launch(nlsg_nm *e) {
+  const dim3 grid(static_cast<unsigned>(e->p.batch)), block(256);
+  switch (e->cfg.objective) {
+    case NLSG_OBJ_ROSENBROCK:
+      hipLaunchKernelGGL(nm_solve_kernel<NLSG_OBJ_ROSENBROCK>, grid, block, e->lds, e->stream, e->p);
+      break;
+    case NLSG_OBJ_SPHERE:
+      hipLaunchKernelGGL(nm_solve_kernel<NLSG_OBJ_SPHERE>, grid, block, e->lds, e->stream, e->p);
+      break;
+    case NLSG_OBJ_STYBLINSKI_TANG:
+      hipLaunchKernelGGL(nm_solve_kernel<NLSG_OBJ_STYBLINSKI_TANG>, grid, block, e->lds, e->stream,
+                         e->p);
+      break;
+    default:
+      hipLaunchKernelGGL(nm_solve_kernel<NLSG_OBJ_RASTRIGIN>, grid, block, e->lds, e->stream, e->p);
+      break;
+  }
+}
+
+int upload_bounds(nlsg_nm *e, const double *upper_host, const double *lower_host) {
+  if (!e->cfg.bounded) return NLSG_OK;
+  if (!upper_host || !lower_host)
+    return fail(NLSG_ERR_INVALID_ARG, "bounded solver needs upper and lower");
+  NLSG_HIP(hipMemcpy(e->upper_dev, upper_host, e->p.n * 8, hipMemcpyHostToDevice));
+  NLSG_HIP(hipMemcpy(e->lower_dev, lower_host, e->p.n * 8, hipMemcpyHostToDevice));
+  return NLSG_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int nlsg_nm_create(const nlsg_nm_config *cfg, nlsg_nm **out) {
+  if (!cfg || !out) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  *out = nullptr;
+  if (cfg->struct_size != sizeof(nlsg_nm_config))
+    return fail(NLSG_ERR_INVALID_ARG, "nlsg_nm_config size mismatch (%u vs %zu)", cfg->struct_size,
+                sizeof(nlsg_nm_config));
+  if (cfg->objective < 0 || cfg->objective > NLSG_OBJ_RASTRIGIN)
+    return fail(NLSG_ERR_INVALID_ARG, "unknown objective %d", cfg->objective);
+  if (cfg->dim < 1 || cfg->batch < 1) return fail(NLSG_ERR_INVALID_ARG, "dim and batch must be >= 1");
+  if (cfg->dim > 128)
+    return fail(NLSG_ERR_UNSUPPORTED, "dim %llu > 128: the simplex no longer fits the 160 KiB LDS",
+                (unsigned long long)cfg->dim);
+  if (cfg->batch > 0x7fffffffull) return fail(NLSG_ERR_UNSUPPORTED, "batch too large");
+  int rc = nm_check_device(cfg->device);
+  if (rc) return rc;
+  NLSG_HIP(hipSetDevice(cfg->device));
+  nlsg_nm *e = new (std::nothrow) nlsg_nm();
+  if (!e) return fail(NLSG_ERR_OOM, "host allocation failed");
+  e->cfg = *cfg;
+  if (cfg->stream) {
+    e->stream = static_cast<hipStream_t>(cfg->stream);
+  } else {
+    hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (he != hipSuccess) {
+      delete e;
+      return fail(NLSG_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(he));
+    }
+    e->own_stream = true;
+  }
+  NmParams &p = e->p;
+  std::memset(&p, 0, sizeof p);
+  const uint64_t B = cfg->batch, n = cfg->dim;
+  e->lds = nm_lds_bytes(n);
+  hipError_t he = hipSuccess;
+  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p.x), B * n * 8);
+  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p.prob), B * sizeof(NmProblem));
+  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&e->upper_dev), n * 8);
+  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&e->lower_dev), n * 8);
+  if (he == hipSuccess) he = hipEventCreate(&e->ev0);
+  if (he == hipSuccess) he = hipEventCreate(&e->ev1);
+  if (he == hipSuccess) he = prepare<NLSG_OBJ_ROSENBROCK>(e->lds);
+  if (he == hipSuccess) he = prepare<NLSG_OBJ_SPHERE>(e->lds);
+  if (he == hipSuccess) he = prepare<NLSG_OBJ_STYBLINSKI_TANG>(e->lds);
+  if (he == hipSuccess) he = prepare<NLSG_OBJ_RASTRIGIN>(e->lds);
+  if (he != hipSuccess) {
+    nlsg_nm_destroy(e);
+    return fail(he == hipErrorOutOfMemory ? NLSG_ERR_OOM : NLSG_ERR_HIP,
+                "device setup failed: %s", hipGetErrorString(he));
+  }
+  p.upper = e->upper_dev;
+  p.lower = e->lower_dev;
+  p.batch = B;
+  p.n = n;
+  p.max_iter = cfg->max_iter;
+  p.no_change_tol = cfg->no_change_best_tol;
+  p.restarts = cfg->restarts;
+  p.step = cfg->step;
+  p.alpha = cfg->alpha;
+  p.gamma = cfg->gamma;
+  p.rho = cfg->rho;
+  p.sigma = cfg->sigma;
+  p.eps = cfg->eps;
+  p.fmul = cfg->minimize ? 1.0 : -1.0;
+  p.bounded = cfg->bounded ? 1 : 0;
+  *out = e;
+  return NLSG_OK;
+}
+
+int nlsg_nm_destroy(nlsg_nm *e) {
+  if (!e) return NLSG_OK;
+  hipSetDevice(e->cfg.device);
+  if (e->stream) hipStreamSynchronize(e->stream);
+  hipFree(e->p.x);
+  hipFree(e->p.prob);
+  hipFree(e->upper_dev);
+  hipFree(e->lower_dev);
+  if (e->ev0) hipEventDestroy(e->ev0);
+  if (e->ev1) hipEventDestroy(e->ev1);
+  if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
+  delete e;
+  return NLSG_OK;
+}
+
+int nlsg_nm_minimize(nlsg_nm *e, double *x_inout_host, const double *upper_host,
+                     const double *lower_host, nlsg_status *status_host, double *eps_out_host) {
+  if (!e || !x_inout_host) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  NLSG_HIP(hipSetDevice(e->cfg.device));
+  int rc = upload_bounds(e, upper_host, lower_host);
+  if (rc) return rc;
+  const uint64_t B = e->p.batch, n = e->p.n;
+  NLSG_HIP(hipMemcpy(e->p.x, x_inout_host, B * n * 8, hipMemcpyHostToDevice));
+  launch(e);
+  NLSG_HIP(hipGetLastError());
+  NLSG_HIP(hipStreamSynchronize(e->stream));
+  NLSG_HIP(hipMemcpy(x_inout_host, e->p.x, B * n * 8, hipMemcpyDeviceToHost));
+  std::vector<NmProblem> pr(B);
+  NLSG_HIP(hipMemcpy(pr.data(), e->p.prob, B * sizeof(NmProblem), hipMemcpyDeviceToHost));
+  for (uint64_t b = 0; b < B; b++) {
+    if (status_host) {
+      nlsg_status &st = status_host[b];
+      st.f_value = pr[b].f;
+      st.iteration = pr[b].iter;
+      st.function_calls_used = pr[b].fcalls;
+      st.gradient_evals_used = 0;
+      st.hessian_evals_used = 0;
+      st.best_index = b;
+      st.val_no_change = 0;
+      st.std_err = pr[b].eps;
+      st.done = 1;
+      st.reserved = 0;
+    }
+    if (eps_out_host) eps_out_host[b] = pr[b].eps;
+  }
+  return NLSG_OK;
+}
+
+int nlsg_nm_time_solve(nlsg_nm *e, const double *x0_host, uint32_t repeats, float *ms_total) {
+  if (!e || !x0_host || !ms_total) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  NLSG_HIP(hipSetDevice(e->cfg.device));
+  float total = 0.f;
+  for (uint32_t r = 0; r < repeats; r++) {
+    NLSG_HIP(hipMemcpy(e->p.x, x0_host, e->p.batch * e->p.n * 8, hipMemcpyHostToDevice));
+    NLSG_HIP(hipEventRecord(e->ev0, e->stream));
+    launch(e);
+    NLSG_HIP(hipEventRecord(e->ev1, e->stream));
+    NLSG_HIP(hipEventSynchronize(e->ev1));
+    NLSG_HIP(hipGetLastError());
+    float ms = 0.f;
+    NLSG_HIP(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+    total += ms;
+  }
+  *ms_total = total;
+  return NLSG_OK;
+}
+
+}  // extern "C"

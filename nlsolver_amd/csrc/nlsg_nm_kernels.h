@@ -1,0 +1,283 @@
+// nlsolver_amd/csrc/nlsg_nm_kernels.h — gfx950 kernel of the batched Nelder-Mead engine.
+//
+// Replaces (nlsolver.h): NelderMead::solve 2166-2299 and its wrappers 2127-2163, simplex
+// ctor 1905-1950, update_centroid 1965-1984, simplex_transform 1986-2007, shrink 2009-2035,
+// max_abs_vec 1894-1904, std_err 2037-2052.
+//
+// One persistent 256-thread workgroup per start; the (n+1) x n simplex, its scores and the
+// work vectors live in LDS (132 KiB at n = 128 of the 160 KiB a CDNA4 CU has), so an
+// iteration touches no HBM at all. The method is a chain of data-dependent decisions
+// (latency bound): control flow is evaluated by thread 0 and broadcast through
+// LDS, vector work is spread over threads (centroid: thread j sums vertex coordinates in the
+// reference's vertex order), objectives are evaluated one vertex per wave with the fixed
+// lane tree. All reference quirks on the path are reproduced (stale centroid).
+#pragma once
+
+#include "nlsg_common.h"
+
+namespace nlsg {
+
+struct NmProblem {
+  double f, eps;
+  uint64_t iter, fcalls;
+};
+
+struct NmParams {
+  double *x;            // [batch][n] in/out
+  const double *upper, *lower;  // [n]
+  NmProblem *prob;      // [batch]
+  uint64_t batch, n, max_iter, no_change_tol, restarts;
+  double step, alpha, gamma, rho, sigma, eps, fmul;
+  int32_t bounded, pad;
+};
+
+struct NmCtl {  // control block in LDS
+  double ref_score, exp_score, cont_score, eps, se;
+  uint64_t best, worst, second_worst, prev_worst, last_best, no_change, iter, fcalls;
+  int stop, shrunk, action;
+};
+
+// objective of the point at `pt` (LDS, n <= 128), evaluated by one wave; all lanes get it
+template <int OBJ>
+__device__ inline double nm_wave_f(const double *pt, uint64_t n, double fmul) {
+  const int lane = lane_id();
+  double xv[1][2];
+  xv[0][0] = (2u * lane < n) ? pt[2 * lane] : 0.0;
+  xv[0][1] = (2u * lane + 1 < n) ? pt[2 * lane + 1] : 0.0;
+  return fmul * wave_objective<OBJ, 1>(xv, n);
+}
+
+template <int OBJ>
+__global__ __launch_bounds__(256) void nm_solve_kernel(NmParams p) {
+  extern __shared__ __align__(16) unsigned char nm_smem[];
+  const uint64_t n = p.n, nv = p.n + 1;
+  double *S = reinterpret_cast<double *>(nm_smem);  // [nv][n]
+  double *scores = S + nv * n;                      // [nv] (padded to even)
+  double *centroid = scores + ((nv + 1) & ~1ull);
+  double *tr = centroid + n, *te = tr + n, *tc = te + n, *x0 = tc + n, *up = x0 + n, *lo = up + n;
+  NmCtl *ctl = reinterpret_cast<NmCtl *>(lo + n);
+  const uint64_t pid = blockIdx.x;
+  const int t = threadIdx.x;
+  const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int lane = lane_id();
+
+  for (uint64_t j = t; j < n; j += 256) {
+    x0[j] = p.x[pid * n + j];
+    up[j] = p.bounded ? p.upper[j] : 0.0;
+    lo[j] = p.bounded ? p.lower[j] : 0.0;
+  }
+  if (t == 0) {
+    ctl->eps = p.eps;
+    ctl->fcalls = 0;
+    ctl->iter = 0;
+  }
+  __syncthreads();
+  uint64_t total_iter = 0;
+  double final_f = 0.0;
+
+  for (uint64_t run = 0; run <= p.restarts; run++) {
+    // ---- simplex ctor (1910-1950) with the effective vertices of SURVEY B1
+    double scale = p.step;
+    if (p.step < 0) {
+      double inf_norm = fabs(x0[0]);  // max_abs_vec, 1894-1904
+      for (uint64_t i = 1; i < n; i++) {
+        const double a = fabs(x0[i]);
+        if (inf_norm < a) inf_norm = a;
+      }
+      const double a = inf_norm < 1.0 ? 1.0 : inf_norm;
+      scale = a < 10 ? a : 10;
+    }
+    for (uint64_t e = t; e < nv * n; e += 256) {
+      const uint64_t v = e / n, j = e % n;
+      double val = x0[j];
+      if (v >= 1 && v < n && j == v) val = val + scale;  // vertex n keeps x (the OOB write)
+      if (v == 0 && p.step < 0) {
+        const double nn = static_cast<double>(n);
+        val = x0[j] + ((1.0 - sqrt(nn + 1.0)) / nn * scale);
+      }
+      S[e] = val;
+    }
+    for (uint64_t j = t; j < n; j += 256) centroid[j] = 0.0;  // :2195
+    __syncthreads();
+    for (uint64_t v = wid; v < nv; v += 4) {  // 2184-2186
+      const double f = nm_wave_f<OBJ>(S + v * n, n, p.fmul);
+      if (lane == 0) scores[v] = f;
+    }
+    __syncthreads();
+    if (t == 0) {
+      ctl->fcalls += nv;
+      ctl->eps = ctl->eps * (scores[0] * ctl->eps);  // 2189 (B2)
+      ctl->worst = 0;
+      ctl->second_worst = 0;
+      ctl->prev_worst = 0;
+      ctl->last_best = 99999999;
+      ctl->no_change = 0;
+      ctl->iter = 0;
+      ctl->shrunk = 0;
+    }
+    __syncthreads();
+
+    for (;;) {
+      // ---- std_err(scores) by wave 0 (lane tree), then the scan by thread 0
+      if (wid == 0) {
+        double acc = 0.0;
+        for (uint64_t i = lane; i < nv; i += 64) acc = acc + scores[i];
+        const double mean = wave_sum(acc) / static_cast<double>(nv);
+        acc = 0.0;
+        for (uint64_t i = lane; i < nv; i += 64) {
+          const double d = scores[i] - mean;
+          acc = acc + d * d;
+        }
+        const double se = sqrt(wave_sum(acc) / static_cast<double>(nv - 1));
+        if (lane == 0) {
+          uint64_t best = 0, worst = 0, second = 0;
+          double sb = scores[0], sw = scores[0];
+          for (uint64_t i = 1; i < nv; i++) {  // 2208-2221 (B3)
+            const double si = scores[i];
+            if (si < sb) {
+              best = i;
+              sb = si;
+            } else if (si > sw) {
+              second = worst;
+              worst = i;
+              sw = si;
+            }
+          }
+          ctl->prev_worst = ctl->worst;
+          ctl->best = best;
+          ctl->worst = worst;
+          ctl->second_worst = second;
+          ctl->se = se;
+          if (ctl->last_best == best) {  // 2223-2230
+            ctl->no_change++;
+          } else {
+            ctl->no_change = 0;
+            ctl->last_best = best;
+          }
+          ctl->stop = (ctl->iter >= p.max_iter || se < ctl->eps ||
+                       ctl->no_change >= p.no_change_tol)
+                          ? 1
+                          : 0;  // 2233-2234
+          if (!ctl->stop) ctl->iter++;
+        }
+      }
+      __syncthreads();
+      if (ctl->stop) break;
+      const uint64_t best = ctl->best, worst = ctl->worst, second = ctl->second_worst;
+      // ---- centroid of all vertices but the worst (1965-1984), only when it can have changed
+      if (ctl->prev_worst != worst || ctl->shrunk) {
+        for (uint64_t j = t; j < n; j += 256) {
+          double c = 0.0;
+          for (uint64_t v = 0; v < nv; v++)
+            if (v != worst) c += S[v * n + j];
+          centroid[j] = c / static_cast<double>(nv - 1);
+        }
+      }
+      __syncthreads();
+      // ---- reflect (2245): c + alpha (c - p), clamped when bounded
+      for (uint64_t j = t; j < n; j += 256) {
+        double v = centroid[j] + p.alpha * (centroid[j] - S[worst * n + j]);
+        if (p.bounded) v = v < lo[j] ? lo[j] : (up[j] < v ? up[j] : v);
+        tr[j] = v;
+      }
+      __syncthreads();
+      if (wid == 0) {
+        const double rs = nm_wave_f<OBJ>(tr, n, p.fmul);
+        if (lane == 0) {
+          ctl->ref_score = rs;
+          ctl->fcalls++;
+          ctl->shrunk = 0;
+          // 0 accept reflection, 1 expand, 2 contract
+          ctl->action = (rs >= scores[best] && rs < scores[second]) ? 0 : (rs < scores[best] ? 1 : 2);
+        }
+      }
+      __syncthreads();
+      const int action = ctl->action;
+      const double ref_score = ctl->ref_score;
+      if (action == 0) {  // 2251-2253
+        for (uint64_t j = t; j < n; j += 256) S[worst * n + j] = tr[j];
+        if (t == 0) scores[worst] = ref_score;
+      } else if (action == 1) {  // expand, 2255-2265: c + gamma (reflected - c)
+        for (uint64_t j = t; j < n; j += 256) {
+          double v = centroid[j] + p.gamma * (tr[j] - centroid[j]);
+          if (p.bounded) v = v < lo[j] ? lo[j] : (up[j] < v ? up[j] : v);
+          te[j] = v;
+        }
+        __syncthreads();
+        if (wid == 0) {
+          const double es = nm_wave_f<OBJ>(te, n, p.fmul);
+          if (lane == 0) {
+            ctl->exp_score = es;
+            ctl->fcalls++;
+          }
+        }
+        __syncthreads();
+        const bool take_exp = ctl->exp_score < ref_score;
+        for (uint64_t j = t; j < n; j += 256) S[worst * n + j] = take_exp ? te[j] : tr[j];
+        if (t == 0) scores[worst] = take_exp ? ctl->exp_score : ref_score;
+      } else {  // contraction, 2266-2297 (B4: the reflect transform for both kinds)
+        const bool outside = ref_score < scores[worst];
+        for (uint64_t j = t; j < n; j += 256) {
+          const double pt = outside ? tr[j] : S[worst * n + j];
+          double v = centroid[j] + p.rho * (centroid[j] - pt);
+          if (p.bounded) v = v < lo[j] ? lo[j] : (up[j] < v ? up[j] : v);
+          tc[j] = v;
+        }
+        __syncthreads();
+        if (wid == 0) {
+          const double cs = nm_wave_f<OBJ>(tc, n, p.fmul);
+          if (lane == 0) {
+            ctl->cont_score = cs;
+            ctl->fcalls++;
+          }
+        }
+        __syncthreads();
+        const double cont_score = ctl->cont_score;
+        const double worst_score = scores[worst];
+        if (cont_score < (outside ? ref_score : worst_score)) {
+          __syncthreads();  // every thread has read scores[worst]
+          for (uint64_t j = t; j < n; j += 256) S[worst * n + j] = tc[j];
+          if (t == 0) scores[worst] = cont_score;
+        } else {  // shrink (2009-2035) and rescoring (2288-2294)
+          __syncthreads();
+          for (uint64_t e = t; e < nv * n; e += 256) {
+            const uint64_t v = e / n, j = e % n;
+            if (v != best) S[e] = S[best * n + j] + p.sigma * (S[e] - S[best * n + j]);
+          }
+          __syncthreads();
+          for (uint64_t v = wid; v < nv; v += 4) {
+            if (v == best) continue;
+            const double f = nm_wave_f<OBJ>(S + v * n, n, p.fmul);
+            if (lane == 0) scores[v] = f;
+          }
+          if (t == 0) {
+            ctl->fcalls += nv - 1;
+            ctl->shrunk = 1;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    // x = current_simplex.vals[best] (2235); restarts continue from it (2129-2132)
+    const uint64_t best = ctl->best;
+    for (uint64_t j = t; j < n; j += 256) x0[j] = S[best * n + j];
+    total_iter += ctl->iter;
+    final_f = scores[best];
+    __syncthreads();
+  }
+  for (uint64_t j = t; j < n; j += 256) p.x[pid * n + j] = x0[j];
+  if (t == 0) {
+    NmProblem *pr = p.prob + pid;
+    pr->f = final_f;
+    pr->eps = ctl->eps;
+    pr->iter = total_iter;
+    pr->fcalls = ctl->fcalls;
+  }
+}
+
+inline size_t nm_lds_bytes(uint64_t n) {
+  const uint64_t nv = n + 1;
+  return (nv * n + ((nv + 1) & ~1ull) + 7 * n) * sizeof(double) + sizeof(NmCtl) + 16;
+}
+
+}  // namespace nlsg

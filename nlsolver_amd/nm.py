@@ -1,0 +1,100 @@
+"""Host-side mirror of the reference's NelderMead class for device objectives, batched.
+
+Reference interface (nlsolver.h:2099-2165):
+    NelderMead<Callable, scalar_t>(f, step = -1, alpha = 1, gamma = 2, rho = 0.5, sigma = 0.5,
+        eps = 1e-6, max_iter = 500, no_change_best_tol = 20, restarts = 0)
+    minimize(x) / maximize(x) / minimize(x, upper, lower) / maximize(x, upper, lower)
+(upper before lower — the opposite of PSO). x may be (n,) or (batch, n): independent starts,
+one simplex per GPU workgroup.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import NMConfig, Status, check, lib
+
+
+class NMEngine:
+    def __init__(self, objective, batch, dim, *, minimize=True, bounded=False, step=-1.0, alpha=1.0,
+                 gamma=2.0, rho=0.5, sigma=0.5, eps=1e-6, max_iter=500, no_change_best_tol=20,
+                 restarts=0, device=0, stream=None):
+        cfg = NMConfig()
+        cfg.struct_size = C.sizeof(NMConfig)
+        cfg.device = device
+        cfg.stream = None if stream is None else (stream or 1)
+        cfg.objective = _capi.OBJECTIVES[objective] if isinstance(objective, str) else objective
+        cfg.minimize, cfg.bounded = int(bool(minimize)), int(bool(bounded))
+        cfg.batch, cfg.dim = batch, dim
+        cfg.step, cfg.alpha, cfg.gamma, cfg.rho, cfg.sigma, cfg.eps = step, alpha, gamma, rho, sigma, eps
+        cfg.max_iter, cfg.no_change_best_tol, cfg.restarts = max_iter, no_change_best_tol, restarts
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        check(lib().nlsg_nm_create(C.byref(cfg), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().nlsg_nm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def minimize(self, x, upper=None, lower=None):
+        B, n = self.cfg.batch, self.cfg.dim
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        assert x.shape == (B, n)
+        up = lo = None
+        if self.cfg.bounded:
+            up = np.ascontiguousarray(np.broadcast_to(upper, (n,)), dtype=np.float64)
+            lo = np.ascontiguousarray(np.broadcast_to(lower, (n,)), dtype=np.float64)
+        st = (Status * B)()
+        eps = np.empty(B)
+        check(lib().nlsg_nm_minimize(self._h, x.ctypes.data_as(_capi.pd),
+                                     up.ctypes.data_as(_capi.pd) if up is not None else None,
+                                     lo.ctypes.data_as(_capi.pd) if lo is not None else None,
+                                     st, eps.ctypes.data_as(_capi.pd)))
+        return x, list(st), eps
+
+    def time_solve(self, x0, repeats=1):
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        ms = C.c_float()
+        check(lib().nlsg_nm_time_solve(self._h, x0.ctypes.data_as(_capi.pd), repeats, C.byref(ms)))
+        return ms.value
+
+
+class NelderMead:
+    """Drop-in for nlsolver::NelderMead on a device objective (same ctor args/defaults)."""
+
+    def __init__(self, f, step=-1.0, alpha=1.0, gamma=2.0, rho=0.5, sigma=0.5, eps=1e-6,
+                 max_iter=500, no_change_best_tol=20, restarts=0, *, device=0):
+        self.f = f
+        self.eps = eps  # mutated by every solve like the reference's member (nlsolver.h:2189)
+        self.args = dict(step=step, alpha=alpha, gamma=gamma, rho=rho, sigma=sigma,
+                         max_iter=max_iter, no_change_best_tol=no_change_best_tol,
+                         restarts=restarts, device=device)
+
+    def _solve(self, x, upper, lower, minimize):
+        if not isinstance(x, np.ndarray) or x.dtype != np.float64 or x.ndim not in (1, 2):
+            raise TypeError("x must be a float64 numpy array of shape (n,) or (batch, n)")
+        xb = x.reshape(1, -1) if x.ndim == 1 else x
+        bounded = upper is not None
+        with NMEngine(self.f, xb.shape[0], xb.shape[1], minimize=minimize, bounded=bounded,
+                      eps=self.eps, **self.args) as eng:
+            out, st, eps = eng.minimize(xb, upper, lower)
+        xb[...] = out
+        if x.ndim == 1:
+            self.eps = float(eps[0])
+            return st[0]
+        return st
+
+    def minimize(self, x, upper=None, lower=None):
+        return self._solve(x, upper, lower, True)
+
+    def maximize(self, x, upper=None, lower=None):
+        return self._solve(x, upper, lower, False)
