@@ -166,6 +166,38 @@ def main_lm(args):
     eng.close()
 
 
+def main_nm(args):
+    """Batched Nelder-Mead (no BASELINE config names it): Rosenbrock-128D,
+    2000 iterations per start, eps = 0, batch = 4096 independent simplexes, one per workgroup, the
+    129 x 128 simplex resident in LDS. One step = one simplex iteration of every start."""
+    import torch
+
+    import nlsolver_amd
+    n, iters = 128, 2000
+    batch = 4096 if args.pop_per_gpu == POP_PER_GPU else args.pop_per_gpu
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    rng = np.random.default_rng(7)
+    x0 = 0.5 + 0.2 * (rng.random((batch, n)) - 0.5)
+    eng = nlsolver_amd.NMEngine("rosenbrock", batch, n, eps=0.0, max_iter=iters,
+                                no_change_best_tol=10**9, device=local_rank)
+    eng.time_solve(x0, 1)
+    ms = eng.time_solve(x0, 2) / 2
+    x, st, _ = eng.minimize(x0.copy())
+    fcalls = sum(s.function_calls_used for s in st)
+    print(json.dumps({
+        "metric": "Nelder-Mead iterations x starts / s (Rosenbrock-128D)",
+        "value": batch * iters / (ms * 1e-3), "unit": "iteration-starts/s", "n_gpus": 1,
+        "steps": iters, "warmup": 1, "ms_per_step": ms / iters, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"Nelder-Mead Rosenbrock-{n}D, {iters} iterations, batch={batch}",
+                   "objective_calls_per_s": fcalls / (ms * 1e-3)},
+        "roofline": {"bound": "latency", "achieved": None, "peak": None, "unit": None,
+                     "frac": None, "traffic": None, "kernel": "nm_solve_kernel", "kernel_ms": ms,
+                     "note": "LDS-resident, decision chain; not roofline-graded (SURVEY §8d)"}}))
+    eng.close()
+
+
 def main_pso(args):
     """BASELINE configs[4]: PSO swarm = 2^20 particles x D=256 sharded over 8 GPUs ->
     131072 particles per GPU (weak scaling). One step = best update + stop tests + one
@@ -258,7 +290,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--pop-per-gpu", type=int, default=POP_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["de", "pso-accel", "pso-vanilla", "bfgs", "lm"],
+    ap.add_argument("--workload", choices=["de", "pso-accel", "pso-vanilla", "bfgs", "lm", "nm"],
                     default="de",
                     help="de = the headline benchmark (BASELINE metric); pso-* = config 5's "
                          "per-GPU shard (secondary, same JSON shape)")
@@ -267,6 +299,8 @@ def main():
         return main_bfgs(args)
     if args.workload == "lm":
         return main_lm(args)
+    if args.workload == "nm":
+        return main_nm(args)
     if args.workload != "de":
         return main_pso(args)
 

@@ -56,7 +56,7 @@ def test_nm_bounded_and_maximize(mod, oracle, minimize):
                                  max_iter=100, eps=0.0, no_change=1000)
         assert st[b].f_value == ref.f_value and np.array_equal(x[b], xr)
         assert st[b].function_calls_used == ref.function_calls_used
-    assert np.all(x <= 2.0) and np.all(x >= -2.0)
+    # (only transformed points are clamped, nlsolver.h:2001-2003: an initial vertex may lie outside)
 
 
 def test_nm_other_objectives(mod, oracle):
