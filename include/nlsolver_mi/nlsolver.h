@@ -223,6 +223,34 @@ struct QuadDiagRank1 {
 // Grad tag for device objectives: their gradient is evaluated by the kernels.
 struct analytic_grad {};
 
+// NLLS model for the batched Levenberg-Marquardt path:
+// r_i(theta) = y_i - tanh(sum_j A_ij theta_j), f = sum r^2; the Gauss-Newton gradient and
+// Hessian (2 J^T r, 2 J^T J) are evaluated by the kernels. A: [problems][m][n] row-major.
+template <typename T = double>
+struct TanhRegression {
+  static constexpr int nlsg_nlls_objective = NLSG_OBJ_TANH_REGRESSION;
+  size_t m, n;
+  std::vector<T> A, y;  // problems*m*n, problems*m
+  TanhRegression(size_t m, size_t n, std::vector<T> A, std::vector<T> y)
+      : m(m), n(n), A(std::move(A)), y(std::move(y)) {}
+  size_t problems() const { return y.size() / m; }
+  T operator()(const std::vector<T> &theta) const {  // problem 0
+    T acc = 0;
+    for (size_t i = 0; i < m; i++) {
+      T z = 0;
+      for (size_t j = 0; j < n; j++) z += A[i * n + j] * theta[j];
+      const T r = y[i] - std::tanh(z);
+      acc += r * r;
+    }
+    return acc;
+  }
+};
+struct gauss_newton {};  // Grad / Hess tag of device NLLS models
+template <typename C, typename = void>
+struct has_nlls_objective : std::false_type {};
+template <typename C>
+struct has_nlls_objective<C, std::void_t<decltype(C::nlsg_nlls_objective)>> : std::true_type {};
+
 template <typename C, typename = void>
 struct has_grad_objective : std::false_type {};
 template <typename C>
@@ -252,6 +280,13 @@ class api {
   decltype(&nlsg_bfgs_create) bfgs_create;
   decltype(&nlsg_bfgs_destroy) bfgs_destroy;
   decltype(&nlsg_bfgs_minimize) bfgs_minimize;
+  decltype(&nlsg_lm_create) lm_create;
+  decltype(&nlsg_lm_destroy) lm_destroy;
+  decltype(&nlsg_lm_set_data) lm_set_data;
+  decltype(&nlsg_lm_minimize) lm_minimize;
+  decltype(&nlsg_nm_create) nm_create;
+  decltype(&nlsg_nm_destroy) nm_destroy;
+  decltype(&nlsg_nm_minimize) nm_minimize;
 
   void check(int rc) const {
     if (rc != NLSG_OK)
@@ -277,6 +312,13 @@ class api {
     bind(h, "nlsg_bfgs_create", bfgs_create);
     bind(h, "nlsg_bfgs_destroy", bfgs_destroy);
     bind(h, "nlsg_bfgs_minimize", bfgs_minimize);
+    bind(h, "nlsg_lm_create", lm_create);
+    bind(h, "nlsg_lm_destroy", lm_destroy);
+    bind(h, "nlsg_lm_set_data", lm_set_data);
+    bind(h, "nlsg_lm_minimize", lm_minimize);
+    bind(h, "nlsg_nm_create", nm_create);
+    bind(h, "nlsg_nm_destroy", nm_destroy);
+    bind(h, "nlsg_nm_minimize", nm_minimize);
     if (abi_version() != NLSG_ABI_VERSION)
       throw device_error("libnlsolver_hip.so ABI version mismatch");
   }
@@ -942,6 +984,393 @@ class BFGS {
         for (size_t i = 0; i < n; i++)
           H[j * n + i] = H[j * n + i] - rho * (s[i] * t[j] + t[i] * s[j] + denom * s[i] * s[j]);
       iter++;
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------
+// NelderMead — nlsolver.h:1894-2300
+// ---------------------------------------------------------------------------
+template <typename Callable, typename scalar_t = double>
+class NelderMead {
+  Callable &f;
+  const scalar_t step, alpha, gamma, rho, sigma;
+  scalar_t eps;  // rescaled by every solve (nlsolver.h:2189)
+  const size_t max_iter, no_change_best_tol, restarts;
+
+ public:
+  // same positional arguments and defaults as nlsolver.h:2110-2115
+  explicit NelderMead(Callable &f, const scalar_t step = -1, const scalar_t alpha = 1,
+                      const scalar_t gamma = 2, const scalar_t rho = 0.5,
+                      const scalar_t sigma = 0.5, const scalar_t eps = 1e-6,
+                      const size_t max_iter = 500, const size_t no_change_best_tol = 20,
+                      const size_t restarts = 0)
+      : f(f), step(step), alpha(alpha), gamma(gamma), rho(rho), sigma(sigma), eps(eps),
+        max_iter(max_iter), no_change_best_tol(no_change_best_tol), restarts(restarts) {}
+  solver_status<scalar_t> minimize(std::vector<scalar_t> &x) {
+    std::vector<scalar_t> none;
+    return run<true, false>(x, none, none);
+  }
+  solver_status<scalar_t> maximize(std::vector<scalar_t> &x) {
+    std::vector<scalar_t> none;
+    return run<false, false>(x, none, none);
+  }
+  // note the argument order (upper, lower), nlsolver.h:2136 / 2155
+  solver_status<scalar_t> minimize(std::vector<scalar_t> &x, const std::vector<scalar_t> &upper,
+                                   const std::vector<scalar_t> &lower) {
+    return run<true, true>(x, upper, lower);
+  }
+  solver_status<scalar_t> maximize(std::vector<scalar_t> &x, const std::vector<scalar_t> &upper,
+                                   const std::vector<scalar_t> &lower) {
+    return run<false, true>(x, upper, lower);
+  }
+
+ private:
+  template <bool minimize, bool bound>
+  solver_status<scalar_t> run(std::vector<scalar_t> &x, const std::vector<scalar_t> &upper,
+                              const std::vector<scalar_t> &lower) {
+    if constexpr (device::is_device_objective<Callable>::value) {
+      static_assert(std::is_same_v<scalar_t, double>, "the device path computes in fp64");
+      const device::api &api = device::api::get();
+      nlsg_nm_config cfg{};
+      cfg.struct_size = sizeof(cfg);
+      if (const char *d = std::getenv("NLSG_DEVICE")) cfg.device = std::atoi(d);
+      cfg.objective = Callable::nlsg_objective;
+      cfg.minimize = minimize ? 1 : 0;
+      cfg.bounded = bound ? 1 : 0;
+      cfg.batch = 1;
+      cfg.dim = x.size();
+      cfg.step = step;
+      cfg.alpha = alpha;
+      cfg.gamma = gamma;
+      cfg.rho = rho;
+      cfg.sigma = sigma;
+      cfg.eps = eps;
+      cfg.max_iter = max_iter;
+      cfg.no_change_best_tol = no_change_best_tol;
+      cfg.restarts = restarts;
+      nlsg_nm *eng = nullptr;
+      api.check(api.nm_create(&cfg, &eng));
+      nlsg_status st{};
+      double eps_after = eps;
+      const int rc = api.nm_minimize(eng, x.data(), bound ? upper.data() : nullptr,
+                                     bound ? lower.data() : nullptr, &st, &eps_after);
+      const std::string msg = rc ? api.last_error() : "";
+      api.nm_destroy(eng);
+      if (rc) throw device_error("nlsg error " + std::to_string(rc) + ": " + msg);
+      eps = eps_after;
+      return solver_status<scalar_t>(st.f_value, st.iteration, st.function_calls_used);
+    } else {
+      auto res = solve_host<minimize, bound>(x, upper, lower);
+      for (size_t i = 0; i < restarts; i++) res.add(solve_host<minimize, bound>(x, upper, lower));
+      return res;
+    }
+  }
+
+  // Host path: NelderMead::solve (nlsolver.h:2166-2299) with the effective initial simplex
+  // of the reference (its write to element [n][n] is out of bounds and is dropped), the eps
+  // rescaling, the running second-worst rule, contraction with the reflect transform and
+  // the centroid that is only recomputed when the worst vertex changed.
+  template <bool minimize, bool bound>
+  solver_status<scalar_t> solve_host(std::vector<scalar_t> &x, const std::vector<scalar_t> &upper,
+                                     const std::vector<scalar_t> &lower) {
+    const size_t n = x.size(), nv = n + 1;
+    std::vector<std::vector<scalar_t>> S(nv, x);
+    scalar_t spread = step;
+    if (step < 0) {
+      scalar_t inf_norm = std::abs(x[0]);
+      for (size_t i = 1; i < n; i++) inf_norm = inf_norm < std::abs(x[i]) ? std::abs(x[i]) : inf_norm;
+      const scalar_t a = inf_norm < 1.0 ? 1.0 : inf_norm;
+      spread = a < 10 ? a : 10;
+    }
+    for (size_t i = 1; i < n; i++) S[i][i] += spread;
+    if (step < 0) {
+      const auto nn = static_cast<scalar_t>(n);
+      for (size_t i = 0; i < n; i++) S[0][i] = x[i] + ((1.0 - std::sqrt(nn + 1.0)) / nn * spread);
+    }
+    size_t calls = 0;
+    auto value = [&](std::vector<scalar_t> &at) {
+      constexpr scalar_t sign = minimize ? 1.0 : -1.0;
+      calls++;
+      return sign * f(at);
+    };
+    auto transform = [&](const std::vector<scalar_t> &pt, const std::vector<scalar_t> &c,
+                         std::vector<scalar_t> &out, scalar_t coef, bool reflect) {
+      for (size_t i = 0; i < n; i++) {
+        scalar_t t = reflect ? c[i] + coef * (c[i] - pt[i]) : c[i] + coef * (pt[i] - c[i]);
+        if constexpr (bound) t = std::clamp(t, lower[i], upper[i]);
+        out[i] = t;
+      }
+    };
+    std::vector<scalar_t> scores(nv);
+    for (size_t v = 0; v < nv; v++) scores[v] = value(S[v]);
+    eps = eps * (scores[0] * eps);
+    size_t best, worst = 0, second = 0, prev_worst = 0, last_best = 99999999, stale = 0, iter = 0;
+    std::vector<scalar_t> centroid(n), refl(n), expd(n), cont(n);
+    bool shrunk = false;
+    for (;;) {
+      best = 0;
+      prev_worst = worst;
+      worst = 0;
+      second = 0;
+      const scalar_t spread_f = std_err(scores);
+      for (size_t i = 1; i < nv; i++) {
+        if (scores[i] < scores[best]) {
+          best = i;
+        } else if (scores[i] > scores[worst]) {
+          second = worst;
+          worst = i;
+        }
+      }
+      if (last_best == best) {
+        stale++;
+      } else {
+        stale = 0;
+        last_best = best;
+      }
+      if (iter >= max_iter || spread_f < eps || stale >= no_change_best_tol) {
+        x = S[best];
+        return solver_status<scalar_t>(scores[best], iter, calls);
+      }
+      iter++;
+      if (prev_worst != worst || shrunk) {
+        std::fill(centroid.begin(), centroid.end(), 0.0);
+        for (size_t v = 0; v < nv; v++)
+          if (v != worst)
+            for (size_t j = 0; j < n; j++) centroid[j] += S[v][j];
+        for (auto &c : centroid) c /= static_cast<scalar_t>(nv - 1);
+        shrunk = false;
+      }
+      transform(S[worst], centroid, refl, alpha, true);
+      const scalar_t r_score = value(refl);
+      if (r_score >= scores[best] && r_score < scores[second]) {
+        S[worst] = refl;
+        scores[worst] = r_score;
+      } else if (r_score < scores[best]) {
+        transform(refl, centroid, expd, gamma, false);
+        const scalar_t e_score = value(expd);
+        S[worst] = e_score < r_score ? expd : refl;
+        scores[worst] = e_score < r_score ? e_score : r_score;
+      } else {
+        const bool outside = r_score < scores[worst];
+        transform(outside ? refl : S[worst], centroid, cont, rho, true);
+        const scalar_t c_score = value(cont);
+        if (c_score < (outside ? r_score : scores[worst])) {
+          S[worst] = cont;
+          scores[worst] = c_score;
+        } else {
+          for (size_t v = 0; v < nv; v++)
+            if (v != best)
+              for (size_t j = 0; j < n; j++) S[v][j] = S[best][j] + sigma * (S[v][j] - S[best][j]);
+          for (size_t v = 0; v < nv; v++)
+            if (v != best) scores[v] = value(S[v]);
+          shrunk = true;
+        }
+      }
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------
+// LevenbergMarquardt — nlsolver.h:251-330, 1414-1517, 3428-3545
+// ---------------------------------------------------------------------------
+namespace finite_difference {
+// 16-point cross stencil of the default Hess functor (nlsolver.h:1447-1515 with accuracy = 1):
+// weights -63, +63, +44, +74 over the offsets below, divided by 600 eps^2, eps = epsilon^(1/4).
+// The offsets are applied to the saved x_i, x_j (the reference walks x incrementally).
+template <typename Callable, typename scalar_t>
+void finite_difference_hessian(Callable &f, std::vector<scalar_t> &x, std::vector<scalar_t> &hess) {
+  const scalar_t eps = std::pow(std::numeric_limits<scalar_t>::epsilon(), static_cast<scalar_t>(0.25));
+  static constexpr int st[16][3] = {
+      {1, -2, -63}, {2, -1, -63}, {-2, 1, -63}, {-1, 2, -63}, {-1, -2, 63}, {-2, -1, 63},
+      {1, 2, 63},   {2, 1, 63},   {2, -2, 44},  {-2, 2, 44},  {-2, -2, -44}, {2, 2, -44},
+      {-1, -1, 74}, {1, 1, 74},   {1, -1, -74}, {-1, 1, -74}};
+  const size_t p = x.size();
+  for (size_t i = 0; i < p; i++)
+    for (size_t j = 0; j < p; j++) {
+      const scalar_t xi = x[i], xj = x[j];
+      scalar_t acc = 0;
+      for (const auto &k : st) {
+        x[i] = xi;
+        x[j] = xj;
+        x[i] += k[0] * eps;
+        x[j] += k[1] * eps;
+        acc += k[2] * f(x);
+      }
+      x[i] = xi;
+      x[j] = xj;
+      hess[i * p + j] = acc / (600.0 * eps * eps);
+    }
+}
+}  // namespace finite_difference
+
+template <typename Callable, typename scalar_t>
+struct fin_diff_h {  // nlsolver.h:2856-2863
+  void operator()(Callable &f, std::vector<scalar_t> &x, std::vector<scalar_t> &hessian) {
+    finite_difference::finite_difference_hessian<Callable, scalar_t>(f, x, hessian);
+  }
+};
+
+namespace math {
+// get_update_with_hessian (nlsolver.h:310-330): diagonal shortcut, else in-place Cholesky +
+// forward / transposed back substitution (251-294). `hess` is overwritten.
+template <typename T>
+void get_update_with_hessian(std::vector<T> &update, std::vector<T> &hess, std::vector<T> &grad) {
+  const size_t n = grad.size();
+  bool diagonal = true;
+  for (size_t i = 0; i < n && diagonal; i++)
+    for (size_t j = 0; j < n; j++)
+      if (i != j && hess[i * n + j] > std::numeric_limits<T>::epsilon() * 1e12) {
+        diagonal = false;
+        break;
+      }
+  if (diagonal) {
+    for (size_t i = 0; i < n; i++) update[i] = grad[i] / hess[i * n + i];
+    return;
+  }
+  for (size_t i = 0; i < n; ++i) {  // cholesky
+    for (size_t j = 0; j < i; ++j) {
+      T sum = 0;
+      for (size_t k = 0; k < j; ++k) sum += hess[i * n + k] * hess[j * n + k];
+      hess[i * n + j] = (1.0 / hess[j * n + j] * (hess[i * n + j] - sum));
+    }
+    T sum = 0;
+    for (size_t k = 0; k < i; ++k) sum += hess[i * n + k] * hess[i * n + k];
+    hess[i * n + i] = std::sqrt(hess[i * n + i] - sum);
+  }
+  std::fill(update.begin(), update.end(), 0.0);
+  for (size_t i = 0; i < n; ++i) {  // L z = g
+    T sum = 0.0;
+    for (size_t j = 0; j < i; ++j) sum += hess[i * n + j] * update[j];
+    update[i] = (grad[i] - sum) / hess[i + i * n];
+  }
+  for (size_t i = n; i-- > 0;) {  // L^T u = z
+    T sum = 0.0;
+    for (size_t j = i + 1; j < n; ++j) sum += hess[j * n + i] * update[j];
+    update[i] = (update[i] - sum) / hess[i * n + i];
+  }
+}
+}  // namespace math
+
+template <typename Callable, typename scalar_t,
+          typename Grad = std::conditional_t<device::has_nlls_objective<Callable>::value,
+                                             device::gauss_newton, fin_diff<Callable, scalar_t>>,
+          typename Hess = std::conditional_t<device::has_nlls_objective<Callable>::value,
+                                             device::gauss_newton, fin_diff_h<Callable, scalar_t>>>
+class LevenbergMarquardt {
+  Callable &f;
+  Grad g;
+  Hess h;
+  scalar_t lambda;  // mutable across calls, like the reference's member (nlsolver.h:3436)
+  const scalar_t upward_mult, downward_mult;
+  const size_t max_iter;
+  const scalar_t f_delta;
+
+ public:
+  // same positional arguments and defaults as nlsolver.h:3443-3447
+  explicit LevenbergMarquardt(Callable &f, const scalar_t lambda = 10,
+                              const scalar_t upward_mult = 10, const scalar_t downward_mult = 10,
+                              const size_t max_iter = 100, const scalar_t f_delta = 1e-12,
+                              Grad g = Grad(), Hess h = Hess())
+      : f(f), g(g), h(h), lambda(lambda), upward_mult(upward_mult), downward_mult(downward_mult),
+        max_iter(max_iter), f_delta(f_delta) {}
+  solver_status<scalar_t> minimize(std::vector<scalar_t> &x) {
+    if constexpr (device::has_nlls_objective<Callable>::value) {
+      std::vector<std::vector<scalar_t>> one{x};
+      auto st = minimize_batch(one);
+      x = one[0];
+      return st[0];
+    } else {
+      return solve_host(x);
+    }
+  }
+  solver_status<scalar_t> maximize(std::vector<scalar_t> &) {
+    static_assert(sizeof(Callable) == 0,
+                  "LevenbergMarquardt currently only supports minimization");  // :3468
+    return solver_status<scalar_t>(0, 0, 0);
+  }
+  // Extension (BASELINE config 4): one start per problem of the model, all solved by one launch.
+  std::vector<solver_status<scalar_t>> minimize_batch(std::vector<std::vector<scalar_t>> &thetas) {
+    static_assert(device::has_nlls_objective<Callable>::value,
+                  "minimize_batch needs a device NLLS model");
+    static_assert(std::is_same_v<scalar_t, double>, "the device path computes in fp64");
+    const device::api &api = device::api::get();
+    const size_t B = thetas.size(), n = f.n;
+    if (B != f.problems()) throw device_error("one start per problem of the model is required");
+    nlsg_lm_config cfg{};
+    cfg.struct_size = sizeof(cfg);
+    if (const char *d = std::getenv("NLSG_DEVICE")) cfg.device = std::atoi(d);
+    cfg.objective = Callable::nlsg_nlls_objective;
+    cfg.solver = NLSG_LM_CHOLESKY;
+    cfg.batch = B;
+    cfg.m = f.m;
+    cfg.n = n;
+    cfg.lambda = lambda;
+    cfg.up = upward_mult;
+    cfg.down = downward_mult;
+    cfg.max_iter = max_iter;
+    cfg.f_delta = f_delta;
+    nlsg_lm *eng = nullptr;
+    api.check(api.lm_create(&cfg, &eng));
+    std::vector<scalar_t> flat(B * n), lam(B);
+    for (size_t p = 0; p < B; p++) std::copy(thetas[p].begin(), thetas[p].end(), flat.begin() + p * n);
+    std::vector<nlsg_status> st(B);
+    int rc = api.lm_set_data(eng, f.A.data(), f.y.data());
+    if (!rc) rc = api.lm_minimize(eng, flat.data(), st.data(), lam.data());
+    const std::string msg = rc ? api.last_error() : "";
+    api.lm_destroy(eng);
+    if (rc) throw device_error("nlsg error " + std::to_string(rc) + ": " + msg);
+    std::vector<solver_status<scalar_t>> out;
+    for (size_t p = 0; p < B; p++) {
+      std::copy(flat.begin() + p * n, flat.begin() + (p + 1) * n, thetas[p].begin());
+      out.emplace_back(st[p].f_value, st[p].iteration, st[p].function_calls_used,
+                       st[p].gradient_evals_used, st[p].hessian_evals_used);
+    }
+    if (B == 1) lambda = lam[0];
+    return out;
+  }
+
+ private:
+  // Host path: LevenbergMarquardt::solve (nlsolver.h:3465-3544): damped Newton, the step is
+  // always accepted, lambda / down on decrease else * up.
+  solver_status<scalar_t> solve_host(std::vector<scalar_t> &x) {
+    const size_t n = x.size();
+    size_t iter = 0, f_calls = 0, g_calls = 0, h_calls = 0;
+    std::vector<scalar_t> gradient(n, 0.0), hessian(n * n, 0.0), update(n);
+    auto f_counted = [&](std::vector<scalar_t> &at) {
+      f_calls++;
+      return f(at);
+    };
+    auto g_counted = [&](std::vector<scalar_t> &at, std::vector<scalar_t> &out) {
+      g_calls++;
+      if constexpr (std::is_same_v<Grad, fin_diff<Callable, scalar_t>>)
+        fin_diff<decltype(f_counted), scalar_t>()(f_counted, at, out);
+      else
+        g(f, at, out);
+    };
+    auto h_counted = [&](std::vector<scalar_t> &at, std::vector<scalar_t> &out) {
+      h_calls++;
+      if constexpr (std::is_same_v<Hess, fin_diff_h<Callable, scalar_t>>)
+        fin_diff_h<decltype(f_counted), scalar_t>()(f_counted, at, out);
+      else
+        h(f, at, out);
+    };
+    g_counted(x, gradient);
+    h_counted(x, hessian);
+    scalar_t previous = 0.0, current = f_counted(x);
+    for (;;) {
+      const scalar_t delta = std::abs(previous - current);
+      if (iter >= max_iter || delta < f_delta || std::isnan(previous))
+        return solver_status<scalar_t>(current, iter, f_calls, g_calls, h_calls);
+      for (size_t i = 0; i < n; i++) hessian[i * n + i] += lambda;
+      math::get_update_with_hessian(update, hessian, gradient);
+      for (size_t i = 0; i < n; i++) x[i] -= update[i];
+      previous = current;
+      current = f_counted(x);
+      iter++;
+      g_counted(x, gradient);
+      h_counted(x, hessian);
+      lambda = current < previous ? lambda / downward_mult : lambda * upward_mult;
     }
   }
 };

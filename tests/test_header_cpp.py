@@ -168,3 +168,79 @@ def test_bfgs_device_batch_through_header_matches_oracle(built, oracle):
             (ref.function_calls_used, ref.iteration, ref.gradient_evals_used)
         assert hx(o["f"]) == ref.f_value
         assert np.array_equal(np.array([hx(v) for v in o["x"]]), xr)
+
+
+NM_CASES = ["example_2d", "d4_200iters", "d4_fixed_step", "d16_bounded", "d8_restarts",
+            "d6_maximize_bounded", "d130_ragged"]
+
+
+def _nm_args(g):
+    return [str(g["D"]), repr(hx(g["step"])), str(g["max_iter"]), repr(hx(g["eps"])),
+            str(g["no_change"]), str(g["restarts"]), repr(hx(g["x0"])), repr(hx(g["x0_step"])),
+            str(g["bounded"]), repr(hx(g["upper"])), repr(hx(g["lower"])), str(g["minimize"])]
+
+
+@pytest.mark.parametrize("name", NM_CASES)
+def test_nm_host_path_through_header_matches_reference_bit_exact(built, golden, name):
+    g = golden("nm.json")[name]
+    o = json.loads(subprocess.check_output([os.path.join(built, "header_nm_lm"), "nm-host",
+                                            *_nm_args(g)], text=True))
+    assert (o["fcalls"], o["iters"]) == (g["fcalls"], g["iters"])
+    assert o["f"] == g["f"] and o["x"] == g["x"]
+
+
+@pytest.mark.parametrize("name,args", [("exp_default", []), ("exp_lambda1_5iters", ["1", "5", "0"])])
+def test_lm_host_path_through_header_matches_reference_bit_exact(built, golden, name, args):
+    g = golden("lm.json")[name]
+    o = json.loads(subprocess.check_output([os.path.join(built, "header_nm_lm"), "lm-host-exp",
+                                            *args], text=True))
+    assert (o["fcalls"], o["iters"], o["gcalls"], o["hcalls"]) == \
+        (g["fcalls"], g["iters"], g["gcalls"], g["hcalls"])
+    assert o["f"] == g["f"] and o["x"] == g["x"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["example_2d", "d4_200iters", "d16_bounded", "d8_restarts"])
+def test_nm_device_objective_through_header_matches_oracle(built, oracle, golden, name):
+    g = golden("nm.json")[name]
+    out = subprocess.check_output([os.path.join(built, "header_nm_lm"), "nm-device", *_nm_args(g)],
+                                  env=dict(os.environ, NLSG_LIBRARY=LIB), text=True)
+    o = json.loads(out)
+    assert "device_error" not in o, o
+    D = g["D"]
+    x0 = hx(g["x0"]) + hx(g["x0_step"]) * np.arange(D, dtype=np.float64)
+    kw = dict(step=hx(g["step"]), eps=hx(g["eps"]), max_iter=g["max_iter"], no_change=g["no_change"],
+              restarts=g["restarts"], minimize=bool(g["minimize"]), order=1)
+    if g["bounded"]:
+        kw.update(upper=hx(g["upper"]), lower=hx(g["lower"]))
+    ref, xr, _, _ = O.nm_run(oracle, x0, **kw)
+    assert (o["fcalls"], o["iters"]) == (ref.function_calls_used, ref.iteration)
+    assert hx(o["f"]) == ref.f_value
+    assert np.array_equal(np.array([hx(v) for v in o["x"]]), xr)
+
+
+@pytest.mark.gpu
+def test_lm_device_model_through_header_matches_oracle(built, oracle):
+    import math
+    m, n, B, iters = 96, 12, 3, 15
+    out = subprocess.check_output([os.path.join(built, "header_nm_lm"), "lm-device", str(m), str(n),
+                                   str(B), str(iters)], env=dict(os.environ, NLSG_LIBRARY=LIB),
+                                  text=True)
+    res = json.loads(out)
+    assert isinstance(res, list) and len(res) == B, res
+    for p, o in enumerate(res):
+        star = np.array([math.sin(0.37 * (j + 3 * p) + 0.1) for j in range(n)])
+        A = np.array([[math.cos(0.11 * (i * n + j) + 1.3 * p) / math.sqrt(n) for j in range(n)]
+                      for i in range(m)])
+        y = np.zeros(m)
+        for i in range(m):
+            z = 0.0
+            for j in range(n):
+                z += A[i, j] * star[j]
+            y[i] = math.tanh(z)
+        th0 = np.array([0.5 * star[j] + 0.05 * math.cos(float(j)) for j in range(n)])
+        ref, xr, lam, _ = O.lm_solve(oracle, A, y, th0, max_iter=iters, f_delta=0.0, order=1)
+        assert (o["iters"], o["fcalls"], o["gcalls"], o["hcalls"]) == \
+            (ref.iteration, ref.function_calls_used, ref.gradient_evals_used, ref.hessian_evals_used)
+        assert hx(o["f"]) == ref.f_value
+        assert np.array_equal(np.array([hx(v) for v in o["x"]]), xr)
