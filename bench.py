@@ -141,8 +141,10 @@ def main_lm(args):
     star = 2 * rng.random((batch, n)) - 1
     y = np.tanh(np.einsum("bmn,bn->bm", A, star))
     theta0 = 0.5 * star + 0.1 * (2 * rng.random((batch, n)) - 1)
+    from nlsolver_amd import _capi
     eng = nlsolver_amd.LMEngine(nlsolver_amd.TanhRegression(A, y), lam=10.0, max_iter=iters,
-                                f_delta=0.0, device=local_rank)
+                                f_delta=0.0, device=local_rank,
+                                solver=_capi.LM_QR if args.lm_solver == "qr" else _capi.LM_CHOLESKY)
     eng.time_solve(theta0, 1)  # warm-up
     reps = 3
     ms = eng.time_solve(theta0, reps) / reps
@@ -157,7 +159,7 @@ def main_lm(args):
         "steps": iters, "warmup": 1, "ms_per_step": ms / iters, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"Levenberg-Marquardt tanh-regression NLLS m={m} n={n}, "
-                               f"batch={batch} (BASELINE configs[3]), Cholesky solve",
+                               f"batch={batch} (BASELINE configs[3]), {args.lm_solver} solve",
                    "max_final_f": max(s.f_value for s in st)},
         "roofline": {"bound": "mfma", "achieved": tflops, "peak": 78.6, "unit": "TFLOP/s",
                      "frac": tflops / 78.6, "traffic": None, "kernel": "lm_solve_kernel",
@@ -290,6 +292,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--pop-per-gpu", type=int, default=POP_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lm-solver", choices=["cholesky", "qr"], default="cholesky",
+                    help="lm workload: damped-system solver (cholesky = the reference class's "
+                         "get_update_with_hessian; qr = tinyqr::lm, as BASELINE configs[3] words it)")
     ap.add_argument("--workload", choices=["de", "pso-accel", "pso-vanilla", "bfgs", "lm", "nm"],
                     default="de",
                     help="de = the headline benchmark (BASELINE metric); pso-* = config 5's "

@@ -42,8 +42,12 @@ int upload_theta(nlsg_lm *e, const double *theta_host) {
 }
 
 void launch_solve(nlsg_lm *e) {
-  hipLaunchKernelGGL(lm_solve_kernel, dim3(static_cast<unsigned>(e->p.batch)), dim3(256),
-                     sizeof(LmShared), e->stream, e->p);
+  const dim3 grid(static_cast<unsigned>(e->p.batch)), block(256);
+  if (e->cfg.solver == NLSG_LM_QR)
+    hipLaunchKernelGGL(lm_solve_kernel<true>, grid, block, sizeof(LmShared) + sizeof(LmQrShared),
+                       e->stream, e->p);
+  else
+    hipLaunchKernelGGL(lm_solve_kernel<false>, grid, block, sizeof(LmShared), e->stream, e->p);
 }
 }  // namespace
 
@@ -57,9 +61,8 @@ int nlsg_lm_create(const nlsg_lm_config *cfg, nlsg_lm **out) {
                 sizeof(nlsg_lm_config));
   if (cfg->objective != NLSG_OBJ_TANH_REGRESSION)
     return fail(NLSG_ERR_INVALID_ARG, "unknown objective %d", cfg->objective);
-  if (cfg->solver != NLSG_LM_CHOLESKY)
-    return fail(NLSG_ERR_UNSUPPORTED, "solver %d: only NLSG_LM_CHOLESKY is built so far",
-                cfg->solver);
+  if (cfg->solver != NLSG_LM_CHOLESKY && cfg->solver != NLSG_LM_QR)
+    return fail(NLSG_ERR_INVALID_ARG, "unknown solver %d", cfg->solver);
   if (cfg->n < 1 || cfg->n > kLmN || cfg->m < 1 || cfg->batch < 1)
     return fail(NLSG_ERR_INVALID_ARG, "need 1 <= n <= 64, m >= 1, batch >= 1");
   if (cfg->batch > 0x7fffffffull) return fail(NLSG_ERR_UNSUPPORTED, "batch too large");
@@ -92,8 +95,12 @@ int nlsg_lm_create(const nlsg_lm_config *cfg, nlsg_lm **out) {
   if (he == hipSuccess) he = hipEventCreate(&e->ev0);
   if (he == hipSuccess) he = hipEventCreate(&e->ev1);
   if (he == hipSuccess)
-    he = hipFuncSetAttribute(reinterpret_cast<const void *>(lm_solve_kernel),
+    he = hipFuncSetAttribute(reinterpret_cast<const void *>(lm_solve_kernel<false>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, sizeof(LmShared));
+  if (he == hipSuccess)
+    he = hipFuncSetAttribute(reinterpret_cast<const void *>(lm_solve_kernel<true>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize,
+                             sizeof(LmShared) + sizeof(LmQrShared));
   if (he != hipSuccess) {
     nlsg_lm_destroy(e);
     return fail(he == hipErrorOutOfMemory ? NLSG_ERR_OOM : NLSG_ERR_HIP,

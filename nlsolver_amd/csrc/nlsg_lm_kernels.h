@@ -46,6 +46,11 @@ struct LmParams {
   double lambda0, up, down, f_delta;
 };
 
+struct LmQrShared {               // extra LDS of the QR solver
+  double Q[64 * kLmHStride];     // the orthogonal factor's transpose, rotated alongside R
+  double c[32], s[32];           // Givens coefficients of the current wavefront step
+};
+
 struct LmShared {
   double J[64 * kLmJStride];  // scaled Jacobian block
   double H[64 * kLmHStride];  // 2 J^T J (+ lambda I), then its Cholesky factor
@@ -199,9 +204,86 @@ __device__ inline void lm_solve_cholesky_wave(LmShared &sh, int n) {
   if (row) sh.upd[t] = u;
 }
 
+// tinyqr::lm on the damped matrix (tinyqr.h:253-310, 437-470): Givens QR in the reference's
+// rotation order (column j, rows bottom-up), executed as wavefronts: rotation (j, i) runs at
+// step (n-1-i) + 2j, all rotations of a step touch disjoint row pairs, so every element sees
+// exactly the sequence of updates the serial loop applies (columns left of j are skipped:
+// they only hold annihilated entries that the cleanup pass zeroes and nothing reads).
+// sh.H is the working R (row-major, = the transposed-input layout of qr_decomposition).
+__device__ inline void lm_solve_qr(LmShared &sh, LmQrShared &qs, int n) {
+  const int t = threadIdx.x, lane = lane_id();
+  const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+  for (int e = t; e < n * n; e += 256) {
+    const int i = e / n, j = e % n;
+    qs.Q[i * kLmHStride + j] = (i == j) ? 1.0 : 0.0;  // make_identity, tinyqr.h:205-210
+  }
+  __syncthreads();
+  for (int step = 0; step <= 2 * n - 4; step++) {
+    const int jlo = step - (n - 2) > 0 ? step - (n - 2) : 0;
+    const int jhi = step / 2 < n - 2 ? step / 2 : n - 2;
+    const int count = jhi - jlo + 1;
+    if (t < count) {  // givens_rotation, tinyqr.h:86-97
+      const int j = jlo + t, i = n - 1 - (step - 2 * j);
+      const double a = sh.H[(i - 1) * kLmHStride + j], b = sh.H[i * kLmHStride + j];
+      double c, sv;
+      if (fabs(b) > fabs(a)) {
+        const double r = a / b;
+        sv = 1.0 / sqrt(r * r + 1.0);
+        c = sv * r;
+      } else {
+        const double r = b / a;
+        c = 1.0 / sqrt(r * r + 1.0);
+        sv = c * r;
+      }
+      qs.c[t] = c;
+      qs.s[t] = sv;
+    }
+    __syncthreads();
+    for (int r = wid; r < count; r += 4) {  // rotate_matrix on R and Q, tinyqr.h:126-139
+      const int j = jlo + r, i = n - 1 - (step - 2 * j);
+      const double c = qs.c[r], sv = qs.s[r];
+      if (lane >= j && lane < n) {
+        double *lo = &sh.H[(i - 1) * kLmHStride + lane], *up = &sh.H[i * kLmHStride + lane];
+        const double t1 = *lo, t2 = *up;
+        *lo = c * t1 + sv * t2;
+        *up = -sv * t1 + c * t2;
+      }
+      if (lane < n) {
+        double *lo = &qs.Q[(i - 1) * kLmHStride + lane], *up = &qs.Q[i * kLmHStride + lane];
+        const double t1 = *lo, t2 = *up;
+        *lo = c * t1 + sv * t2;
+        *up = -sv * t1 + c * t2;
+      }
+    }
+    __syncthreads();
+  }
+  // cleanup with lm()'s tol = 1e-12 (tinyqr.h:278-282, 465) on the entries back_solve reads
+  for (int e = t; e < n * n; e += 256) {
+    const int i = e / n, j = e % n;
+    if (j >= i && fabs(sh.H[i * kLmHStride + j]) < 1e-12) sh.H[i * kLmHStride + j] = 0.0;
+  }
+  __syncthreads();
+  // back_solve (tinyqr.h:437-459): Q^T y lazily per row, then the triangular sweep with the
+  // inner sums taken from j = n-1 down to i+1 (oracle order 1)
+  if (t < 64) {
+    double ytmp = 0;
+    if (t < n)
+      for (int j = 0; j < n; j++) ytmp += qs.Q[t * kLmHStride + j] * sh.g[j];
+    double temp = 0.0, u = 0.0;
+    for (int j = n - 1; j >= 0; j--) {
+      if (t == j) u = (ytmp - temp) / sh.H[j * kLmHStride + j];
+      const double uj = __shfl(u, j, 64);
+      if (t < j) temp += sh.H[t * kLmHStride + j] * uj;
+    }
+    if (t < n) sh.upd[t] = u;
+  }
+}
+
+template <bool QR>
 __global__ __launch_bounds__(256) void lm_solve_kernel(LmParams p) {
   extern __shared__ __align__(16) unsigned char lm_smem[];
   LmShared &sh = *reinterpret_cast<LmShared *>(lm_smem);
+  LmQrShared &qs = *reinterpret_cast<LmQrShared *>(lm_smem + sizeof(LmShared));  // QR only
   const uint64_t pid = blockIdx.x;
   const int t = threadIdx.x;
   const int n = static_cast<int>(p.n);
@@ -216,9 +298,12 @@ __global__ __launch_bounds__(256) void lm_solve_kernel(LmParams p) {
     if (iter >= p.max_iter || delta < p.f_delta || isnan(prev)) break;  // :3520-3527
     if (t < n) sh.H[t * kLmHStride + t] += lambda;                      // :3529-3531
     __syncthreads();
-    if (t < 64) {  // wave 0 solves the damped system and applies the step
-      lm_solve_cholesky_wave(sh, n);
+    if (QR) {
+      lm_solve_qr(sh, qs, n);
       if (t < n) sh.theta[t] = sh.theta[t] - sh.upd[t];  // always accepted, :3534
+    } else if (t < 64) {  // wave 0 solves the damped system and applies the step
+      lm_solve_cholesky_wave(sh, n);
+      if (t < n) sh.theta[t] = sh.theta[t] - sh.upd[t];
     }
     __syncthreads();
     prev = cur;

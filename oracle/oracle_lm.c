@@ -104,16 +104,17 @@ void orc_update_with_hessian(double *update, double *hess, const double *grad, s
 }
 
 /* ---- tinyqr ------------------------------------------------------------------ */
-static void givens(double a, double b, double *c, double *s) { /* tinyqr.h:86-97 */
+/* order = 1: r*r instead of pow(r, 2) (the kernel has no libm) */
+static void givens(double a, double b, double *c, double *s, int order) { /* tinyqr.h:86-97 */
   if (fabs(b) > fabs(a)) {
     const double r = a / b;
-    const double sv = 1.0 / sqrt(pow(r, 2) + 1.0);
+    const double sv = 1.0 / sqrt((order ? r * r : pow(r, 2)) + 1.0);
     *c = sv * r;
     *s = sv;
     return;
   }
   const double r = b / a;
-  const double cv = 1.0 / sqrt(pow(r, 2) + 1.0);
+  const double cv = 1.0 / sqrt((order ? r * r : pow(r, 2)) + 1.0);
   *c = cv;
   *s = cv * r;
 }
@@ -128,7 +129,13 @@ static void rotate(double *lower, double *upper, double c, double s, size_t p) {
 }
 /* qr_decomposition (tinyqr.h:291-310): X column-major n x p. Q out: p rows of length n
  * (Q[i*n + j]); R out: p x p with R[j*p + i] = R(i,j). Qfull is n*n scratch, Rw n*p. */
+static void qr_decomposition_order(const double *X, size_t n, size_t p, double tol, double *Q,
+                                   double *R, int order);
 void orc_qr_decomposition(const double *X, size_t n, size_t p, double tol, double *Q, double *R) {
+  qr_decomposition_order(X, n, p, tol, Q, R, 0);
+}
+static void qr_decomposition_order(const double *X, size_t n, size_t p, double tol, double *Q,
+                                   double *R, int order) {
   double *Qf = (double *)calloc(n * n, sizeof(double));
   double *Rw = (double *)calloc(n * p, sizeof(double));
   for (size_t i = 0; i < n; i++) Qf[i * n + i] = 1.0;
@@ -137,7 +144,7 @@ void orc_qr_decomposition(const double *X, size_t n, size_t p, double tol, doubl
   for (size_t j = 0; j < p; j++) /* qr_impl, :253-283 */
     for (size_t i = n - 1; i > j; --i) {
       double c, s;
-      givens(Rw[(i - 1) * p + j], Rw[i * p + j], &c, &s);
+      givens(Rw[(i - 1) * p + j], Rw[i * p + j], &c, &s, order);
       rotate(Rw + (i - 1) * p, Rw + i * p, c, s, p);
       rotate(Qf + (i - 1) * n, Qf + i * n, c, s, n);
     }
@@ -155,12 +162,21 @@ void orc_qr_decomposition(const double *X, size_t n, size_t p, double tol, doubl
 }
 /* lm(X, y) = back_solve(qr(X)) (tinyqr.h:437-470), tol = 1e-12 as lm() passes it */
 void orc_tinyqr_lm(const double *X, const double *y, size_t n, size_t p, double *beta) {
+  orc_tinyqr_lm_order(X, y, n, p, beta, 0);
+}
+/* order = 1: Givens without pow(), and the back-substitution sums taken from j = p-1 down
+ * to i+1 (the order in which the kernel's column sweep produces them) */
+void orc_tinyqr_lm_order(const double *X, const double *y, size_t n, size_t p, double *beta,
+                         int order) {
   double *Q = (double *)malloc(n * p * sizeof(double)), *R = (double *)malloc(p * p * sizeof(double));
-  orc_qr_decomposition(X, n, p, 1e-12, Q, R);
+  qr_decomposition_order(X, n, p, 1e-12, Q, R, order);
   for (size_t i = 0; i < p; i++) beta[i] = 0.0;
   for (size_t i = p; i-- > 0;) {
     double temp = 0.0;
-    for (size_t j = i + 1; j < p; ++j) temp += R[j * p + i] * beta[j];
+    if (order == 0)
+      for (size_t j = i + 1; j < p; ++j) temp += R[j * p + i] * beta[j];
+    else
+      for (size_t j = p; j-- > i + 1;) temp += R[j * p + i] * beta[j];
     double ytmp = 0;
     for (size_t j = 0; j < n; ++j) ytmp += Q[i * n + j] * y[j];
     beta[i] = (ytmp - temp) / R[i * p + i];
@@ -294,7 +310,7 @@ orc_status orc_lm_solve(const orc_nlls *q, double *x, double *lambda, double up,
     } else {
       for (size_t i = 0; i < n; i++) /* column-major copy of the row-major damped matrix */
         for (size_t j = 0; j < n; j++) Xc[j * n + i] = H[i * n + j];
-      orc_tinyqr_lm(Xc, g, n, n, upd);
+      orc_tinyqr_lm_order(Xc, g, n, n, upd, order);
     }
     for (size_t i = 0; i < n; i++) x[i] -= upd[i]; /* :3534 (always accepted) */
     prev = cur;

@@ -73,3 +73,33 @@ def test_lm_config4_shape_sample(mod, oracle):
         ref, xr, lam_r, _ = O.lm_solve(oracle, A[b], y[b], t0[b], order=1, **kw)
         assert st[b].f_value == ref.f_value and np.array_equal(th[b], xr)
     assert all(s.iteration == 20 and s.f_value < 1e-20 for s in st)
+
+
+@pytest.mark.parametrize("m,n,batch", [(16, 4, 4), (64, 8, 5), (100, 33, 3), (128, 64, 4), (512, 64, 6),
+                                       (40, 2, 3)])
+@pytest.mark.parametrize("kw", [dict(lam=10.0, max_iter=12, f_delta=0.0),
+                                dict(lam=10.0, max_iter=100, f_delta=1e-12)])
+def test_lm_qr_solver_bit_exact_vs_kernel_order_oracle(mod, oracle, m, n, batch, kw):
+    """solver = QR: tinyqr::lm on the damped matrix (the composition BASELINE config 4 names),
+    Givens rotations executed as wavefronts; bit-exact vs oracle tinyqr in order 1."""
+    from nlsolver_amd import _capi
+    A, y, t0 = problems(oracle, 40, batch, m, n)
+    with mod.LMEngine(mod.TanhRegression(A, y), solver=_capi.LM_QR, **kw) as eng:
+        th, st, lam = eng.minimize(t0.copy())
+    for b in range(batch):
+        ref, xr, lam_r, _ = O.lm_solve(oracle, A[b], y[b], t0[b], solver=1, order=1, **kw)
+        assert (st[b].iteration, st[b].function_calls_used) == (ref.iteration, ref.function_calls_used)
+        assert st[b].f_value == ref.f_value, f"problem {b}"
+        assert np.array_equal(th[b], xr), f"problem {b}"
+        assert lam[b] == lam_r
+
+
+def test_lm_qr_and_cholesky_agree_to_rounding(mod, oracle):
+    from nlsolver_amd import _capi
+    A, y, t0 = problems(oracle, 7, 4, 256, 64)
+    kw = dict(lam=10.0, max_iter=6, f_delta=0.0)
+    with mod.LMEngine(mod.TanhRegression(A, y), solver=_capi.LM_QR, **kw) as eng:
+        tq, sq, _ = eng.minimize(t0.copy())
+    with mod.LMEngine(mod.TanhRegression(A, y), **kw) as eng:
+        tc, sc, _ = eng.minimize(t0.copy())
+    assert np.allclose(tq, tc, rtol=1e-8, atol=1e-10) and not np.array_equal(tq, tc)
