@@ -56,6 +56,16 @@ def cpu_baseline():
                       f"OpenMP {threads} threads"}
 
 
+def ref_baseline(cmd, key, unit, sample):
+    """Times the unmodified reference (oracle/_ref/ref_driver <cmd>) on this host, 1 thread."""
+    drv = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    if not os.path.exists(drv):
+        return None
+    r = json.loads(subprocess.check_output([drv, *map(str, cmd)], text=True))
+    return {"value": r[key], "unit": unit, "cores": 1, "kind": "reference",
+            "sample": f"{sample} ({r['seconds']:.1f} s), 1 thread (library is single-threaded by design)"}
+
+
 def pmc_traffic(pop_local):
     """HBM bytes per launch of de_generation_kernel from the committed rocprofv3 PMC passes
     (profiles/r01/de_pmc_summary.json; separate FETCH_SIZE / WRITE_SIZE runs of this script),
@@ -119,7 +129,10 @@ def main_bfgs(args):
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel": "bfgs_hy_kernel + bfgs_update_kernel", "kernel_ms": hess_ms,
-                     "algorithmic_bytes_per_launch": bytes_per_iter}}))
+                     "algorithmic_bytes_per_launch": bytes_per_iter},
+        **({} if args.no_cpu_baseline else {"cpu_baseline": ref_baseline(
+            ["bench-bfgs", n, 24], "iterations_per_s", "iteration-problems/s",
+            f"reference BFGS, same quadratic dim={n}, 24 starts x 50 iterations")})}))
     eng.close()
 
 
@@ -164,7 +177,11 @@ def main_lm(args):
         "roofline": {"bound": "mfma", "achieved": tflops, "peak": 78.6, "unit": "TFLOP/s",
                      "frac": tflops / 78.6, "traffic": None, "kernel": "lm_solve_kernel",
                      "kernel_ms": ms, "algorithmic_flops_per_launch": flops,
-                     "hbm_GBps": hbm / (ms * 1e-3) / 1e9}}))
+                     "hbm_GBps": hbm / (ms * 1e-3) / 1e9},
+        **({} if args.no_cpu_baseline else {"cpu_baseline": ref_baseline(
+            ["bench-lm", m, n, 256, iters], "iterations_per_s", "iteration-problems/s",
+            f"reference LevenbergMarquardt + GN functors, m={m} n={n}, 256 problems x {iters} "
+            "iterations")})}))
     eng.close()
 
 
@@ -196,7 +213,10 @@ def main_nm(args):
                    "objective_calls_per_s": fcalls / (ms * 1e-3)},
         "roofline": {"bound": "latency", "achieved": None, "peak": None, "unit": None,
                      "frac": None, "traffic": None, "kernel": "nm_solve_kernel", "kernel_ms": ms,
-                     "note": "LDS-resident, decision chain; not roofline-graded (SURVEY §8d)"}}))
+                     "note": "LDS-resident, decision chain; not roofline-graded (SURVEY §8d)"},
+        **({} if args.no_cpu_baseline else {"cpu_baseline": ref_baseline(
+            ["bench-nm", n, 400000], "iterations_per_s", "iteration-starts/s",
+            f"reference NelderMead Rosenbrock-{n}D, one start, 400000 iterations")})}))
     eng.close()
 
 
@@ -233,18 +253,11 @@ def main_pso(args):
         torch.cuda.synchronize()
 
     if distributed:
-        stream = torch.cuda.current_stream(device).cuda_stream
-        eng = nlsolver_amd.PSOEngine("rosenbrock", n, Dp, shard_lo=rank * n_local, shard_n=n_local,
-                                     stream=stream, **kw)
-        rec = eng.record_doubles()
-        send = torch.zeros(rec, dtype=torch.float64, device=device)
-        gathered = torch.zeros(world * rec, dtype=torch.float64, device=device)
-
-        def stepper(k):
-            for _ in range(k):
-                eng.turn_begin(send.data_ptr())
-                dist.all_gather_into_tensor(gathered, send)
-                eng.turn_end(gathered.data_ptr(), world)
+        from nlsolver_amd.dist import ShardedPSO
+        drv = ShardedPSO(dist, lambda lo, m_, stream: nlsolver_amd.PSOEngine(
+            "rosenbrock", n, Dp, shard_lo=lo, shard_n=m_, stream=stream, **kw), n, Dp, device)
+        eng = drv.engine
+        stepper = drv.step
     else:
         eng = nlsolver_amd.PSOEngine("rosenbrock", n, Dp, **kw)
         stepper = eng.step
@@ -278,7 +291,10 @@ def main_pso(args):
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "pso_move_kernel", "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": bytes_per * n_local}}))
+                         "algorithmic_bytes_per_launch": bytes_per * n_local},
+            **({} if (args.no_cpu_baseline or world > 1 or vanilla) else {"cpu_baseline": ref_baseline(
+                ["bench-pso", Dp, 4096, 40], "particle_evals_per_s", "particle-evals/s",
+                f"reference PSO Accelerated Rosenbrock-{Dp}D, 4096 particles x 40 iterations")})}))
     eng.close()
     if distributed:
         dist.barrier()

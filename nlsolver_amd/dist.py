@@ -1,36 +1,39 @@
 """Population sharding across the GPUs of one node.
 
-One process per GPU. Rank r owns the contiguous rows [r*pop/G, (r+1)*pop/G) of the
-population (island model: donors are drawn inside the shard, the RNG is keyed by
-the GLOBAL agent id). Per generation ONE collective: an all-gather of each rank's
-best record (D+5 doubles) over RCCL (`torch.distributed`, backend "nccl"); every
-rank then runs the same deterministic finaliser on the gathered records, so the
-solver state (best, counters, stop flag) is identical on all ranks without a
-second exchange.
+One process per GPU. Rank r owns the contiguous rows [r*n/G, (r+1)*n/G) of the population /
+swarm (DE: island model — donors are drawn inside the shard; the RNG is keyed by the GLOBAL row
+id). Per generation ONE collective: an all-gather of each rank's best record (D+5 doubles) over
+RCCL (`torch.distributed`, backend "nccl"); every rank then runs the same deterministic
+finaliser on the gathered records, so the solver state (best, counters, stop flag) is identical
+on all ranks without a second exchange.
 
-torch is plumbing here (device buffers for the records, the stream, the
-collective); the kernels are launched through the C-ABI on torch's current stream.
+torch is plumbing here (device buffers for the records, the stream, the collective); the kernels
+are launched through the C-ABI on torch's current stream. Batched BFGS / LM / NM problems are
+independent: they shard by simply giving every rank its own slice of the batch (no collective).
 """
 import numpy as np
 
 
-def shard_bounds(pop, world, rank):
-    """Contiguous equal split; pop must divide evenly (keeps every shard's tile tree equal)."""
-    if pop % world:
-        raise ValueError(f"population {pop} is not divisible by world size {world}")
-    n = pop // world
-    return rank * n, n
+def shard_bounds(n, world, rank):
+    """Contiguous equal split; n must divide evenly (keeps every shard's tile tree equal)."""
+    if n % world:
+        raise ValueError(f"population {n} is not divisible by world size {world}")
+    m = n // world
+    return rank * m, m
 
 
-class ShardedDE:
-    """Drives one DE shard per rank; `engine_factory(shard_lo, shard_n, stream)` builds the
-    rank's engine (nlsolver_amd.DEEngine on GPUs; tests substitute a CPU stand-in)."""
+class ShardedSwarm:
+    """Drives one shard per rank of a DE population or a PSO swarm.
 
-    def __init__(self, dist, engine_factory, pop, dim, device):
+    `engine_factory(shard_lo, shard_n, stream)` builds the rank's engine: an
+    nlsolver_amd.DEEngine / PSOEngine on GPUs (tests substitute a CPU stand-in with the same
+    record_doubles / turn_begin / turn_end interface)."""
+
+    def __init__(self, dist, engine_factory, n, dim, device):
         import torch
         self.torch, self.dist = torch, dist
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
-        self.lo, self.n = shard_bounds(pop, self.world, self.rank)
+        self.lo, self.n = shard_bounds(n, self.world, self.rank)
         self.device = device
         stream = None
         if device.type == "cuda":
@@ -41,8 +44,9 @@ class ShardedDE:
         self.send = torch.zeros(rec, dtype=torch.float64, device=device)
         self.gathered = torch.zeros(self.world * rec, dtype=torch.float64, device=device)
 
-    def init(self, x0):
-        self.engine.init(np.ascontiguousarray(x0, dtype=np.float64))
+    def init(self, *args):
+        """DE: init(x0); PSO: init(lower, upper)."""
+        self.engine.init(*[np.ascontiguousarray(a, dtype=np.float64) for a in args])
 
     def turn(self):
         """One turn of the reference loop on the sharded population."""
@@ -53,3 +57,7 @@ class ShardedDE:
     def step(self, turns=1):
         for _ in range(turns):
             self.turn()
+
+
+ShardedDE = ShardedSwarm
+ShardedPSO = ShardedSwarm

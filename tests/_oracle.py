@@ -333,3 +333,36 @@ def nm_run(lib, x0, *, obj="rosenbrock", minimize=True, upper=None, lower=None, 
                         alpha, gamma, rho, sigma, C.cast(C.byref(eps_c), pd), max_iter, no_change,
                         restarts, order, C.byref(lg) if lg else None)
     return st, x, eps_c.value, ((lx[:lg.count], lf[:lg.count]) if lg else None)
+
+
+class OraclePSOShardEngine:
+    """CPU stand-in for nlsolver_amd.PSOEngine on one shard (gloo tests)."""
+
+    def __init__(self, lib, obj, n, D, lo, m, **kw):
+        self.lib, self.lo, self.m, self.D, self.n = lib, lo, m, D, n
+        self.obj, self.kw = obj, dict(kw, n_shards=n // m)
+
+    def record_doubles(self):
+        return self.D + 5
+
+    def init(self, lower, upper):
+        self.run = PSOSyncRun(self.lib, self.obj, self.n, self.D, lower, upper, **self.kw)
+        mask = np.ones(self.n, bool)
+        mask[self.lo:self.lo + self.m] = False
+        self.run.pos[mask] = np.nan  # this rank never looks at rows it does not own
+        self.run.cur_val[mask] = np.nan
+        self.run.pbest_val[mask] = np.nan
+
+    def turn_begin(self, send_ptr):
+        rec = np.ctypeslib.as_array(C.cast(send_ptr, pd), (self.D + 5,))
+        if not self.run.s.done:
+            self.lib.orc_pso_shard_record(C.byref(self.run.s), self.lo, self.m, _ptr(rec))
+
+    def turn_end(self, gathered_ptr, world):
+        s = self.run.s
+        if s.done:
+            return
+        if self.lib.orc_pso_apply_records(C.byref(s), C.cast(gathered_ptr, pd), world):
+            return
+        self.lib.orc_pso_shard_move(C.byref(s), self.lo, self.m, 1)
+        self.lib.orc_pso_commit(C.byref(s))

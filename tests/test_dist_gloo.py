@@ -68,3 +68,47 @@ def test_world2_gloo_matches_single_process_oracle(tmp_path, oracle, kw):
             assert got["std_err"][0] == ref.s.std_err
     if kw.get("eps", 0) > 0 or kw.get("best_val_no_change", 1000) < 10:
         assert ref.s.done == 1 and ref.s.iter < turns  # the stop test really fired mid-run
+
+
+def _pso_worker(rank, world, port, cfg, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nlsolver_amd.dist import ShardedPSO
+    lib = O.load()
+    n, D, turns, kw = cfg["n"], cfg["D"], cfg["turns"], cfg["kw"]
+    drv = ShardedPSO(dist, lambda lo, m, stream: O.OraclePSOShardEngine(lib, "rosenbrock", n, D, lo, m, **kw),
+                     n, D, torch.device("cpu"))
+    drv.init(np.full(D, -2.048), np.full(D, 2.048))
+    drv.step(turns)
+    run = drv.engine.run
+    sl = slice(drv.lo, drv.lo + drv.n)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), P=run.pos[sl], B=run.pbest_val[sl],
+             G=run.gbest_x, state=np.array([run.s.gbest_idx, run.s.iter, run.s.val_no_change,
+                                            run.s.fevals, run.s.done], dtype=np.int64),
+             gval=np.array([run.s.gbest_val, run.s.std_err]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kw", [dict(type=O.PSO_ACCELERATED, eps=0.0, best_val_no_change=1000),
+                                dict(type=O.PSO_VANILLA, eps=0.0, best_val_no_change=1000),
+                                dict(type=O.PSO_ACCELERATED, eps=2000.0, best_val_no_change=1000)])
+def test_world2_gloo_pso_matches_single_process_oracle(tmp_path, oracle, kw):
+    world, n, D, turns = 2, 64, 16, 10
+    cfg = dict(n=n, D=D, turns=turns, kw=kw)
+    mp.start_processes(_pso_worker, args=(world, _free_port(), cfg, str(tmp_path)), nprocs=world,
+                       join=True, start_method="fork")
+    ref = O.PSOSyncRun(oracle, "rosenbrock", n, D, -2.048, 2.048, n_shards=world, **kw)
+    ref.step(turns)
+    m = n // world
+    for r in range(world):
+        got = np.load(tmp_path / f"rank{r}.npz")
+        assert np.array_equal(got["P"], ref.pos[r * m:(r + 1) * m])
+        assert np.array_equal(got["B"], ref.pbest_val[r * m:(r + 1) * m])
+        assert np.array_equal(got["G"], ref.gbest_x)
+        assert got["state"].tolist() == [ref.s.gbest_idx, ref.s.iter, ref.s.val_no_change,
+                                         ref.s.fevals, ref.s.done]
+        assert got["gval"][0] == ref.s.gbest_val
+        if kw["eps"] > 0:
+            assert got["gval"][1] == ref.s.std_err
