@@ -151,6 +151,16 @@ int nlsg_de_time_turns(nlsg_de *e, uint64_t turns, float *ms_total);
 uint64_t nlsg_de_record_doubles(const nlsg_de *e);
 int nlsg_de_turn_begin(nlsg_de *e, double *send_dev);
 int nlsg_de_turn_end(nlsg_de *e, const double *gathered_dev, int32_t world);
+/* The two halves of nlsg_de_turn_end. For strategy random (nlsg_de_can_speculate) the
+ * generation only depends on the exchange through the stop flag and writes the OTHER
+ * population / score buffers, so the host may order a turn as
+ *   turn_begin -> start all-gather (async) -> turn_generation -> wait -> turn_finalize
+ * hiding the collective behind the generation; if the finaliser fires a stop test, the
+ * speculative generation's output is never adopted. Strategy best must keep
+ *   turn_begin -> all-gather -> turn_finalize -> turn_generation. */
+int nlsg_de_turn_finalize(nlsg_de *e, const double *gathered_dev, int32_t world);
+int nlsg_de_turn_generation(nlsg_de *e);
+int nlsg_de_can_speculate(const nlsg_de *e);
 
 /* ========================================================================== */
 /* Particle Swarm Optimisation — replaces PSO::solve (nlsolver.h:2593-2624),   */

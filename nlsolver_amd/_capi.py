@@ -102,6 +102,9 @@ SYMBOLS = {
     "nlsg_de_record_doubles": (u64, [_H]),
     "nlsg_de_turn_begin": (C.c_int, [_H, C.c_void_p]),
     "nlsg_de_turn_end": (C.c_int, [_H, C.c_void_p, i32]),
+    "nlsg_de_turn_finalize": (C.c_int, [_H, C.c_void_p, i32]),
+    "nlsg_de_turn_generation": (C.c_int, [_H]),
+    "nlsg_de_can_speculate": (C.c_int, [_H]),
     "nlsg_pso_create": (C.c_int, [C.POINTER(PSOConfig), C.POINTER(_H)]),
     "nlsg_pso_destroy": (C.c_int, [_H]),
     "nlsg_pso_init": (C.c_int, [_H, pd, pd]),

@@ -34,14 +34,15 @@ struct DeState {
   uint64_t fcalls;
   double std_err;
   int32_t done;
-  int32_t parity;          // population buffer holding the current generation
-  int32_t pending;         // a generation ran since the last scan (iter++ due)
-  int32_t pad;
+  int32_t parity;          // population / score buffer holding the current generation
+  int32_t pad[2];
 };
 
 struct DeParams {
   double *buf[2];      // population ping-pong
-  double *scores;      // [shard_n]
+  double *scores[2];   // [shard_n] each, ping-pong with the population: a generation reads
+                       // scores[src] and writes scores[src^1], so it never destroys the
+                       // state it started from (it may run speculatively, see nlsg_de.hip)
   double *best_x;      // [D] row of the incumbent best (valid after a scan)
   uint64_t *trace;     // [shard_n*5] or nullptr
   DeState *state;
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256) void de_init_kernel(DeParams p, const double *
   }
   store_row<CHUNKS, VEC>(p.buf[0] + a * p.D, p.D, xv);
   const double f = p.fmul * wave_objective<OBJ, CHUNKS>(xv, p.D);  // :2423-2425
-  if (lane == 0) p.scores[a] = f;
+  if (lane == 0) p.scores[0][a] = f;
 }
 
 __global__ void de_reset_state_kernel(DeParams p) {
@@ -90,23 +91,22 @@ __global__ void de_reset_state_kernel(DeParams p) {
   s->std_err = __builtin_nan("");
   s->done = 0;
   s->parity = 0;
-  s->pending = 0;
 }
 
 // ---- one generation ----------------------------------------------------------
 template <int OBJ, int CHUNKS, bool VEC>
-__global__ __launch_bounds__(256) void de_generation_kernel(DeParams p, int par_override,
-                                                          uint64_t gen_override) {
-  // par_override >= 0: timing mode (nlsg_de_time_generation_kernel) — buffer
-  // parity and generation number come from the host instead of the state.
+__global__ __launch_bounds__(256) void de_generation_kernel(DeParams p, int par, uint64_t generation,
+                                                          int ignore_done) {
+  // `generation` (k+1) and the source buffer `par` (k & 1) come from the host: the k-th
+  // turn's head may still be running when this kernel starts (speculative launch for
+  // strategy random); the device state is only consulted for the stop flag, which is
+  // final for every head older than that one.
   const DeState *__restrict__ st = p.state;
-  if (par_override < 0 && st->done) return;  // a stop test fired: the turn is a no-op
+  if (!ignore_done && st->done) return;  // a stop test fired: the turn is a no-op
   const uint64_t a = static_cast<uint64_t>(blockIdx.x) * 4 +
                      __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
   if (a >= p.shard_n) return;
   const int lane = lane_id();
-  const int par = par_override >= 0 ? par_override : st->parity;
-  const uint64_t generation = par_override >= 0 ? gen_override : st->iter + 1;
   const double *__restrict__ cur = p.buf[par];
   double *__restrict__ nxt = p.buf[par ^ 1];
   const uint64_t D = p.D;
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void de_generation_kernel(DeParams p, int par_
   // depend on the strategy) but every lane reads the 16 zero bytes.
   const bool rnd = p.strategy == NLSG_DE_RANDOM;
   load_row<CHUNKS, VEC>(p.best_x, rnd ? 0 : D, p.zero, keep);
-  const double old_score = p.scores[a];
+  const double old_score = p.scores[par][a];
 
   // propose_new_agent (nlsolver.h:2357-2375)
   double trial[CHUNKS][2];
@@ -172,10 +172,10 @@ __global__ __launch_bounds__(256) void de_generation_kernel(DeParams p, int par_
   double *out = nxt + a * D;
   if (accept) {
     store_row<CHUNKS, VEC>(out, D, trial);
-    if (lane == 0) p.scores[a] = score;
   } else {
     store_row<CHUNKS, VEC>(out, D, own);
   }
+  if (lane == 0) p.scores[par ^ 1][a] = accept ? score : old_score;
   if (p.trace != nullptr && lane == 0) {
     uint64_t *t = p.trace + a * kTraceWords;
     t[0] = r0;
@@ -187,19 +187,17 @@ __global__ __launch_bounds__(256) void de_generation_kernel(DeParams p, int par_
 }
 
 // ---- best scan + stop tests -------------------------------------------------
-// Applies the iter++ of the generation that ran since the previous scan.
-__device__ inline void apply_pending(DeState *st, const DeParams &p) {
-  if (st->pending) {
-    st->iter += 1;
-    st->fcalls += p.pop;
-    st->parity ^= 1;
-    st->pending = 0;
-  }
+// Head number k looks at the population after k generations: buffer k & 1. It records
+// that position in the state; a head that fires a stop test freezes the state there.
+__device__ inline void head_position(DeState *st, const DeParams &p, uint64_t k) {
+  st->iter = k;
+  st->fcalls = p.pop * (k + 1);
+  st->parity = static_cast<int32_t>(k & 1);
 }
 
 // First level of the best scan (and of std_err's first pass): one block per
 // tile of kTile scores.
-__global__ __launch_bounds__(256) void de_scan_partial_kernel(DeParams p) {
+__global__ __launch_bounds__(256) void de_scan_partial_kernel(DeParams p, int par) {
   __shared__ double red[4];
   __shared__ double mv[4];
   __shared__ uint64_t mi[4];
@@ -209,7 +207,7 @@ __global__ __launch_bounds__(256) void de_scan_partial_kernel(DeParams p) {
   double bv = __builtin_inf();
   uint64_t bi = ~0ull;
   for (uint64_t i = base + threadIdx.x; i < base + kTile && i < p.shard_n; i += 256) {
-    const double sc = p.scores[i];
+    const double sc = p.scores[par][i];
     acc = acc + sc;
     argmin_combine(bv, bi, sc, i);
   }
@@ -225,8 +223,8 @@ __global__ __launch_bounds__(256) void de_scan_partial_kernel(DeParams p) {
 // Shard minimum with the reference's tie rule (strict '<' scan starting from the
 // incumbent, nlsolver.h:2432-2437): the incumbent survives when nobody in the
 // shard is strictly better. Returns (score, GLOBAL index, owned) in thread 0.
-__device__ inline void shard_best(const DeParams &p, const DeState *st, double *mv, uint64_t *mi,
-                                  double &bv, uint64_t &gi, bool &mine) {
+__device__ inline void shard_best(const DeParams &p, const DeState *st, int par, double *mv,
+                                  uint64_t *mi, double &bv, uint64_t &gi, bool &mine) {
   bv = __builtin_inf();
   uint64_t bi = ~0ull;
   for (uint32_t j = threadIdx.x; j < p.ntiles; j += 256)
@@ -238,7 +236,7 @@ __device__ inline void shard_best(const DeParams &p, const DeState *st, double *
     const uint64_t inc = st->best_id;
     gi = (bi == ~0ull) ? inc : p.shard_lo + bi;
     if (inc >= p.shard_lo && inc < p.shard_lo + p.shard_n) {
-      const double inc_score = p.scores[inc - p.shard_lo];
+      const double inc_score = p.scores[par][inc - p.shard_lo];
       if (!(bv < inc_score)) {
         gi = inc;
         bv = inc_score;
@@ -261,14 +259,12 @@ __device__ inline void finish_turn(DeState *st, const DeParams &p, uint64_t bi, 
   if (st->iter >= p.max_iter || st->val_no_change >= p.best_val_no_change ||
       (p.eps > 0 && se < p.eps)) {  // :2441-2443
     st->done = 1;
-  } else {
-    st->pending = 1;  // the generation enqueued right after this kernel will run
   }
 }
 
 // One-GPU, eps <= 0 (std_err cannot decide): the whole head of a turn in one
 // single-block launch.
-__global__ __launch_bounds__(256) void de_head_kernel(DeParams p) {
+__global__ __launch_bounds__(256) void de_head_kernel(DeParams p, uint64_t k) {
   __shared__ double mv[4];
   __shared__ uint64_t mi[4];
   __shared__ uint64_t s_row;
@@ -276,14 +272,15 @@ __global__ __launch_bounds__(256) void de_head_kernel(DeParams p) {
   __shared__ int s_par;
   DeState *st = p.state;
   if (st->done) return;
-  if (threadIdx.x == 0) apply_pending(st, p);
+  const int par = static_cast<int>(k & 1);
+  if (threadIdx.x == 0) head_position(st, p, k);
   __syncthreads();
   double bv;
   uint64_t gi;
   bool mine;
-  shard_best(p, st, mv, mi, bv, gi, mine);
+  shard_best(p, st, par, mv, mi, bv, gi, mine);
   if (threadIdx.x == 0) {
-    s_par = st->parity;
+    s_par = par;
     finish_turn(st, p, gi, bv, mine, __builtin_nan(""));
     s_row = gi - p.shard_lo;
     s_have = mine ? 1 : 0;
@@ -296,14 +293,15 @@ __global__ __launch_bounds__(256) void de_head_kernel(DeParams p) {
 
 // ---- std_err (eps > 0) and the sharded path ------------------------------------
 // Second pass of std_err (nlsolver.h:2046-2049) with the mean of pass one.
-__global__ __launch_bounds__(256) void de_var_partial_kernel(DeParams p, const double *mean_ptr) {
+__global__ __launch_bounds__(256) void de_var_partial_kernel(DeParams p, const double *mean_ptr,
+                                                           int par) {
   __shared__ double red[4];
   if (p.state->done) return;
   const double mean = *mean_ptr;
   const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kTile;
   double acc = 0.0;
   for (uint64_t i = base + threadIdx.x; i < base + kTile && i < p.shard_n; i += 256) {
-    const double d = p.scores[i] - mean;
+    const double d = p.scores[par][i] - mean;
     acc = acc + d * d;
   }
   const double total = block_tree_256(acc, red);
@@ -312,7 +310,8 @@ __global__ __launch_bounds__(256) void de_var_partial_kernel(DeParams p, const d
 
 // `rec` != nullptr (only when eps <= 0, i.e. no second std_err pass is needed):
 // the exchange record is packed by this launch as well.
-__global__ __launch_bounds__(256) void de_local_kernel(DeParams p, ShardLocal *loc, double *rec) {
+__global__ __launch_bounds__(256) void de_local_kernel(DeParams p, ShardLocal *loc, double *rec,
+                                                     uint64_t k) {
   __shared__ double red[4];
   __shared__ double mv[4];
   __shared__ uint64_t mi[4];
@@ -320,12 +319,13 @@ __global__ __launch_bounds__(256) void de_local_kernel(DeParams p, ShardLocal *l
   __shared__ int s_mine, s_par;
   DeState *st = p.state;
   if (st->done) return;
-  if (threadIdx.x == 0) apply_pending(st, p);
+  const int par = static_cast<int>(k & 1);
+  if (threadIdx.x == 0) head_position(st, p, k);
   __syncthreads();
   double bv;
   uint64_t gi;
   bool mine;
-  shard_best(p, st, mv, mi, bv, gi, mine);
+  shard_best(p, st, par, mv, mi, bv, gi, mine);
   double total = 0.0;
   if (p.eps > 0) {
     double acc = 0.0;
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void de_local_kernel(DeParams p, ShardLocal *l
     }
     s_gi = gi;
     s_mine = mine ? 1 : 0;
-    s_par = st->parity;
+    s_par = par;
   }
   if (rec == nullptr) return;
   __syncthreads();
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void de_var_local_kernel(DeParams p, ShardLoca
 // for a shard whose scores are all NaN and that does not own the incumbent).
 
 __global__ __launch_bounds__(256) void de_pack_record_kernel(DeParams p, const ShardLocal *loc,
-                                                           double *rec) {
+                                                           double *rec, int par) {
   const DeState *st = p.state;
   if (st->done) return;
   const uint64_t gi = loc->mini;
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256) void de_pack_record_kernel(DeParams p, const S
     rec[3] = loc->m2;
     rec[4] = loc->valid;
   }
-  const double *row = p.buf[st->parity] + (mine ? (gi - p.shard_lo) : 0) * p.D;
+  const double *row = p.buf[par] + (mine ? (gi - p.shard_lo) : 0) * p.D;
   for (uint64_t d = threadIdx.x; d < p.D; d += 256) rec[kRecHeader + d] = mine ? row[d] : 0.0;
 }
 
@@ -444,7 +444,10 @@ __global__ __launch_bounds__(256) void de_finalize_kernel(DeParams p, const doub
   for (uint64_t d = threadIdx.x; d < p.D; d += 256) p.best_x[d] = src[d];
 }
 
-// Applies a pending iter++ without scanning (used before reading the state).
-__global__ void de_settle_kernel(DeParams p) { apply_pending(p.state, p); }
+// Before the host reads the state: unless a stop test fired, the engine stands after the
+// k generations it has launched (the last head only saw k-1 of them).
+__global__ void de_settle_kernel(DeParams p, uint64_t k) {
+  if (!p.state->done) head_position(p.state, p, k);
+}
 
 }  // namespace nlsg

@@ -130,6 +130,15 @@ class DEEngine:
     def turn_end(self, gathered_dev_ptr, world):
         check(lib().nlsg_de_turn_end(self._h, gathered_dev_ptr, world))
 
+    def turn_finalize(self, gathered_dev_ptr, world):
+        check(lib().nlsg_de_turn_finalize(self._h, gathered_dev_ptr, world))
+
+    def turn_generation(self):
+        check(lib().nlsg_de_turn_generation(self._h))
+
+    def can_speculate(self):
+        return bool(lib().nlsg_de_can_speculate(self._h))
+
 
 class DE:
     """Drop-in for nlsolver::DE on a device objective (same ctor args/defaults)."""

@@ -49,10 +49,23 @@ class ShardedSwarm:
         self.engine.init(*[np.ascontiguousarray(a, dtype=np.float64) for a in args])
 
     def turn(self):
-        """One turn of the reference loop on the sharded population."""
-        self.engine.turn_begin(self.send.data_ptr())
-        self.dist.all_gather_into_tensor(self.gathered, self.send)
-        self.engine.turn_end(self.gathered.data_ptr(), self.world)
+        """One turn of the reference loop on the sharded population.
+
+        DE with strategy random: the generation depends on the exchange only through the stop
+        flag and is non-destructive, so it is launched while the all-gather is in flight
+        (async collective on RCCL's stream) and the finaliser runs after it; a stop decided by
+        the finaliser simply leaves the speculative generation unadopted. Everything else
+        (strategy best, PSO: the move needs the exchanged best) keeps the serial order."""
+        eng = self.engine
+        eng.turn_begin(self.send.data_ptr())
+        if getattr(eng, "can_speculate", lambda: False)():
+            work = self.dist.all_gather_into_tensor(self.gathered, self.send, async_op=True)
+            eng.turn_generation()
+            work.wait()
+            eng.turn_finalize(self.gathered.data_ptr(), self.world)
+        else:
+            self.dist.all_gather_into_tensor(self.gathered, self.send)
+            eng.turn_end(self.gathered.data_ptr(), self.world)
 
     def step(self, turns=1):
         for _ in range(turns):

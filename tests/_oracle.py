@@ -256,6 +256,34 @@ class OracleShardEngine:
         if not self.run.s.done:
             self.lib.orc_de_shard_record(C.byref(self.run.s), self.lo, self.n, _ptr(rec))
 
+    # the product's engine offers the turn in three pieces so that the generation can be
+    # launched speculatively (strategy random); this stand-in mirrors that contract
+    def can_speculate(self):
+        return self.kw.get("strategy", 1) == 1
+
+    def turn_generation(self):
+        """Generation k+1 from the current state WITHOUT adopting it (non-destructive)."""
+        s = self.run.s
+        self._spec = None
+        if s.done:
+            return
+        keep_scores = self.run.scores.copy()
+        self.lib.orc_de_shard_generation(C.byref(s), self.lo, self.n, 1)
+        self._spec = (keep_scores, self.run.scores.copy())
+        self.run.scores[:] = keep_scores  # the finaliser must still see generation k
+
+    def turn_finalize(self, gathered_ptr, world):
+        s = self.run.s
+        if s.done:
+            return
+        best_x = np.zeros(self.D)
+        done = self.lib.orc_de_apply_records(C.byref(s), C.cast(gathered_ptr, pd), world, _ptr(best_x))
+        if done:
+            return  # the speculative generation is never adopted
+        if self._spec is not None:
+            self.run.scores[:] = self._spec[1]
+            self.lib.orc_de_commit(C.byref(s))
+
     def turn_end(self, gathered_ptr, world):
         s = self.run.s
         if s.done:

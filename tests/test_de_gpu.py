@@ -211,11 +211,19 @@ def test_sharded_path_on_one_gpu_bit_exact(eng_mod, oracle, kw, pop, D, shards):
     gathered = torch.zeros(shards * rec, dtype=torch.float64, device=dev)
     for e in engs:
         e.init(x0)
+    speculate = engs[0].can_speculate()
+    assert speculate == (kw["strategy"] == 1)
     for _ in range(turns):
         for r, e in enumerate(engs):
             e.turn_begin(gathered[r * rec:(r + 1) * rec].data_ptr())
-        for e in engs:
-            e.turn_end(gathered.data_ptr(), shards)
+        if speculate:  # the order ShardedSwarm uses around an async all-gather
+            for e in engs:
+                e.turn_generation()
+            for e in engs:
+                e.turn_finalize(gathered.data_ptr(), shards)
+        else:
+            for e in engs:
+                e.turn_end(gathered.data_ptr(), shards)
     for r, e in enumerate(engs):
         P, S = e.download()
         assert np.array_equal(P, ref.population[r * n:(r + 1) * n]), f"shard {r} population"
@@ -229,3 +237,62 @@ def test_sharded_path_on_one_gpu_bit_exact(eng_mod, oracle, kw, pop, D, shards):
         assert bi == ref.s.best_id and bf == ref.scores[bi]
         assert np.array_equal(bx, ref.population[bi])
         e.close()
+
+
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_overlapped_and_serial_turns_are_identical(eng_mod, oracle, overlap, monkeypatch):
+    """One GPU, strategy random: fully serial turns (default) and turns with the head on a side
+    stream next to a speculative generation (NLSG_DE_OVERLAP=1) give the same bits, including the
+    turn at which a stop test fires (the speculative generation after it must not be adopted)."""
+    monkeypatch.setenv("NLSG_DE_OVERLAP", overlap)
+    pop, D = 2048, 128
+    x0 = x0_for(D, 0.6)
+    base = dict(CR=0.2, F=0.5)  # a regime in which ~10 % of the trials are accepted
+    probe = O.DESyncRun(oracle, "rosenbrock", pop, D, x0, eps=1e-300, max_iter=1000,
+                        best_val_no_change=1000, **base)
+    ses = []
+    for _ in range(8):
+        probe.step()
+        ses.append(probe.s.std_err)
+    eps_mid = ses[5] * (1 + 1e-9)  # std_err drops below this at turn <= 5
+    for kw in (dict(eps=0.0, max_iter=9, best_val_no_change=1000),
+               dict(eps=0.0, max_iter=1000, best_val_no_change=2),
+               dict(eps=eps_mid, max_iter=1000, best_val_no_change=1000)):
+        kw = dict(kw, **base)
+        ref = O.DESyncRun(oracle, "rosenbrock", pop, D, x0, **kw)
+        for _ in range(40):
+            ref.step()
+        assert ref.s.done and ref.s.iter > 0
+        with eng_mod.DEEngine("rosenbrock", pop, D, **kw) as eng:
+            eng.init(x0)
+            eng.step(40)
+            P, S = eng.download()
+            st = eng.status()
+            bx, bf, bi = eng.best()
+        assert st.done == 1 and (st.iteration, st.function_calls_used, st.best_index) == \
+            (ref.s.iter, ref.s.fcalls, ref.s.best_id)
+        assert np.array_equal(P, ref.population) and np.array_equal(S, ref.scores)
+        assert np.array_equal(bx, ref.best_x) and bf == ref.scores[bi]
+
+
+@pytest.mark.parametrize("pop,D", [(256, 128), (64, 130), (48, 257), (40, 600), (64, 1024)])
+@pytest.mark.parametrize("strategy", [0, 1])
+def test_generations_with_acceptances_bit_exact(eng_mod, oracle, pop, D, strategy):
+    """With the default CR = 0.9, F = 0.8 and x0 = 4.096 a 128-D population accepts no trial in
+    its first generations (every parity test above then only exercises the keep-own-row
+    branch at D >= 128). CR = 0.2, F = 0.5 from a tighter start accepts ~10 %: the trial-row
+    store of every chunk count is compared too."""
+    x0 = x0_for(D, 0.6)
+    kw = dict(strategy=strategy, CR=0.2, F=0.5, eps=0.0, best_val_no_change=10**6)
+    ref = O.DESyncRun(oracle, "rosenbrock", pop, D, x0, trace=True, **kw)
+    accepted = 0
+    with eng_mod.DEEngine("rosenbrock", pop, D, trace=True, **kw) as eng:
+        eng.init(x0)
+        for g in range(10):
+            eng.step(1)
+            ref.step(1)
+            P, S, T = eng.download(trace=True)
+            assert np.array_equal(T, ref.trace), f"trace gen {g}"
+            assert np.array_equal(P, ref.population) and np.array_equal(S, ref.scores), f"gen {g}"
+            accepted += int(T[:, 4].sum())
+    assert accepted > 0 or D > 600  # (64 agents in 1024-D accept nothing in 10 generations)
