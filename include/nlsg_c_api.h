@@ -305,6 +305,9 @@ int nlsg_lm_minimize(nlsg_lm *e, double *theta_inout_host, nlsg_status *status_h
                      double *lambda_out_host);
 /* Same launch bracketed by hipEvents (theta restored from theta0 each time). */
 int nlsg_lm_time_solve(nlsg_lm *e, const double *theta0_host, uint32_t repeats, float *ms_total);
+/* Measurement aid: `repeats` launches of the evaluation kernel (f, g = 2 J^T r, H = 2 J^T J at
+ * theta0 for every problem; the Gauss-Newton functors of nlsolver.h:3513-3516 / 3535-3537). */
+int nlsg_lm_time_eval_kernel(nlsg_lm *e, const double *theta0_host, uint32_t repeats, float *ms_total);
 
 /* ========================================================================== */
 /* Batched Nelder-Mead — replaces NelderMead::solve (nlsolver.h:2166-2299), the  */

@@ -1,4 +1,5 @@
 // nlsolver_amd/csrc/nlsg_lm.hip — host side of the batched LM engine + C-ABI.
+#include <cstdlib>
 #include <new>
 #include <vector>
 
@@ -12,6 +13,7 @@ struct nlsg_lm {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   double *A_dev = nullptr, *y_dev = nullptr, *zero_dev = nullptr;
+  unsigned long long *count_dev = nullptr;
   bool has_data = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -41,13 +43,38 @@ int upload_theta(nlsg_lm *e, const double *theta_host) {
   return NLSG_OK;
 }
 
-void launch_solve(nlsg_lm *e) {
-  const dim3 grid(static_cast<unsigned>(e->p.batch)), block(256);
-  if (e->cfg.solver == NLSG_LM_QR)
-    hipLaunchKernelGGL(lm_solve_kernel<true>, grid, block, sizeof(LmShared) + sizeof(LmQrShared),
-                       e->stream, e->p);
-  else
-    hipLaunchKernelGGL(lm_solve_kernel<false>, grid, block, sizeof(LmShared), e->stream, e->p);
+// QR solver: one persistent workgroup per problem runs the whole solve in one launch.
+// Cholesky solver: split pipeline, all problems in lock step (eval kernel, step kernel); the
+// host polls the number of unfinished problems every few iterations.
+int launch_solve(nlsg_lm *e) {
+  const dim3 grid(static_cast<unsigned>(e->p.batch));
+  if (e->cfg.solver == NLSG_LM_QR) {
+    hipLaunchKernelGGL(lm_solve_kernel<true>, grid, dim3(256),
+                       sizeof(LmShared) + sizeof(LmQrShared), e->stream, e->p);
+    return NLSG_OK;
+  }
+  hipLaunchKernelGGL(lm_eval_wave_kernel, grid, dim3(64), 0, e->stream, e->p, 1);
+  uint64_t launched = 0;
+  for (;;) {
+    // max_iter iterations plus the turn whose stop test fires
+    const uint64_t left = e->p.max_iter + 1 - launched;
+    const uint64_t chunk = left < 8 ? left : 8;
+    for (uint64_t i = 0; i < chunk; i++) {
+      hipLaunchKernelGGL(lm_step_kernel, grid, dim3(64), 0, e->stream, e->p);
+      hipLaunchKernelGGL(lm_eval_wave_kernel, grid, dim3(64), 0, e->stream, e->p, 0);
+    }
+    launched += chunk;
+    if (launched >= e->p.max_iter + 1) break;
+    NLSG_HIP(hipMemsetAsync(e->count_dev, 0, 8, e->stream));
+    hipLaunchKernelGGL(lm_count_unfinished_kernel,
+                       dim3(static_cast<unsigned>((e->p.batch + 255) / 256)), dim3(256), 0,
+                       e->stream, e->p, e->count_dev);
+    unsigned long long open = 0;
+    NLSG_HIP(hipMemcpyAsync(&open, e->count_dev, 8, hipMemcpyDeviceToHost, e->stream));
+    NLSG_HIP(hipStreamSynchronize(e->stream));
+    if (open == 0) break;
+  }
+  return NLSG_OK;
 }
 }  // namespace
 
@@ -86,10 +113,15 @@ int nlsg_lm_create(const nlsg_lm_config *cfg, nlsg_lm **out) {
   std::memset(&p, 0, sizeof p);
   const uint64_t B = cfg->batch, m = cfg->m;
   hipError_t he = hipSuccess;
-  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&e->A_dev), B * m * kLmN * 8);
-  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&e->y_dev), B * m * 8);
+  const uint64_t nstep = (m + 15) / 16;
+  p.nstep = nstep;
+  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&e->A_dev), nstep * B * 16 * kLmN * 8);
+  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&e->y_dev), nstep * B * 16 * 8);
   if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p.theta), B * kLmN * 8);
   if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p.prob), B * sizeof(LmProblem));
+  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p.Hg), B * kLmTri * 8);
+  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p.gg), B * kLmN * 8);
+  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&e->count_dev), 8);
   if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&e->zero_dev), 16);
   if (he == hipSuccess) he = hipMemset(e->zero_dev, 0, 16);
   if (he == hipSuccess) he = hipEventCreate(&e->ev0);
@@ -129,6 +161,9 @@ int nlsg_lm_destroy(nlsg_lm *e) {
   hipFree(e->y_dev);
   hipFree(e->p.theta);
   hipFree(e->p.prob);
+  hipFree(e->p.Hg);
+  hipFree(e->p.gg);
+  hipFree(e->count_dev);
   hipFree(e->zero_dev);
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
@@ -141,18 +176,22 @@ int nlsg_lm_set_data(nlsg_lm *e, const double *a_host, const double *y_host) {
   if (!e || !a_host || !y_host) return fail(NLSG_ERR_INVALID_ARG, "null argument");
   NLSG_HIP(hipSetDevice(e->cfg.device));
   const uint64_t B = e->p.batch, m = e->p.m, n = e->p.n;
-  if (n == kLmN) {
-    NLSG_HIP(hipMemcpy(e->A_dev, a_host, B * m * kLmN * 8, hipMemcpyHostToDevice));
-  } else {  // repack rows to the 64-column device layout, one problem at a time
-    std::vector<double> row(m * kLmN);
-    for (uint64_t b = 0; b < B; b++) {
-      std::fill(row.begin(), row.end(), 0.0);
-      for (uint64_t i = 0; i < m; i++)
-        for (uint64_t j = 0; j < n; j++) row[i * kLmN + j] = a_host[(b * m + i) * n + j];
-      NLSG_HIP(hipMemcpy(e->A_dev + b * m * kLmN, row.data(), m * kLmN * 8, hipMemcpyHostToDevice));
-    }
+  // host layout [problem][m][n] -> device layout [row group][problem][16][64] (zero padded):
+  // problems that run side by side read one contiguous stretch of HBM per row group instead
+  // of addresses a whole problem (m * 512 bytes) apart, which camp on a few channels
+  double *raw = nullptr;
+  NLSG_HIP(hipMalloc(reinterpret_cast<void **>(&raw), B * m * (n + 1) * 8));
+  hipError_t he = hipMemcpy(raw, a_host, B * m * n * 8, hipMemcpyHostToDevice);
+  if (he == hipSuccess) he = hipMemcpy(raw + B * m * n, y_host, B * m * 8, hipMemcpyHostToDevice);
+  if (he == hipSuccess) {
+    const uint64_t total = e->p.nstep * B * 16 * kLmN;
+    hipLaunchKernelGGL(lm_repack_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256),
+                       0, e->stream, e->p, raw, raw + B * m * n, e->A_dev, e->y_dev);
+    he = hipGetLastError();
   }
-  NLSG_HIP(hipMemcpy(e->y_dev, y_host, B * m * 8, hipMemcpyHostToDevice));
+  if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+  hipFree(raw);
+  NLSG_HIP(he);
   e->has_data = true;
   return NLSG_OK;
 }
@@ -164,7 +203,8 @@ int nlsg_lm_minimize(nlsg_lm *e, double *theta_inout_host, nlsg_status *status_h
   NLSG_HIP(hipSetDevice(e->cfg.device));
   int rc = upload_theta(e, theta_inout_host);
   if (rc) return rc;
-  launch_solve(e);
+  rc = launch_solve(e);
+  if (rc) return rc;
   NLSG_HIP(hipGetLastError());
   NLSG_HIP(hipStreamSynchronize(e->stream));
   const uint64_t B = e->p.batch, n = e->p.n;
@@ -202,7 +242,32 @@ int nlsg_lm_time_solve(nlsg_lm *e, const double *theta0_host, uint32_t repeats, 
     int rc = upload_theta(e, theta0_host);
     if (rc) return rc;
     NLSG_HIP(hipEventRecord(e->ev0, e->stream));
-    launch_solve(e);
+    rc = launch_solve(e);
+    if (rc) return rc;
+    NLSG_HIP(hipEventRecord(e->ev1, e->stream));
+    NLSG_HIP(hipEventSynchronize(e->ev1));
+    NLSG_HIP(hipGetLastError());
+    float ms = 0.f;
+    NLSG_HIP(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+    total += ms;
+  }
+  *ms_total = total;
+  return NLSG_OK;
+}
+
+// Times `repeats` launches of the dominant kernel of the Cholesky pipeline (f, g, H at theta0
+// for every problem) on the engine's stream, HIP events around each launch.
+int nlsg_lm_time_eval_kernel(nlsg_lm *e, const double *theta0_host, uint32_t repeats, float *ms_total) {
+  if (!e || !theta0_host || !ms_total) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  if (!e->has_data) return fail(NLSG_ERR_STATE, "nlsg_lm_set_data has not been called");
+  NLSG_HIP(hipSetDevice(e->cfg.device));
+  int rc = upload_theta(e, theta0_host);
+  if (rc) return rc;
+  float total = 0.f;
+  for (uint32_t r = 0; r < repeats; r++) {
+    NLSG_HIP(hipEventRecord(e->ev0, e->stream));
+    hipLaunchKernelGGL(lm_eval_wave_kernel, dim3(static_cast<unsigned>(e->p.batch)), dim3(64), 0,
+                       e->stream, e->p, 1);
     NLSG_HIP(hipEventRecord(e->ev1, e->stream));
     NLSG_HIP(hipEventSynchronize(e->ev1));
     NLSG_HIP(hipGetLastError());

@@ -29,9 +29,10 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 constexpr int kLmN = 64;        // parameters are padded to 64 columns
 constexpr int kLmJStride = 80;  // LDS row stride of the Jacobian block (doubles)
 constexpr int kLmHStride = 65;  // LDS row stride of the damped matrix (doubles)
+constexpr int kLmTri = 33 * 64;  // packed lower triangle of a 64 x 64 matrix (2080) + pad
 
 struct LmProblem {
-  double f, lambda;
+  double f, lambda, prev;
   uint64_t iter, fcalls;
   int32_t done, pad;
 };
@@ -43,7 +44,10 @@ struct LmParams {
   LmProblem *prob;   // [batch]
   const double *zero;
   uint64_t batch, m, n, max_iter;
+  uint64_t nstep;    // ceil(m / 16): row groups of the device layout of A and y
   double lambda0, up, down, f_delta;
+  double *Hg;        // [batch][kLmTri] lower triangle of 2 J^T J, packed by rows (split pipeline)
+  double *gg;        // [batch][64] 2 J^T r (split pipeline)
 };
 
 struct LmQrShared {               // extra LDS of the QR solver
@@ -61,31 +65,112 @@ struct LmShared {
   int flag;
 };
 
-// f, g, H at sh.theta. Every thread returns f.
-__device__ inline double lm_evaluate(const LmParams &p, LmShared &sh, uint64_t pid) {
+// Row accessors of the damped matrix for the Cholesky solve: full rows with a padded stride
+// (persistent kernel) or the packed lower triangle (split pipeline; the solve only reads
+// H[i][j] with j <= i: Cholesky, both substitutions, and is_diagonal by symmetry).
+struct LmRowsFull {
+  double *base;
+  __device__ double &operator()(int i, int j) const { return base[i * kLmHStride + j]; }
+};
+struct LmRowsTri {
+  double *base;
+  __device__ double &operator()(int i, int j) const { return base[i * (i + 1) / 2 + j]; }
+};
+
+// LDS-only workgroup barrier: __syncthreads() also drains vmcnt, which would stall on the
+// global prefetch of the next row block issued just before it.
+__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// 2 J^T J is bitwise symmetric (every element is one k-ordered fma chain of commuting
+// products), so only the 10 lower 16 x 16 tiles are computed. For v_mfma_f64_16x16x4 the A
+// operand of column block b (A[i][k] = J[k][16b+i]) and its B operand (B[k][j] = J[k][16b+j])
+// are the same register, so a role needs one LDS read per distinct block:
+//   role 0: (0,0) (1,0) (3,0)   role 1: (1,1) (3,1)   role 2: (2,0) (2,1) (2,2)   role 3: (3,2) (3,3)
+// Role r also accumulates J^T r for block r (always among its operands).
+template <int ROLE>
+struct LmTiles;
+template <>
+struct LmTiles<0> { static constexpr int n = 3, rb[3] = {0, 1, 3}, cb[3] = {0, 0, 0}; };
+template <>
+struct LmTiles<1> { static constexpr int n = 2, rb[3] = {1, 3, 0}, cb[3] = {1, 1, 0}; };
+template <>
+struct LmTiles<2> { static constexpr int n = 3, rb[3] = {2, 2, 2}, cb[3] = {0, 1, 2}; };
+template <>
+struct LmTiles<3> { static constexpr int n = 2, rb[3] = {3, 3, 0}, cb[3] = {2, 3, 0}; };
+
+template <int ROLE>
+__device__ inline void lm_mfma_block(const double *J, const double *r, v4d (&acc)[3], double &gacc) {
+  using T = LmTiles<ROLE>;
+  const int lane = lane_id();
+  const int kk = lane >> 4, cc = lane & 15;
+  constexpr bool need[4] = {
+      T::rb[0] == 0 || T::cb[0] == 0 || (T::n > 1 && (T::rb[1] == 0 || T::cb[1] == 0)) || (T::n > 2 && (T::rb[2] == 0 || T::cb[2] == 0)),
+      T::rb[0] == 1 || T::cb[0] == 1 || (T::n > 1 && (T::rb[1] == 1 || T::cb[1] == 1)) || (T::n > 2 && (T::rb[2] == 1 || T::cb[2] == 1)),
+      T::rb[0] == 2 || T::cb[0] == 2 || (T::n > 1 && (T::rb[1] == 2 || T::cb[1] == 2)) || (T::n > 2 && (T::rb[2] == 2 || T::cb[2] == 2)),
+      T::rb[0] == 3 || T::cb[0] == 3 || (T::n > 1 && (T::rb[1] == 3 || T::cb[1] == 3)) || (T::n > 2 && (T::rb[2] == 3 || T::cb[2] == 3))};
+#pragma unroll 4
+  for (int ks = 0; ks < 16; ks++) {
+    const double *row = &J[(4 * ks + kk) * kLmJStride];
+    double op[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) op[b] = need[b] ? row[16 * b + cc] : 0.0;
+    gacc = gacc + op[ROLE] * r[4 * ks + kk];
+#pragma unroll
+    for (int i = 0; i < T::n; i++)
+      acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[T::rb[i]], op[T::cb[i]], acc[i], 0, 0, 0);
+  }
+}
+
+template <int ROLE, bool TO_GLOBAL, typename SH>
+__device__ inline void lm_publish_tiles(const LmParams &p, SH &sh, uint64_t pid, const v4d (&acc)[3]) {
+  using T = LmTiles<ROLE>;
+  const int lane = lane_id();
+  const int kk = lane >> 4, cc = lane & 15;
+#pragma unroll
+  for (int i = 0; i < T::n; i++)
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) {
+      const int row = 16 * T::rb[i] + kk + 4 * rg, col = 16 * T::cb[i] + cc;
+      const double v = 2 * acc[i][rg];
+      if constexpr (TO_GLOBAL) {
+        if (col <= row) p.Hg[pid * kLmTri + row * (row + 1) / 2 + col] = v;
+      } else {
+        sh.H[row * kLmHStride + col] = v;
+        sh.H[col * kLmHStride + row] = v;  // mirror (diagonal tiles rewrite identical bits)
+      }
+    }
+}
+
+// f, g, H at sh.theta. Every thread returns f. TO_GLOBAL: the lower triangle of H and g go
+// to p.Hg / p.gg (split pipeline) instead of sh.H / sh.g.
+template <bool TO_GLOBAL, typename SH>
+__device__ inline double lm_evaluate(const LmParams &p, SH &sh, uint64_t pid) {
   const int lane = lane_id();
   const int w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+  // odd problems swap the 3-tile and 2-tile roles so every SIMD sees the same MFMA load
+  const int role = w ^ static_cast<int>(pid & 1);
   const int half = lane >> 5, lp = lane & 31;
   const double th0 = sh.theta[2 * lp], th1 = sh.theta[2 * lp + 1];
-  const double *Ap = p.A + pid * p.m * kLmN;
-  const double *yp = p.y + pid * p.m;
-  v4d acc[4];
+  v4d acc[3];
 #pragma unroll
-  for (int c = 0; c < 4; c++) acc[c] = v4d{0.0, 0.0, 0.0, 0.0};
+  for (int c = 0; c < 3; c++) acc[c] = v4d{0.0, 0.0, 0.0, 0.0};
   double gacc = 0.0, facc = 0.0;
   const uint64_t nblk = (p.m + 63) / 64;
-  for (uint64_t blk = 0; blk < nblk; blk++) {
-    // ---- stream 64 rows: two rows per wave instruction, 8 instructions per wave
-    double2 a[8];
-    double yv[8];
+  // ---- stream 64 rows per block: two rows per wave instruction, 8 instructions per wave;
+  // lane lp < 8 of each half also fetches y of "its" row k = lp
+  double2 a[8];
+  double ysel;
+  auto fetch = [&](uint64_t blk) {
+    const uint64_t s = blk * 4 + w;  // rows 16 s .. 16 s + 15 (zero padded past m)
+    const bool in = s < p.nstep;
+    const double *Ab = p.A + (s * p.batch + pid) * (16 * kLmN);
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const int rb = 2 * (8 * w + k) + half;
-      const uint64_t i = blk * 64 + rb;
-      const bool in = i < p.m;
-      a[k] = *reinterpret_cast<const double2 *>(in ? Ap + i * kLmN + 2 * lp : p.zero);
-      yv[k] = *(in ? yp + i : p.zero);
-    }
+    for (int k = 0; k < 8; k++)
+      a[k] = *reinterpret_cast<const double2 *>(in ? Ab + (2 * k + half) * kLmN + 2 * lp : p.zero);
+    ysel = *(in ? p.y + (s * p.batch + pid) * 16 + 2 * (lp & 7) + half : p.zero);
+  };
+  fetch(0);
+  for (uint64_t blk = 0; blk < nblk; blk++) {
     // z = A theta for the wave's 16 rows: one 32-lane butterfly per load instruction
     double z[8];
 #pragma unroll
@@ -96,12 +181,9 @@ __device__ inline double lm_evaluate(const LmParams &p, LmShared &sh, uint64_t p
     }
     // tanh / residual / weight ONCE per row: lane lp < 8 of each half takes row k = lp
     // (instead of all 32 lanes of the half repeating the same transcendental 8 times)
-    double zsel = z[0], ysel = yv[0];
+    double zsel = z[0];
 #pragma unroll
-    for (int k = 1; k < 8; k++) {
-      zsel = (lp == k) ? z[k] : zsel;
-      ysel = (lp == k) ? yv[k] : ysel;
-    }
+    for (int k = 1; k < 8; k++) zsel = ((lp & 7) == k) ? z[k] : zsel;
     const double tsel = det_tanh(zsel);
     const double rsel = ysel - tsel;
     const double wsel = 1 - tsel * tsel;
@@ -117,35 +199,35 @@ __device__ inline double lm_evaluate(const LmParams &p, LmShared &sh, uint64_t p
       jv.y = -(wgt * a[k].y);
       *reinterpret_cast<double2 *>(&sh.J[rb * kLmJStride + 2 * lp]) = jv;
     }
-    __syncthreads();
-    // ---- J^T J on the matrix cores, J^T r on the VALU (same A operand)
-    const int kk = lane >> 4, cc = lane & 15;
-#pragma unroll 4
-    for (int ks = 0; ks < 16; ks++) {
-      const double *row = &sh.J[(4 * ks + kk) * kLmJStride];
-      const double aop = row[16 * w + cc];
-      gacc = gacc + aop * sh.r[4 * ks + kk];
-#pragma unroll
-      for (int c = 0; c < 4; c++)
-        acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, row[16 * c + cc], acc[c], 0, 0, 0);
+    // the next block's rows travel from HBM while this one is on the matrix cores
+    if (blk + 1 < nblk) fetch(blk + 1);
+    lds_barrier();
+    // ---- J^T J on the matrix cores, J^T r on the VALU (same operand)
+    switch (role) {
+      case 0: lm_mfma_block<0>(sh.J, sh.r, acc, gacc); break;
+      case 1: lm_mfma_block<1>(sh.J, sh.r, acc, gacc); break;
+      case 2: lm_mfma_block<2>(sh.J, sh.r, acc, gacc); break;
+      default: lm_mfma_block<3>(sh.J, sh.r, acc, gacc); break;
     }
-    __syncthreads();
+    lds_barrier();
   }
   // ---- publish H = 2 J^T J, g = 2 J^T r, f
-  {
-    const int kk = lane >> 4, cc = lane & 15;
-#pragma unroll
-    for (int c = 0; c < 4; c++)
-#pragma unroll
-      for (int rg = 0; rg < 4; rg++)
-        sh.H[(16 * w + kk + 4 * rg) * kLmHStride + 16 * c + cc] = 2 * acc[c][rg];
-    sh.gpart[kk][16 * w + cc] = gacc;
-    if (lp == 0) sh.fpart[2 * w + half] = facc;
+  switch (role) {
+    case 0: lm_publish_tiles<0, TO_GLOBAL>(p, sh, pid, acc); break;
+    case 1: lm_publish_tiles<1, TO_GLOBAL>(p, sh, pid, acc); break;
+    case 2: lm_publish_tiles<2, TO_GLOBAL>(p, sh, pid, acc); break;
+    default: lm_publish_tiles<3, TO_GLOBAL>(p, sh, pid, acc); break;
   }
+  sh.gpart[lane >> 4][16 * role + (lane & 15)] = gacc;
+  if (lp == 0) sh.fpart[2 * w + half] = facc;
   __syncthreads();
   if (threadIdx.x < 64) {
     const int j = threadIdx.x;
-    sh.g[j] = 2 * (((sh.gpart[0][j] + sh.gpart[1][j]) + sh.gpart[2][j]) + sh.gpart[3][j]);
+    const double gj = 2 * (((sh.gpart[0][j] + sh.gpart[1][j]) + sh.gpart[2][j]) + sh.gpart[3][j]);
+    if constexpr (TO_GLOBAL)
+      p.gg[pid * kLmN + j] = gj;
+    else
+      sh.g[j] = gj;
   }
   double f = 0.0;
 #pragma unroll
@@ -157,51 +239,104 @@ __device__ inline double lm_evaluate(const LmParams &p, LmShared &sh, uint64_t p
 // get_update_with_hessian (nlsolver.h:310-330) on the n x n leading block of sh.H.
 // Runs in ONE wave (lane = matrix row, n <= 64): no workgroup barriers inside; values
 // cross lanes through LDS (a wave's DS instructions execute in order) or a lane broadcast.
-__device__ inline void lm_solve_cholesky_wave(LmShared &sh, int n) {
+// value of lane `src` (wave-uniform index) through scalar registers
+__device__ inline double lane_broadcast(double v, int src) {
+  const uint64_t b = __double_as_longlong(v);
+  const uint32_t lo = __builtin_amdgcn_readlane(static_cast<int>(b & 0xffffffffu), src);
+  const uint32_t hi = __builtin_amdgcn_readlane(static_cast<int>(b >> 32), src);
+  return __longlong_as_double((static_cast<uint64_t>(hi) << 32) | lo);
+}
+
+template <typename Rows>
+__device__ inline void lm_solve_cholesky_wave(Rows H, const double *g, double *upd, int n) {
   const int t = lane_id();
   const bool row = t < n;
-  // is_diagonal (:295-307): any off-diagonal above eps * 1e12 (positive values only)
+  // is_diagonal (:295-307): any off-diagonal above eps * 1e12 (positive values only); the
+  // matrix is bitwise symmetric (fma chains of commuting products), so the lower triangle
+  // decides. Reads past the lane's own row end stay inside the buffer and are masked.
   bool off = false;
-  if (row)
-    for (int j = 0; j < n; j++)
-      off = off || (j != t && sh.H[t * kLmHStride + j] > 2.220446049250313e-16 * 1e12);
+  for (int j0 = 0; j0 < n; j0 += 8) {
+    double h[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) h[c] = H(t, min(j0 + c, 63));
+#pragma unroll
+    for (int c = 0; c < 8; c++) off |= (j0 + c < t) & row & (h[c] > 2.220446049250313e-16 * 1e12);
+  }
+  const double gt = g[t];
   if (__ballot(off) == 0ull) {
-    if (row) sh.upd[t] = sh.g[t] / sh.H[t * kLmHStride + t];
+    if (row) upd[t] = gt / H(t, t);
     return;
   }
-  // cholesky (:251-269), column by column; every element's sum runs over k in order
-  double *Ht = &sh.H[t * kLmHStride];
-  for (int j = 0; j < n; j++) {
-    const double *Hj = &sh.H[j * kLmHStride];
-    double sum = 0;
-    if (row && t >= j) {
-#pragma unroll 8
-      for (int k = 0; k < j; k++) sum += Ht[k] * Hj[k];
+  // cholesky (:251-269): every element's sum runs over k in order. Columns are taken four at
+  // a time so one LDS read of L[t][k] feeds four sums; the other factor L[j][k] is the same
+  // read's value in lane j, broadcast through a scalar register (no second LDS read).
+  for (int j0 = 0; j0 < n; j0 += 4) {
+    double s4[4] = {0.0, 0.0, 0.0, 0.0};
+    const bool act = row && t >= j0;
+    for (int k = 0; k < j0; k += 4) {  // j0 is a multiple of 4
+      double x[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) x[q] = H(t, k + q);  // lanes t < j0: in-buffer, unused
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) s4[c] += x[q] * lane_broadcast(x[q], min(j0 + c, 63));
     }
-    // diagonal first (lane j: sum = sum_k L[j][k]^2), then the column below it
-    double d = 0.0;
-    if (t == j) d = sqrt(Ht[j] - sum);
-    d = __shfl(d, j, 64);
-    if (t == j) Ht[j] = d;
-    if (row && t > j) Ht[j] = (1.0 / d * (Ht[j] - sum));
+    double hd[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) hd[c] = H(t, min(j0 + c, 63));
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const int j = j0 + c;
+      if (j < n) {  // wave-uniform
+        // diagonal first (lane j: sum = sum_k L[j][k]^2), then the column below it
+        double v = 0.0;
+        if (t == j) v = sqrt(hd[c] - s4[c]);
+        const double d = lane_broadcast(v, j);
+        if (act && t > j) v = (1.0 / d * (hd[c] - s4[c]));
+        if (act && t >= j) H(t, j) = v;
+        // the panel's later columns continue their sums with k = j
+#pragma unroll
+        for (int c2 = c + 1; c2 < 4; c2++) s4[c2] += v * lane_broadcast(v, min(j0 + c2, 63));
+      }
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
+  const double dg = H(t, t);
   // forwardsolve_inplace (:282-294): column sweep, each row's sum grows in j order
   double sum = 0.0, u = 0.0;
-  for (int j = 0; j < n; j++) {
-    if (t == j) u = (sh.g[j] - sum) / Ht[j];
-    const double uj = __shfl(u, j, 64);
-    if (row && t > j) sum += Ht[j] * uj;
+  for (int j0 = 0; j0 < n; j0 += 4) {
+    double h[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) h[c] = H(t, min(j0 + c, 63));
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const int j = j0 + c;
+      if (j < n) {
+        if (t == j) u = (gt - sum) / dg;
+        const double uj = lane_broadcast(u, j);
+        if (row && t > j) sum += h[c] * uj;
+      }
+    }
   }
   // backsolve_inplace_t (:270-281) with the inner sums taken from j = n-1 down to i+1
   sum = 0.0;
-  for (int j = n - 1; j >= 0; j--) {
-    if (t == j) u = (u - sum) / Ht[j];
-    const double uj = __shfl(u, j, 64);
-    if (row && t < j) sum += sh.H[j * kLmHStride + t] * uj;
+  for (int j0 = ((n - 1) | 3); j0 >= 0; j0 -= 4) {  // j0, j0-1, j0-2, j0-3
+    double h[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) h[c] = H(j0 - c, min(t, j0 - c));  // row j, column t (t < j)
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const int j = j0 - c;
+      if (j < n) {
+        if (t == j) u = (u - sum) / dg;
+        const double uj = lane_broadcast(u, j);
+        if (row && t < j) sum += h[c] * uj;
+      }
+    }
   }
-  if (row) sh.upd[t] = u;
+  if (row) upd[t] = u;
 }
 
 // tinyqr::lm on the damped matrix (tinyqr.h:253-310, 437-470): Givens QR in the reference's
@@ -272,7 +407,7 @@ __device__ inline void lm_solve_qr(LmShared &sh, LmQrShared &qs, int n) {
     double temp = 0.0, u = 0.0;
     for (int j = n - 1; j >= 0; j--) {
       if (t == j) u = (ytmp - temp) / sh.H[j * kLmHStride + j];
-      const double uj = __shfl(u, j, 64);
+      const double uj = lane_broadcast(u, j);
       if (t < j) temp += sh.H[t * kLmHStride + j] * uj;
     }
     if (t < n) sh.upd[t] = u;
@@ -291,7 +426,7 @@ __global__ __launch_bounds__(256) void lm_solve_kernel(LmParams p) {
   __syncthreads();
   double lambda = p.lambda0;
   uint64_t iter = 0, fcalls = 1;
-  double cur = lm_evaluate(p, sh, pid);  // g, H, f at x0 (:3513-3516)
+  double cur = lm_evaluate<false>(p, sh, pid);  // g, H, f at x0 (:3513-3516)
   double prev = 0.0;
   for (;;) {
     const double delta = fabs(prev - cur);
@@ -302,12 +437,12 @@ __global__ __launch_bounds__(256) void lm_solve_kernel(LmParams p) {
       lm_solve_qr(sh, qs, n);
       if (t < n) sh.theta[t] = sh.theta[t] - sh.upd[t];  // always accepted, :3534
     } else if (t < 64) {  // wave 0 solves the damped system and applies the step
-      lm_solve_cholesky_wave(sh, n);
+      lm_solve_cholesky_wave(LmRowsFull{sh.H}, sh.g, sh.upd, n);
       if (t < n) sh.theta[t] = sh.theta[t] - sh.upd[t];
     }
     __syncthreads();
     prev = cur;
-    cur = lm_evaluate(p, sh, pid);
+    cur = lm_evaluate<false>(p, sh, pid);
     fcalls++;
     iter++;
     lambda = cur < prev ? lambda / p.down : lambda * p.up;  // :3541-3542
@@ -321,6 +456,200 @@ __global__ __launch_bounds__(256) void lm_solve_kernel(LmParams p) {
     pr->fcalls = fcalls;
     pr->done = 1;
   }
+}
+
+// ---- split pipeline (Cholesky solver): all problems advance in lock step -----------------
+// lm_eval_wave_kernel  one WAVE per problem: f, g, H at theta. The wave streams its m x 64
+//                      block of A sixteen rows at a time (next sixteen in flight meanwhile),
+//                      scales them into a wave-private LDS tile and feeds all ten lower
+//                      16 x 16 tiles of J^T J from it. No workgroup barrier anywhere: the
+//                      waves of a SIMD drift apart, so one wave's load / tanh phase is covered
+//                      by the others' MFMA phases (fp64 MFMA and fp64 VALU share the DP pipe,
+//                      the bound is their sum).
+// lm_step_kernel       one WAVE per problem: stop tests, damping, Cholesky solve, theta update
+// Same reduction structure as lm_evaluate (rows -> k-steps of 4, f partials per (row/16 % 4,
+// row parity), g partials per row % 4), hence the same bits.
+struct LmWaveShared {
+  double J[16 * kLmJStride];
+  double r[16];
+};
+
+__global__ __launch_bounds__(64, 2) void lm_eval_wave_kernel(LmParams p, int first) {
+  __shared__ LmWaveShared sh;
+  const uint64_t pid = blockIdx.x;
+  LmProblem *pr = p.prob + pid;
+  if (!first && pr->done) return;
+  const int lane = threadIdx.x;
+  const int half = lane >> 5, lp = lane & 31, kk = lane >> 4, cc = lane & 15;
+  const double th0 = p.theta[pid * kLmN + 2 * lp], th1 = p.theta[pid * kLmN + 2 * lp + 1];
+  // device layout of A: [row group s][problem][16 rows][64], zero padded past m; y alike
+  const double *Ap = p.A + pid * (16 * kLmN) + 2 * lp;
+  const double *yp = p.y + pid * 16 + 2 * (lp & 7) + half;
+  const uint64_t stride = p.batch * (16 * kLmN), ystride = p.batch * 16;
+  v4d acc[10];
+#pragma unroll
+  for (int i = 0; i < 10; i++) acc[i] = v4d{0.0, 0.0, 0.0, 0.0};
+  double gacc[4] = {0.0, 0.0, 0.0, 0.0}, facc[4] = {0.0, 0.0, 0.0, 0.0};
+  const uint64_t nstep = p.nstep;
+  double2 a[8];
+  double ysel;
+  auto fetch = [&](uint64_t s) {
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+      a[k] = *reinterpret_cast<const double2 *>(Ap + s * stride + (2 * k + half) * kLmN);
+    ysel = yp[s * ystride];
+  };
+  auto step = [&](uint64_t s, double &fw) {
+    // z = A theta for 16 rows: one 32-lane butterfly per load instruction
+    double z[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      z[k] = a[k].x * th0 + a[k].y * th1;
+#pragma unroll
+      for (int off = 16; off >= 1; off >>= 1) z[k] = z[k] + __shfl_xor(z[k], off, 64);
+    }
+    // tanh / residual / weight once per row: lane lp of each half takes row k = lp & 7
+    double zsel = z[0];
+#pragma unroll
+    for (int k = 1; k < 8; k++) zsel = ((lp & 7) == k) ? z[k] : zsel;
+    const double tsel = det_tanh(zsel);
+    const double rsel = ysel - tsel;
+    const double wsel = 1 - tsel * tsel;
+    if (lp < 8) sh.r[2 * lp + half] = rsel;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const double r = __shfl(rsel, 32 * half + k, 64);
+      const double wgt = __shfl(wsel, 32 * half + k, 64);
+      fw = fw + r * r;
+      double2 jv;
+      jv.x = -(wgt * a[k].x);
+      jv.y = -(wgt * a[k].y);
+      *reinterpret_cast<double2 *>(&sh.J[(2 * k + half) * kLmJStride + 2 * lp]) = jv;
+    }
+    // the next sixteen rows travel from HBM while these are on the matrix cores
+    if (s + 1 < nstep) fetch(s + 1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- J^T J on the matrix cores, J^T r on the VALU (same operands); for
+    // v_mfma_f64_16x16x4 the A operand of column block b (A[i][k] = J[k][16b+i]) and its B
+    // operand (B[k][j] = J[k][16b+j]) are the same register
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const double *row = &sh.J[(4 * q + kk) * kLmJStride];
+      const double rv = sh.r[4 * q + kk];
+      double op[4];
+#pragma unroll
+      for (int b = 0; b < 4; b++) op[b] = row[16 * b + cc];
+#pragma unroll
+      for (int b = 0; b < 4; b++) gacc[b] = gacc[b] + op[b] * rv;
+#pragma unroll
+      for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+        for (int cb = 0; cb <= rb; cb++)
+          acc[rb * (rb + 1) / 2 + cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(
+              op[rb], op[cb], acc[rb * (rb + 1) / 2 + cb], 0, 0, 0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+  fetch(0);
+  for (uint64_t s0 = 0; s0 < nstep; s0 += 4) {
+    step(s0, facc[0]);
+    if (s0 + 1 < nstep) step(s0 + 1, facc[1]);
+    if (s0 + 2 < nstep) step(s0 + 2, facc[2]);
+    if (s0 + 3 < nstep) step(s0 + 3, facc[3]);
+  }
+  // ---- publish the lower triangle of H = 2 J^T J, g = 2 J^T r, f
+#pragma unroll
+  for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+    for (int cb = 0; cb <= rb; cb++)
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const int row = 16 * rb + kk + 4 * rg, col = 16 * cb + cc;
+        if (col <= row)
+          p.Hg[pid * kLmTri + row * (row + 1) / 2 + col] = 2 * acc[rb * (rb + 1) / 2 + cb][rg];
+      }
+#pragma unroll
+  for (int b = 0; b < 4; b++) {
+    const double g0 = __shfl(gacc[b], cc, 64), g1 = __shfl(gacc[b], cc + 16, 64);
+    const double g2 = __shfl(gacc[b], cc + 32, 64), g3 = __shfl(gacc[b], cc + 48, 64);
+    if (kk == 0) p.gg[pid * kLmN + 16 * b + cc] = 2 * (((g0 + g1) + g2) + g3);
+  }
+  double f = 0.0;
+#pragma unroll
+  for (int w = 0; w < 4; w++) {
+    f = f + __shfl(facc[w], 0, 64);
+    f = f + __shfl(facc[w], 32, 64);
+  }
+  if (lane == 0) {
+    if (first) {  // g, H, f at x0 (:3513-3516)
+      pr->prev = 0.0;
+      pr->f = f;
+      pr->lambda = p.lambda0;
+      pr->iter = 0;
+      pr->fcalls = 1;
+      pr->done = 0;
+    } else {  // :3535-3542
+      const double prev = pr->f;
+      pr->prev = prev;
+      pr->f = f;
+      pr->fcalls += 1;
+      pr->iter += 1;
+      pr->lambda = f < prev ? pr->lambda / p.down : pr->lambda * p.up;
+    }
+  }
+}
+
+struct LmStepShared {  // per wave
+  double tri[kLmTri];
+  double g[64], upd[64];
+};
+
+__global__ __launch_bounds__(64) void lm_step_kernel(LmParams p) {
+  __shared__ LmStepShared sh;
+  const uint64_t pid = blockIdx.x;
+  LmProblem *pr = p.prob + pid;
+  if (pr->done) return;
+  const int t = threadIdx.x, n = static_cast<int>(p.n);
+  const double prev = pr->prev, cur = pr->f;
+  if (pr->iter >= p.max_iter || fabs(prev - cur) < p.f_delta || isnan(prev)) {  // :3520-3527
+    if (t == 0) pr->done = 1;
+    return;
+  }
+  {  // all loads in flight before the first LDS write (the pad holds stale, unused values)
+    const double *src = p.Hg + pid * kLmTri;
+    double h[33];
+#pragma unroll
+    for (int q = 0; q < 33; q++) h[q] = src[64 * q + t];
+    const double gv = p.gg[pid * kLmN + t];
+#pragma unroll
+    for (int q = 0; q < 33; q++) sh.tri[64 * q + t] = h[q];
+    sh.g[t] = gv;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (t < n) sh.tri[t * (t + 1) / 2 + t] += pr->lambda;  // :3529-3531
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  lm_solve_cholesky_wave(LmRowsTri{sh.tri}, sh.g, sh.upd, n);
+  if (t < n) p.theta[pid * kLmN + t] = p.theta[pid * kLmN + t] - sh.upd[t];  // :3534
+}
+
+// host layout -> device layout of A and y (see nlsg_lm_set_data)
+__global__ void lm_repack_kernel(LmParams p, const double *a_raw, const double *y_raw, double *A,
+                                 double *y) {
+  const uint64_t e = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (e >= p.nstep * p.batch * 16 * kLmN) return;
+  const uint64_t c = e % kLmN, r = (e / kLmN) % 16, b = (e / (16 * kLmN)) % p.batch;
+  const uint64_t s = e / (16 * kLmN * p.batch), i = 16 * s + r;
+  A[e] = (i < p.m && c < p.n) ? a_raw[(b * p.m + i) * p.n + c] : 0.0;
+  if (c == 0) y[(s * p.batch + b) * 16 + r] = i < p.m ? y_raw[b * p.m + i] : 0.0;
+}
+
+__global__ void lm_count_unfinished_kernel(LmParams p, unsigned long long *count) {
+  const uint64_t pid = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (pid < p.batch && !p.prob[pid].done) atomicAdd(count, 1ull);
 }
 
 }  // namespace nlsg

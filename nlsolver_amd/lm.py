@@ -76,6 +76,14 @@ class LMEngine:
         check(lib().nlsg_lm_time_solve(self._h, theta0.ctypes.data_as(_capi.pd), repeats, C.byref(ms)))
         return ms.value
 
+    def time_eval_kernel(self, theta0, repeats=1):
+        """Total ms of `repeats` launches of the evaluation kernel (f, g, H at theta0)."""
+        theta0 = np.ascontiguousarray(theta0, dtype=np.float64)
+        ms = C.c_float()
+        check(lib().nlsg_lm_time_eval_kernel(self._h, theta0.ctypes.data_as(_capi.pd), repeats,
+                                             C.byref(ms)))
+        return ms.value
+
 
 class LevenbergMarquardt:
     """Drop-in for nlsolver::LevenbergMarquardt on a device NLLS model; x: (n,) or (batch, n)."""
