@@ -361,7 +361,9 @@ def main():
 
     pop_local = args.pop_per_gpu
     pop = pop_local * world
-    common = dict(minimize=True, strategy=nlsolver_amd.DE_RANDOM, CR=0.9, F=0.8, eps=0.0,
+    # eps > 0 (too small to ever fire): std_err of all scores is evaluated in every generation's
+    # stop test, as DE::solve does (nlsolver.h:2443), not skipped as it may be for eps <= 0
+    common = dict(minimize=True, strategy=nlsolver_amd.DE_RANDOM, CR=0.9, F=0.8, eps=1e-300,
                   max_iter=10**12, best_val_no_change=10**12, seed=12374563468,
                   device=local_rank)
     x0 = np.full(D, 4.096)
@@ -430,7 +432,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"Rosenbrock-{D}D DE strategy=random CR=0.9 F=0.8, "
                                    f"pop={pop_local} per GPU (BASELINE configs[1]), "
-                                   "one step = best scan + stop tests + one generation",
+                                   "one step = best scan + std_err + stop tests + one generation",
                        "global_pop": pop, "dim": D,
                        # share of rank 0's agents that accepted at least one trial during the
                        # timed steps (selection is data dependent; the kernel does the same

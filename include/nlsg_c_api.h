@@ -162,6 +162,20 @@ int nlsg_de_turn_finalize(nlsg_de *e, const double *gathered_dev, int32_t world)
 int nlsg_de_turn_generation(nlsg_de *e);
 int nlsg_de_can_speculate(const nlsg_de *e);
 
+/* The same turns with the exchange issued by the library itself (RCCL all-gather on a second
+ * stream, hidden behind the generation for strategy random): no host round trip per turn.
+ *   nlsg_comm_load(path)       resolve RCCL from the shared object the process already uses
+ *                              (PyTorch's librccl.so; NULL/"" = "librccl.so" on the loader path)
+ *   nlsg_comm_unique_id(id)    128-byte ncclUniqueId; one rank calls it, the host broadcasts it
+ *   nlsg_de_comm_attach        collective: every rank, same id; the engine's shard must be
+ *                              rank * shard_n .. of a population of world * shard_n
+ *   nlsg_de_step_sharded       `turns` turns of while(true) (nlsolver.h:2429-2475) on the
+ *                              sharded population; results equal turn_begin/.../turn_end */
+int nlsg_comm_load(const char *rccl_path);
+int nlsg_comm_unique_id(unsigned char *id_out_128);
+int nlsg_de_comm_attach(nlsg_de *e, const unsigned char *unique_id_128, int32_t world, int32_t rank);
+int nlsg_de_step_sharded(nlsg_de *e, uint64_t turns);
+
 /* ========================================================================== */
 /* Particle Swarm Optimisation — replaces PSO::solve (nlsolver.h:2593-2624),   */
 /* init_solver_state (2626-2657), update_velocities (2658-2677),               */

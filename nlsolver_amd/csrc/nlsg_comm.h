@@ -1,0 +1,123 @@
+// nlsolver_amd/csrc/nlsg_comm.h — the per-turn exchange of a sharded population inside the
+// library: an RCCL all-gather of every rank's best record, issued by the engine
+// itself on a second HIP stream. A host-driven turn (Python -> torch.distributed) costs ~85 us
+// of CPU per turn, more than the 50 us generation it orders; driven from here the host only
+// enqueues and the collective runs beside the generation.
+//
+// RCCL is not linked: the process already holds one copy (PyTorch's, loaded for
+// torch.distributed), and a second instance would be a second set of transports. The host
+// passes that library's path to nlsg_comm_load(), which resolves the five entry points it needs.
+#pragma once
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include "nlsg_common.h"
+
+namespace nlsg {
+
+struct RcclApi {
+  void *lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t,
+                            hipStream_t) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+RcclApi &rccl_api();  // nlsg_comm.hip
+
+#define NLSG_RCCL(call)                                                              \
+  do {                                                                               \
+    ncclResult_t r_ = (call);                                                        \
+    if (r_ != ncclSuccess)                                                           \
+      return ::nlsg::fail(NLSG_ERR_HIP, "%s failed: %s (%s:%d)", #call,              \
+                          ::nlsg::rccl_api().GetErrorString(r_), __FILE__, __LINE__); \
+  } while (0)
+
+// One shard's end of the exchange.
+struct ShardComm {
+  ncclComm_t comm = nullptr;
+  hipStream_t stream = nullptr;  // the collective's stream
+  hipEvent_t sent[2] = {nullptr, nullptr};      // record is ready (compute stream)
+  hipEvent_t gathered_ev[2] = {nullptr, nullptr};  // records of all shards have arrived
+  double *gathered = nullptr;    // [world][rec_doubles]
+  uint64_t rec_doubles = 0;
+  int world = 0, rank = 0;
+};
+
+inline void comm_detach(ShardComm *c) {
+  if (!c) return;
+  if (c->comm && rccl_api().CommDestroy) rccl_api().CommDestroy(c->comm);
+  for (int i = 0; i < 2; i++) {
+    if (c->sent[i]) hipEventDestroy(c->sent[i]);
+    if (c->gathered_ev[i]) hipEventDestroy(c->gathered_ev[i]);
+  }
+  if (c->stream) hipStreamDestroy(c->stream);
+  hipFree(c->gathered);
+  delete c;
+}
+
+// Collective call: every rank of the job attaches with the same id (nlsg_comm_unique_id on one
+// rank, broadcast by the host).
+inline int comm_attach(ShardComm **out, const unsigned char *id, int world, int rank,
+                       uint64_t rec_doubles) {
+  RcclApi &api = rccl_api();
+  if (!api.lib) return fail(NLSG_ERR_STATE, "nlsg_comm_load has not been called");
+  if (!id || world < 1 || rank < 0 || rank >= world)
+    return fail(NLSG_ERR_INVALID_ARG, "bad communicator arguments (world %d, rank %d)", world, rank);
+  ShardComm *c = new ShardComm;
+  c->world = world;
+  c->rank = rank;
+  c->rec_doubles = rec_doubles;
+  // highest priority: its own hardware queue (streams of equal priority share a small pool and
+  // a queue runs its packets in order, which would put the collective in front of the
+  // generation instead of beside it), and the small collective kernel is not starved by the
+  // generation's grid
+  int prio_low = 0, prio_high = 0;
+  hipError_t he = hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+  if (he == hipSuccess)
+    he = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_high);
+  for (int i = 0; i < 2 && he == hipSuccess; i++) {
+    he = hipEventCreateWithFlags(&c->sent[i], hipEventDisableTiming);
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&c->gathered_ev[i], hipEventDisableTiming);
+  }
+  if (he == hipSuccess)
+    he = hipMalloc(reinterpret_cast<void **>(&c->gathered), world * rec_doubles * sizeof(double));
+  if (he != hipSuccess) {
+    comm_detach(c);
+    return fail(NLSG_ERR_HIP, "communicator resources: %s", hipGetErrorString(he));
+  }
+  ncclUniqueId uid;
+  static_assert(sizeof(uid) == 128, "ncclUniqueId is 128 bytes");
+  std::memcpy(&uid, id, sizeof uid);
+  const ncclResult_t r = api.CommInitRank(&c->comm, world, uid, rank);
+  if (r != ncclSuccess) {
+    c->comm = nullptr;
+    comm_detach(c);
+    return fail(NLSG_ERR_HIP, "ncclCommInitRank failed: %s", api.GetErrorString(r));
+  }
+  *out = c;
+  return NLSG_OK;
+}
+
+// HIP 7.0: an event recorded on the hipStreamLegacy handle crashes the next
+// hipStreamWaitEvent on it; the null stream is the same stream and works.
+inline hipStream_t event_stream(hipStream_t s) { return s == hipStreamLegacy ? nullptr : s; }
+
+// Turn k: all-gather `send` (ready on `compute` at the time of the call) into c->gathered on the
+// collective's stream; comm_join makes `compute` wait for it.
+inline int comm_all_gather(ShardComm *c, const double *send, hipStream_t compute, uint64_t k) {
+  NLSG_HIP(hipEventRecord(c->sent[k & 1], event_stream(compute)));
+  NLSG_HIP(hipStreamWaitEvent(c->stream, c->sent[k & 1], 0));
+  NLSG_RCCL(rccl_api().AllGather(send, c->gathered, c->rec_doubles, ncclDouble, c->comm, c->stream));
+  NLSG_HIP(hipEventRecord(c->gathered_ev[k & 1], c->stream));
+  return NLSG_OK;
+}
+inline int comm_join(ShardComm *c, hipStream_t compute, uint64_t k) {
+  NLSG_HIP(hipStreamWaitEvent(event_stream(compute), c->gathered_ev[k & 1], 0));
+  return NLSG_OK;
+}
+
+}  // namespace nlsg

@@ -7,6 +7,7 @@
 #include <new>
 #include <vector>
 
+#include "nlsg_comm.h"
 #include "nlsg_de_kernels.h"
 
 using namespace nlsg;
@@ -18,7 +19,6 @@ struct nlsg_de {
   bool own_stream = false;
   double *x0_dev = nullptr;
   double *zero_dev = nullptr;
-  ShardLocal *loc = nullptr;
   double *rec = nullptr;  // local record (single-GPU finaliser input)
   int chunks = 0;
   bool initialised = false;
@@ -29,7 +29,9 @@ struct nlsg_de {
   hipStream_t side = nullptr;
   hipEvent_t ev_gen[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_head[4] = {nullptr, nullptr, nullptr, nullptr};
+  ShardComm *comm = nullptr;  // set by nlsg_de_comm_attach
   bool overlap = false;
+  bool fused = false;   // head k and generation k+1 share one launch (strategy random, one GPU)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -97,38 +99,27 @@ void launch_generation(nlsg_de *e, int par, uint64_t generation, int ignore_done
 #undef CALL
 }
 
-// head of turn k when std_err can decide (eps > 0) or the population is sharded:
-// shard summary (best with the incumbent rule, two-pass sum / M2) -> record
-void launch_local_summary(nlsg_de *e, double *rec_dev, hipStream_t st) {
-  const uint64_t k = e->k;
-  const int par = static_cast<int>(k & 1);
-  hipLaunchKernelGGL(de_scan_partial_kernel, dim3(e->p.ntiles), dim3(256), 0, st, e->p, par);
-  if (!(e->cfg.eps > 0)) {  // no second std_err pass: scan summary and record in one launch
-    hipLaunchKernelGGL(de_local_kernel, dim3(1), dim3(256), 0, st, e->p, e->loc, rec_dev, k);
-    return;
-  }
-  hipLaunchKernelGGL(de_local_kernel, dim3(1), dim3(256), 0, st, e->p, e->loc,
-                     static_cast<double *>(nullptr), k);
-  hipLaunchKernelGGL(de_var_partial_kernel, dim3(e->p.ntiles), dim3(256), 0, st, e->p,
-                     &e->loc->mean, par);
-  hipLaunchKernelGGL(de_var_local_kernel, dim3(1), dim3(256), 0, st, e->p, e->loc);
-  hipLaunchKernelGGL(de_pack_record_kernel, dim3(1), dim3(256), 0, st, e->p, e->loc, rec_dev, par);
+// head k and generation k+1 in one launch (de_turn_kernel)
+void launch_fused_turn(nlsg_de *e, int par, uint64_t generation) {
+  const dim3 grid(static_cast<unsigned>((e->p.shard_n + 3) / 4 + e->p.ntiles)), block(256);
+#define CALL(OBJ, C)                                                                        \
+  if (e->p.vec)                                                                             \
+    hipLaunchKernelGGL((de_turn_kernel<OBJ, C, true>), grid, block, 0, e->stream, e->p, par, \
+                       generation);                                                         \
+  else                                                                                      \
+    hipLaunchKernelGGL((de_turn_kernel<OBJ, C, false>), grid, block, 0, e->stream, e->p,    \
+                       par, generation)
+  NLSG_FOR_OBJ(e->cfg.objective, e->chunks, CALL)
+#undef CALL
 }
 
-// the whole head of turn k on one GPU, on stream `st`
-void launch_head_single(nlsg_de *e, hipStream_t st) {
-  if (e->cfg.eps > 0) {
-    launch_local_summary(e, e->rec, st);
-    hipLaunchKernelGGL(de_finalize_kernel, dim3(1), dim3(256), 0, st, e->p, e->rec, 1,
-                       static_cast<uint64_t>(kRecHeader) + e->p.D);
-  } else {
-    // std_err < eps (nlsolver.h:2443) is false for every value std_err can take
-    // when eps <= 0 or NaN: the head of the turn is two small launches
-    hipLaunchKernelGGL(de_scan_partial_kernel, dim3(e->p.ntiles), dim3(256), 0, st, e->p,
-                       static_cast<int>(e->k & 1));
-    hipLaunchKernelGGL(de_head_kernel, dim3(1), dim3(256), 0, st, e->p, e->k);
-  }
+// Head of turn k outside a fused turn, one launch. rec_dev == nullptr: one GPU, the head
+// finishes the turn; else the shard's exchange record.
+void launch_head(nlsg_de *e, double *rec_dev, hipStream_t st) {
+  hipLaunchKernelGGL(de_scan_head_kernel, dim3(e->p.ntiles), dim3(256), 0, st, e->p, e->k, rec_dev);
 }
+void launch_local_summary(nlsg_de *e, double *rec_dev, hipStream_t st) { launch_head(e, rec_dev, st); }
+void launch_head_single(nlsg_de *e, hipStream_t st) { launch_head(e, nullptr, st); }
 
 // One turn on one GPU. Serial form: head k, then generation k+1. Overlapped form
 // (strategy random): generation k+1 is launched on the main stream as soon as head k-1 is
@@ -136,7 +127,9 @@ void launch_head_single(nlsg_de *e, hipStream_t st) {
 // generation's output (other buffers) is simply never adopted.
 int launch_turn_single(nlsg_de *e) {
   const uint64_t k = e->k;
-  if (!e->overlap) {
+  if (e->fused) {
+    launch_fused_turn(e, static_cast<int>(k & 1), k + 1);
+  } else if (!e->overlap) {
     launch_head_single(e, e->stream);
     launch_generation(e, static_cast<int>(k & 1), k + 1);
   } else {
@@ -257,11 +250,12 @@ int nlsg_de_create(const nlsg_de_config *cfg, nlsg_de **out) {
   p.ntiles = static_cast<uint32_t>((n + kTile - 1) / kTile);
   if (he == hipSuccess)
     he = alloc(reinterpret_cast<void **>(&p.part), p.ntiles * sizeof(TilePartial));
+  if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&p.ticket), 8);
+  if (he == hipSuccess) he = hipMemset(p.ticket, 0, 8);
   if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&e->zero_dev), 16);
   if (he == hipSuccess) he = hipMemset(e->zero_dev, 0, 16);
   p.zero = e->zero_dev;
   if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&e->x0_dev), D * sizeof(double));
-  if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&e->loc), sizeof(ShardLocal));
   if (he == hipSuccess)
     he = alloc(reinterpret_cast<void **>(&e->rec), (kRecHeader + D) * sizeof(double));
   if (he == hipSuccess) he = hipEventCreate(&e->ev0);
@@ -271,6 +265,9 @@ int nlsg_de_create(const nlsg_de_config *cfg, nlsg_de **out) {
   // head they hide, measured at pop = 65536 (61.7 vs 58.7 us per turn).
   const char *ov = std::getenv("NLSG_DE_OVERLAP");
   e->overlap = cfg->strategy == NLSG_DE_RANDOM && cfg->shard_n == cfg->pop && ov && ov[0] == '1';
+  const char *fu = std::getenv("NLSG_DE_FUSED_TURN");
+  e->fused = cfg->strategy == NLSG_DE_RANDOM && cfg->shard_n == cfg->pop &&
+             !e->overlap && !cfg->trace && !(fu && fu[0] == '0');  // the trace buffer is not double-buffered
   if (e->overlap) {
     if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking);
     for (int i = 0; i < 4; i++) {
@@ -320,9 +317,10 @@ int nlsg_de_destroy(nlsg_de *e) {
   hipFree(e->p.trace);
   hipFree(e->p.state);
   hipFree(e->p.part);
+  hipFree(e->p.ticket);
+  comm_detach(e->comm);
   hipFree(e->x0_dev);
   hipFree(e->zero_dev);
-  hipFree(e->loc);
   hipFree(e->rec);
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
@@ -526,6 +524,46 @@ int nlsg_de_turn_generation(nlsg_de *e) {
 
 int nlsg_de_can_speculate(const nlsg_de *e) {
   return (e && e->cfg.strategy == NLSG_DE_RANDOM) ? 1 : 0;
+}
+
+int nlsg_de_comm_attach(nlsg_de *e, const unsigned char *unique_id, int32_t world, int32_t rank) {
+  if (!e) return fail(NLSG_ERR_INVALID_ARG, "null engine");
+  if (e->comm) return fail(NLSG_ERR_STATE, "a communicator is already attached");
+  if (static_cast<uint64_t>(world) * e->p.shard_n != e->p.pop ||
+      static_cast<uint64_t>(rank) * e->p.shard_n != e->p.shard_lo)
+    return fail(NLSG_ERR_INVALID_ARG, "shard [%llu, +%llu) of %llu does not match rank %d of %d",
+                (unsigned long long)e->p.shard_lo, (unsigned long long)e->p.shard_n,
+                (unsigned long long)e->p.pop, rank, world);
+  NLSG_HIP(hipSetDevice(e->cfg.device));
+  return comm_attach(&e->comm, unique_id, world, rank, static_cast<uint64_t>(kRecHeader) + e->p.D);
+}
+
+// `turns` sharded turns without a host round trip: head k -> record, all-gather on the
+// collective's stream, finaliser, generation k+1 -- for strategy random the generation is
+// enqueued before the finaliser and runs while the records travel (speculative, see
+// nlsg_de_turn_generation).
+int nlsg_de_step_sharded(nlsg_de *e, uint64_t turns) {
+  if (!e) return fail(NLSG_ERR_INVALID_ARG, "null engine");
+  if (!e->initialised) return fail(NLSG_ERR_STATE, "nlsg_de_init has not been called");
+  if (!e->comm) return fail(NLSG_ERR_STATE, "nlsg_de_comm_attach has not been called");
+  NLSG_HIP(hipSetDevice(e->cfg.device));
+  const bool speculate = e->cfg.strategy == NLSG_DE_RANDOM;
+  const uint64_t stride = static_cast<uint64_t>(kRecHeader) + e->p.D;
+  for (uint64_t t = 0; t < turns; t++) {
+    const uint64_t k = e->k;
+    launch_local_summary(e, e->rec, e->stream);
+    int rc = comm_all_gather(e->comm, e->rec, e->stream, k);
+    if (rc) return rc;
+    if (speculate) launch_generation(e, static_cast<int>(k & 1), k + 1);
+    rc = comm_join(e->comm, e->stream, k);
+    if (rc) return rc;
+    hipLaunchKernelGGL(de_finalize_kernel, dim3(1), dim3(256), 0, e->stream, e->p,
+                       e->comm->gathered, e->comm->world, stride);
+    if (!speculate) launch_generation(e, static_cast<int>(k & 1), k + 1);
+    e->k = k + 1;
+  }
+  NLSG_HIP(hipGetLastError());
+  return NLSG_OK;
 }
 
 }  // extern "C"

@@ -3,9 +3,10 @@
 // Replaces the loops of DE::solve (nlsolver.h:2414-2476):
 //   de_init_kernel        init_agents + initial scoring      (2315-2323, 2423-2425)
 //   de_generation_kernel  generate_indices + propose_new_agent + f() + selection (2449-2472)
-//   de_scan_partial_kernel + de_head_kernel
-//                         best scan, no-change counter, stop tests (2429-2447)
-//   de_var_* kernels      second pass of std_err (2037-2052), only when eps > 0 can decide
+//   de_scan_head_kernel   best scan, std_err (2037-2052) when eps > 0 can decide, no-change
+//                         counter, stop tests (2429-2447) -- or the shard's exchange record
+//   de_turn_kernel        head k and generation k+1 in one launch (strategy random)
+//   de_finalize_kernel    the head's decisions from the records of all shards
 //
 // Data layout in HBM: population row-major [shard_n][D] fp64, two buffers
 // (synchronous generation: donors are read from `cur`, survivors written to
@@ -47,6 +48,7 @@ struct DeParams {
   uint64_t *trace;     // [shard_n*5] or nullptr
   DeState *state;
   TilePartial *part;   // [ntiles] written by de_scan_partial_kernel
+  uint32_t *ticket;    // arrival counter of de_scan_head_kernel's blocks (zero between launches)
   const double *zero;  // 16 bytes of zeros: source for lanes past the row end
   uint32_t ntiles;
   uint32_t pad0;
@@ -194,16 +196,15 @@ __device__ inline void de_process_agent(const DeParams &p, double *__restrict__ 
 // One agent per wave. (Two agents per wave — ten gathers in flight — measured -7 % kernel time at
 // pop = 65536 but +9 % at pop = 2^20 and only -2 % per turn; not kept.)
 template <int OBJ, int CHUNKS, bool VEC>
-__global__ __launch_bounds__(256) void de_generation_kernel(DeParams p, int par, uint64_t generation,
-                                                          int ignore_done) {
+__device__ inline void de_generation_block(const DeParams &p, int par, uint64_t generation,
+                                           int ignore_done, uint64_t block) {
   // `generation` (k+1) and the source buffer `par` (k & 1) come from the host: the k-th
   // turn's head may still be running when this kernel starts (speculative launch for
   // strategy random); the device state is only consulted for the stop flag, which is
   // final for every head older than that one.
   const DeState *__restrict__ st = p.state;
   if (!ignore_done && st->done) return;  // a stop test fired: the turn is a no-op
-  const uint64_t a0 = static_cast<uint64_t>(blockIdx.x) * 4 +
-                      __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+  const uint64_t a0 = block * 4 + __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
   if (a0 >= p.shard_n) return;
   const double *__restrict__ cur = p.buf[par];
   double *__restrict__ nxt = p.buf[par ^ 1];
@@ -214,6 +215,12 @@ __global__ __launch_bounds__(256) void de_generation_kernel(DeParams p, int par,
   de_process_agent<OBJ, CHUNKS, VEC>(p, nxt, par, A);
 }
 
+template <int OBJ, int CHUNKS, bool VEC>
+__global__ __launch_bounds__(256) void de_generation_kernel(DeParams p, int par, uint64_t generation,
+                                                          int ignore_done) {
+  de_generation_block<OBJ, CHUNKS, VEC>(p, par, generation, ignore_done, blockIdx.x);
+}
+
 // ---- best scan + stop tests -------------------------------------------------
 // Head number k looks at the population after k generations: buffer k & 1. It records
 // that position in the state; a head that fires a stop test freezes the state there.
@@ -221,57 +228,6 @@ __device__ inline void head_position(DeState *st, const DeParams &p, uint64_t k)
   st->iter = k;
   st->fcalls = p.pop * (k + 1);
   st->parity = static_cast<int32_t>(k & 1);
-}
-
-// First level of the best scan (and of std_err's first pass): one block per
-// tile of kTile scores.
-__global__ __launch_bounds__(256) void de_scan_partial_kernel(DeParams p, int par) {
-  __shared__ double red[4];
-  __shared__ double mv[4];
-  __shared__ uint64_t mi[4];
-  if (p.state->done) return;
-  const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kTile;
-  double acc = 0.0;
-  double bv = __builtin_inf();
-  uint64_t bi = ~0ull;
-  for (uint64_t i = base + threadIdx.x; i < base + kTile && i < p.shard_n; i += 256) {
-    const double sc = p.scores[par][i];
-    acc = acc + sc;
-    argmin_combine(bv, bi, sc, i);
-  }
-  const double total = block_tree_256(acc, red);
-  block_argmin_256(bv, bi, mv, mi);
-  if (threadIdx.x == 0) {
-    p.part[blockIdx.x].sum = total;
-    p.part[blockIdx.x].minv = bv;
-    p.part[blockIdx.x].mini = bi;
-  }
-}
-
-// Shard minimum with the reference's tie rule (strict '<' scan starting from the
-// incumbent, nlsolver.h:2432-2437): the incumbent survives when nobody in the
-// shard is strictly better. Returns (score, GLOBAL index, owned) in thread 0.
-__device__ inline void shard_best(const DeParams &p, const DeState *st, int par, double *mv,
-                                  uint64_t *mi, double &bv, uint64_t &gi, bool &mine) {
-  bv = __builtin_inf();
-  uint64_t bi = ~0ull;
-  for (uint32_t j = threadIdx.x; j < p.ntiles; j += 256)
-    argmin_combine(bv, bi, p.part[j].minv, p.part[j].mini);
-  block_argmin_256(bv, bi, mv, mi);
-  gi = 0;
-  mine = false;
-  if (threadIdx.x == 0) {
-    const uint64_t inc = st->best_id;
-    gi = (bi == ~0ull) ? inc : p.shard_lo + bi;
-    if (inc >= p.shard_lo && inc < p.shard_lo + p.shard_n) {
-      const double inc_score = p.scores[par][inc - p.shard_lo];
-      if (!(bv < inc_score)) {
-        gi = inc;
-        bv = inc_score;
-      }
-    }
-    mine = gi >= p.shard_lo && gi < p.shard_lo + p.shard_n;
-  }
 }
 
 // Counters and stop tests shared by the two finalisers (thread 0 only).
@@ -290,132 +246,175 @@ __device__ inline void finish_turn(DeState *st, const DeParams &p, uint64_t bi, 
   }
 }
 
-// One-GPU, eps <= 0 (std_err cannot decide): the whole head of a turn in one
-// single-block launch.
-__global__ __launch_bounds__(256) void de_head_kernel(DeParams p, uint64_t k) {
+// ---- the head of a turn ---------------------------------------------------------
+// Separate scan / finisher launches cost a dependent dispatch each (~5 us; 10 us of a 59 us
+// turn at pop 65536 for eps <= 0, five launches and ~25 us with a two-pass std_err), so a head
+// is ONE launch: one block per tile of kTile scores reduces it -- minimum and first index and,
+// when std_err can decide (eps > 0), the tile's sum and its M2 about the TILE mean, scores held
+// in registers -- publishes that with write-through stores, drains them and takes a ticket;
+// the block that takes the last ticket reads every partial with cache-bypassing loads and
+// finishes: best with the incumbent rule, std_err, counters, stop tests, best_x -- or, on a
+// shard, the exchange record
+//   [minv, mini(bits), sum, M2 about the shard mean, valid, x_best[0..D)]   (kRecHeader + D)
+// (`valid` is 0 only for a shard whose scores are all NaN and that does not own the incumbent).
+// std_err (nlsolver.h:2037-2052) in one pass: tiles are merged the way shards are,
+//   total = tree_t(sum_t), mean = total / n, M2 = tree_t(M2_t + n_t (sum_t / n_t - mean)^2)
+// (a population of one tile is exactly the two-pass formula). min / first-index are order-
+// independent and the sums keep their fixed trees (thread-sequential partials, wave butterfly,
+// ((w0+w1)+w2)+w3 per tile, the same tree over tiles), so which block ends up last does not
+// matter. No release / acquire fence: a release would write back every dirty line that
+// generation blocks of the same launch hold in the XCD's L2.
+__device__ inline void sc1_store(double *ptr, double v) {
+  __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline double sc1_load(const double *ptr) {
+  return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// thread 0, after the block's partial stores: true in the block that arrived last
+__device__ inline bool take_ticket(const DeParams &p) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const uint32_t t = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (t != p.ntiles - 1) return false;
+  __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return true;
+}
+
+// `rec` == nullptr: one GPU, the launch finishes the turn; else the shard's exchange record
+__device__ inline void de_scan_head_block(const DeParams &p, uint64_t k, uint32_t tile, double *rec) {
+  __shared__ double red[4];
   __shared__ double mv[4];
   __shared__ uint64_t mi[4];
   __shared__ uint64_t s_row;
   __shared__ int s_have;
-  __shared__ int s_par;
+  __shared__ int s_last;
   DeState *st = p.state;
-  if (st->done) return;
+  if (st->done) return;  // only written by a last block, after every block got here
   const int par = static_cast<int>(k & 1);
-  if (threadIdx.x == 0) head_position(st, p, k);
-  __syncthreads();
-  double bv;
-  uint64_t gi;
-  bool mine;
-  shard_best(p, st, par, mv, mi, bv, gi, mine);
+  const bool need_se = p.eps > 0;
+  const double *__restrict__ sc = p.scores[par];
+  const uint64_t base = static_cast<uint64_t>(tile) * kTile;
+  const uint64_t tile_n = (p.shard_n - base) < kTile ? (p.shard_n - base) : kTile;
+  double v[kTile / 256];
+  double acc = 0.0;
+  double bv = __builtin_inf();
+  uint64_t bi = ~0ull;
+#pragma unroll
+  for (int q = 0; q < kTile / 256; q++) {
+    const uint64_t i = threadIdx.x + 256u * q;
+    v[q] = sc[base + (i < tile_n ? i : 0)];  // clamped, masked below
+  }
+#pragma unroll
+  for (int q = 0; q < kTile / 256; q++) {
+    const uint64_t i = threadIdx.x + 256u * q;
+    if (i < tile_n) {
+      acc = acc + v[q];
+      argmin_combine(bv, bi, v[q], base + i);
+    }
+  }
+  double tile_sum = 0.0, tile_m2 = 0.0;
+  if (need_se) {
+    tile_sum = block_tree_256(acc, red);
+    const double tile_mean = tile_sum / static_cast<double>(tile_n);
+    acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < kTile / 256; q++) {
+      const double d = v[q] - tile_mean;
+      if (threadIdx.x + 256u * q < tile_n) acc = acc + d * d;  // :2046-2049
+    }
+    tile_m2 = block_tree_256(acc, red);
+  }
+  block_argmin_256(bv, bi, mv, mi);
   if (threadIdx.x == 0) {
-    s_par = par;
-    finish_turn(st, p, gi, bv, mine, __builtin_nan(""));
+    sc1_store(&p.part[tile].minv, bv);
+    __hip_atomic_store(&p.part[tile].mini, bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (need_se) {
+      sc1_store(&p.part[tile].sum, tile_sum);
+      sc1_store(&p.part[tile].m2, tile_m2);
+    }
+    s_last = take_ticket(p) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  if (threadIdx.x == 0) head_position(st, p, k);
+  bv = __builtin_inf();
+  bi = ~0ull;
+  for (uint32_t j = threadIdx.x; j < p.ntiles; j += 256)
+    argmin_combine(bv, bi, sc1_load(&p.part[j].minv),
+                   __hip_atomic_load(&p.part[j].mini, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  block_argmin_256(bv, bi, mv, mi);
+  double total = 0.0, m2 = 0.0;
+  if (need_se) {
+    acc = 0.0;
+    for (uint32_t j = threadIdx.x; j < p.ntiles; j += 256) acc = acc + sc1_load(&p.part[j].sum);
+    total = block_tree_256(acc, red);
+    const double mean = total / static_cast<double>(p.shard_n);  // :2044
+    acc = 0.0;
+    for (uint32_t j = threadIdx.x; j < p.ntiles; j += 256) {
+      const uint64_t jb = static_cast<uint64_t>(j) * kTile;
+      const double nj = static_cast<double>((p.shard_n - jb) < kTile ? (p.shard_n - jb) : kTile);
+      const double dm = sc1_load(&p.part[j].sum) / nj - mean;
+      acc = acc + (sc1_load(&p.part[j].m2) + nj * (dm * dm));
+    }
+    m2 = block_tree_256(acc, red);
+  }
+  if (threadIdx.x == 0) {
+    // Shard minimum with the reference's tie rule (strict '<' scan starting from the
+    // incumbent, nlsolver.h:2432-2437): the incumbent survives when nobody in the shard is
+    // strictly better.
+    const uint64_t inc = st->best_id;
+    uint64_t gi = (bi == ~0ull) ? inc : p.shard_lo + bi;
+    if (inc >= p.shard_lo && inc < p.shard_lo + p.shard_n) {
+      const double inc_score = sc[inc - p.shard_lo];
+      if (!(bv < inc_score)) {
+        gi = inc;
+        bv = inc_score;
+      }
+    }
+    const bool mine = gi >= p.shard_lo && gi < p.shard_lo + p.shard_n;
+    if (rec == nullptr) {
+      finish_turn(st, p, gi, bv, mine,
+                  need_se ? sqrt(m2 / static_cast<double>(p.pop - 1))  // :2050-2051
+                          : __builtin_nan(""));
+    } else {
+      rec[0] = bv;
+      rec[1] = __longlong_as_double(static_cast<long long>(gi));
+      rec[2] = total;
+      rec[3] = m2;
+      rec[4] = mine ? 1.0 : 0.0;
+    }
     s_row = gi - p.shard_lo;
     s_have = mine ? 1 : 0;
   }
   __syncthreads();
-  if (!s_have) return;
-  const double *row = p.buf[s_par] + s_row * p.D;  // x = agents[best_id], :2444
-  for (uint64_t d = threadIdx.x; d < p.D; d += 256) p.best_x[d] = row[d];
-}
-
-// ---- std_err (eps > 0) and the sharded path ------------------------------------
-// Second pass of std_err (nlsolver.h:2046-2049) with the mean of pass one.
-__global__ __launch_bounds__(256) void de_var_partial_kernel(DeParams p, const double *mean_ptr,
-                                                           int par) {
-  __shared__ double red[4];
-  if (p.state->done) return;
-  const double mean = *mean_ptr;
-  const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kTile;
-  double acc = 0.0;
-  for (uint64_t i = base + threadIdx.x; i < base + kTile && i < p.shard_n; i += 256) {
-    const double d = p.scores[par][i] - mean;
-    acc = acc + d * d;
+  const bool have = s_have != 0;
+  const double *row = p.buf[par] + (have ? s_row : 0) * p.D;  // x = agents[best_id], :2444
+  if (rec != nullptr) {
+    for (uint64_t d = threadIdx.x; d < p.D; d += 256) rec[kRecHeader + d] = have ? row[d] : 0.0;
+  } else if (have) {
+    for (uint64_t d = threadIdx.x; d < p.D; d += 256) p.best_x[d] = row[d];
   }
-  const double total = block_tree_256(acc, red);
-  if (threadIdx.x == 0) p.part[blockIdx.x].m2 = total;
 }
 
-// `rec` != nullptr (only when eps <= 0, i.e. no second std_err pass is needed):
-// the exchange record is packed by this launch as well.
-__global__ __launch_bounds__(256) void de_local_kernel(DeParams p, ShardLocal *loc, double *rec,
-                                                     uint64_t k) {
-  __shared__ double red[4];
-  __shared__ double mv[4];
-  __shared__ uint64_t mi[4];
-  __shared__ uint64_t s_gi;
-  __shared__ int s_mine, s_par;
-  DeState *st = p.state;
-  if (st->done) return;
-  const int par = static_cast<int>(k & 1);
-  if (threadIdx.x == 0) head_position(st, p, k);
-  __syncthreads();
-  double bv;
-  uint64_t gi;
-  bool mine;
-  shard_best(p, st, par, mv, mi, bv, gi, mine);
-  double total = 0.0;
-  if (p.eps > 0) {
-    double acc = 0.0;
-    for (uint32_t j = threadIdx.x; j < p.ntiles; j += 256) acc = acc + p.part[j].sum;
-    total = block_tree_256(acc, red);
+__global__ __launch_bounds__(256) void de_scan_head_kernel(DeParams p, uint64_t k, double *rec) {
+  de_scan_head_block(p, k, blockIdx.x, rec);
+}
+
+// One launch per turn for strategy random (one GPU): the first ntiles blocks run
+// head k (scan of population k, stop tests), the others build generation k+1 from population
+// k at the same time. Random donors do not depend on the head's result; if head k fires a
+// stop test, generation k+1 went to the other buffers and is never adopted (exactly the
+// speculative turn of the sharded path), so results equal the serial order head -> generation.
+template <int OBJ, int CHUNKS, bool VEC>
+__global__ __launch_bounds__(256) void de_turn_kernel(DeParams p, int par, uint64_t generation) {
+  if (blockIdx.x < p.ntiles) {
+    de_scan_head_block(p, generation - 1, blockIdx.x, nullptr);
+    return;
   }
-  if (threadIdx.x == 0) {
-    loc->sum = total;
-    loc->mean = total / static_cast<double>(p.shard_n);  // :2044
-    loc->minv = bv;
-    loc->mini = gi;
-    loc->m2 = 0.0;
-    loc->valid = mine ? 1.0 : 0.0;
-    if (rec != nullptr) {
-      rec[0] = bv;
-      rec[1] = __longlong_as_double(static_cast<long long>(gi));
-      rec[2] = total;
-      rec[3] = 0.0;
-      rec[4] = mine ? 1.0 : 0.0;
-    }
-    s_gi = gi;
-    s_mine = mine ? 1 : 0;
-    s_par = par;
-  }
-  if (rec == nullptr) return;
-  __syncthreads();
-  const double *row = p.buf[s_par] + (s_mine ? (s_gi - p.shard_lo) : 0) * p.D;
-  for (uint64_t d = threadIdx.x; d < p.D; d += 256)
-    rec[kRecHeader + d] = s_mine ? row[d] : 0.0;
+  de_generation_block<OBJ, CHUNKS, VEC>(p, par, generation, 0, blockIdx.x - p.ntiles);
 }
 
-__global__ __launch_bounds__(256) void de_var_local_kernel(DeParams p, ShardLocal *loc) {
-  __shared__ double red[4];
-  if (p.state->done) return;
-  double acc = 0.0;
-  for (uint32_t j = threadIdx.x; j < p.ntiles; j += 256) acc = acc + p.part[j].m2;
-  const double total = block_tree_256(acc, red);
-  if (threadIdx.x == 0) loc->m2 = total;
-}
-
-// Record exchanged between ranks (kRecHeader + D doubles):
-//   [minv, mini(bits), sum, m2, valid, x_best[0..D)]
-// `valid` is 1 when the record's row belongs to the sending shard (it is 0 only
-// for a shard whose scores are all NaN and that does not own the incumbent).
-
-__global__ __launch_bounds__(256) void de_pack_record_kernel(DeParams p, const ShardLocal *loc,
-                                                           double *rec, int par) {
-  const DeState *st = p.state;
-  if (st->done) return;
-  const uint64_t gi = loc->mini;
-  const bool mine = loc->valid == 1.0;
-  if (threadIdx.x == 0) {
-    rec[0] = loc->minv;
-    rec[1] = __longlong_as_double(static_cast<long long>(gi));
-    rec[2] = loc->sum;
-    rec[3] = loc->m2;
-    rec[4] = loc->valid;
-  }
-  const double *row = p.buf[par] + (mine ? (gi - p.shard_lo) : 0) * p.D;
-  for (uint64_t d = threadIdx.x; d < p.D; d += 256) rec[kRecHeader + d] = mine ? row[d] : 0.0;
-}
-
+// ---- the sharded path ----------------------------------------------------------
 // Finaliser over `world` records (world == 1: the local record): global best
 // (lower value; on ties the incumbent, then the lower global index), counters,
 // stop tests (nlsolver.h:2439-2447), best_x. Single block.

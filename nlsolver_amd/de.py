@@ -139,6 +139,14 @@ class DEEngine:
     def can_speculate(self):
         return bool(lib().nlsg_de_can_speculate(self._h))
 
+    def comm_attach(self, unique_id, world, rank):
+        """Collective: joins the library-side RCCL communicator (see nlsolver_amd.dist)."""
+        buf = (C.c_ubyte * 128).from_buffer_copy(bytes(unique_id))
+        check(lib().nlsg_de_comm_attach(self._h, buf, world, rank))
+
+    def step_sharded(self, turns=1):
+        check(lib().nlsg_de_step_sharded(self._h, turns))
+
 
 class DE:
     """Drop-in for nlsolver::DE on a device objective (same ctor args/defaults)."""

@@ -77,6 +77,7 @@ double orc_std_err_serial(const double *x, size_t n);
 double orc_block_tree_sum(const double *v, size_t n);
 double orc_tiled_sum(const double *v, size_t n);
 double orc_tiled_sumsq_dev(const double *v, size_t n, double mean);
+double orc_tiled_m2_merged(const double *v, size_t n, double *sum_out);
 double orc_std_err_tree(const double *x, size_t n);
 
 /* --------------------------------------------------------------------- DE --- */

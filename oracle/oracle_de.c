@@ -177,8 +177,10 @@ static void sync_agent(const orc_de_sync *s, uint64_t kg, size_t a, double *tria
 /* ---- the turn head, in the record form the multi-GPU path exchanges ---------
  * Record of one shard (ORC_DE_REC_HEADER + D doubles):
  *   [minv, mini (u64 bits), sum, m2, valid, x_best[0..D)]
- * One shard (n_shards == 1) degenerates to the reference's scan + two-pass
- * std_err; several shards merge (n, sum, M2) per shard in rank order. */
+ * (sum, m2) of a shard come from its tiles of 1024 scores, each reduced in one pass to
+ * (sum_t, M2_t about the tile mean) and merged (orc_tiled_m2_merged); several shards merge
+ * (n, sum, M2) the same way in rank order. A population of one tile degenerates to the
+ * reference's two-pass std_err (nlsolver.h:2037-2052) in tree order. */
 static uint64_t dbl_bits(double d) {
   uint64_t u;
   memcpy(&u, &d, 8);
@@ -212,8 +214,7 @@ void orc_de_shard_record(const orc_de_sync *s, size_t lo, size_t n, double *rec)
   const int mine = gi >= lo && gi < lo + n;
   double sum = 0.0, m2 = 0.0;
   if (s->eps > 0) {
-    sum = orc_tiled_sum(sc, n);
-    m2 = orc_tiled_sumsq_dev(sc, n, sum / (double)n);
+    m2 = orc_tiled_m2_merged(sc, n, &sum); /* tiles merged the way shards are */
   }
   rec[0] = bv;
   rec[1] = bits_dbl(gi);

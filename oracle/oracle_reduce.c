@@ -67,6 +67,35 @@ double orc_tiled_sumsq_dev(const double *v, size_t n, double mean) {
   return tiled(v, n, 1, mean);
 }
 
+/* The DE engine's one-pass form: every tile of 1024 scores yields (sum_t, M2_t about the
+ * tile's own mean), both with the block tree; tiles are merged like shards are (Chan et al.):
+ *   total = tree_t(sum_t), mean = total / n,
+ *   M2 = tree_t( M2_t + n_t * (mean_t - mean)^2 ),  mean_t = sum_t / n_t.
+ * One tile (n <= 1024): identical to orc_tiled_sumsq_dev about the mean. *sum_out = total. */
+double orc_tiled_m2_merged(const double *v, size_t n, double *sum_out) {
+  const size_t T = 1024;
+  const size_t nt = (n + T - 1) / T;
+  double *sum = (double *)calloc(nt ? nt : 1, sizeof(double));
+  double *term = (double *)malloc((nt ? nt : 1) * sizeof(double));
+  for (size_t j = 0; j < nt; j++) {
+    const size_t len = (n - j * T) < T ? (n - j * T) : T;
+    sum[j] = block_tree(v + j * T, len, 0, 0.0);
+    term[j] = block_tree(v + j * T, len, 1, sum[j] / (double)len);
+  }
+  const double total = block_tree(sum, nt, 0, 0.0);
+  const double mean = total / (double)n;
+  for (size_t j = 0; j < nt; j++) {
+    const size_t len = (n - j * T) < T ? (n - j * T) : T;
+    const double dm = sum[j] / (double)len - mean;
+    term[j] = term[j] + (double)len * (dm * dm);
+  }
+  const double m2 = block_tree(term, nt, 0, 0.0);
+  free(sum);
+  free(term);
+  if (sum_out) *sum_out = total;
+  return m2;
+}
+
 /* std_err with the device tree (same formula as nlsolver.h:2037-2052 but
  * d*d instead of pow(d,2) and tree summation). */
 double orc_std_err_tree(const double *x, size_t n) {

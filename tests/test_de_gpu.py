@@ -239,12 +239,14 @@ def test_sharded_path_on_one_gpu_bit_exact(eng_mod, oracle, kw, pop, D, shards):
         e.close()
 
 
-@pytest.mark.parametrize("overlap", ["0", "1"])
-def test_overlapped_and_serial_turns_are_identical(eng_mod, oracle, overlap, monkeypatch):
-    """One GPU, strategy random: fully serial turns (default) and turns with the head on a side
-    stream next to a speculative generation (NLSG_DE_OVERLAP=1) give the same bits, including the
-    turn at which a stop test fires (the speculative generation after it must not be adopted)."""
-    monkeypatch.setenv("NLSG_DE_OVERLAP", overlap)
+@pytest.mark.parametrize("mode", ["fused", "serial", "overlap"])
+def test_overlapped_and_serial_turns_are_identical(eng_mod, oracle, mode, monkeypatch):
+    """One GPU, strategy random: head k and generation k+1 in one launch (default when eps <= 0),
+    fully serial turns (NLSG_DE_FUSED_TURN=0) and turns with the head on a side stream next to a
+    speculative generation (NLSG_DE_OVERLAP=1) give the same bits, including the turn at which a
+    stop test fires (the speculative generation after it must not be adopted)."""
+    monkeypatch.setenv("NLSG_DE_OVERLAP", "1" if mode == "overlap" else "0")
+    monkeypatch.setenv("NLSG_DE_FUSED_TURN", "1" if mode == "fused" else "0")
     pop, D = 2048, 128
     x0 = x0_for(D, 0.6)
     base = dict(CR=0.2, F=0.5)  # a regime in which ~10 % of the trials are accepted

@@ -1,0 +1,80 @@
+"""The sharded DE turn on a real GPU with RCCL (world = 1: the only size a one-GPU box offers):
+the library-driven turn (nlsg_de_step_sharded: RCCL all-gather issued by the engine on a second
+stream) and the host-driven turn (torch.distributed all_gather_into_tensor between turn_begin and
+turn_end) must both reproduce the unsharded engine bit for bit, including the turn at which a stop
+test fires. Runs in a child process so the process group does not outlive the test."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import json, os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import nlsolver_amd
+from nlsolver_amd.dist import ShardedDE
+
+native = sys.argv[2] == "native"
+os.environ["NLSG_DIST_NATIVE"] = "1" if native else "0"
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", sys.argv[3])
+torch.cuda.set_device(0)
+device = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+pop, D = 4096, 128
+x0 = np.full(D, 0.6)
+out = []
+for kw in (dict(strategy=nlsolver_amd.DE_RANDOM, eps=0.0, max_iter=9, best_val_no_change=1000),
+           dict(strategy=nlsolver_amd.DE_RANDOM, eps=0.0, max_iter=1000, best_val_no_change=2),
+           dict(strategy=nlsolver_amd.DE_RANDOM, eps=1e-300, max_iter=12, best_val_no_change=1000),
+           dict(strategy=nlsolver_amd.DE_BEST, eps=1e-300, max_iter=7, best_val_no_change=1000)):
+    kw = dict(kw, CR=0.2, F=0.5, seed=99)
+    with nlsolver_amd.DEEngine("rosenbrock", pop, D, **kw) as ref:
+        ref.init(x0)
+        ref.step(30)
+        P0, S0 = ref.download()
+        st0 = ref.status()
+        bx0, bf0, bi0 = ref.best()
+    drv = ShardedDE(dist, lambda lo, n, stream: nlsolver_amd.DEEngine(
+        "rosenbrock", pop, D, shard_lo=lo, shard_n=n, stream=stream, **kw), pop, D, device)
+    assert drv.native == native
+    drv.init(x0)
+    drv.step(30)
+    torch.cuda.synchronize()
+    P1, S1 = drv.engine.download()
+    st1 = drv.engine.status()
+    bx1, bf1, bi1 = drv.engine.best()
+    drv.engine.close()
+    out.append(dict(
+        done=(st0.done, st1.done), iters=(st0.iteration, st1.iteration),
+        fcalls=(st0.function_calls_used, st1.function_calls_used),
+        best=(int(bi0), int(bi1)), same_pop=bool(np.array_equal(P0, P1)),
+        same_scores=bool(np.array_equal(S0, S1)), same_best=bool(np.array_equal(bx0, bx1) and bf0 == bf1),
+        std_err=(repr(st0.std_err), repr(st1.std_err))))
+dist.destroy_process_group()
+print("RESULT " + json.dumps(out))
+"""
+
+
+@pytest.mark.parametrize("mode,port", [("native", "29631"), ("host", "29632")])
+def test_sharded_turn_world1_matches_unsharded_engine(mode, port):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", CHILD, ROOT, mode, port], capture_output=True,
+                       text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    for case in json.loads(line[7:]):
+        assert case["done"] == [1, 1], case
+        assert case["iters"][0] == case["iters"][1] and case["fcalls"][0] == case["fcalls"][1], case
+        assert case["best"][0] == case["best"][1], case
+        assert case["same_pop"] and case["same_scores"] and case["same_best"], case
+        assert case["std_err"][0] == case["std_err"][1], case
