@@ -40,8 +40,8 @@ RcclApi &rccl_api();  // nlsg_comm.hip
 struct ShardComm {
   ncclComm_t comm = nullptr;
   hipStream_t stream = nullptr;  // the collective's stream
-  hipEvent_t sent[2] = {nullptr, nullptr};      // record is ready (compute stream)
-  hipEvent_t gathered_ev[2] = {nullptr, nullptr};  // records of all shards have arrived
+  hipEvent_t pop_ready[2] = {nullptr, nullptr};  // generation k is complete (engine's stream)
+  hipEvent_t head_done[2] = {nullptr, nullptr};  // head k is complete (collective's stream)
   double *gathered = nullptr;    // [world][rec_doubles]
   uint64_t rec_doubles = 0;
   int world = 0, rank = 0;
@@ -51,8 +51,8 @@ inline void comm_detach(ShardComm *c) {
   if (!c) return;
   if (c->comm && rccl_api().CommDestroy) rccl_api().CommDestroy(c->comm);
   for (int i = 0; i < 2; i++) {
-    if (c->sent[i]) hipEventDestroy(c->sent[i]);
-    if (c->gathered_ev[i]) hipEventDestroy(c->gathered_ev[i]);
+    if (c->pop_ready[i]) hipEventDestroy(c->pop_ready[i]);
+    if (c->head_done[i]) hipEventDestroy(c->head_done[i]);
   }
   if (c->stream) hipStreamDestroy(c->stream);
   hipFree(c->gathered);
@@ -80,8 +80,8 @@ inline int comm_attach(ShardComm **out, const unsigned char *id, int world, int 
   if (he == hipSuccess)
     he = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_high);
   for (int i = 0; i < 2 && he == hipSuccess; i++) {
-    he = hipEventCreateWithFlags(&c->sent[i], hipEventDisableTiming);
-    if (he == hipSuccess) he = hipEventCreateWithFlags(&c->gathered_ev[i], hipEventDisableTiming);
+    he = hipEventCreateWithFlags(&c->pop_ready[i], hipEventDisableTiming);
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&c->head_done[i], hipEventDisableTiming);
   }
   if (he == hipSuccess)
     he = hipMalloc(reinterpret_cast<void **>(&c->gathered), world * rec_doubles * sizeof(double));
@@ -105,19 +105,5 @@ inline int comm_attach(ShardComm **out, const unsigned char *id, int world, int 
 // HIP 7.0: an event recorded on the hipStreamLegacy handle crashes the next
 // hipStreamWaitEvent on it; the null stream is the same stream and works.
 inline hipStream_t event_stream(hipStream_t s) { return s == hipStreamLegacy ? nullptr : s; }
-
-// Turn k: all-gather `send` (ready on `compute` at the time of the call) into c->gathered on the
-// collective's stream; comm_join makes `compute` wait for it.
-inline int comm_all_gather(ShardComm *c, const double *send, hipStream_t compute, uint64_t k) {
-  NLSG_HIP(hipEventRecord(c->sent[k & 1], event_stream(compute)));
-  NLSG_HIP(hipStreamWaitEvent(c->stream, c->sent[k & 1], 0));
-  NLSG_RCCL(rccl_api().AllGather(send, c->gathered, c->rec_doubles, ncclDouble, c->comm, c->stream));
-  NLSG_HIP(hipEventRecord(c->gathered_ev[k & 1], c->stream));
-  return NLSG_OK;
-}
-inline int comm_join(ShardComm *c, hipStream_t compute, uint64_t k) {
-  NLSG_HIP(hipStreamWaitEvent(event_stream(compute), c->gathered_ev[k & 1], 0));
-  return NLSG_OK;
-}
 
 }  // namespace nlsg

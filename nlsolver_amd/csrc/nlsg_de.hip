@@ -538,30 +538,51 @@ int nlsg_de_comm_attach(nlsg_de *e, const unsigned char *unique_id, int32_t worl
   return comm_attach(&e->comm, unique_id, world, rank, static_cast<uint64_t>(kRecHeader) + e->p.D);
 }
 
-// `turns` sharded turns without a host round trip: head k -> record, all-gather on the
-// collective's stream, finaliser, generation k+1 -- for strategy random the generation is
-// enqueued before the finaliser and runs while the records travel (speculative, see
-// nlsg_de_turn_generation).
+// `turns` sharded turns without a host round trip.
+// Strategy best: head k -> all-gather -> finaliser -> generation k+1, all on the engine's
+// stream (nothing can overlap, so no cross-stream dependency is paid for).
+// Strategy random: the generation needs the exchange only for the stop flag and writes the
+// other buffers, so the whole head of turn k (summary, all-gather, finaliser) runs on the
+// collective's stream beside generation k+1; generation k+1 waits for finaliser k-1 only.
+// If finaliser k fires a stop test, generation k+1 is never adopted and k+2 is a no-op.
 int nlsg_de_step_sharded(nlsg_de *e, uint64_t turns) {
   if (!e) return fail(NLSG_ERR_INVALID_ARG, "null engine");
   if (!e->initialised) return fail(NLSG_ERR_STATE, "nlsg_de_init has not been called");
   if (!e->comm) return fail(NLSG_ERR_STATE, "nlsg_de_comm_attach has not been called");
+  if (turns == 0) return NLSG_OK;
   NLSG_HIP(hipSetDevice(e->cfg.device));
-  const bool speculate = e->cfg.strategy == NLSG_DE_RANDOM;
+  ShardComm *c = e->comm;
   const uint64_t stride = static_cast<uint64_t>(kRecHeader) + e->p.D;
+  if (e->cfg.strategy != NLSG_DE_RANDOM) {
+    for (uint64_t t = 0; t < turns; t++) {
+      const uint64_t k = e->k;
+      launch_local_summary(e, e->rec, e->stream);
+      NLSG_RCCL(rccl_api().AllGather(e->rec, c->gathered, stride, ncclDouble, c->comm, e->stream));
+      hipLaunchKernelGGL(de_finalize_kernel, dim3(1), dim3(256), 0, e->stream, e->p, c->gathered,
+                         c->world, stride);
+      launch_generation(e, static_cast<int>(k & 1), k + 1);
+      e->k = k + 1;
+    }
+    NLSG_HIP(hipGetLastError());
+    return NLSG_OK;
+  }
+  hipStream_t S = event_stream(e->stream), C = c->stream;
+  NLSG_HIP(hipEventRecord(c->pop_ready[e->k & 1], S));  // population k exists
   for (uint64_t t = 0; t < turns; t++) {
     const uint64_t k = e->k;
-    launch_local_summary(e, e->rec, e->stream);
-    int rc = comm_all_gather(e->comm, e->rec, e->stream, k);
-    if (rc) return rc;
-    if (speculate) launch_generation(e, static_cast<int>(k & 1), k + 1);
-    rc = comm_join(e->comm, e->stream, k);
-    if (rc) return rc;
-    hipLaunchKernelGGL(de_finalize_kernel, dim3(1), dim3(256), 0, e->stream, e->p,
-                       e->comm->gathered, e->comm->world, stride);
-    if (!speculate) launch_generation(e, static_cast<int>(k & 1), k + 1);
+    NLSG_HIP(hipStreamWaitEvent(C, c->pop_ready[k & 1], 0));
+    launch_local_summary(e, e->rec, C);
+    NLSG_RCCL(rccl_api().AllGather(e->rec, c->gathered, stride, ncclDouble, c->comm, C));
+    hipLaunchKernelGGL(de_finalize_kernel, dim3(1), dim3(256), 0, C, e->p, c->gathered, c->world,
+                       stride);
+    NLSG_HIP(hipEventRecord(c->head_done[k & 1], C));
+    if (t > 0) NLSG_HIP(hipStreamWaitEvent(S, c->head_done[(k - 1) & 1], 0));
+    launch_generation(e, static_cast<int>(k & 1), k + 1);
+    NLSG_HIP(hipEventRecord(c->pop_ready[(k + 1) & 1], S));
     e->k = k + 1;
   }
+  // the engine's stream ends behind the last head (status / download / the next call)
+  NLSG_HIP(hipStreamWaitEvent(S, c->head_done[(e->k - 1) & 1], 0));
   NLSG_HIP(hipGetLastError());
   return NLSG_OK;
 }
