@@ -13,6 +13,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <type_traits>
 
 #include "../../include/nlsg_c_api.h"
 
@@ -72,10 +73,54 @@ __host__ __device__ inline uint64_t clamp_index(double u, uint64_t n) {
 // ---------------------------------------------------------------------------
 __device__ inline int lane_id() { return static_cast<int>(threadIdx.x) & 63; }
 
+// lane_xor<OFF>(v): the value lane (l ^ OFF) holds, without the LDS crossbar (`__shfl_xor`
+// compiles to ds_bpermute, ~100 cycles of latency per level of a butterfly; these are VALU
+// moves): OFF 1, 2 quad permutes, 4 two bank-masked row shifts, 8 a row rotate (DPP),
+// 16 / 32 the gfx950 row / half swaps. Checked lane by lane against l ^ OFF on the device.
+template <int CTRL, int BANK>
+__device__ inline uint32_t dpp_mov32(uint32_t old, uint32_t src) {
+  return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(old), static_cast<int>(src),
+                                                           CTRL, 0xF, BANK, false));
+}
+template <int OFF>
+__device__ inline uint32_t lane_xor32(uint32_t v) {
+  static_assert(OFF == 1 || OFF == 2 || OFF == 4 || OFF == 8 || OFF == 16 || OFF == 32, "");
+  if constexpr (OFF == 1) return dpp_mov32<0xB1, 0xF>(v, v);        // quad_perm [1,0,3,2]
+  if constexpr (OFF == 2) return dpp_mov32<0x4E, 0xF>(v, v);        // quad_perm [2,3,0,1]
+  if constexpr (OFF == 4)                                            // row_shl:4 -> banks 0,2
+    return dpp_mov32<0x114, 0xA>(dpp_mov32<0x104, 0x5>(v, v), v);    // row_shr:4 -> banks 1,3
+  if constexpr (OFF == 8) return dpp_mov32<0x128, 0xF>(v, v);        // row_ror:8
+  if constexpr (OFF == 16) {
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return ((threadIdx.x >> 4) & 1) ? r[0] : r[1];
+  }
+  if constexpr (OFF == 32) {
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return ((threadIdx.x >> 5) & 1) ? r[0] : r[1];
+  }
+  return v;
+}
+template <int OFF>
+__device__ inline uint64_t lane_xor(uint64_t v) {
+  const uint32_t lo = lane_xor32<OFF>(static_cast<uint32_t>(v));
+  const uint32_t hi = lane_xor32<OFF>(static_cast<uint32_t>(v >> 32));
+  return (static_cast<uint64_t>(hi) << 32) | lo;
+}
+template <int OFF>
+__device__ inline double lane_xor(double v) {
+  return __longlong_as_double(static_cast<long long>(
+      lane_xor<OFF>(static_cast<uint64_t>(__double_as_longlong(v)))));
+}
+// f(integral_constant<int, OFF>) for OFF = FIRST, FIRST/2, ..., 1
+template <int FIRST, typename F>
+__device__ inline void butterfly_levels(F &&f) {
+  f(std::integral_constant<int, FIRST>{});
+  if constexpr (FIRST > 1) butterfly_levels<FIRST / 2>(f);
+}
+
 // xor butterfly (32,16,8,4,2,1): every lane ends with the same bit pattern.
 __device__ inline double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off, 64);
+  butterfly_levels<32>([&](auto off) { v = v + lane_xor<decltype(off)::value>(v); });
   return v;
 }
 
@@ -227,14 +272,21 @@ __device__ inline void argmin_combine(double &v, uint64_t &i, double ov, uint64_
   }
 }
 
+// higher value wins; equal values keep the lower index; NaN never wins
+__device__ inline void argmax_combine(double &v, uint64_t &i, double ov, uint64_t oi) {
+  if (ov > v || (ov == v && oi < i)) {
+    v = ov;
+    i = oi;
+  }
+}
+
 // wave- then block-level argmin; thread 0 returns the block result
 __device__ inline void block_argmin_256(double &bv, uint64_t &bi, double *mv, uint64_t *mi) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    const double ov = __shfl_xor(bv, off, 64);
-    const uint64_t oi = __shfl_xor(bi, off, 64);
+  butterfly_levels<32>([&](auto off) {
+    const double ov = lane_xor<decltype(off)::value>(bv);
+    const uint64_t oi = lane_xor<decltype(off)::value>(bi);
     argmin_combine(bv, bi, ov, oi);
-  }
+  });
   const int wid = static_cast<int>(threadIdx.x) >> 6;
   __syncthreads();
   if (lane_id() == 0) {

@@ -176,8 +176,7 @@ __device__ inline double lm_evaluate(const LmParams &p, SH &sh, uint64_t pid) {
 #pragma unroll
     for (int k = 0; k < 8; k++) {
       z[k] = a[k].x * th0 + a[k].y * th1;
-#pragma unroll
-      for (int off = 16; off >= 1; off >>= 1) z[k] = z[k] + __shfl_xor(z[k], off, 64);
+      butterfly_levels<16>([&](auto off) { z[k] = z[k] + lane_xor<decltype(off)::value>(z[k]); });
     }
     // tanh / residual / weight ONCE per row: lane lp < 8 of each half takes row k = lp
     // (instead of all 32 lanes of the half repeating the same transcendental 8 times)
@@ -505,8 +504,7 @@ __global__ __launch_bounds__(64, 2) void lm_eval_wave_kernel(LmParams p, int fir
 #pragma unroll
     for (int k = 0; k < 8; k++) {
       z[k] = a[k].x * th0 + a[k].y * th1;
-#pragma unroll
-      for (int off = 16; off >= 1; off >>= 1) z[k] = z[k] + __shfl_xor(z[k], off, 64);
+      butterfly_levels<16>([&](auto off) { z[k] = z[k] + lane_xor<decltype(off)::value>(z[k]); });
     }
     // tanh / residual / weight once per row: lane lp of each half takes row k = lp & 7
     double zsel = z[0];

@@ -118,31 +118,60 @@ __global__ __launch_bounds__(256) void nm_solve_kernel(NmParams p) {
     __syncthreads();
 
     for (;;) {
-      // ---- std_err(scores) by wave 0 (lane tree), then the scan by thread 0
+      // ---- std_err(scores) and the best / worst / second-worst scan by wave 0
       if (wid == 0) {
+        // Two butterfly sweeps, each carrying everything that is ready for it (the shuffles of
+        // one level are independent, so their LDS-crossbar latencies overlap):
+        //   1: sum of the scores | first index of the minimum | first index of the maximum
+        //   2: sum of squared deviations | first index of the maximum of scores[0 .. worst)
+        // The serial scan of 2208-2221 (B3) in closed form: best = first index of the minimum,
+        // worst = first index of the maximum (an element that lowers the running minimum can
+        // never raise the running maximum, so the else-if loses nothing), second = the holder
+        // of the running maximum just before `worst` took over. NaN never wins a comparison;
+        // a NaN at index 0 freezes all three at 0.
         double acc = 0.0;
-        for (uint64_t i = lane; i < nv; i += 64) acc = acc + scores[i];
-        const double mean = wave_sum(acc) / static_cast<double>(nv);
-        acc = 0.0;
+        double mnv = __builtin_inf(), mxv = -__builtin_inf();
+        uint64_t mni = ~0ull, mxi = ~0ull;
         for (uint64_t i = lane; i < nv; i += 64) {
-          const double d = scores[i] - mean;
-          acc = acc + d * d;
+          const double si = scores[i];
+          acc = acc + si;
+          argmin_combine(mnv, mni, si, i);
+          argmax_combine(mxv, mxi, si, i);
         }
-        const double se = sqrt(wave_sum(acc) / static_cast<double>(nv - 1));
+        butterfly_levels<32>([&](auto off) {
+          constexpr int o = decltype(off)::value;
+          const double oa = lane_xor<o>(acc);
+          const double omn = lane_xor<o>(mnv), omx = lane_xor<o>(mxv);
+          const uint64_t omni = lane_xor<o>(mni), omxi = lane_xor<o>(mxi);
+          acc = acc + oa;
+          argmin_combine(mnv, mni, omn, omni);
+          argmax_combine(mxv, mxi, omx, omxi);
+        });
+        const double mean = acc / static_cast<double>(nv);
+        const bool frozen = isnan(scores[0]);
+        const uint64_t worst_i = (frozen || mxi == ~0ull) ? 0 : mxi;
+        acc = 0.0;
+        double sv = -__builtin_inf();
+        uint64_t svi = ~0ull;
+        for (uint64_t i = lane; i < nv; i += 64) {
+          const double si = scores[i];
+          const double d = si - mean;
+          acc = acc + d * d;
+          if (i < worst_i) argmax_combine(sv, svi, si, i);
+        }
+        butterfly_levels<32>([&](auto off) {
+          constexpr int o = decltype(off)::value;
+          const double oa = lane_xor<o>(acc);
+          const double osv = lane_xor<o>(sv);
+          const uint64_t osvi = lane_xor<o>(svi);
+          acc = acc + oa;
+          argmax_combine(sv, svi, osv, osvi);
+        });
+        const double se = sqrt(acc / static_cast<double>(nv - 1));
         if (lane == 0) {
-          uint64_t best = 0, worst = 0, second = 0;
-          double sb = scores[0], sw = scores[0];
-          for (uint64_t i = 1; i < nv; i++) {  // 2208-2221 (B3)
-            const double si = scores[i];
-            if (si < sb) {
-              best = i;
-              sb = si;
-            } else if (si > sw) {
-              second = worst;
-              worst = i;
-              sw = si;
-            }
-          }
+          const uint64_t best = (frozen || mni == ~0ull) ? 0 : mni;
+          const uint64_t worst = worst_i;
+          const uint64_t second = (svi == ~0ull) ? 0 : svi;
           ctl->prev_worst = ctl->worst;
           ctl->best = best;
           ctl->worst = worst;
@@ -166,10 +195,12 @@ __global__ __launch_bounds__(256) void nm_solve_kernel(NmParams p) {
       const uint64_t best = ctl->best, worst = ctl->worst, second = ctl->second_worst;
       // ---- centroid of all vertices but the worst (1965-1984), only when it can have changed
       if (ctl->prev_worst != worst || ctl->shrunk) {
-        for (uint64_t j = t; j < n; j += 256) {
+        for (uint64_t j = t; j < n; j += 256) {  // two branch-free runs: loads pipeline
           double c = 0.0;
-          for (uint64_t v = 0; v < nv; v++)
-            if (v != worst) c += S[v * n + j];
+#pragma unroll 8
+          for (uint64_t v = 0; v < worst; v++) c += S[v * n + j];
+#pragma unroll 8
+          for (uint64_t v = worst + 1; v < nv; v++) c += S[v * n + j];
           centroid[j] = c / static_cast<double>(nv - 1);
         }
       }
@@ -240,15 +271,38 @@ __global__ __launch_bounds__(256) void nm_solve_kernel(NmParams p) {
           if (t == 0) scores[worst] = cont_score;
         } else {  // shrink (2009-2035) and rescoring (2288-2294)
           __syncthreads();
-          for (uint64_t e = t; e < nv * n; e += 256) {
-            const uint64_t v = e / n, j = e % n;
-            if (v != best) S[e] = S[best * n + j] + p.sigma * (S[e] - S[best * n + j]);
-          }
-          __syncthreads();
-          for (uint64_t v = wid; v < nv; v += 4) {
-            if (v == best) continue;
-            const double f = nm_wave_f<OBJ>(S + v * n, n, p.fmul);
-            if (lane == 0) scores[v] = f;
+          // One pass per vertex: the wave that owns row v shrinks it towards the best vertex
+          // and scores it from the registers it holds; four rows at a time so that their
+          // lane trees overlap (the method spends most iterations here on Rosenbrock-128D:
+          // the reference's second-worst rule, SURVEY B3, rarely accepts a reflection).
+          {
+            const bool in0 = 2u * lane < n, in1 = 2u * lane + 1 < n;
+            const double b0 = in0 ? S[best * n + 2 * lane] : 0.0;
+            const double b1 = in1 ? S[best * n + 2 * lane + 1] : 0.0;
+            for (uint64_t v0 = wid; v0 < nv; v0 += 16) {
+              double xv[4][1][2];
+#pragma unroll
+              for (int q = 0; q < 4; q++) {
+                const uint64_t v = v0 + 4 * q;
+                const bool live = v < nv && v != best;
+                double *row = S + (live ? v : best) * n;
+                const double o0 = in0 ? row[2 * lane] : 0.0, o1 = in1 ? row[2 * lane + 1] : 0.0;
+                xv[q][0][0] = b0 + p.sigma * (o0 - b0);
+                xv[q][0][1] = b1 + p.sigma * (o1 - b1);
+                if (live && in0) row[2 * lane] = xv[q][0][0];
+                if (live && in1) row[2 * lane + 1] = xv[q][0][1];
+                if (!in0) xv[q][0][0] = 0.0;
+                if (!in1) xv[q][0][1] = 0.0;
+              }
+              double f[4];
+#pragma unroll
+              for (int q = 0; q < 4; q++) f[q] = p.fmul * wave_objective<OBJ, 1>(xv[q], n);
+#pragma unroll
+              for (int q = 0; q < 4; q++) {
+                const uint64_t v = v0 + 4 * q;
+                if (lane == 0 && v < nv && v != best) scores[v] = f[q];
+              }
+            }
           }
           if (t == 0) {
             ctl->fcalls += nv - 1;
