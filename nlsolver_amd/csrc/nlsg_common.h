@@ -111,6 +111,20 @@ __device__ inline double lane_xor(double v) {
   return __longlong_as_double(static_cast<long long>(
       lane_xor<OFF>(static_cast<uint64_t>(__double_as_longlong(v)))));
 }
+// lane l+1's value (lane 63 keeps its own): DPP wave_shl:1
+__device__ inline double lane_down1(double v) {
+  const uint64_t b = static_cast<uint64_t>(__double_as_longlong(v));
+  const uint32_t lo = dpp_mov32<0x130, 0xF>(static_cast<uint32_t>(b), static_cast<uint32_t>(b));
+  const uint32_t hi = dpp_mov32<0x130, 0xF>(static_cast<uint32_t>(b >> 32), static_cast<uint32_t>(b >> 32));
+  return __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(hi) << 32) | lo));
+}
+// lane 0's value through scalar registers
+__device__ inline double lane_first(double v) {
+  const uint64_t b = static_cast<uint64_t>(__double_as_longlong(v));
+  const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<int>(b & 0xffffffffu));
+  const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<int>(b >> 32));
+  return __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(hi) << 32) | lo));
+}
 // f(integral_constant<int, OFF>) for OFF = FIRST, FIRST/2, ..., 1
 template <int FIRST, typename F>
 __device__ inline void butterfly_levels(F &&f) {
@@ -195,10 +209,10 @@ __device__ inline double wave_objective(const double (&xv)[CHUNKS][2], uint64_t 
     const uint64_t e0 = static_cast<uint64_t>(c) * 128 + 2 * static_cast<uint64_t>(lane);
     double xn = 0.0;
     if (O::kChain) {
-      // x[e0+2]: lane+1's first element, or lane 0 of the next chunk for lane 63
-      const double same = __shfl_down(xv[c][0], 1, 64);
+      // x[e0+2]: lane+1's first element (DPP wave shift), or lane 0 of the next chunk for lane 63
+      const double same = lane_down1(xv[c][0]);
       double next = 0.0;
-      if (c + 1 < CHUNKS) next = __shfl(xv[c + 1][0], 0, 64);
+      if (c + 1 < CHUNKS) next = lane_first(xv[c + 1][0]);
       xn = (lane == 63) ? next : same;
     }
     if (e0 < nt) acc = acc + O::term(xv[c][0], xv[c][1]);
