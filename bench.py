@@ -450,6 +450,8 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
+    if distributed:
+        dist.barrier()  # no rank tears its communicator down while another is still measuring
     eng.close()
     if distributed:
         dist.barrier()

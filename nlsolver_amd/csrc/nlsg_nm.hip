@@ -38,7 +38,7 @@ hipError_t prepare(size_t lds) {
 }
 
 void launch(nlsg_nm *e) {
-  const dim3 grid(static_cast<unsigned>(e->p.batch)), block(256);
+  const dim3 grid(static_cast<unsigned>(e->p.batch)), block(kNmThreads);
   switch (e->cfg.objective) {
     case NLSG_OBJ_ROSENBROCK:
       hipLaunchKernelGGL(nm_solve_kernel<NLSG_OBJ_ROSENBROCK>, grid, block, e->lds, e->stream, e->p);

@@ -120,13 +120,17 @@ __global__ __launch_bounds__(256) void pso_move_kernel(PsoParams p, int timing, 
   if (TYPE == NLSG_PSO_ACCELERATED)  // :2613 inertia = pow(init_inertia, iter)
     inertia = iter < p.tab_len ? p.inertia_tab[iter] : pow(p.inertia, static_cast<double>(iter));
 
+  // draws 2e and 2e+1 of element e = 128 c + 2 lane + k: ctr_key(kp, j) = mix64(kp + G (j + 1))
+  // with j + 1 = (4 lane + 1) + (256 c + 2 k [+ 1]) -- one 64-bit multiply per wave, the rest
+  // are compile-time constants (64-bit multiplies are four quarter-rate 32-bit ones each)
+  const uint64_t kp_lane = kp + kGolden * (4 * static_cast<uint64_t>(lane) + 1);
 #pragma unroll
   for (int c = 0; c < CHUNKS; c++) {
 #pragma unroll
     for (int k = 0; k < 2; k++) {
       const uint64_t e = static_cast<uint64_t>(c) * 128 + 2 * static_cast<uint64_t>(lane) + k;
-      const double u1 = u01(ctr_key(kp, 2 * e));
-      const double u2 = u01(ctr_key(kp, 2 * e + 1));
+      const double u1 = u01(mix64(kp_lane + kGolden * static_cast<uint64_t>(256 * c + 2 * k)));
+      const double u2 = u01(mix64(kp_lane + kGolden * static_cast<uint64_t>(256 * c + 2 * k + 1)));
       double pnew;
       if (TYPE == NLSG_PSO_ACCELERATED) {
         // rnorm (2479-2485): sqrt(-2 log u1) * cos(2 pi_ u2), pi_ = 3.141593

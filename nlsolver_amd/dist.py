@@ -72,7 +72,10 @@ class ShardedSwarm:
         from . import _capi
         import ctypes as C
         torch = self.torch
-        _capi.check(_capi.lib().nlsg_comm_load(rccl_library_path().encode()))
+        try:  # the same outcome on every rank (same installation): safe to fall back on
+            _capi.check(_capi.lib().nlsg_comm_load(rccl_library_path().encode()))
+        except RuntimeError:
+            return
         uid = (C.c_ubyte * 128)()
         if self.rank == 0:
             _capi.check(_capi.lib().nlsg_comm_unique_id(uid))
