@@ -85,6 +85,25 @@ def pmc_traffic(pop_local):
     return (2.0 * fetch + write) * 1024.0
 
 
+def pmc_bytes(tag, kernels, default_sizes=True):
+    """HBM bytes per launch summed over `kernels` (name fragments) from the committed PMC passes
+    of `bench.py --workload <tag>` at its default size (profiles/r01/pmc_summary.json, made by
+    profiles/summarize_pmc.py): 2 x FETCH_SIZE + WRITE_SIZE KiB, the gfx950 correction of
+    MI355X_MICROARCH.md. None when not profiled or the run is not at the default size."""
+    path = os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")
+    if not default_sizes or not os.path.exists(path):
+        return None
+    prof = json.load(open(path)).get(tag, {})
+    total = 0.0
+    for frag in kernels:
+        f = next((v["mean_KiB"] for k, v in prof.get("FETCH_SIZE", {}).items() if frag in k), None)
+        w = next((v["mean_KiB"] for k, v in prof.get("WRITE_SIZE", {}).items() if frag in k), None)
+        if f is None or w is None:
+            return None
+        total += (2.0 * f + w) * 1024.0
+    return total
+
+
 def main_bfgs(args):
     """BASELINE configs[2]: BFGS on the convex quadratic, dim=1024, batch=4096 independent
     starts on one GPU. One step = one BFGS iteration of every problem (stop tests, direction,
@@ -127,7 +146,9 @@ def main_bfgs(args):
                                "independent starts (BASELINE configs[2])",
                    "unfinished_problems": open_},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": pmc_bytes("bfgs", ["bfgs_hy_kernel", "bfgs_update_kernel"],
+                                          batch == 4096),
                      "kernel": "bfgs_hy_kernel + bfgs_update_kernel", "kernel_ms": hess_ms,
                      "algorithmic_bytes_per_launch": bytes_per_iter},
         **({} if args.no_cpu_baseline else {"cpu_baseline": ref_baseline(
@@ -187,7 +208,10 @@ def main_lm(args):
                                f"batch={batch} (BASELINE configs[3]), {args.lm_solver} solve",
                    "max_final_f": max(s.f_value for s in st)},
         "roofline": {"bound": "mfma", "achieved": tflops, "peak": 78.6, "unit": "TFLOP/s",
-                     "frac": tflops / 78.6, "traffic": None, "kernel": kname,
+                     "frac": tflops / 78.6,
+                     "traffic": None if args.lm_solver == "qr" else pmc_bytes(
+                         "lm", ["lm_eval_wave_kernel"], batch == 8192),
+                     "kernel": kname,
                      "kernel_ms": kms, "algorithmic_flops_per_launch": flops,
                      "hbm_GBps": hbm_gbps, "hbm_frac": hbm_gbps / 8000.0},
         **({} if args.no_cpu_baseline else {"cpu_baseline": ref_baseline(
@@ -301,7 +325,9 @@ def main_pso(args):
                        "global_swarm": n, "dim": Dp,
                        "parallelism": f"swarm-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_bytes("pso_vanilla" if vanilla else "pso_accel",
+                                              ["pso_move_kernel"], n_local == 131072),
                          "kernel": "pso_move_kernel", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": bytes_per * n_local},
             **({} if (args.no_cpu_baseline or world > 1 or vanilla) else {"cpu_baseline": ref_baseline(
