@@ -157,6 +157,55 @@ def main_bfgs(args):
     eng.close()
 
 
+def main_bfgs_fd(args):
+    """BFGS with the reference's DEFAULT gradient (fin_diff, nlsolver.h:1385-1413) on the device:
+    Rosenbrock-128D, batch = 4096 independent starts, 20 iterations. One step = one BFGS iteration
+    of every problem; each gradient costs 4 n = 512 objective evaluations of 128 terms, made by
+    the problem's wave one after the other."""
+    import torch
+
+    import nlsolver_amd
+    n, iters = 128, 20
+    batch = 4096 if args.pop_per_gpu == POP_PER_GPU else args.pop_per_gpu
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    rng = np.random.default_rng(12374563468 % 2**32)
+    x0 = 0.8 + 0.4 * (rng.random((batch, n)) - 0.5)
+    eng = nlsolver_amd.BFGSEngine("rosenbrock", batch, dim=n, max_iter=iters, grad_eps=0.0,
+                                  alpha=1.0, device=local_rank)
+    eng.init(x0)
+    eng.step(2)
+    torch.cuda.synchronize()
+    eng.init(x0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.step(iters + 1)  # the last turn only fires the stop test and evaluates f once
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    x, st = eng.download()
+    fcalls = sum(s.function_calls_used for s in st)
+    assert all(s.done and s.iteration == iters for s in st)
+    print(json.dumps({
+        "metric": "BFGS iterations x problems / s (Rosenbrock-128D, finite-difference gradient)",
+        "value": batch * iters / dt, "unit": "iteration-problems/s", "n_gpus": 1, "steps": iters,
+        "warmup": 2, "ms_per_step": dt / iters * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"BFGS + More-Thuente, default fin_diff gradient, Rosenbrock-{n}D, "
+                               f"batch={batch} independent starts",
+                   "objective_calls_per_s": fcalls / dt,
+                   "mean_final_f": float(np.mean([s.f_value for s in st]))},
+        "roofline": {"bound": "latency", "achieved": None, "peak": None, "unit": None,
+                     "frac": None, "traffic": None, "kernel": "bfgs_search_kernel",
+                     "kernel_ms": dt / iters * 1e3,
+                     "note": "4 n dependent objective evaluations per gradient in one wave; "
+                             "not roofline-graded"},
+        **({} if args.no_cpu_baseline else {"cpu_baseline": ref_baseline(
+            ["bench-bfgs-fd", n, 256, iters], "iterations_per_s", "iteration-problems/s",
+            f"reference BFGS, default fin_diff gradient, Rosenbrock-{n}D, 256 starts x {iters} "
+            "iterations")})}))
+    eng.close()
+
+
 def main_lm(args):
     """BASELINE configs[3]: Levenberg-Marquardt NLLS m=512, n=64, batch=8192 on one GPU
     (tanh regression, 20 iterations, lambda0 = 10, up = down = 10, f_delta = 0). One step = one
@@ -349,13 +398,15 @@ def main():
     ap.add_argument("--lm-solver", choices=["cholesky", "qr"], default="cholesky",
                     help="lm workload: damped-system solver (cholesky = the reference class's "
                          "get_update_with_hessian; qr = tinyqr::lm, as BASELINE configs[3] words it)")
-    ap.add_argument("--workload", choices=["de", "pso-accel", "pso-vanilla", "bfgs", "lm", "nm"],
+    ap.add_argument("--workload", choices=["de", "pso-accel", "pso-vanilla", "bfgs", "bfgs-fd", "lm", "nm"],
                     default="de",
                     help="de = the headline benchmark (BASELINE metric); pso-* = config 5's "
                          "per-GPU shard (secondary, same JSON shape)")
     args = ap.parse_args()
     if args.workload == "bfgs":
         return main_bfgs(args)
+    if args.workload == "bfgs-fd":
+        return main_bfgs_fd(args)
     if args.workload == "lm":
         return main_lm(args)
     if args.workload == "nm":

@@ -248,7 +248,10 @@ typedef struct {
   uint32_t struct_size;
   int32_t device;
   void *stream;
-  int32_t objective;   /* nlsg_grad_objective                                    */
+  int32_t objective;   /* nlsg_grad_objective (analytic gradient functor), or one of */
+                       /* NLSG_OBJ_ROSENBROCK / SPHERE / STYBLINSKI_TANG with the    */
+                       /* reference's default gradient fin_diff (nlsolver.h:         */
+                       /* 1385-1413, 2849-2855), evaluated on the device; dim <= 256 */
   int32_t reserved;
   uint64_t batch;      /* independent problems                                    */
   uint64_t dim;        /* x.size() of each problem (<= 1024)                      */
@@ -257,7 +260,7 @@ typedef struct {
   double quad_c;       /* rank-1 weight of NLSG_OBJ_QUAD_DIAG_RANK1               */
 } nlsg_bfgs_config;
 
-/* diag_host / lin_host: d[dim], b[dim] of the objective (copied). */
+/* diag_host / lin_host: d[dim], b[dim] of the quadratic (copied); NULL for the others. */
 int nlsg_bfgs_create(const nlsg_bfgs_config *cfg, const double *diag_host,
                      const double *lin_host, nlsg_bfgs **out);
 int nlsg_bfgs_destroy(nlsg_bfgs *e);

@@ -877,8 +877,25 @@ class BFGS {
   explicit BFGS(Callable &f, Grad g = Grad(), const size_t max_iter = 100,
                 const scalar_t grad_eps = 5e-3, const scalar_t alpha = 1)
       : f(f), g(g), max_iter(max_iter), grad_eps(grad_eps), alpha(alpha) {}
+  // Device coverage of the default-gradient path (fin_diff on a built-in objective): the
+  // objectives whose arithmetic is deterministic on the device, up to 256 dimensions.
+  static constexpr bool device_fd() {
+    if constexpr (device::is_device_objective<Callable>::value &&
+                  std::is_same_v<Grad, fin_diff<Callable, scalar_t>>)
+      return Callable::nlsg_objective == NLSG_OBJ_ROSENBROCK ||
+             Callable::nlsg_objective == NLSG_OBJ_SPHERE ||
+             Callable::nlsg_objective == NLSG_OBJ_STYBLINSKI_TANG;
+    else
+      return false;
+  }
   solver_status<scalar_t> minimize(std::vector<scalar_t> &x) {
     if constexpr (device::has_grad_objective<Callable>::value) {
+      std::vector<std::vector<scalar_t>> one{x};
+      auto st = minimize_batch(one);
+      x = one[0];
+      return st[0];
+    } else if constexpr (device_fd()) {
+      if (x.size() > 256) return solve_host(x);  // beyond the device coverage: host functor path
       std::vector<std::vector<scalar_t>> one{x};
       auto st = minimize_batch(one);
       x = one[0];
@@ -894,23 +911,29 @@ class BFGS {
   // Extension (BASELINE config 3): `xs.size()` independent starts solved in lock step on
   // the GPU; the reference solves one start per minimize() call.
   std::vector<solver_status<scalar_t>> minimize_batch(std::vector<std::vector<scalar_t>> &xs) {
-    static_assert(device::has_grad_objective<Callable>::value,
-                  "minimize_batch needs a device objective with an analytic gradient");
+    static_assert(device::has_grad_objective<Callable>::value || device_fd(),
+                  "minimize_batch needs a device objective: one with an analytic gradient, or "
+                  "Rosenbrock / Sphere / StyblinskiTang with the default finite-difference one");
     static_assert(std::is_same_v<scalar_t, double>, "the device path computes in fp64");
     const device::api &api = device::api::get();
     const size_t B = xs.size(), n = B ? xs[0].size() : 0;
     nlsg_bfgs_config cfg{};
     cfg.struct_size = sizeof(cfg);
     if (const char *d = std::getenv("NLSG_DEVICE")) cfg.device = std::atoi(d);
-    cfg.objective = Callable::nlsg_grad_objective;
     cfg.batch = B;
     cfg.dim = n;
     cfg.max_iter = max_iter;
     cfg.grad_eps = grad_eps;
     cfg.alpha = alpha;
-    cfg.quad_c = f.c;
     nlsg_bfgs *eng = nullptr;
-    api.check(api.bfgs_create(&cfg, f.d.data(), f.b.data(), &eng));
+    if constexpr (device::has_grad_objective<Callable>::value) {
+      cfg.objective = Callable::nlsg_grad_objective;
+      cfg.quad_c = f.c;
+      api.check(api.bfgs_create(&cfg, f.d.data(), f.b.data(), &eng));
+    } else {  // fin_diff (nlsolver.h:2849-2855) evaluated on the device
+      cfg.objective = Callable::nlsg_objective;
+      api.check(api.bfgs_create(&cfg, nullptr, nullptr, &eng));
+    }
     std::vector<scalar_t> flat(B * n);
     for (size_t p = 0; p < B; p++) std::copy(xs[p].begin(), xs[p].end(), flat.begin() + p * n);
     std::vector<nlsg_status> st(B);

@@ -3,9 +3,12 @@
 Reference interface (nlsolver.h:3169-3196):
     BFGS<Callable, scalar_t, Grad>(f, g = fin_diff, max_iter = 100, grad_eps = 5e-3, alpha = 1)
     solver_status minimize(std::vector<T>& x)          (one start per call)
-Here `f` is a device objective with an analytic gradient (QuadDiagRank1); minimize() accepts one
-start (n,) or a batch of independent starts (batch, n) — BASELINE config 3 — solved in lock step
-on the GPU, and returns one status per start.
+Here `f` is a device objective: QuadDiagRank1 with its analytic gradient, or the name of a
+built-in objective ("rosenbrock", "sphere", "styblinski_tang"; dim <= 256), for which the
+reference's DEFAULT gradient runs on the device (fin_diff = finite_difference_gradient<.,.,1>,
+nlsolver.h:1385-1413: four probes per coordinate, each counted as a function call). minimize()
+accepts one start (n,) or a batch of independent starts (batch, n) — BASELINE config 3 — solved
+in lock step on the GPU, and returns one status per start.
 """
 import ctypes as C
 
@@ -31,17 +34,25 @@ class QuadDiagRank1:
 
 
 class BFGSEngine:
-    def __init__(self, objective, batch, *, max_iter=100, grad_eps=5e-3, alpha=1.0, device=0,
-                 stream=None):
+    def __init__(self, objective, batch, *, dim=None, max_iter=100, grad_eps=5e-3, alpha=1.0,
+                 device=0, stream=None):
         cfg = BFGSConfig()
         cfg.struct_size = C.sizeof(BFGSConfig)
         cfg.device = device
         cfg.stream = None if stream is None else (stream or 1)
-        cfg.objective = objective.nlsg_objective
-        cfg.batch, cfg.dim = batch, objective.d.size
-        cfg.max_iter, cfg.grad_eps, cfg.alpha, cfg.quad_c = max_iter, grad_eps, alpha, objective.c
-        self.cfg = cfg
+        cfg.batch = batch
+        cfg.max_iter, cfg.grad_eps, cfg.alpha = max_iter, grad_eps, alpha
         self._h = C.c_void_p()
+        if isinstance(objective, str):  # built-in objective + finite-difference gradient
+            if dim is None:
+                raise TypeError("a built-in objective needs dim=")
+            cfg.objective, cfg.dim, cfg.quad_c = _capi.OBJECTIVES[objective], dim, 0.0
+            self.cfg = cfg
+            check(lib().nlsg_bfgs_create(C.byref(cfg), None, None, C.byref(self._h)))
+            return
+        cfg.objective = objective.nlsg_objective
+        cfg.dim, cfg.quad_c = objective.d.size, objective.c
+        self.cfg = cfg
         check(lib().nlsg_bfgs_create(C.byref(cfg), objective.d.ctypes.data_as(_capi.pd),
                                      objective.b.ctypes.data_as(_capi.pd), C.byref(self._h)))
 
@@ -106,7 +117,8 @@ class BFGS:
 
     def __init__(self, f, g=None, max_iter=100, grad_eps=5e-3, alpha=1.0, *, device=0):
         if g is not None:
-            raise TypeError("device objectives carry their analytic gradient; pass g=None")
+            raise TypeError("device objectives carry their analytic gradient or use the default "
+                            "finite-difference one; pass g=None")
         self.f = f
         self.args = dict(max_iter=max_iter, grad_eps=grad_eps, alpha=alpha, device=device)
 
@@ -115,7 +127,8 @@ class BFGS:
             raise TypeError("x must be a float64 numpy array of shape (n,) or (batch, n); "
                             "it is updated in place")
         xb = x.reshape(1, -1) if x.ndim == 1 else x
-        with BFGSEngine(self.f, xb.shape[0], **self.args) as eng:
+        extra = dict(dim=xb.shape[1]) if isinstance(self.f, str) else {}
+        with BFGSEngine(self.f, xb.shape[0], **extra, **self.args) as eng:
             out, st = eng.minimize(xb)
         xb[...] = out
         return st[0] if x.ndim == 1 else st

@@ -38,10 +38,49 @@ namespace {
     }                                                                                            \
   } while (0)
 
+// search / init kernels also depend on what is minimised: the quadratic for every dim, the
+// finite-difference models for dim <= 256
+#define BFGS_MODEL_CASE(KERNEL, C, V, grid, ...)                                                    \
+  switch (e->p.model) {                                                                             \
+    case kBfgsQuad:                                                                                 \
+      hipLaunchKernelGGL((KERNEL<C, V, kBfgsQuad>), dim3(grid), dim3(256), 0, e->stream, __VA_ARGS__); \
+      break;                                                                                        \
+    case NLSG_OBJ_ROSENBROCK:                                                                       \
+      if constexpr (C <= 2)                                                                         \
+        hipLaunchKernelGGL((KERNEL<C, V, NLSG_OBJ_ROSENBROCK>), dim3(grid), dim3(256), 0, e->stream, \
+                           __VA_ARGS__);                                                            \
+      break;                                                                                        \
+    case NLSG_OBJ_SPHERE:                                                                           \
+      if constexpr (C <= 2)                                                                         \
+        hipLaunchKernelGGL((KERNEL<C, V, NLSG_OBJ_SPHERE>), dim3(grid), dim3(256), 0, e->stream,    \
+                           __VA_ARGS__);                                                            \
+      break;                                                                                        \
+    case NLSG_OBJ_STYBLINSKI_TANG:                                                                  \
+      if constexpr (C <= 2)                                                                         \
+        hipLaunchKernelGGL((KERNEL<C, V, NLSG_OBJ_STYBLINSKI_TANG>), dim3(grid), dim3(256), 0,      \
+                           e->stream, __VA_ARGS__);                                                 \
+      break;                                                                                        \
+    default: break;                                                                                 \
+  }
+#define BFGS_DISPATCH_MODEL(KERNEL, grid, ...)                           \
+  do {                                                                   \
+    switch (e->chunks * 2 + (e->vec ? 1 : 0)) {                          \
+      case 2: BFGS_MODEL_CASE(KERNEL, 1, false, grid, __VA_ARGS__) break; \
+      case 3: BFGS_MODEL_CASE(KERNEL, 1, true, grid, __VA_ARGS__) break;  \
+      case 4: BFGS_MODEL_CASE(KERNEL, 2, false, grid, __VA_ARGS__) break; \
+      case 5: BFGS_MODEL_CASE(KERNEL, 2, true, grid, __VA_ARGS__) break;  \
+      case 8: BFGS_MODEL_CASE(KERNEL, 4, false, grid, __VA_ARGS__) break; \
+      case 9: BFGS_MODEL_CASE(KERNEL, 4, true, grid, __VA_ARGS__) break;  \
+      case 16: BFGS_MODEL_CASE(KERNEL, 8, false, grid, __VA_ARGS__) break; \
+      case 17: BFGS_MODEL_CASE(KERNEL, 8, true, grid, __VA_ARGS__) break;  \
+      default: break;                                                    \
+    }                                                                    \
+  } while (0)
+
 void launch_iteration(nlsg_bfgs *e, bool timed) {
   const unsigned wave_grid = static_cast<unsigned>((e->p.batch + 3) / 4);
   const unsigned row_grid = static_cast<unsigned>(e->p.batch * e->bpp);
-  BFGS_DISPATCH(bfgs_search_kernel, wave_grid, e->p);
+  BFGS_DISPATCH_MODEL(bfgs_search_kernel, wave_grid, e->p);
   if (timed) hipEventRecord(e->ev2, e->stream);
   BFGS_DISPATCH(bfgs_hy_kernel, row_grid, e->p, e->bpp);
   BFGS_DISPATCH(bfgs_update_kernel, row_grid, e->p, e->bpp);
@@ -68,13 +107,21 @@ extern "C" {
 
 int nlsg_bfgs_create(const nlsg_bfgs_config *cfg, const double *diag_host, const double *lin_host,
                      nlsg_bfgs **out) {
-  if (!cfg || !out || !diag_host || !lin_host) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  if (!cfg || !out) return fail(NLSG_ERR_INVALID_ARG, "null argument");
   *out = nullptr;
   if (cfg->struct_size != sizeof(nlsg_bfgs_config))
     return fail(NLSG_ERR_INVALID_ARG, "nlsg_bfgs_config size mismatch (%u vs %zu)",
                 cfg->struct_size, sizeof(nlsg_bfgs_config));
-  if (cfg->objective != NLSG_OBJ_QUAD_DIAG_RANK1)
-    return fail(NLSG_ERR_INVALID_ARG, "unknown objective %d", cfg->objective);
+  const bool quad = cfg->objective == NLSG_OBJ_QUAD_DIAG_RANK1;
+  const bool fd = cfg->objective == NLSG_OBJ_ROSENBROCK || cfg->objective == NLSG_OBJ_SPHERE ||
+                  cfg->objective == NLSG_OBJ_STYBLINSKI_TANG;
+  if (!quad && !fd) return fail(NLSG_ERR_INVALID_ARG, "unknown objective %d", cfg->objective);
+  if (quad && (!diag_host || !lin_host))
+    return fail(NLSG_ERR_INVALID_ARG, "the quadratic needs its d and b vectors");
+  if (fd && cfg->dim > 256)
+    return fail(NLSG_ERR_UNSUPPORTED,
+                "dim %llu > 256: finite-difference objectives are covered up to 256 dimensions",
+                (unsigned long long)cfg->dim);
   if (cfg->dim < 1 || cfg->batch < 1) return fail(NLSG_ERR_INVALID_ARG, "dim and batch must be >= 1");
   if (cfg->dim > 1024)
     return fail(NLSG_ERR_UNSUPPORTED, "dim %llu > 1024 is not covered by the device path",
@@ -123,9 +170,11 @@ int nlsg_bfgs_create(const nlsg_bfgs_config *cfg, const double *diag_host, const
   if (he == hipSuccess) he = hipMemset(e->zero_dev, 0, 16);
   if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&e->count_dev), 8);
   if (he == hipSuccess)
-    he = hipMemcpy(e->qd_dev, diag_host, n * sizeof(double), hipMemcpyHostToDevice);
+    he = quad ? hipMemcpy(e->qd_dev, diag_host, n * sizeof(double), hipMemcpyHostToDevice)
+              : hipMemset(e->qd_dev, 0, n * sizeof(double));
   if (he == hipSuccess)
-    he = hipMemcpy(e->qb_dev, lin_host, n * sizeof(double), hipMemcpyHostToDevice);
+    he = quad ? hipMemcpy(e->qb_dev, lin_host, n * sizeof(double), hipMemcpyHostToDevice)
+              : hipMemset(e->qb_dev, 0, n * sizeof(double));
   if (he == hipSuccess) he = hipEventCreate(&e->ev0);
   if (he == hipSuccess) he = hipEventCreate(&e->ev1);
   if (he == hipSuccess) he = hipEventCreate(&e->ev2);
@@ -144,6 +193,7 @@ int nlsg_bfgs_create(const nlsg_bfgs_config *cfg, const double *diag_host, const
   p.grad_eps = cfg->grad_eps;
   p.alpha = cfg->alpha;
   p.qc = cfg->quad_c;
+  p.model = quad ? kBfgsQuad : cfg->objective;
   *out = e;
   return NLSG_OK;
 }
@@ -177,7 +227,7 @@ int nlsg_bfgs_init(nlsg_bfgs *e, const double *x0_host) {
   NLSG_HIP(hipMemcpyAsync(e->p.x, x0_host, e->p.batch * e->p.n * sizeof(double),
                           hipMemcpyHostToDevice, e->stream));
   NLSG_HIP(hipStreamSynchronize(e->stream));
-  BFGS_DISPATCH(bfgs_init_kernel, static_cast<unsigned>((e->p.batch + 3) / 4), e->p);
+  BFGS_DISPATCH_MODEL(bfgs_init_kernel, static_cast<unsigned>((e->p.batch + 3) / 4), e->p);
   NLSG_HIP(hipGetLastError());
   e->initialised = true;
   return NLSG_OK;

@@ -35,6 +35,7 @@ struct BfgsParams {
   const double *zero;
   uint64_t batch, n, max_iter;
   double grad_eps, alpha, qc;
+  int32_t model, pad;  // kBfgsQuad, or the nlsg_objective minimised with a finite-difference gradient
 };
 
 // ---- wave-level vector helpers (vectors replicated in every lane layout) --------
@@ -92,6 +93,84 @@ __device__ inline void quad_g(const double (&x)[CHUNKS][2], const double (&d)[CH
     }
   }
 }
+
+// ---- what is minimised ---------------------------------------------------------------
+// kBfgsQuad: the G6 quadratic with its analytic gradient functor. Otherwise a built-in
+// objective (Objective<OBJ>) with the reference's DEFAULT gradient, fin_diff =
+// finite_difference_gradient<Callable, scalar_t, 1> (nlsolver.h:1385-1413, 2849-2855): per
+// coordinate four probes x_d + {-2,-1,1,2} eps weighted {1,-8,8,-1}, divided by 12 eps,
+// eps = DBL_EPSILON * 10e7. The probes go through the counting wrapper (3218-3224), so each
+// counts as a function call. One wave evaluates them one after the other, each a full
+// evaluation in the lane-tree order (oracle_bfgs.c model_g).
+constexpr int kBfgsQuad = -1;
+
+template <int MODEL, int CHUNKS>
+struct BfgsModel {  // finite differences on Objective<MODEL>
+  uint64_t n;
+  template <bool VEC>
+  __device__ inline void load(const BfgsParams &p) {
+    n = p.n;
+  }
+  __device__ inline double f(const double (&x)[CHUNKS][2], uint64_t &fcalls) const {
+    fcalls++;
+    return wave_objective<MODEL, CHUNKS>(x, n);
+  }
+  __device__ inline void grad(const double (&x)[CHUNKS][2], double (&g)[CHUNKS][2],
+                              uint64_t &fcalls, uint64_t &gcalls) const {
+    gcalls++;
+    constexpr double eps = 2.220446049250313e-16 * 10e7;
+    constexpr double coeff[4] = {1, -8, 8, -1}, coeff2[4] = {-2, -1, 1, 2};
+    constexpr double dd_val = 12 * eps;
+    const int lane = lane_id();
+#pragma unroll
+    for (int c = 0; c < CHUNKS; c++) g[c][0] = g[c][1] = 0.0;
+    for (uint64_t d = 0; d < n; d++) {
+      const int cc = static_cast<int>(d >> 7), kk = static_cast<int>(d & 1);
+      const bool mine = lane == static_cast<int>((d & 127) >> 1);
+      double acc = 0.0;
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        double xp[CHUNKS][2];
+#pragma unroll
+        for (int c = 0; c < CHUNKS; c++)
+#pragma unroll
+          for (int k = 0; k < 2; k++)
+            xp[c][k] = (mine && c == cc && k == kk) ? x[c][k] + coeff2[s] * eps : x[c][k];
+        acc = acc + coeff[s] * wave_objective<MODEL, CHUNKS>(xp, n);
+      }
+      fcalls += 4;
+      const double gd = acc / dd_val;
+#pragma unroll
+      for (int c = 0; c < CHUNKS; c++)
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+          if (mine && c == cc && k == kk) g[c][k] = gd;
+    }
+  }
+};
+
+template <int CHUNKS>
+struct BfgsModel<kBfgsQuad, CHUNKS> {
+  double qd[CHUNKS][2], qb[CHUNKS][2];
+  double qc;
+  uint64_t n;
+  template <bool VEC>
+  __device__ inline void load(const BfgsParams &p) {
+    n = p.n;
+    qc = p.qc;
+    load_row<CHUNKS, VEC>(p.qd, n, p.zero, qd);
+    load_row<CHUNKS, VEC>(p.qb, n, p.zero, qb);
+  }
+  __device__ inline double f(const double (&x)[CHUNKS][2], uint64_t &fcalls) const {
+    fcalls++;
+    return quad_f<CHUNKS>(x, qd, qb, qc);
+  }
+  __device__ inline void grad(const double (&x)[CHUNKS][2], double (&g)[CHUNKS][2],
+                              uint64_t &, uint64_t &gcalls) const {
+    gcalls++;
+    quad_g<CHUNKS>(x, qd, qb, qc, n, g);
+  }
+};
 
 // ---- More-Thuente (scalar code, identical in every lane) -------------------------
 __device__ inline double mt_max_abs3(double x, double y, double z) {
@@ -220,8 +299,11 @@ __device__ inline void load_vec(const double *p, uint64_t n, const double *zero,
 }
 
 // One wave per problem: everything of an iteration except the two H passes.
-template <int CHUNKS, bool VEC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void
+// Long vectors (CHUNKS >= 4) want the whole register file of a SIMD for one wave; short ones
+// (every finite-difference model) leave room for four, which is what hides the latency of the
+// 4 n dependent evaluations per gradient.
+template <int CHUNKS, bool VEC, int MODEL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CHUNKS >= 4 ? 1 : 4))) void
 bfgs_search_kernel(BfgsParams p) {
   const uint64_t pid = static_cast<uint64_t>(blockIdx.x) * 4 +
                        __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
@@ -230,22 +312,22 @@ bfgs_search_kernel(BfgsParams p) {
   if (pr->done) return;
   const int lane = lane_id();
   const uint64_t n = p.n;
-  double x[CHUNKS][2], g[CHUNKS][2], dir[CHUNKS][2], qd[CHUNKS][2], qb[CHUNKS][2];
+  double x[CHUNKS][2], g[CHUNKS][2], dir[CHUNKS][2];
+  BfgsModel<MODEL, CHUNKS> model;
+  model.template load<VEC>(p);
   load_vec<CHUNKS, VEC>(p.x + pid * n, n, p.zero, x);
   load_vec<CHUNKS, VEC>(p.g + pid * n, n, p.zero, g);
   load_vec<CHUNKS, VEC>(p.dir + pid * n, n, p.zero, dir);
-  load_vec<CHUNKS, VEC>(p.qd, n, p.zero, qd);
-  load_vec<CHUNKS, VEC>(p.qb, n, p.zero, qb);
   uint64_t iter = pr->iter, fcalls = pr->fcalls, gcalls = pr->gcalls;
   double prev_norm = pr->prev_norm, cur_norm = pr->cur_norm;
 
   // stop tests, nlsolver.h:3239-3246
   if (iter >= p.max_iter || cur_norm < p.grad_eps || fabs(cur_norm - prev_norm) < p.grad_eps ||
       isinf(cur_norm)) {
-    const double fv = quad_f<CHUNKS>(x, qd, qb, p.qc);
+    const double fv = model.f(x, fcalls);
     if (lane == 0) {
       pr->fval = fv;
-      pr->fcalls = fcalls + 1;
+      pr->fcalls = fcalls;
       pr->done = 1;
     }
     return;
@@ -277,8 +359,7 @@ bfgs_search_kernel(BfgsParams p) {
     pg[c][1] = g[c][1];
   }
   // more_thuente_search (1880-1891) -> cvsrch (1673-1793)
-  const double f0 = quad_f<CHUNKS>(x, qd, qb, p.qc);
-  fcalls++;
+  const double f0 = model.f(x, fcalls);
   double stp = p.alpha;
   {
     int info = 0, infoc = 1;
@@ -310,10 +391,8 @@ bfgs_search_kernel(BfgsParams p) {
           tmp[c][0] = x[c][0] + stp * dir[c][0];
           tmp[c][1] = x[c][1] + stp * dir[c][1];
         }
-        const double fcur = quad_f<CHUNKS>(tmp, qd, qb, p.qc);
-        fcalls++;
-        quad_g<CHUNKS>(tmp, qd, qb, p.qc, n, g);
-        gcalls++;
+        const double fcur = model.f(tmp, fcalls);
+        model.grad(tmp, g, fcalls, gcalls);
         nfev++;
         const double dg = wave_dot<CHUNKS>(g, dir);
         const double ftest1 = finit + stp * dgtest;
@@ -356,8 +435,7 @@ bfgs_search_kernel(BfgsParams p) {
       x[c][h] = x[c][h] + s[c][h];
     }
   }
-  quad_g<CHUNKS>(x, qd, qb, p.qc, n, g);
-  gcalls++;
+  model.grad(x, g, fcalls, gcalls);
   prev_norm = cur_norm;
   cur_norm = sqrt(wave_dot<CHUNKS>(g, g));
 #pragma unroll
@@ -383,17 +461,18 @@ bfgs_search_kernel(BfgsParams p) {
 }
 
 // g = grad(x0), norms as at nlsolver.h:3234-3237
-template <int CHUNKS, bool VEC>
+template <int CHUNKS, bool VEC, int MODEL>
 __global__ __launch_bounds__(256) void bfgs_init_kernel(BfgsParams p) {
   const uint64_t pid = static_cast<uint64_t>(blockIdx.x) * 4 +
                        __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
   if (pid >= p.batch) return;
   const uint64_t n = p.n;
-  double x[CHUNKS][2], g[CHUNKS][2], qd[CHUNKS][2], qb[CHUNKS][2];
+  double x[CHUNKS][2], g[CHUNKS][2];
+  BfgsModel<MODEL, CHUNKS> model;
+  model.template load<VEC>(p);
   load_vec<CHUNKS, VEC>(p.x + pid * n, n, p.zero, x);
-  load_vec<CHUNKS, VEC>(p.qd, n, p.zero, qd);
-  load_vec<CHUNKS, VEC>(p.qb, n, p.zero, qb);
-  quad_g<CHUNKS>(x, qd, qb, p.qc, n, g);
+  uint64_t fcalls = 0, gcalls = 0;
+  model.grad(x, g, fcalls, gcalls);
   store_row<CHUNKS, VEC>(p.g + pid * n, n, g);
   if (lane_id() == 0) {
     BfgsProblem *pr = p.prob + pid;
@@ -402,8 +481,8 @@ __global__ __launch_bounds__(256) void bfgs_init_kernel(BfgsParams p) {
     pr->rho = 0.0;
     pr->fval = 0.0;
     pr->iter = 0;
-    pr->fcalls = 0;
-    pr->gcalls = 1;
+    pr->fcalls = fcalls;
+    pr->gcalls = gcalls;
     pr->done = 0;
     pr->identity = 1;
   }

@@ -188,6 +188,11 @@ typedef struct {
  * tree = 1: the HIP kernel's lane tree. */
 orc_status orc_bfgs_quad(const orc_quad *q, double *x, size_t n, size_t max_iter, double grad_eps,
                          double alpha, int tree, orc_bfgs_counters *cnt);
+/* the same on a built-in objective with the reference's default gradient, fin_diff
+ * (finite_difference_gradient<.,.,1>, nlsolver.h:1385-1413): 4 n probes per gradient, each
+ * counted as a function call (3218-3224). */
+orc_status orc_bfgs_fd(int obj, double *x, size_t n, size_t max_iter, double grad_eps, double alpha,
+                       int tree, orc_bfgs_counters *cnt);
 void orc_update_inverse_hessian(double *H, const double *s, const double *y, double *t, double rho,
                                 size_t n, int tree);
 

@@ -45,7 +45,7 @@ static double dot_(const ctx_t *c, const double *a, const double *b) { /* math::
 }
 
 /* ---- the G6 quadratic: f = 1/2 sum d x^2 + 1/2 c (sum x)^2 - sum b x ---------- */
-static double quad_f(const ctx_t *c, const orc_quad *q, const double *x) {
+static double quad_f_raw(const ctx_t *c, const orc_quad *q, const double *x) {
   for (size_t i = 0; i < c->n; i++) c->scratch[i] = q->d[i] * x[i] * x[i];
   const double qq = reduce_terms(c->scratch, c->n, c->tree);
   const double sx = reduce_terms(x, c->n, c->tree);
@@ -53,9 +53,52 @@ static double quad_f(const ctx_t *c, const orc_quad *q, const double *x) {
   const double lin = reduce_terms(c->scratch, c->n, c->tree);
   return 0.5 * qq + 0.5 * q->c * (sx * sx) - lin;
 }
-static void quad_g(const ctx_t *c, const orc_quad *q, const double *x, double *g) {
+static void quad_g_raw(const ctx_t *c, const orc_quad *q, const double *x, double *g) {
   const double sx = reduce_terms(x, c->n, c->tree);
   for (size_t i = 0; i < c->n; i++) g[i] = q->d[i] * x[i] + q->c * sx - q->b[i];
+}
+
+/* ---- what BFGS minimises: the quadratic with its analytic gradient functor, or a built-in
+ * objective (oracle_objective.c) with the reference's DEFAULT gradient, fin_diff =
+ * finite_difference_gradient<Callable, scalar_t, 1> (nlsolver.h:1385-1413, 2849-2855). The
+ * probes go through the counting wrapper f_lam (3218-3224), so they count as function calls. */
+typedef struct {
+  const orc_quad *q; /* NULL: built-in objective `obj` + finite differences */
+  int obj;
+} model_t;
+
+static void log_f(orc_bfgs_counters *cnt, double v) {
+  cnt->f_calls++;
+  if (cnt->f_log && cnt->f_count < cnt->f_cap) cnt->f_log[cnt->f_count] = v;
+  cnt->f_count++;
+}
+static double model_f(const ctx_t *c, const model_t *m, const double *x, orc_bfgs_counters *cnt) {
+  const double v = m->q ? quad_f_raw(c, m->q, x)
+                        : (c->tree ? orc_objective_tree(m->obj, x, c->n)
+                                   : orc_objective_seq(m->obj, x, c->n));
+  log_f(cnt, v);
+  return v;
+}
+static void model_g(const ctx_t *c, const model_t *m, double *x, double *g, orc_bfgs_counters *cnt) {
+  cnt->g_calls++;
+  if (m->q) {
+    quad_g_raw(c, m->q, x, g);
+    return;
+  }
+  /* accuracy = 1: coeff {1, -8, 8, -1}, coeff2 {-2, -1, 1, 2}, dd = 12 (:1390-1399) */
+  const double eps = 2.220446049250313e-16 * 10e7;
+  static const double coeff[4] = {1, -8, 8, -1}, coeff2[4] = {-2, -1, 1, 2};
+  const double dd_val = 12 * eps;
+  for (size_t d = 0; d < c->n; d++) {
+    double acc = 0.0; /* std::fill(grad, 0) :1402 */
+    for (int s = 0; s < 4; s++) {
+      const double tmp = x[d];
+      x[d] += coeff2[s] * eps;
+      acc += coeff[s] * model_f(c, m, x, cnt);
+      x[d] = tmp;
+    }
+    g[d] = acc / dd_val;
+  }
 }
 
 /* ---- cstep, nlsolver.h:1527-1671 ------------------------------------------ */
@@ -180,7 +223,7 @@ static int cstep(double *stx, double *fx, double *dx, double *sty, double *fy, d
 
 /* ---- cvsrch, nlsolver.h:1673-1793; returns the final step through *stp. The
  * gradient vector is overwritten with the gradient at the last trial point. */
-static void cvsrch(const ctx_t *c, const orc_quad *q, const double *x, double f0, double *gradient,
+static void cvsrch(const ctx_t *c, const model_t *q, const double *x, double f0, double *gradient,
                    double *stp, const double *dir, double *tmp, orc_bfgs_counters *cnt) {
   int info = 0, infoc = 1;
   const double xtol = 1e-15, ftol = 1e-4, gtol = 1e-2, stpmin = 1e-15, stpmax = 1e15, xtrapf = 4;
@@ -206,12 +249,8 @@ static void cvsrch(const ctx_t *c, const orc_quad *q, const double *x, double f0
         (infoc == 0) || (brackt && ((stmax - stmin) <= (xtol * stmax))))
       *stp = stx; /* :1728-1734 */
     for (size_t i = 0; i < c->n; i++) tmp[i] = x[i] + *stp * dir[i]; /* :1737 */
-    const double fcur = quad_f(c, q, tmp);
-    cnt->f_calls++;
-    if (cnt->f_log && cnt->f_count < cnt->f_cap) cnt->f_log[cnt->f_count] = fcur;
-    cnt->f_count++;
-    quad_g(c, q, tmp, gradient);
-    cnt->g_calls++;
+    const double fcur = model_f(c, q, tmp, cnt);
+    model_g(c, q, tmp, gradient, cnt);
     nfev++;
     const double dg = dot_(c, gradient, dir);
     const double ftest1 = finit + *stp * dgtest;
@@ -259,10 +298,9 @@ void orc_update_inverse_hessian(double *H, const double *s, const double *y, dou
   free(scratch);
 }
 
-/* BFGS::solve<true>, nlsolver.h:3196-3285 on the G6 quadratic with its analytic
- * gradient. x is in/out. */
-orc_status orc_bfgs_quad(const orc_quad *q, double *x, size_t n, size_t max_iter, double grad_eps,
-                         double alpha, int tree, orc_bfgs_counters *cnt) {
+/* BFGS::solve<true>, nlsolver.h:3196-3285. x is in/out. */
+static orc_status bfgs_solve(const model_t *q, double *x, size_t n, size_t max_iter, double grad_eps,
+                             double alpha, int tree, orc_bfgs_counters *cnt) {
   double *H = (double *)calloc(n * n, sizeof(double));
   double *dir = (double *)calloc(n, sizeof(double)), *g = (double *)calloc(n, sizeof(double));
   double *pg = (double *)calloc(n, sizeof(double)), *y = (double *)calloc(n, sizeof(double));
@@ -273,17 +311,13 @@ orc_status orc_bfgs_quad(const orc_quad *q, double *x, size_t n, size_t max_iter
   if (!cnt) cnt = &local;
   for (size_t i = 0; i < n; i++) H[i + i * n] = 1.0; /* :3212 */
   size_t iter = 0;
-  quad_g(&c, q, x, g); /* :3234 */
-  cnt->g_calls++;
+  model_g(&c, q, x, g, cnt); /* :3234 */
   double prev_norm = 1e9, cur_norm = 1e8; /* :3236-3237 */
   double fval;
   for (;;) {
     if (iter >= max_iter || cur_norm < grad_eps || fabs(cur_norm - prev_norm) < grad_eps ||
         isinf(cur_norm)) { /* :3239-3246 */
-      fval = quad_f(&c, q, x);
-      cnt->f_calls++;
-      if (cnt->f_log && cnt->f_count < cnt->f_cap) cnt->f_log[cnt->f_count] = fval;
-      cnt->f_count++;
+      fval = model_f(&c, q, x, cnt);
       break;
     }
     for (size_t j = 0; j < n; j++) dir[j] = -dot_(&c, H + j * n, g); /* :3248-3251 */
@@ -297,16 +331,12 @@ orc_status orc_bfgs_quad(const orc_quad *q, double *x, size_t n, size_t max_iter
     }
     memcpy(pg, g, n * sizeof(double)); /* :3261 */
     /* more_thuente_search overload without f value: evaluates f(x) first (:1885) */
-    const double f0 = quad_f(&c, q, x);
-    cnt->f_calls++;
-    if (cnt->f_log && cnt->f_count < cnt->f_cap) cnt->f_log[cnt->f_count] = f0;
-    cnt->f_count++;
+    const double f0 = model_f(&c, q, x, cnt);
     double rate = alpha;
     cvsrch(&c, q, x, f0, g, &rate, dir, tmp, cnt);
     for (size_t i = 0; i < n; i++) s[i] = dir[i] * rate; /* :3266 */
     for (size_t i = 0; i < n; i++) x[i] += s[i];         /* :3268 */
-    quad_g(&c, q, x, g);                                 /* :3271 */
-    cnt->g_calls++;
+    model_g(&c, q, x, g, cnt);                           /* :3271 */
     prev_norm = cur_norm;
     cur_norm = sqrt(dot_(&c, g, g)); /* math::norm :91-99 */
     for (size_t i = 0; i < n; i++) y[i] = g[i] - pg[i]; /* :3275 */
@@ -332,4 +362,18 @@ orc_status orc_bfgs_quad(const orc_quad *q, double *x, size_t n, size_t max_iter
   free(t);
   free(scratch);
   return st;
+}
+
+/* the G6 quadratic with its analytic gradient functor */
+orc_status orc_bfgs_quad(const orc_quad *q, double *x, size_t n, size_t max_iter, double grad_eps,
+                         double alpha, int tree, orc_bfgs_counters *cnt) {
+  const model_t m = {q, 0};
+  return bfgs_solve(&m, x, n, max_iter, grad_eps, alpha, tree, cnt);
+}
+
+/* a built-in objective (ORC_OBJ_*) with the default finite-difference gradient */
+orc_status orc_bfgs_fd(int obj, double *x, size_t n, size_t max_iter, double grad_eps, double alpha,
+                       int tree, orc_bfgs_counters *cnt) {
+  const model_t m = {NULL, obj};
+  return bfgs_solve(&m, x, n, max_iter, grad_eps, alpha, tree, cnt);
 }

@@ -113,6 +113,18 @@ def bfgs_quad(lib, x0, *, max_iter=100, grad_eps=5e-3, alpha=1.0, tree=0, log=Fa
     return st, x, (flog[:cnt.f_count] if log else None)
 
 
+def bfgs_fd(lib, obj, x0, *, max_iter=100, grad_eps=5e-3, alpha=1.0, tree=0, log_cap=0):
+    """Oracle BFGS on a built-in objective with the default finite-difference gradient;
+    returns (status, x, f_log of at most log_cap values or None, number of objective calls)."""
+    x = np.ascontiguousarray(x0, dtype=np.float64).copy()
+    cnt = BfgsCounters()
+    flog = np.zeros(log_cap) if log_cap else None
+    if log_cap:
+        cnt.f_log, cnt.f_cap = _ptr(flog), flog.size
+    st = lib.orc_bfgs_fd(OBJ[obj], _ptr(x), x.size, max_iter, grad_eps, alpha, tree, C.byref(cnt))
+    return st, x, (flog[:min(cnt.f_count, log_cap)] if log_cap else None), cnt.f_count
+
+
 def load():
     if not os.path.exists(LIB):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
@@ -165,6 +177,8 @@ def load():
     lib.orc_bfgs_quad.restype = Status
     lib.orc_bfgs_quad.argtypes = [C.POINTER(Quad), pd, sz, sz, f64, f64, C.c_int,
                                   C.POINTER(BfgsCounters)]
+    lib.orc_bfgs_fd.restype = Status
+    lib.orc_bfgs_fd.argtypes = [C.c_int, pd, sz, sz, f64, f64, C.c_int, C.POINTER(BfgsCounters)]
     lib.orc_update_inverse_hessian.argtypes = [pd, pd, pd, pd, f64, sz, C.c_int]
     for name in ("orc_exp", "orc_tanh"):
         fn = getattr(lib, name)

@@ -2,6 +2,7 @@
 //   header_bfgs host n max_iter grad_eps alpha x0 x0_step    host functor + analytic Grad functor
 //   header_bfgs findiff                                      default fin_diff gradient (example.cpp style)
 //   header_bfgs device n batch max_iter grad_eps alpha       device objective, batched starts
+//   header_bfgs device-fd n max_iter grad_eps alpha x0 x0_step   device::Rosenbrock, default Grad
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -102,6 +103,27 @@ int main(int argc, char **argv) {
     }
     return 0;
   }
-  std::fprintf(stderr, "usage: header_bfgs host|findiff|device ...\n");
+  if (argc >= 8 && !std::strcmp(argv[1], "device-fd")) {
+    // the reference's default-gradient call, objective type swapped for the device one:
+    // BFGS<Rosenbrock, double>(prob).minimize(x) (example.cpp:171-173)
+    const size_t n = std::strtoull(argv[2], nullptr, 10);
+    nlsolver::device::Rosenbrock<double> prob;
+    auto solver = nlsolver::BFGS<decltype(prob), double>(prob, {}, std::strtoull(argv[3], nullptr, 10),
+                                                         std::strtod(argv[4], nullptr),
+                                                         std::strtod(argv[5], nullptr));
+    std::vector<double> x(n);
+    for (size_t i = 0; i < n; i++)
+      x[i] = std::strtod(argv[6], nullptr) + std::strtod(argv[7], nullptr) * static_cast<double>(i);
+    try {
+      auto st = solver.minimize(x);
+      print_status(st, x);
+      std::printf("\n");
+    } catch (const nlsolver::device_error &e) {
+      std::printf("{\"device_error\":\"%s\"}\n", e.what());
+      return 3;
+    }
+    return 0;
+  }
+  std::fprintf(stderr, "usage: header_bfgs host|findiff|device|device-fd ...\n");
   return 2;
 }

@@ -32,6 +32,21 @@ def main():
     }
     write("bfgs.json", g6)
 
+    # BFGS with the DEFAULT gradient (fin_diff = finite_difference_gradient<.,.,1>,
+    # nlsolver.h:1385-1413, 2849-2855) on built-in objectives; all objective values counted.
+    # args: objective(0 Rosenbrock chain, 1 sphere, 2 Styblinski-Tang) n max_iter grad_eps alpha
+    #       x0 x0_step trace_cap
+    g6fd = {
+        "rosenbrock_n2": run("bfgs-fd", 0, 2, 100, 1e-8, 1, -1.2, 2.2, 64),
+        "rosenbrock_n4": run("bfgs-fd", 0, 4, 100, 1e-8, 1, -1.2, 0.7, 64),
+        "rosenbrock_n16_default_stop": run("bfgs-fd", 0, 16, 100, 5e-3, 1, 0.8, 0.02, 64),
+        "rosenbrock_n128_20iters": run("bfgs-fd", 0, 128, 20, 0.0, 1, 0.9, 0.001, 64),
+        "sphere_n5": run("bfgs-fd", 1, 5, 100, 1e-10, 1, 3, -0.5, 64),
+        "sphere_n130_alpha_half": run("bfgs-fd", 1, 130, 30, 1e-10, 0.5, 1, 0.01, 64),
+        "styblinski_tang_n8": run("bfgs-fd", 2, 8, 100, 1e-8, 1, -2.5, 0.1, 64),
+    }
+    write("bfgs_fd.json", g6fd)
+
     # G8/G9 — LevenbergMarquardt (nlsolver.h:3428-3545) with Gauss-Newton functors, its
     # Cholesky solve (251-330) and tinyqr (291-310, 437-470).
     seed = 12374563468

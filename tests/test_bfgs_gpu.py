@@ -102,3 +102,45 @@ def test_bfgs_config3_shape_sample(mod, oracle):
         assert np.array_equal(x[p], xr)
         iters.add(st[p].iteration)
     assert len(iters) > 1
+
+
+@pytest.mark.parametrize("obj,n,batch", [("rosenbrock", 2, 6), ("rosenbrock", 5, 4),
+                                         ("rosenbrock", 16, 5), ("rosenbrock", 128, 4),
+                                         ("rosenbrock", 130, 3), ("rosenbrock", 256, 2),
+                                         ("sphere", 7, 4), ("styblinski_tang", 64, 4)])
+@pytest.mark.parametrize("kw", [dict(max_iter=6, grad_eps=0.0, alpha=1.0),
+                                dict(max_iter=40, grad_eps=5e-3, alpha=0.5)])
+def test_bfgs_default_finite_difference_gradient_bit_exact(mod, oracle, obj, n, batch, kw):
+    """The reference's default-gradient path (fin_diff, nlsolver.h:1385-1413) on built-in
+    objectives: every probe is a full evaluation in the lane-tree order, so iterates, objective
+    value and the counters (4 n function calls per gradient) equal the tree oracle bit for bit."""
+    rng = np.random.default_rng(1000 + n)
+    x0 = 0.8 + 0.4 * (rng.random((batch, n)) - 0.5)
+    with mod.BFGSEngine(obj, batch, dim=n, **kw) as eng:
+        x, st = eng.minimize(x0.copy())
+    for p in range(batch):
+        ref, xr, _, _ = O.bfgs_fd(oracle, obj, x0[p], tree=1, **kw)
+        assert (st[p].iteration, st[p].function_calls_used, st[p].gradient_evals_used) == \
+            (ref.iteration, ref.function_calls_used, ref.gradient_evals_used), f"problem {p}"
+        assert st[p].f_value == ref.f_value, f"problem {p}"
+        assert np.array_equal(x[p], xr), f"problem {p}"
+        assert st[p].done == 1
+
+
+def test_bfgs_finite_difference_close_to_reference(mod, oracle, golden):
+    """Device (lane tree) vs the reference itself (golden, sequential sums), short horizon."""
+    from tests.test_oracle_golden import hx
+    g = golden("bfgs_fd.json")["rosenbrock_n128_20iters"]
+    x0 = (hx(g["x0"]) + hx(g["x0_step"]) * np.arange(g["n"], dtype=np.float64)).reshape(1, -1)
+    with mod.BFGSEngine("rosenbrock", 1, dim=g["n"], max_iter=3, grad_eps=0.0, alpha=1.0) as eng:
+        x, st = eng.minimize(x0.copy())
+    ref, xr, _, _ = O.bfgs_fd(oracle, "rosenbrock", x0[0], max_iter=3, grad_eps=0.0, alpha=1.0,
+                              tree=0)
+    assert (st[0].iteration, st[0].gradient_evals_used) == (ref.iteration, ref.gradient_evals_used)
+    assert abs(st[0].f_value - ref.f_value) <= 1e-6 * abs(ref.f_value)
+    assert np.max(np.abs(x[0] - xr)) <= 1e-5
+
+
+def test_bfgs_finite_difference_rejects_large_dim(mod):
+    with pytest.raises(RuntimeError, match="256"):
+        mod.BFGSEngine("rosenbrock", 2, dim=300)

@@ -170,6 +170,33 @@ def test_bfgs_device_batch_through_header_matches_oracle(built, oracle):
         assert np.array_equal(np.array([hx(v) for v in o["x"]]), xr)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 16, 128])
+def test_bfgs_default_gradient_on_device_objective_through_header(built, oracle, n):
+    """BFGS<device::Rosenbrock<double>>(f).minimize(x): the default fin_diff gradient runs on the
+    GPU (nlsolver.h:1385-1413 restated in the search kernel); bit-exact vs the tree oracle."""
+    args = dict(max_iter=8, grad_eps=0.0, alpha=1.0)
+    out = subprocess.check_output(
+        [os.path.join(built, "header_bfgs"), "device-fd", str(n), "8", "0.0", "1.0", "0.9", "0.001"],
+        env=dict(os.environ, NLSG_LIBRARY=LIB), text=True)
+    o = json.loads(out)
+    assert "device_error" not in o, o
+    x0 = 0.9 + 0.001 * np.arange(n, dtype=np.float64)
+    ref, xr, _, _ = O.bfgs_fd(oracle, "rosenbrock", x0, tree=1, **args)
+    assert (o["fcalls"], o["iters"], o["gcalls"]) == \
+        (ref.function_calls_used, ref.iteration, ref.gradient_evals_used)
+    assert hx(o["f"]) == ref.f_value
+    assert np.array_equal(np.array([hx(v) for v in o["x"]]), xr)
+
+
+def test_bfgs_device_objective_without_library_fails_loudly(built):
+    """No CPU fallback on the device path: without the HIP library the call throws."""
+    r = subprocess.run([os.path.join(built, "header_bfgs"), "device-fd", "4", "5", "0.0", "1.0",
+                        "0.9", "0.01"], env=dict(os.environ, NLSG_LIBRARY="/nonexistent/lib.so"),
+                       capture_output=True, text=True)
+    assert r.returncode == 3 and "device_error" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
 NM_CASES = ["example_2d", "d4_200iters", "d4_fixed_step", "d16_bounded", "d8_restarts",
             "d6_maximize_bounded", "d130_ragged"]
 
