@@ -11,6 +11,8 @@ input: x0_i = 4.096, CR=0.9, F=0.8, strategy random, early stops disabled.
 GPU owns 65536 agents.) Rank 0 prints ONE JSON line.
 """
 import argparse
+import contextlib
+import io
 import json
 import os
 import subprocess
@@ -133,6 +135,10 @@ def main_bfgs(args):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     open_ = eng.unfinished()
+    # the H-pass figure is taken on iterations 8..11 of a fresh run: dense H for every problem
+    # (towards convergence the reset guard re-identities H and the passes skip their reads)
+    eng.init(x0)
+    eng.step(8)
     total_ms, hess_ms = eng.time_steps(4)
     hess_ms /= 4
     bytes_per_iter = 3 * n * n * 8 * batch  # read H (t = H y) + read & write H (update)
@@ -243,7 +249,7 @@ def main_lm(args):
     else:
         # dominant kernel of the split pipeline, timed on its own: ten lower 16 x 16 tiles of
         # J^T J per 4-row k-step are what the matrix cores execute (the matrix is symmetric)
-        eng.time_eval_kernel(theta0, 10)  # warm-up (clocks settle over the first launches)
+        eng.time_eval_kernel(theta0, 60)  # untimed: clocks back up after the host-side pauses
         kname, kms = "lm_eval_wave_kernel", eng.time_eval_kernel(theta0, 20) / 20
         flops = 2.0 * m * 10 * 256 * batch
     tflops = flops / (kms * 1e-3) / 1e12
@@ -347,6 +353,8 @@ def main_pso(args):
         eng = nlsolver_amd.PSOEngine("rosenbrock", n, Dp, **kw)
         stepper = eng.step
     eng.init(-2.048, 2.048)
+    stepper(300)  # untimed device wake-up (see the DE benchmark), then start over
+    eng.init(-2.048, 2.048)
     stepper(args.warmup)
     barrier()
     t0 = time.perf_counter()
@@ -360,6 +368,7 @@ def main_pso(args):
     assert eng.status().iteration == args.warmup + args.steps
     if rank == 0:
         launches = max(min(args.steps, 200), 20)
+        eng.step(200)  # untimed: clocks back up after the host-side pauses
         kern_ms = eng.time_move_kernel(launches) / launches
         bytes_per = (40 if vanilla else 16) * Dp + 24  # rows r/w + cur/pbest values
         achieved = bytes_per * n_local / (kern_ms * 1e-3) / 1e9
@@ -460,10 +469,15 @@ def main():
     else:
         eng = nlsolver_amd.DEEngine("rosenbrock", pop, D, **common)
         stepper = eng.step
+    # No host-side pause may sit right before the timed region: ~15 ms of GPU idleness (e.g. the
+    # 64 MB download below) drops the clocks and the next ~25 ms of kernels run 3-4x slower
+    # (measured: the first 200 turns after the download took 36 ms instead of 9.8 ms). So the
+    # reference scores are read first, then the device is kept busy (untimed) until it is timed.
+    eng.init(x0)
+    scores_before = eng.download()[1]
+    stepper(2000)
     eng.init(x0)
     stepper(args.warmup)
-    barrier()
-    scores_before = eng.download()[1]
     barrier()
     t0 = time.perf_counter()
     stepper(args.steps)
@@ -483,9 +497,11 @@ def main():
     if not distributed:
         with nlsolver_amd.DEEngine("rosenbrock", pop, D, **dict(common, CR=0.2, F=0.5)) as e2:
             e2.init(np.full(D, 0.6))
+            s0 = e2.download()[1]
+            e2.step(2000)
+            e2.init(np.full(D, 0.6))
             e2.step(args.warmup)
             torch.cuda.synchronize()
-            s0 = e2.download()[1]
             t1 = time.perf_counter()
             e2.step(args.steps)
             torch.cuda.synchronize()
@@ -497,6 +513,7 @@ def main():
     if rank == 0:
         # dominant kernel: de_generation_kernel, timed alone with hipEvents on its stream
         launches = max(args.steps, 20)
+        eng.step(1000)  # untimed: clocks back up after the host-side pauses (status, downloads)
         kern_ms = eng.time_generation_kernel(launches) / launches
         achieved = BYTES_PER_CANDIDATE * pop_local / (kern_ms * 1e-3) / 1e9
         out = {
@@ -512,8 +529,8 @@ def main():
                                    "one step = best scan + std_err + stop tests + one generation",
                        "global_pop": pop, "dim": D,
                        # share of rank 0's agents that accepted at least one trial during the
-                       # timed steps (selection is data dependent; the kernel does the same
-                       # loads, evaluation and row store either way)
+                       # warm-up + timed steps (selection is data dependent; the kernel does
+                       # the same loads, evaluation and row store either way)
                        "agents_improved_frac": improved,
                        "accepting_regime": accepting,
                        "parallelism": f"population-sharded x{world} (island donors, "
@@ -538,4 +555,19 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    # Exactly one line on stdout: libraries write banners to file descriptor 1 (RCCL prints its
+    # version block there when a communicator is created), so everything written to fd 1 while
+    # the benchmark runs is sent to stderr and only the result line goes to the real stdout.
+    sys.stdout.flush()
+    _real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    _buf = io.StringIO()
+    with contextlib.redirect_stdout(_buf):
+        main()
+    sys.stdout.flush()
+    os.dup2(_real_stdout, 1)
+    _lines = [l for l in _buf.getvalue().splitlines() if l.strip()]
+    for l in _lines[:-1]:
+        print(l, file=sys.stderr)
+    if _lines:
+        os.write(1, (_lines[-1] + "\n").encode())
