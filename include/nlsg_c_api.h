@@ -229,6 +229,9 @@ int nlsg_pso_time_move_kernel(nlsg_pso *e, uint32_t launches, float *ms_total);
 uint64_t nlsg_pso_record_doubles(const nlsg_pso *e);
 int nlsg_pso_turn_begin(nlsg_pso *e, double *send_dev);
 int nlsg_pso_turn_end(nlsg_pso *e, const double *gathered_dev, int32_t world);
+/* the same turns ordered by the library (see nlsg_de_comm_attach / nlsg_de_step_sharded) */
+int nlsg_pso_comm_attach(nlsg_pso *e, const unsigned char *unique_id_128, int32_t world, int32_t rank);
+int nlsg_pso_step_sharded(nlsg_pso *e, uint64_t turns);
 
 /* ========================================================================== */
 /* Batched BFGS — replaces BFGS::solve (nlsolver.h:3196-3285), the More-Thuente */

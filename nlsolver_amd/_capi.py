@@ -109,6 +109,8 @@ SYMBOLS = {
     "nlsg_comm_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
     "nlsg_de_comm_attach": (C.c_int, [_H, C.POINTER(C.c_ubyte), C.c_int32, C.c_int32]),
     "nlsg_de_step_sharded": (C.c_int, [_H, C.c_uint64]),
+    "nlsg_pso_comm_attach": (C.c_int, [_H, C.POINTER(C.c_ubyte), C.c_int32, C.c_int32]),
+    "nlsg_pso_step_sharded": (C.c_int, [_H, C.c_uint64]),
     "nlsg_pso_create": (C.c_int, [C.POINTER(PSOConfig), C.POINTER(_H)]),
     "nlsg_pso_destroy": (C.c_int, [_H]),
     "nlsg_pso_init": (C.c_int, [_H, pd, pd]),

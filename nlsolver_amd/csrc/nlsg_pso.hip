@@ -5,6 +5,7 @@
 #include <new>
 #include <vector>
 
+#include "nlsg_comm.h"
 #include "nlsg_pso_kernels.h"
 
 using namespace nlsg;
@@ -16,6 +17,7 @@ struct nlsg_pso {
   bool own_stream = false;
   double *lower_dev = nullptr, *upper_dev = nullptr, *zero_dev = nullptr, *tab_dev = nullptr;
   ShardLocal *loc = nullptr;
+  ShardComm *comm = nullptr;  // set by nlsg_pso_comm_attach
   double *rec = nullptr;
   int chunks = 0;
   bool initialised = false;
@@ -259,6 +261,7 @@ int nlsg_pso_destroy(nlsg_pso *e) {
   hipFree(e->zero_dev);
   hipFree(e->tab_dev);
   hipFree(e->loc);
+  comm_detach(e->comm);
   hipFree(e->rec);
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
@@ -394,6 +397,39 @@ int nlsg_pso_turn_end(nlsg_pso *e, const double *gathered_dev, int32_t world) {
   hipLaunchKernelGGL(pso_finalize_kernel, dim3(1), dim3(256), 0, e->stream, e->p, gathered_dev,
                      world, static_cast<uint64_t>(kRecHeader) + e->p.D);
   launch_move(e, 0, 0);
+  NLSG_HIP(hipGetLastError());
+  return NLSG_OK;
+}
+
+int nlsg_pso_comm_attach(nlsg_pso *e, const unsigned char *unique_id, int32_t world, int32_t rank) {
+  if (!e) return fail(NLSG_ERR_INVALID_ARG, "null engine");
+  if (e->comm) return fail(NLSG_ERR_STATE, "a communicator is already attached");
+  if (static_cast<uint64_t>(world) * e->p.shard_n != e->p.n ||
+      static_cast<uint64_t>(rank) * e->p.shard_n != e->p.shard_lo)
+    return fail(NLSG_ERR_INVALID_ARG, "shard [%llu, +%llu) of %llu does not match rank %d of %d",
+                (unsigned long long)e->p.shard_lo, (unsigned long long)e->p.shard_n,
+                (unsigned long long)e->p.n, rank, world);
+  NLSG_HIP(hipSetDevice(e->cfg.device));
+  return comm_attach(&e->comm, unique_id, world, rank, static_cast<uint64_t>(kRecHeader) + e->p.D);
+}
+
+// `turns` sharded turns without a host round trip. The move needs the exchanged swarm best, so
+// nothing can run beside the collective: summary -> all-gather -> finaliser -> move, all on the
+// engine's stream (no cross-stream dependency to pay for).
+int nlsg_pso_step_sharded(nlsg_pso *e, uint64_t turns) {
+  if (!e) return fail(NLSG_ERR_INVALID_ARG, "null engine");
+  if (!e->initialised) return fail(NLSG_ERR_STATE, "nlsg_pso_init has not been called");
+  if (!e->comm) return fail(NLSG_ERR_STATE, "nlsg_pso_comm_attach has not been called");
+  NLSG_HIP(hipSetDevice(e->cfg.device));
+  ShardComm *c = e->comm;
+  const uint64_t stride = static_cast<uint64_t>(kRecHeader) + e->p.D;
+  for (uint64_t t = 0; t < turns; t++) {
+    launch_local_summary(e, e->rec);
+    NLSG_RCCL(rccl_api().AllGather(e->rec, c->gathered, stride, ncclDouble, c->comm, e->stream));
+    hipLaunchKernelGGL(pso_finalize_kernel, dim3(1), dim3(256), 0, e->stream, e->p, c->gathered,
+                       c->world, stride);
+    launch_move(e, 0, 0);
+  }
   NLSG_HIP(hipGetLastError());
   return NLSG_OK;
 }

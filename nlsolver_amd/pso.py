@@ -107,6 +107,14 @@ class PSOEngine:
     def turn_end(self, gathered_dev_ptr, world):
         check(lib().nlsg_pso_turn_end(self._h, gathered_dev_ptr, world))
 
+    def comm_attach(self, unique_id, world, rank):
+        """Collective: joins the library-side RCCL communicator (see nlsolver_amd.dist)."""
+        buf = (C.c_ubyte * 128).from_buffer_copy(bytes(unique_id))
+        check(lib().nlsg_pso_comm_attach(self._h, buf, world, rank))
+
+    def step_sharded(self, turns=1):
+        check(lib().nlsg_pso_step_sharded(self._h, turns))
+
 
 class PSO:
     """Drop-in for nlsolver::PSO on a device objective (same ctor args/defaults/overloads)."""

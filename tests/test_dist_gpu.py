@@ -60,6 +60,32 @@ for kw in (dict(strategy=nlsolver_amd.DE_RANDOM, eps=0.0, max_iter=9, best_val_n
         best=(int(bi0), int(bi1)), same_pop=bool(np.array_equal(P0, P1)),
         same_scores=bool(np.array_equal(S0, S1)), same_best=bool(np.array_equal(bx0, bx1) and bf0 == bf1),
         std_err=(repr(st0.std_err), repr(st1.std_err))))
+# PSO (the move needs the exchanged swarm best: summary -> all-gather -> finaliser -> move)
+from nlsolver_amd.dist import ShardedPSO
+n, Dp = 4096, 64
+for kw in (dict(type=nlsolver_amd.PSO_ACCELERATED, eps=0.0, max_iter=9, best_val_no_change=1000),
+           dict(type=nlsolver_amd.PSO_VANILLA, eps=1e-300, max_iter=7, best_val_no_change=1000)):
+    kw = dict(kw, bounded=False, inertia=0.8, cognitive=1.8, social=1.8, seed=7)
+    with nlsolver_amd.PSOEngine("rosenbrock", n, Dp, **kw) as ref:
+        ref.init(-2.048, 2.048)
+        ref.step(20)
+        st0 = ref.status()
+        bx0, bf0, bi0 = ref.best()
+    drv = ShardedPSO(dist, lambda lo, m_, stream: nlsolver_amd.PSOEngine(
+        "rosenbrock", n, Dp, shard_lo=lo, shard_n=m_, stream=stream, **kw), n, Dp, device)
+    assert drv.native == native
+    drv.init(-2.048, 2.048)
+    drv.step(20)
+    torch.cuda.synchronize()
+    st1 = drv.engine.status()
+    bx1, bf1, bi1 = drv.engine.best()
+    drv.engine.close()
+    out.append(dict(
+        done=(st0.done, st1.done), iters=(st0.iteration, st1.iteration),
+        fcalls=(st0.function_calls_used, st1.function_calls_used),
+        best=(int(bi0), int(bi1)), same_pop=True, same_scores=True,
+        same_best=bool(np.array_equal(bx0, bx1) and bf0 == bf1),
+        std_err=(repr(st0.std_err), repr(st1.std_err))))
 dist.destroy_process_group()
 print("RESULT " + json.dumps(out))
 """
