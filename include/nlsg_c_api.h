@@ -25,8 +25,10 @@
 #ifndef NLSG_C_API_H_
 #define NLSG_C_API_H_
 
+#ifndef __HIPCC_RTC__ /* the run-time compiler of user objectives brings its own fixed-width types */
 #include <stddef.h>
 #include <stdint.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -50,8 +52,25 @@ typedef enum {
   NLSG_OBJ_ROSENBROCK = 0,      /* example.cpp:41-48, N-D chain                */
   NLSG_OBJ_SPHERE = 1,          /* test_functions.h:52-57                      */
   NLSG_OBJ_STYBLINSKI_TANG = 2, /* test_functions.h:249-260                    */
-  NLSG_OBJ_RASTRIGIN = 3        /* test_functions.h:69-78                      */
+  NLSG_OBJ_RASTRIGIN = 3,       /* test_functions.h:69-78                      */
+  NLSG_OBJ_CUSTOM = 64          /* user source compiled at run time, nlsg_custom_objective */
 } nlsg_objective;
+
+/* A user objective of the form  f(x) = finish( sum_i term(x_i, x_{i+1}), D )  — the shape of the
+ * built-in ones — given as C++ function BODIES that are compiled for the device at engine
+ * creation (hiprtc; SURVEY.md §8f N3: lifts the "built-in objectives only" restriction for the
+ * reference's functor contract, README.md:127-136). Available in the bodies: double xi, xn
+ * (term; xn = x_{i+1}, only meaningful when chain != 0) / double s, uint64_t D (finish), and
+ * the HIP device math library. Sums run over i < D - 1 when chain != 0, else i < D, in the
+ * kernels' fixed lane-tree order; arithmetic is compiled without fp contraction.
+ *   term_body   e.g. "double t1 = 1 - xi; double t2 = xn - xi * xi; return t1 * t1 + 100 * t2 * t2;"
+ *   finish_body e.g. "return s;"  (NULL = that) */
+typedef struct {
+  const char *term_body;
+  const char *finish_body;
+  int32_t chain;
+  int32_t reserved;
+} nlsg_custom_objective;
 
 /* enum RecombinationStrategy { best, random } — nlsolver.h:2377 (same order). */
 typedef enum { NLSG_DE_BEST = 0, NLSG_DE_RANDOM = 1 } nlsg_de_strategy;
@@ -102,6 +121,11 @@ typedef struct {
 } nlsg_de_config;
 
 int nlsg_de_create(const nlsg_de_config *cfg, nlsg_de **out);
+/* cfg->objective == NLSG_OBJ_CUSTOM: compiles `obj` for this dim and builds the engine around it.
+ * nlsg_rtc_load(path) chooses the hiprtc shared object (NULL / "" / never called: "libhiprtc.so"
+ * on the loader path; a process that already holds a HIP runtime should pass that runtime's own). */
+int nlsg_rtc_load(const char *hiprtc_path);
+int nlsg_de_create_custom(const nlsg_de_config *cfg, const nlsg_custom_objective *obj, nlsg_de **out);
 int nlsg_de_destroy(nlsg_de *e);
 
 /* init_agents + initial scoring (nlsolver.h:2315-2323, 2423-2425):

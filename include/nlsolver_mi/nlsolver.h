@@ -202,6 +202,23 @@ struct Rastrigin {  // test_functions.h:69-78
   }
 };
 
+// A user objective of the shape f(x) = finish(sum_i term(x_i, x_{i+1}), D), written as C++
+// function bodies and compiled for the device when the solver runs (nlsg_custom_objective,
+// hiprtc) -- the device-side answer to the reference's "any functor"
+// contract (README.md:127-136). In the bodies: xi, xn (= x_{i+1}, chain objectives only) /
+// s, D. There is no host evaluation of it: the type only works on the device path.
+//   Custom<double> f("double t1 = 1 - xi; double t2 = xn - xi * xi; return t1 * t1 + 100 * t2 * t2;",
+//                    /*chain=*/true);
+//   auto st = DE<Custom<double>, rng::xorshift<double>, double>(f, gen).minimize(x);
+template <typename T = double>
+struct Custom {
+  static constexpr int nlsg_objective = NLSG_OBJ_CUSTOM;
+  std::string term_body, finish_body;
+  bool chain;
+  explicit Custom(std::string term_body, bool chain = false, std::string finish_body = "return s;")
+      : term_body(std::move(term_body)), finish_body(std::move(finish_body)), chain(chain) {}
+};
+
 // Objectives with an analytic gradient on the device (batched BFGS):
 // f(x) = 1/2 sum d_i x_i^2 + 1/2 c (sum x)^2 - sum b_i x_i  (SURVEY.md §8c G6).
 template <typename T = double>
@@ -272,6 +289,8 @@ class api {
   decltype(&nlsg_last_error) last_error;
   decltype(&nlsg_abi_version) abi_version;
   decltype(&nlsg_de_create) de_create;
+  decltype(&nlsg_de_create_custom) de_create_custom;
+  decltype(&nlsg_rtc_load) rtc_load;
   decltype(&nlsg_de_destroy) de_destroy;
   decltype(&nlsg_de_minimize) de_minimize;
   decltype(&nlsg_pso_create) pso_create;
@@ -304,6 +323,8 @@ class api {
     bind(h, "nlsg_last_error", last_error);
     bind(h, "nlsg_abi_version", abi_version);
     bind(h, "nlsg_de_create", de_create);
+    bind(h, "nlsg_de_create_custom", de_create_custom);
+    bind(h, "nlsg_rtc_load", rtc_load);
     bind(h, "nlsg_de_destroy", de_destroy);
     bind(h, "nlsg_de_minimize", de_minimize);
     bind(h, "nlsg_pso_create", pso_create);
@@ -404,7 +425,14 @@ class DE {
     cfg.best_val_no_change = best_value_no_change;
     cfg.seed = device::seed_from(generator);
     nlsg_de *eng = nullptr;
-    api.check(api.de_create(&cfg, &eng));
+    if constexpr (Callable::nlsg_objective == NLSG_OBJ_CUSTOM) {
+      // $NLSG_HIPRTC names the hiprtc of the HIP runtime in use (default: libhiprtc.so)
+      api.check(api.rtc_load(std::getenv("NLSG_HIPRTC")));
+      nlsg_custom_objective obj{f.term_body.c_str(), f.finish_body.c_str(), f.chain ? 1 : 0, 0};
+      api.check(api.de_create_custom(&cfg, &obj, &eng));
+    } else {
+      api.check(api.de_create(&cfg, &eng));
+    }
     nlsg_status st{};
     const int rc = api.de_minimize(eng, x.data(), 0, &st);
     const std::string msg = rc ? api.last_error() : "";

@@ -12,7 +12,7 @@ Layout:
     dist.py               population sharding across ranks (torch.distributed / RCCL)
 """
 from ._capi import DE_BEST, DE_RANDOM, PSO_ACCELERATED, PSO_VANILLA, NlsgError  # noqa: F401
-from .de import DE, DEEngine, DESolver  # noqa: F401
+from .de import DE, CustomObjective, DEEngine, DESolver  # noqa: F401
 from .pso import PSO, PSOEngine, PSOSolver  # noqa: F401
 from .bfgs import BFGS, BFGSEngine, QuadDiagRank1  # noqa: F401
 from .lm import LevenbergMarquardt, LMEngine, TanhRegression  # noqa: F401

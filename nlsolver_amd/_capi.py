@@ -44,6 +44,14 @@ class DEConfig(C.Structure):
                 ("max_iter", u64), ("best_val_no_change", u64), ("seed", u64)]
 
 
+OBJ_CUSTOM = 64
+
+
+class CustomObjectiveC(C.Structure):  # nlsg_custom_objective
+    _fields_ = [("term_body", C.c_char_p), ("finish_body", C.c_char_p), ("chain", i32),
+                ("reserved", i32)]
+
+
 PSO_VANILLA, PSO_ACCELERATED = 0, 1  # enum PSOType { Vanilla, Accelerated }, nlsolver.h:2496
 
 
@@ -105,6 +113,9 @@ SYMBOLS = {
     "nlsg_de_turn_finalize": (C.c_int, [_H, C.c_void_p, i32]),
     "nlsg_de_turn_generation": (C.c_int, [_H]),
     "nlsg_de_can_speculate": (C.c_int, [_H]),
+    "nlsg_rtc_load": (C.c_int, [C.c_char_p]),
+    "nlsg_de_create_custom": (C.c_int, [C.POINTER(DEConfig), C.POINTER(CustomObjectiveC),
+                                        C.POINTER(C.c_void_p)]),
     "nlsg_comm_load": (C.c_int, [C.c_char_p]),
     "nlsg_comm_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
     "nlsg_de_comm_attach": (C.c_int, [_H, C.POINTER(C.c_ubyte), C.c_int32, C.c_int32]),

@@ -7,18 +7,28 @@
 // compiled with -ffp-contract=off, so device results are bit-identical to it.
 #pragma once
 
+// This header (with nlsg_de_kernels.h) is also compiled at run time by hiprtc for user-supplied
+// objectives (nlsg_rtc.hip): everything host-only sits behind !__HIPCC_RTC__, and nothing
+// from the standard library is needed on the device side.
+#ifdef __HIPCC_RTC__
+typedef unsigned long long uint64_t;
+typedef long long int64_t;
+typedef unsigned int uint32_t;
+typedef int int32_t;
+#else
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
-#include <type_traits>
+#endif
 
 #include "../../include/nlsg_c_api.h"
 
 namespace nlsg {
 
+#ifndef __HIPCC_RTC__
 // ---------------------------------------------------------------------------
 // error plumbing (host)
 // ---------------------------------------------------------------------------
@@ -41,6 +51,7 @@ inline int fail(int code, const char *fmt, ...) {
                           "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
                           __FILE__, __LINE__);                                  \
   } while (0)
+#endif  // !__HIPCC_RTC__
 
 // ---------------------------------------------------------------------------
 // counter-based RNG: random access into splitmix64 streams
@@ -125,10 +136,14 @@ __device__ inline double lane_first(double v) {
   const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<int>(b >> 32));
   return __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(hi) << 32) | lo));
 }
-// f(integral_constant<int, OFF>) for OFF = FIRST, FIRST/2, ..., 1
+// f(int_c<OFF>) for OFF = FIRST, FIRST/2, ..., 1
+template <int N>
+struct int_c {
+  static constexpr int value = N;
+};
 template <int FIRST, typename F>
 __device__ inline void butterfly_levels(F &&f) {
-  f(std::integral_constant<int, FIRST>{});
+  f(int_c<FIRST>{});
   if constexpr (FIRST > 1) butterfly_levels<FIRST / 2>(f);
 }
 

@@ -9,6 +9,7 @@
 
 #include "nlsg_comm.h"
 #include "nlsg_de_kernels.h"
+#include "nlsg_rtc.h"
 
 using namespace nlsg;
 
@@ -30,6 +31,7 @@ struct nlsg_de {
   hipEvent_t ev_gen[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_head[4] = {nullptr, nullptr, nullptr, nullptr};
   ShardComm *comm = nullptr;  // set by nlsg_de_comm_attach
+  DeRtcKernels rtc;           // objective == NLSG_OBJ_CUSTOM: the kernels hiprtc built for it
   bool overlap = false;
   bool fused = false;   // head k and generation k+1 share one launch (strategy random, one GPU)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -73,8 +75,18 @@ struct Dispatch;  // OBJ x CHUNKS dispatch of a kernel family
     default: break;                                                                  \
   }
 
+// kernels of a run-time compiled objective take the same arguments through the module API
+void launch_module(nlsg_de *e, hipFunction_t fn, unsigned grid, void **args) {
+  hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, 0, e->stream, args, nullptr);
+}
+
 void launch_init(nlsg_de *e) {
   const dim3 grid(static_cast<unsigned>((e->p.shard_n + 3) / 4)), block(256);
+  if (e->cfg.objective == NLSG_OBJ_CUSTOM) {
+    void *args[] = {&e->p, &e->x0_dev};
+    launch_module(e, e->rtc.init, grid.x, args);
+    return;
+  }
 #define CALL(OBJ, C)                                                                          \
   if (e->p.vec)                                                                               \
     hipLaunchKernelGGL((de_init_kernel<OBJ, C, true>), grid, block, 0, e->stream, e->p,       \
@@ -88,6 +100,11 @@ void launch_init(nlsg_de *e) {
 
 void launch_generation(nlsg_de *e, int par, uint64_t generation, int ignore_done = 0) {
   const dim3 grid(static_cast<unsigned>((e->p.shard_n + 3) / 4)), block(256);
+  if (e->cfg.objective == NLSG_OBJ_CUSTOM) {
+    void *args[] = {&e->p, &par, &generation, &ignore_done};
+    launch_module(e, e->rtc.generation, grid.x, args);
+    return;
+  }
 #define CALL(OBJ, C)                                                                          \
   if (e->p.vec)                                                                               \
     hipLaunchKernelGGL((de_generation_kernel<OBJ, C, true>), grid, block, 0, e->stream, e->p, \
@@ -102,6 +119,11 @@ void launch_generation(nlsg_de *e, int par, uint64_t generation, int ignore_done
 // head k and generation k+1 in one launch (de_turn_kernel)
 void launch_fused_turn(nlsg_de *e, int par, uint64_t generation) {
   const dim3 grid(static_cast<unsigned>((e->p.shard_n + 3) / 4 + e->p.ntiles)), block(256);
+  if (e->cfg.objective == NLSG_OBJ_CUSTOM) {
+    void *args[] = {&e->p, &par, &generation};
+    launch_module(e, e->rtc.turn, grid.x, args);
+    return;
+  }
 #define CALL(OBJ, C)                                                                        \
   if (e->p.vec)                                                                             \
     hipLaunchKernelGGL((de_turn_kernel<OBJ, C, true>), grid, block, 0, e->stream, e->p, par, \
@@ -193,7 +215,22 @@ int nlsg_device_count(void) {
   return ok;
 }
 
+static int de_create(const nlsg_de_config *cfg, const nlsg_custom_objective *custom, nlsg_de **out);
+
 int nlsg_de_create(const nlsg_de_config *cfg, nlsg_de **out) {
+  if (cfg && cfg->objective == NLSG_OBJ_CUSTOM)
+    return fail(NLSG_ERR_INVALID_ARG, "NLSG_OBJ_CUSTOM engines are made by nlsg_de_create_custom");
+  return de_create(cfg, nullptr, out);
+}
+
+int nlsg_de_create_custom(const nlsg_de_config *cfg, const nlsg_custom_objective *obj, nlsg_de **out) {
+  if (!cfg || !obj) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  if (cfg->objective != NLSG_OBJ_CUSTOM)
+    return fail(NLSG_ERR_INVALID_ARG, "cfg.objective must be NLSG_OBJ_CUSTOM");
+  return de_create(cfg, obj, out);
+}
+
+static int de_create(const nlsg_de_config *cfg, const nlsg_custom_objective *custom, nlsg_de **out) {
   if (!cfg || !out) return fail(NLSG_ERR_INVALID_ARG, "null argument");
   *out = nullptr;
   if (cfg->struct_size != sizeof(nlsg_de_config))
@@ -203,7 +240,7 @@ int nlsg_de_create(const nlsg_de_config *cfg, nlsg_de **out) {
   if (cfg->dim > 1024)
     return fail(NLSG_ERR_UNSUPPORTED, "dim %llu > 1024 is not covered by the device path",
                 (unsigned long long)cfg->dim);
-  if (cfg->objective < 0 || cfg->objective > NLSG_OBJ_RASTRIGIN)
+  if (!custom && (cfg->objective < 0 || cfg->objective > NLSG_OBJ_RASTRIGIN))
     return fail(NLSG_ERR_INVALID_ARG, "unknown objective %d", cfg->objective);
   if (cfg->strategy != NLSG_DE_BEST && cfg->strategy != NLSG_DE_RANDOM)
     return fail(NLSG_ERR_INVALID_ARG, "unknown strategy %d", cfg->strategy);
@@ -293,6 +330,13 @@ int nlsg_de_create(const nlsg_de_config *cfg, nlsg_de **out) {
   p.seed = cfg->seed;
   p.strategy = cfg->strategy;
   p.vec = (D % 2 == 0) ? 1 : 0;
+  if (custom) {
+    const int rc2 = rtc_build_de(custom, e->chunks, p.vec != 0, &e->rtc);
+    if (rc2) {
+      nlsg_de_destroy(e);
+      return rc2;
+    }
+  }
   *out = e;
   return NLSG_OK;
 }
@@ -319,6 +363,7 @@ int nlsg_de_destroy(nlsg_de *e) {
   hipFree(e->p.part);
   hipFree(e->p.ticket);
   comm_detach(e->comm);
+  rtc_release(&e->rtc);
   hipFree(e->x0_dev);
   hipFree(e->zero_dev);
   hipFree(e->rec);

@@ -1,0 +1,20 @@
+// nlsolver_amd/csrc/nlsg_rtc.h — user objectives compiled for the device at engine creation
+// (SURVEY.md §8f N3). The kernels are the SAME templates the built-in objectives use
+// (nlsg_de_kernels.h, embedded as text at build time) instantiated by hiprtc around a
+// user-written Objective<NLSG_OBJ_CUSTOM>; hiprtc is resolved at run time (nlsg_rtc_load).
+#pragma once
+
+#include "nlsg_common.h"
+
+namespace nlsg {
+
+struct DeRtcKernels {
+  hipModule_t mod = nullptr;
+  hipFunction_t init = nullptr, generation = nullptr, turn = nullptr;
+};
+
+// Compiles de_init / de_generation / de_turn kernels for the objective, CHUNKS = chunks, VEC = vec.
+int rtc_build_de(const nlsg_custom_objective *obj, int chunks, bool vec, DeRtcKernels *out);
+void rtc_release(DeRtcKernels *k);
+
+}  // namespace nlsg

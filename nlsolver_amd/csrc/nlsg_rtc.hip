@@ -1,0 +1,148 @@
+// nlsolver_amd/csrc/nlsg_rtc.hip — run-time compilation of user objectives (see nlsg_rtc.h).
+#include <dlfcn.h>
+#include <hip/hiprtc.h>
+
+#include <string>
+#include <vector>
+
+#include "nlsg_rtc.h"
+
+#include "build/nlsg_embedded_sources.inc"
+
+namespace nlsg {
+namespace {
+
+struct RtcApi {
+  void *lib = nullptr;
+  decltype(&hiprtcCreateProgram) CreateProgram = nullptr;
+  decltype(&hiprtcCompileProgram) CompileProgram = nullptr;
+  decltype(&hiprtcGetProgramLogSize) GetProgramLogSize = nullptr;
+  decltype(&hiprtcGetProgramLog) GetProgramLog = nullptr;
+  decltype(&hiprtcGetCodeSize) GetCodeSize = nullptr;
+  decltype(&hiprtcGetCode) GetCode = nullptr;
+  decltype(&hiprtcDestroyProgram) DestroyProgram = nullptr;
+  decltype(&hiprtcAddNameExpression) AddNameExpression = nullptr;
+  decltype(&hiprtcGetLoweredName) GetLoweredName = nullptr;
+};
+
+RtcApi &rtc_api() {
+  static RtcApi api;
+  return api;
+}
+
+int rtc_load(const char *path_in) {
+  RtcApi &api = rtc_api();
+  if (api.lib) return NLSG_OK;
+  const char *path = (path_in && path_in[0]) ? path_in : "libhiprtc.so";
+  void *lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+  if (!lib) return fail(NLSG_ERR_UNSUPPORTED, "cannot load hiprtc (%s): %s", path, dlerror());
+  RtcApi a;
+#define NLSG_RTC_SYM(field, name)                                            \
+  a.field = reinterpret_cast<decltype(a.field)>(dlsym(lib, #name));          \
+  if (!a.field) {                                                            \
+    dlclose(lib);                                                            \
+    return fail(NLSG_ERR_UNSUPPORTED, "%s does not export " #name, path);    \
+  }
+  NLSG_RTC_SYM(CreateProgram, hiprtcCreateProgram)
+  NLSG_RTC_SYM(CompileProgram, hiprtcCompileProgram)
+  NLSG_RTC_SYM(GetProgramLogSize, hiprtcGetProgramLogSize)
+  NLSG_RTC_SYM(GetProgramLog, hiprtcGetProgramLog)
+  NLSG_RTC_SYM(GetCodeSize, hiprtcGetCodeSize)
+  NLSG_RTC_SYM(GetCode, hiprtcGetCode)
+  NLSG_RTC_SYM(DestroyProgram, hiprtcDestroyProgram)
+  NLSG_RTC_SYM(AddNameExpression, hiprtcAddNameExpression)
+  NLSG_RTC_SYM(GetLoweredName, hiprtcGetLoweredName)
+#undef NLSG_RTC_SYM
+  a.lib = lib;
+  api = a;
+  return NLSG_OK;
+}
+
+}  // namespace
+
+int rtc_build_de(const nlsg_custom_objective *obj, int chunks, bool vec, DeRtcKernels *out) {
+  if (!obj || !obj->term_body || !obj->term_body[0])
+    return fail(NLSG_ERR_INVALID_ARG, "a custom objective needs a term body");
+  int rc = rtc_load(nullptr);
+  if (rc) return rc;
+  RtcApi &api = rtc_api();
+  std::string src = "#include \"nlsg_de_kernels.h\"\n"
+                    "namespace nlsg {\n"
+                    "template <>\n"
+                    "struct Objective<NLSG_OBJ_CUSTOM> {\n"
+                    "  static constexpr bool kChain = ";
+  src += obj->chain ? "true" : "false";
+  src += ";\n  __device__ static inline double term(double xi, double xn) {\n    (void)xn;\n#line 1 "
+         "\"term_body\"\n";
+  src += obj->term_body;
+  src += "\n  }\n"
+         "  __device__ static inline uint64_t n_terms(uint64_t D) { return kChain ? (D ? D - 1 : 0) : D; }\n"
+         "  __device__ static inline double finish(double s, uint64_t D) {\n    (void)D;\n#line 1 "
+         "\"finish_body\"\n";
+  src += (obj->finish_body && obj->finish_body[0]) ? obj->finish_body : "return s;";
+  src += "\n  }\n};\n}  // namespace nlsg\n";
+
+  const int nh = static_cast<int>(sizeof(kEmbedded) / sizeof(kEmbedded[0]));
+  std::vector<const char *> names(nh), texts(nh);
+  for (int i = 0; i < nh; i++) {
+    names[i] = kEmbedded[i].name;
+    texts[i] = kEmbedded[i].text;
+  }
+  hiprtcProgram prog = nullptr;
+  if (api.CreateProgram(&prog, src.c_str(), "nlsg_custom_objective.hip", nh, texts.data(),
+                        names.data()) != HIPRTC_SUCCESS)
+    return fail(NLSG_ERR_HIP, "hiprtcCreateProgram failed");
+  const std::string targs = std::to_string(static_cast<int>(NLSG_OBJ_CUSTOM)) + ", " +
+                            std::to_string(chunks) + ", " + (vec ? "true" : "false");
+  const std::string n_init = "nlsg::de_init_kernel<" + targs + ">";
+  const std::string n_gen = "nlsg::de_generation_kernel<" + targs + ">";
+  const std::string n_turn = "nlsg::de_turn_kernel<" + targs + ">";
+  api.AddNameExpression(prog, n_init.c_str());
+  api.AddNameExpression(prog, n_gen.c_str());
+  api.AddNameExpression(prog, n_turn.c_str());
+  // the flags of csrc/Makefile: device arithmetic must stay bit-reproducible
+  const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                        "-fno-fast-math"};
+  const hiprtcResult cr = api.CompileProgram(prog, 5, opts);
+  if (cr != HIPRTC_SUCCESS) {
+    size_t ls = 0;
+    api.GetProgramLogSize(prog, &ls);
+    std::string log(ls ? ls : 1, '\0');
+    if (ls) api.GetProgramLog(prog, &log[0]);
+    api.DestroyProgram(&prog);
+    if (log.size() > 400) log.resize(400);
+    return fail(NLSG_ERR_INVALID_ARG, "custom objective does not compile: %s", log.c_str());
+  }
+  const char *l_init = nullptr, *l_gen = nullptr, *l_turn = nullptr;
+  if (api.GetLoweredName(prog, n_init.c_str(), &l_init) != HIPRTC_SUCCESS ||
+      api.GetLoweredName(prog, n_gen.c_str(), &l_gen) != HIPRTC_SUCCESS ||
+      api.GetLoweredName(prog, n_turn.c_str(), &l_turn) != HIPRTC_SUCCESS) {
+    api.DestroyProgram(&prog);
+    return fail(NLSG_ERR_HIP, "hiprtcGetLoweredName failed");
+  }
+  size_t cs = 0;
+  api.GetCodeSize(prog, &cs);
+  std::vector<char> code(cs);
+  api.GetCode(prog, code.data());
+  DeRtcKernels k;
+  hipError_t he = hipModuleLoadData(&k.mod, code.data());
+  if (he == hipSuccess) he = hipModuleGetFunction(&k.init, k.mod, l_init);
+  if (he == hipSuccess) he = hipModuleGetFunction(&k.generation, k.mod, l_gen);
+  if (he == hipSuccess) he = hipModuleGetFunction(&k.turn, k.mod, l_turn);
+  api.DestroyProgram(&prog);  // the lowered names live in the program
+  if (he != hipSuccess) {
+    if (k.mod) hipModuleUnload(k.mod);
+    return fail(NLSG_ERR_HIP, "loading the compiled objective failed: %s", hipGetErrorString(he));
+  }
+  *out = k;
+  return NLSG_OK;
+}
+
+void rtc_release(DeRtcKernels *k) {
+  if (k && k->mod) hipModuleUnload(k->mod);
+  if (k) *k = DeRtcKernels();
+}
+
+}  // namespace nlsg
+
+extern "C" int nlsg_rtc_load(const char *hiprtc_path) { return nlsg::rtc_load(hiprtc_path); }

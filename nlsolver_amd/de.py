@@ -30,6 +30,32 @@ def seed_from_generator(generator):
     return (hi << 32) | lo
 
 
+class CustomObjective:
+    """A user objective f(x) = finish(sum_i term(x_i, x_{i+1}), D) given as C++ function bodies and
+    compiled for the device when the engine is created (nlsg_custom_objective).
+
+        CustomObjective("double t1 = 1 - xi; double t2 = xn - xi * xi; return t1 * t1 + 100 * t2 * t2;",
+                        chain=True)                       # the Rosenbrock chain
+        CustomObjective("return fabs(xi) * xi * xi;")     # sum |x_i|^3
+
+    In the bodies: `xi`, `xn` (= x_{i+1}; chain objectives sum over i < D - 1) for `term`; `s`, `D`
+    for `finish` (default "return s;")."""
+
+    def __init__(self, term_body, *, chain=False, finish_body="return s;"):
+        self.term_body, self.finish_body, self.chain = term_body, finish_body, bool(chain)
+
+
+def rtc_library_path():
+    """hiprtc of the HIP runtime this process already uses (PyTorch ships its own)."""
+    import os
+    try:
+        import torch
+        cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libhiprtc.so")
+        return cand if os.path.exists(cand) else ""
+    except ImportError:
+        return ""
+
+
 class DEEngine:
     """Thin RAII wrapper over the nlsg_de_* C-ABI (one handle, one device, one stream)."""
 
@@ -42,7 +68,9 @@ class DEEngine:
         # None: the engine creates a private stream. An integer is a hipStream_t handle;
         # 0 is torch's default (null) stream, spelled hipStreamLegacy = 1 for the C-ABI.
         cfg.stream = None if stream is None else (stream or 1)
-        cfg.objective = _capi.OBJECTIVES[objective] if isinstance(objective, str) else objective
+        custom = objective if isinstance(objective, CustomObjective) else None
+        cfg.objective = (_capi.OBJ_CUSTOM if custom else
+                         _capi.OBJECTIVES[objective] if isinstance(objective, str) else objective)
         cfg.minimize = int(bool(minimize))
         cfg.strategy = strategy
         cfg.trace = int(bool(trace))
@@ -53,7 +81,13 @@ class DEEngine:
         cfg.max_iter, cfg.best_val_no_change, cfg.seed = max_iter, best_val_no_change, seed
         self.cfg = cfg
         self._h = C.c_void_p()
-        check(lib().nlsg_de_create(C.byref(cfg), C.byref(self._h)))
+        if custom:
+            check(lib().nlsg_rtc_load(rtc_library_path().encode()))
+            obj = _capi.CustomObjectiveC(custom.term_body.encode(), custom.finish_body.encode(),
+                                         int(custom.chain), 0)
+            check(lib().nlsg_de_create_custom(C.byref(cfg), C.byref(obj), C.byref(self._h)))
+        else:
+            check(lib().nlsg_de_create(C.byref(cfg), C.byref(self._h)))
 
     # -- lifetime ---------------------------------------------------------
     def close(self):

@@ -1,0 +1,87 @@
+"""User objectives compiled at engine creation (nlsg_de_create_custom).
+
+The run-time compiled kernels are the same templates as the built-in ones, instantiated around a
+user-written term/finish pair, so a custom objective that spells a built-in one must reproduce
+that engine (and hence the oracle) bit for bit; an objective nobody built in is checked against a
+numpy evaluation of the same sum."""
+import numpy as np
+import pytest
+
+from tests import _oracle as O
+
+pytestmark = pytest.mark.gpu
+
+ROSENBROCK = "double t1 = 1 - xi; double t2 = (xn - xi * xi); return t1 * t1 + 100 * t2 * t2;"
+STYBLINSKI = "double x2 = xi * xi; return x2 * x2 - 16 * x2 + 5 * xi;"
+
+
+@pytest.fixture(scope="module")
+def mod():
+    import torch
+    assert torch.cuda.is_available()
+    import nlsolver_amd
+    return nlsolver_amd
+
+
+def run(mod, objective, pop, D, x0, turns, **kw):
+    with mod.DEEngine(objective, pop, D, **kw) as eng:
+        eng.init(x0)
+        eng.step(turns)
+        P, S = eng.download()
+        st = eng.status()
+        bx, bf, bi = eng.best()
+    return P, S, st, bx, bf, bi
+
+
+@pytest.mark.parametrize("D,pop", [(2, 64), (16, 256), (128, 2048), (130, 512), (257, 128)])
+@pytest.mark.parametrize("strategy", [0, 1])
+def test_custom_rosenbrock_equals_builtin_bit_for_bit(mod, oracle, D, pop, strategy):
+    kw = dict(strategy=strategy, CR=0.2, F=0.5, eps=1e-300, max_iter=1000, best_val_no_change=1000,
+              seed=4242)
+    x0 = np.full(D, 0.6)
+    a = run(mod, "rosenbrock", pop, D, x0, 12, **kw)
+    b = run(mod, mod.CustomObjective(ROSENBROCK, chain=True), pop, D, x0, 12, **kw)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert (a[2].iteration, a[2].function_calls_used, a[2].best_index, a[2].std_err) == \
+        (b[2].iteration, b[2].function_calls_used, b[2].best_index, b[2].std_err)
+    assert np.array_equal(a[3], b[3]) and a[4] == b[4]
+    # and therefore the oracle
+    ref = O.DESyncRun(oracle, "rosenbrock", pop, D, x0, **kw)
+    ref.step(12)
+    assert np.array_equal(b[0], ref.population) and np.array_equal(b[1], ref.scores)
+
+
+def test_custom_finish_and_maximize(mod):
+    """Styblinski-Tang spells its halving in `finish`; maximize flips the sign like the built-in."""
+    kw = dict(minimize=False, CR=0.5, F=0.7, eps=0.0, max_iter=1000, best_val_no_change=1000, seed=9)
+    D, pop = 64, 512
+    x0 = np.full(D, 3.0)
+    a = run(mod, "styblinski_tang", pop, D, x0, 8, **kw)
+    b = run(mod, mod.CustomObjective(STYBLINSKI, finish_body="return s / 2.0;"), pop, D, x0, 8, **kw)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[5] == b[5]
+
+
+def test_objective_nobody_built_in(mod):
+    """f(x) = sqrt(sum_i (|x_i|^3 + 0.1 x_i x_{i+1})): every score equals the numpy value of the
+    same expression within rounding of the different summation order, and DE decreases it."""
+    D, pop = 96, 1024
+    obj = mod.CustomObjective("return fabs(xi) * xi * xi + 0.1 * xi * xn;", chain=True,
+                              finish_body="return sqrt(s > 0 ? s : 0.0);")
+    x0 = np.full(D, 2.0)
+    with mod.DEEngine(obj, pop, D, CR=0.3, F=0.5, eps=0.0, max_iter=10**6,
+                      best_val_no_change=10**6, seed=3) as eng:
+        eng.init(x0)
+        P0, S0 = eng.download()
+        eng.step(60)
+        P, S = eng.download()
+        bx, bf, bi = eng.best()
+    def f(X):
+        s = np.sum(np.abs(X[:, :-1]) ** 3 + 0.1 * X[:, :-1] * X[:, 1:], axis=1)
+        return np.sqrt(np.maximum(s, 0.0))
+    assert np.allclose(S0, f(P0), rtol=1e-13, atol=0) and np.allclose(S, f(P), rtol=1e-13, atol=0)
+    assert bf == S[bi] and S.min() < S0.min() and np.mean(S < S0) > 0.9
+
+
+def test_source_that_does_not_compile_is_reported(mod):
+    with pytest.raises(RuntimeError, match="does not compile"):
+        mod.DEEngine(mod.CustomObjective("return xi +;"), 64, 8)

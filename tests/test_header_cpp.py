@@ -63,11 +63,18 @@ def test_device_objective_has_no_cpu_fallback(built):
     ("random", 128, 4096, 25, 0.0, 1000, 4.096),
     ("best", 130, 512, 10, 0.0, 1000, 2.0),
 ])
+@pytest.mark.parametrize("kind", ["builtin", "custom"])
 def test_device_objective_through_header_matches_oracle(built, oracle, strategy, D, pop, max_iter,
-                                                        eps, no_change, x0):
+                                                        eps, no_change, x0, kind):
+    """kind = custom: the objective is device::Custom<double> (source text compiled at solve time);
+    it spells the Rosenbrock chain, so the same oracle run must come out."""
+    # the test binary links no HIP runtime of its own: libnlsolver_hip.so brings the system one,
+    # and with it the system hiprtc (the default of nlsg_rtc_load)
+    env = dict(os.environ, NLSG_LIBRARY=LIB)
     out = subprocess.check_output(
         [os.path.join(built, "header_device"), strategy, str(D), str(pop), str(max_iter),
-         repr(eps), str(no_change), repr(x0)], env=dict(os.environ, NLSG_LIBRARY=LIB), text=True)
+         repr(eps), str(no_change), repr(x0)] + (["custom"] if kind == "custom" else []),
+        env=env, text=True)
     o = json.loads(out)
     assert "device_error" not in o, o
     # the header keys the device RNG with two draws of the caller's generator
