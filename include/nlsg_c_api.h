@@ -233,6 +233,8 @@ typedef struct {
 } nlsg_pso_config;
 
 int nlsg_pso_create(const nlsg_pso_config *cfg, nlsg_pso **out);
+/* cfg->objective == NLSG_OBJ_CUSTOM, as nlsg_de_create_custom */
+int nlsg_pso_create_custom(const nlsg_pso_config *cfg, const nlsg_custom_objective *obj, nlsg_pso **out);
 int nlsg_pso_destroy(nlsg_pso *e);
 /* init_solver_state + the first update_best_positions' evaluations (2626-2657, 2595). */
 int nlsg_pso_init(nlsg_pso *e, const double *lower_host, const double *upper_host);

@@ -294,6 +294,7 @@ class api {
   decltype(&nlsg_de_destroy) de_destroy;
   decltype(&nlsg_de_minimize) de_minimize;
   decltype(&nlsg_pso_create) pso_create;
+  decltype(&nlsg_pso_create_custom) pso_create_custom;
   decltype(&nlsg_pso_destroy) pso_destroy;
   decltype(&nlsg_pso_minimize) pso_minimize;
   decltype(&nlsg_bfgs_create) bfgs_create;
@@ -328,6 +329,7 @@ class api {
     bind(h, "nlsg_de_destroy", de_destroy);
     bind(h, "nlsg_de_minimize", de_minimize);
     bind(h, "nlsg_pso_create", pso_create);
+    bind(h, "nlsg_pso_create_custom", pso_create_custom);
     bind(h, "nlsg_pso_destroy", pso_destroy);
     bind(h, "nlsg_pso_minimize", pso_minimize);
     bind(h, "nlsg_bfgs_create", bfgs_create);
@@ -595,7 +597,13 @@ class PSO {
       cfg.best_val_no_change = best_val_no_change;
       cfg.seed = device::seed_from(generator);
       nlsg_pso *eng = nullptr;
-      api.check(api.pso_create(&cfg, &eng));
+      if constexpr (Callable::nlsg_objective == NLSG_OBJ_CUSTOM) {
+        api.check(api.rtc_load(std::getenv("NLSG_HIPRTC")));
+        nlsg_custom_objective obj{f.term_body.c_str(), f.finish_body.c_str(), f.chain ? 1 : 0, 0};
+        api.check(api.pso_create_custom(&cfg, &obj, &eng));
+      } else {
+        api.check(api.pso_create(&cfg, &eng));
+      }
       nlsg_status st{};
       const int rc = api.pso_minimize(eng, x.data(), lower.data(), upper.data(), 0, &st);
       const std::string msg = rc ? api.last_error() : "";

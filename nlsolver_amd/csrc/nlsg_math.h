@@ -10,8 +10,10 @@
 // classic minimax kernels (Sun fdlibm coefficient sets).
 #pragma once
 
+#ifndef __HIPCC_RTC__  // also compiled at run time for user objectives (nlsg_rtc.hip)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 namespace nlsg {
 

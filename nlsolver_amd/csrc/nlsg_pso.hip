@@ -7,6 +7,7 @@
 
 #include "nlsg_comm.h"
 #include "nlsg_pso_kernels.h"
+#include "nlsg_rtc.h"
 
 using namespace nlsg;
 
@@ -18,6 +19,7 @@ struct nlsg_pso {
   double *lower_dev = nullptr, *upper_dev = nullptr, *zero_dev = nullptr, *tab_dev = nullptr;
   ShardLocal *loc = nullptr;
   ShardComm *comm = nullptr;  // set by nlsg_pso_comm_attach
+  PsoRtcKernels rtc;          // objective == NLSG_OBJ_CUSTOM: the kernels hiprtc built for it
   double *rec = nullptr;
   int chunks = 0;
   bool initialised = false;
@@ -62,6 +64,11 @@ int pso_check_device(int device) {
 void launch_init(nlsg_pso *e) {
   const dim3 grid(static_cast<unsigned>((e->p.shard_n + 3) / 4)), block(256);
   const bool vec = e->p.D % 2 == 0;
+  if (e->cfg.objective == NLSG_OBJ_CUSTOM) {
+    void *args[] = {&e->p};
+    hipModuleLaunchKernel(e->rtc.init, grid.x, 1, 1, 256, 1, 1, 0, e->stream, args, nullptr);
+    return;
+  }
 #define CALL(OBJ, C)                                                                        \
   if (vec)                                                                                  \
     hipLaunchKernelGGL((pso_init_kernel<OBJ, C, true>), grid, block, 0, e->stream, e->p);   \
@@ -75,6 +82,11 @@ void launch_move(nlsg_pso *e, int timing, uint64_t iter_ovr) {
   const dim3 grid(static_cast<unsigned>((e->p.shard_n + 3) / 4)), block(256);
   const bool vec = e->p.D % 2 == 0;
   const bool accel = e->cfg.type == NLSG_PSO_ACCELERATED;
+  if (e->cfg.objective == NLSG_OBJ_CUSTOM) {
+    void *args[] = {&e->p, &timing, &iter_ovr};
+    hipModuleLaunchKernel(e->rtc.move, grid.x, 1, 1, 256, 1, 1, 0, e->stream, args, nullptr);
+    return;
+  }
 #define CALL(OBJ, C)                                                                          \
   if (vec && accel)                                                                           \
     hipLaunchKernelGGL((pso_move_kernel<OBJ, C, true, NLSG_PSO_ACCELERATED>), grid, block, 0, \
@@ -144,7 +156,23 @@ void fill_status(const PsoState &s, nlsg_status *out) {
 
 extern "C" {
 
+static int pso_create(const nlsg_pso_config *cfg, const nlsg_custom_objective *custom, nlsg_pso **out);
+
 int nlsg_pso_create(const nlsg_pso_config *cfg, nlsg_pso **out) {
+  if (cfg && cfg->objective == NLSG_OBJ_CUSTOM)
+    return fail(NLSG_ERR_INVALID_ARG, "NLSG_OBJ_CUSTOM engines are made by nlsg_pso_create_custom");
+  return pso_create(cfg, nullptr, out);
+}
+
+int nlsg_pso_create_custom(const nlsg_pso_config *cfg, const nlsg_custom_objective *obj,
+                           nlsg_pso **out) {
+  if (!cfg || !obj) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  if (cfg->objective != NLSG_OBJ_CUSTOM)
+    return fail(NLSG_ERR_INVALID_ARG, "cfg.objective must be NLSG_OBJ_CUSTOM");
+  return pso_create(cfg, obj, out);
+}
+
+static int pso_create(const nlsg_pso_config *cfg, const nlsg_custom_objective *custom, nlsg_pso **out) {
   if (!cfg || !out) return fail(NLSG_ERR_INVALID_ARG, "null argument");
   *out = nullptr;
   if (cfg->struct_size != sizeof(nlsg_pso_config))
@@ -154,7 +182,7 @@ int nlsg_pso_create(const nlsg_pso_config *cfg, nlsg_pso **out) {
   if (cfg->dim > 1024)
     return fail(NLSG_ERR_UNSUPPORTED, "dim %llu > 1024 is not covered by the device path",
                 (unsigned long long)cfg->dim);
-  if (cfg->objective < 0 || cfg->objective > NLSG_OBJ_RASTRIGIN)
+  if (!custom && (cfg->objective < 0 || cfg->objective > NLSG_OBJ_RASTRIGIN))
     return fail(NLSG_ERR_INVALID_ARG, "unknown objective %d", cfg->objective);
   if (cfg->type != NLSG_PSO_VANILLA && cfg->type != NLSG_PSO_ACCELERATED)
     return fail(NLSG_ERR_INVALID_ARG, "unknown PSO type %d", cfg->type);
@@ -240,6 +268,13 @@ int nlsg_pso_create(const nlsg_pso_config *cfg, nlsg_pso **out) {
   p.seed = cfg->seed;
   p.type = cfg->type;
   p.bounded = cfg->bounded ? 1 : 0;
+  if (custom) {
+    const int rc2 = rtc_build_pso(custom, e->chunks, p.D % 2 == 0, cfg->type, &e->rtc);
+    if (rc2) {
+      nlsg_pso_destroy(e);
+      return rc2;
+    }
+  }
   *out = e;
   return NLSG_OK;
 }
@@ -262,6 +297,7 @@ int nlsg_pso_destroy(nlsg_pso *e) {
   hipFree(e->tab_dev);
   hipFree(e->loc);
   comm_detach(e->comm);
+  rtc_release(&e->rtc);
   hipFree(e->rec);
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);

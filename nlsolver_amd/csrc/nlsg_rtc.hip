@@ -60,13 +60,17 @@ int rtc_load(const char *path_in) {
 
 }  // namespace
 
-int rtc_build_de(const nlsg_custom_objective *obj, int chunks, bool vec, DeRtcKernels *out) {
+// Compiles `kernel_header` around the user's Objective<NLSG_OBJ_CUSTOM> and returns the module
+// with one function per name expression (kernel template-ids).
+static int rtc_compile(const nlsg_custom_objective *obj, const char *kernel_header,
+                       const std::vector<std::string> &name_exprs, hipModule_t *mod_out,
+                       std::vector<hipFunction_t> *fns_out) {
   if (!obj || !obj->term_body || !obj->term_body[0])
     return fail(NLSG_ERR_INVALID_ARG, "a custom objective needs a term body");
   int rc = rtc_load(nullptr);
   if (rc) return rc;
   RtcApi &api = rtc_api();
-  std::string src = "#include \"nlsg_de_kernels.h\"\n"
+  std::string src = std::string("#include \"") + kernel_header + "\"\n"
                     "namespace nlsg {\n"
                     "template <>\n"
                     "struct Objective<NLSG_OBJ_CUSTOM> {\n"
@@ -92,14 +96,7 @@ int rtc_build_de(const nlsg_custom_objective *obj, int chunks, bool vec, DeRtcKe
   if (api.CreateProgram(&prog, src.c_str(), "nlsg_custom_objective.hip", nh, texts.data(),
                         names.data()) != HIPRTC_SUCCESS)
     return fail(NLSG_ERR_HIP, "hiprtcCreateProgram failed");
-  const std::string targs = std::to_string(static_cast<int>(NLSG_OBJ_CUSTOM)) + ", " +
-                            std::to_string(chunks) + ", " + (vec ? "true" : "false");
-  const std::string n_init = "nlsg::de_init_kernel<" + targs + ">";
-  const std::string n_gen = "nlsg::de_generation_kernel<" + targs + ">";
-  const std::string n_turn = "nlsg::de_turn_kernel<" + targs + ">";
-  api.AddNameExpression(prog, n_init.c_str());
-  api.AddNameExpression(prog, n_gen.c_str());
-  api.AddNameExpression(prog, n_turn.c_str());
+  for (const std::string &n : name_exprs) api.AddNameExpression(prog, n.c_str());
   // the flags of csrc/Makefile: device arithmetic must stay bit-reproducible
   const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
                         "-fno-fast-math"};
@@ -113,27 +110,63 @@ int rtc_build_de(const nlsg_custom_objective *obj, int chunks, bool vec, DeRtcKe
     if (log.size() > 400) log.resize(400);
     return fail(NLSG_ERR_INVALID_ARG, "custom objective does not compile: %s", log.c_str());
   }
-  const char *l_init = nullptr, *l_gen = nullptr, *l_turn = nullptr;
-  if (api.GetLoweredName(prog, n_init.c_str(), &l_init) != HIPRTC_SUCCESS ||
-      api.GetLoweredName(prog, n_gen.c_str(), &l_gen) != HIPRTC_SUCCESS ||
-      api.GetLoweredName(prog, n_turn.c_str(), &l_turn) != HIPRTC_SUCCESS) {
-    api.DestroyProgram(&prog);
-    return fail(NLSG_ERR_HIP, "hiprtcGetLoweredName failed");
-  }
   size_t cs = 0;
   api.GetCodeSize(prog, &cs);
   std::vector<char> code(cs);
   api.GetCode(prog, code.data());
-  DeRtcKernels k;
-  hipError_t he = hipModuleLoadData(&k.mod, code.data());
-  if (he == hipSuccess) he = hipModuleGetFunction(&k.init, k.mod, l_init);
-  if (he == hipSuccess) he = hipModuleGetFunction(&k.generation, k.mod, l_gen);
-  if (he == hipSuccess) he = hipModuleGetFunction(&k.turn, k.mod, l_turn);
-  api.DestroyProgram(&prog);  // the lowered names live in the program
+  hipModule_t mod = nullptr;
+  hipError_t he = hipModuleLoadData(&mod, code.data());
+  std::vector<hipFunction_t> fns(name_exprs.size(), nullptr);
+  for (size_t i = 0; i < name_exprs.size() && he == hipSuccess; i++) {
+    const char *lowered = nullptr;  // lives in the program: look the function up before destroying it
+    if (api.GetLoweredName(prog, name_exprs[i].c_str(), &lowered) != HIPRTC_SUCCESS) {
+      he = hipErrorNotFound;
+      break;
+    }
+    he = hipModuleGetFunction(&fns[i], mod, lowered);
+  }
+  api.DestroyProgram(&prog);
   if (he != hipSuccess) {
-    if (k.mod) hipModuleUnload(k.mod);
+    if (mod) hipModuleUnload(mod);
     return fail(NLSG_ERR_HIP, "loading the compiled objective failed: %s", hipGetErrorString(he));
   }
+  *mod_out = mod;
+  *fns_out = fns;
+  return NLSG_OK;
+}
+
+static std::string targs(int chunks, bool vec) {
+  return std::to_string(static_cast<int>(NLSG_OBJ_CUSTOM)) + ", " + std::to_string(chunks) + ", " +
+         (vec ? "true" : "false");
+}
+
+int rtc_build_de(const nlsg_custom_objective *obj, int chunks, bool vec, DeRtcKernels *out) {
+  const std::string t = targs(chunks, vec);
+  std::vector<hipFunction_t> f;
+  DeRtcKernels k;
+  const int rc = rtc_compile(obj, "nlsg_de_kernels.h",
+                             {"nlsg::de_init_kernel<" + t + ">", "nlsg::de_generation_kernel<" + t + ">",
+                              "nlsg::de_turn_kernel<" + t + ">"},
+                             &k.mod, &f);
+  if (rc) return rc;
+  k.init = f[0];
+  k.generation = f[1];
+  k.turn = f[2];
+  *out = k;
+  return NLSG_OK;
+}
+
+int rtc_build_pso(const nlsg_custom_objective *obj, int chunks, bool vec, int type, PsoRtcKernels *out) {
+  const std::string t = targs(chunks, vec);
+  std::vector<hipFunction_t> f;
+  PsoRtcKernels k;
+  const int rc = rtc_compile(obj, "nlsg_pso_kernels.h",
+                             {"nlsg::pso_init_kernel<" + t + ">",
+                              "nlsg::pso_move_kernel<" + t + ", " + std::to_string(type) + ">"},
+                             &k.mod, &f);
+  if (rc) return rc;
+  k.init = f[0];
+  k.move = f[1];
   *out = k;
   return NLSG_OK;
 }
@@ -141,6 +174,10 @@ int rtc_build_de(const nlsg_custom_objective *obj, int chunks, bool vec, DeRtcKe
 void rtc_release(DeRtcKernels *k) {
   if (k && k->mod) hipModuleUnload(k->mod);
   if (k) *k = DeRtcKernels();
+}
+void rtc_release(PsoRtcKernels *k) {
+  if (k && k->mod) hipModuleUnload(k->mod);
+  if (k) *k = PsoRtcKernels();
 }
 
 }  // namespace nlsg

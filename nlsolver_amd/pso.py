@@ -27,7 +27,10 @@ class PSOEngine:
         cfg.struct_size = C.sizeof(PSOConfig)
         cfg.device = device
         cfg.stream = None if stream is None else (stream or 1)
-        cfg.objective = _capi.OBJECTIVES[objective] if isinstance(objective, str) else objective
+        from .de import CustomObjective, rtc_library_path
+        custom = objective if isinstance(objective, CustomObjective) else None
+        cfg.objective = (_capi.OBJ_CUSTOM if custom else
+                         _capi.OBJECTIVES[objective] if isinstance(objective, str) else objective)
         cfg.minimize, cfg.type, cfg.bounded = int(bool(minimize)), type, int(bool(bounded))
         cfg.n_particles, cfg.dim = n_particles, dim
         cfg.shard_lo = shard_lo
@@ -36,7 +39,13 @@ class PSOEngine:
         cfg.max_iter, cfg.best_val_no_change, cfg.seed = max_iter, best_val_no_change, seed
         self.cfg = cfg
         self._h = C.c_void_p()
-        check(lib().nlsg_pso_create(C.byref(cfg), C.byref(self._h)))
+        if custom:
+            check(lib().nlsg_rtc_load(rtc_library_path().encode()))
+            obj = _capi.CustomObjectiveC(custom.term_body.encode(), custom.finish_body.encode(),
+                                         int(custom.chain), 0)
+            check(lib().nlsg_pso_create_custom(C.byref(cfg), C.byref(obj), C.byref(self._h)))
+        else:
+            check(lib().nlsg_pso_create(C.byref(cfg), C.byref(self._h)))
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:

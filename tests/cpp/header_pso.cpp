@@ -1,6 +1,7 @@
 // tests/cpp/header_pso.cpp — PSO through the drop-in header.
 //   header_pso host                       host-functor path: the reference's goldens
-//   header_pso device <accel|vanilla> D particles max_iter eps no_change bound [bounded]
+//   header_pso device <accel|vanilla> D particles max_iter eps no_change bound [bounded] [custom]
+// "custom": the objective is device::Custom<double> (the Rosenbrock chain as source text)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -85,11 +86,15 @@ static int host() {
   return 0;
 }
 
-using Objective = nlsolver::device::Rosenbrock<double>;
-template <PSOType T>
+static nlsolver::device::Rosenbrock<double> make(nlsolver::device::Rosenbrock<double> *) { return {}; }
+static nlsolver::device::Custom<double> make(nlsolver::device::Custom<double> *) {
+  return nlsolver::device::Custom<double>(
+      "double t1 = 1 - xi; double t2 = (xn - xi * xi); return t1 * t1 + 100 * t2 * t2;", true);
+}
+template <PSOType T, typename Objective>
 static int dev(size_t D, size_t np, size_t max_iter, double eps, size_t no_change, double bound,
                bool bounded) {
-  Objective f;
+  Objective f = make(static_cast<Objective *>(nullptr));
   xorshift<double> gen;
   std::vector<double> x(D, bound), lo(D, -bound), hi(D, bound);
   try {
@@ -115,9 +120,15 @@ int main(int argc, char **argv) {
     const size_t no_change = std::strtoull(argv[7], nullptr, 10);
     const double bound = std::strtod(argv[8], nullptr);
     const bool bounded = argc > 9 && std::atoi(argv[9]) != 0;
-    if (!std::strcmp(argv[2], "accel"))
-      return dev<PSOType::Accelerated>(D, np, max_iter, eps, no_change, bound, bounded);
-    return dev<PSOType::Vanilla>(D, np, max_iter, eps, no_change, bound, bounded);
+    const bool accel = !std::strcmp(argv[2], "accel");
+    if (argc > 10 && !std::strcmp(argv[10], "custom")) {
+      using C = nlsolver::device::Custom<double>;
+      return accel ? dev<PSOType::Accelerated, C>(D, np, max_iter, eps, no_change, bound, bounded)
+                   : dev<PSOType::Vanilla, C>(D, np, max_iter, eps, no_change, bound, bounded);
+    }
+    using R = nlsolver::device::Rosenbrock<double>;
+    return accel ? dev<PSOType::Accelerated, R>(D, np, max_iter, eps, no_change, bound, bounded)
+                 : dev<PSOType::Vanilla, R>(D, np, max_iter, eps, no_change, bound, bounded);
   }
   std::fprintf(stderr, "usage: header_pso host | device <accel|vanilla> D np max_iter eps no_change bound [bounded]\n");
   return 2;

@@ -85,3 +85,26 @@ def test_objective_nobody_built_in(mod):
 def test_source_that_does_not_compile_is_reported(mod):
     with pytest.raises(RuntimeError, match="does not compile"):
         mod.DEEngine(mod.CustomObjective("return xi +;"), 64, 8)
+
+
+@pytest.mark.parametrize("ptype", ["accelerated", "vanilla"])
+@pytest.mark.parametrize("D,n", [(16, 256), (256, 1024), (130, 96)])
+def test_pso_custom_rosenbrock_equals_builtin_bit_for_bit(mod, ptype, D, n):
+    """The same hook in the PSO engine (nlsg_pso_create_custom): move + evaluate kernels compiled
+    around the user's objective reproduce the built-in engine exactly."""
+    kw = dict(type=mod.PSO_ACCELERATED if ptype == "accelerated" else mod.PSO_VANILLA, bounded=True,
+              inertia=0.8, cognitive=1.8, social=1.8, eps=0.0, max_iter=1000,
+              best_val_no_change=1000, seed=11)
+    out = []
+    for obj in ("rosenbrock", mod.CustomObjective(ROSENBROCK, chain=True)):
+        with mod.PSOEngine(obj, n, D, **kw) as eng:
+            eng.init(-2.048, 2.048)
+            eng.step(10)
+            st = eng.status()
+            bx, bf, bi = eng.best()
+            dl = eng.download()
+        out.append((st.iteration, st.function_calls_used, bi, bf, bx, dl))
+    a, b = out
+    assert a[:4] == b[:4] and np.array_equal(a[4], b[4])
+    for u, v in zip(a[5], b[5]):
+        assert u is None and v is None or np.array_equal(u, v)

@@ -114,11 +114,14 @@ def test_pso_host_path_through_header_matches_reference_bit_exact(built, golden)
     ("accel", 256, 512, 12, 0.0, 1000, 2.048, 1),
     ("vanilla", 16, 64, 40, 1e-3, 50, 2.0, 1),
 ])
+@pytest.mark.parametrize("objective", ["builtin", "custom"])
 def test_pso_device_objective_through_header_matches_oracle(built, oracle, kind, D, n, max_iter,
-                                                            eps, no_change, bound, bounded):
+                                                            eps, no_change, bound, bounded,
+                                                            objective):
     out = subprocess.check_output(
         [os.path.join(built, "header_pso"), "device", kind, str(D), str(n), str(max_iter),
-         repr(eps), str(no_change), repr(bound), str(bounded)],
+         repr(eps), str(no_change), repr(bound), str(bounded)] +
+        (["custom"] if objective == "custom" else []),
         env=dict(os.environ, NLSG_LIBRARY=LIB), text=True)
     o = json.loads(out)
     assert "device_error" not in o, o
