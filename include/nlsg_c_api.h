@@ -379,6 +379,8 @@ typedef struct {
 } nlsg_nm_config;
 
 int nlsg_nm_create(const nlsg_nm_config *cfg, nlsg_nm **out);
+/* cfg->objective == NLSG_OBJ_CUSTOM, as nlsg_de_create_custom */
+int nlsg_nm_create_custom(const nlsg_nm_config *cfg, const nlsg_custom_objective *obj, nlsg_nm **out);
 int nlsg_nm_destroy(nlsg_nm *e);
 /* x [batch][dim] in/out; upper/lower [dim] (shared by the batch; NULL when unbounded; note
  * the reference's argument order: upper first). One status per start; eps_out receives each

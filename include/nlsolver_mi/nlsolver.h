@@ -305,6 +305,7 @@ class api {
   decltype(&nlsg_lm_set_data) lm_set_data;
   decltype(&nlsg_lm_minimize) lm_minimize;
   decltype(&nlsg_nm_create) nm_create;
+  decltype(&nlsg_nm_create_custom) nm_create_custom;
   decltype(&nlsg_nm_destroy) nm_destroy;
   decltype(&nlsg_nm_minimize) nm_minimize;
 
@@ -340,6 +341,7 @@ class api {
     bind(h, "nlsg_lm_set_data", lm_set_data);
     bind(h, "nlsg_lm_minimize", lm_minimize);
     bind(h, "nlsg_nm_create", nm_create);
+    bind(h, "nlsg_nm_create_custom", nm_create_custom);
     bind(h, "nlsg_nm_destroy", nm_destroy);
     bind(h, "nlsg_nm_minimize", nm_minimize);
     if (abi_version() != NLSG_ABI_VERSION)
@@ -1109,7 +1111,13 @@ class NelderMead {
       cfg.no_change_best_tol = no_change_best_tol;
       cfg.restarts = restarts;
       nlsg_nm *eng = nullptr;
-      api.check(api.nm_create(&cfg, &eng));
+      if constexpr (Callable::nlsg_objective == NLSG_OBJ_CUSTOM) {
+        api.check(api.rtc_load(std::getenv("NLSG_HIPRTC")));
+        nlsg_custom_objective obj{f.term_body.c_str(), f.finish_body.c_str(), f.chain ? 1 : 0, 0};
+        api.check(api.nm_create_custom(&cfg, &obj, &eng));
+      } else {
+        api.check(api.nm_create(&cfg, &eng));
+      }
       nlsg_status st{};
       double eps_after = eps;
       const int rc = api.nm_minimize(eng, x.data(), bound ? upper.data() : nullptr,

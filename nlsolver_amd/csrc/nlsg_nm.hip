@@ -3,10 +3,12 @@
 #include <vector>
 
 #include "nlsg_nm_kernels.h"
+#include "nlsg_rtc.h"
 
 using namespace nlsg;
 
 struct nlsg_nm {
+  NmRtcKernels rtc;  // objective == NLSG_OBJ_CUSTOM: the kernel hiprtc built for it
   nlsg_nm_config cfg;
   NmParams p;
   hipStream_t stream = nullptr;
@@ -39,6 +41,12 @@ hipError_t prepare(size_t lds) {
 
 void launch(nlsg_nm *e) {
   const dim3 grid(static_cast<unsigned>(e->p.batch)), block(kNmThreads);
+  if (e->cfg.objective == NLSG_OBJ_CUSTOM) {
+    void *args[] = {&e->p};
+    hipModuleLaunchKernel(e->rtc.solve, grid.x, 1, 1, kNmThreads, 1, 1,
+                          static_cast<unsigned>(e->lds), e->stream, args, nullptr);
+    return;
+  }
   switch (e->cfg.objective) {
     case NLSG_OBJ_ROSENBROCK:
       hipLaunchKernelGGL(nm_solve_kernel<NLSG_OBJ_ROSENBROCK>, grid, block, e->lds, e->stream, e->p);
@@ -68,13 +76,28 @@ int upload_bounds(nlsg_nm *e, const double *upper_host, const double *lower_host
 
 extern "C" {
 
+static int nm_create(const nlsg_nm_config *cfg, const nlsg_custom_objective *custom, nlsg_nm **out);
+
 int nlsg_nm_create(const nlsg_nm_config *cfg, nlsg_nm **out) {
+  if (cfg && cfg->objective == NLSG_OBJ_CUSTOM)
+    return fail(NLSG_ERR_INVALID_ARG, "NLSG_OBJ_CUSTOM engines are made by nlsg_nm_create_custom");
+  return nm_create(cfg, nullptr, out);
+}
+
+int nlsg_nm_create_custom(const nlsg_nm_config *cfg, const nlsg_custom_objective *obj, nlsg_nm **out) {
+  if (!cfg || !obj) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  if (cfg->objective != NLSG_OBJ_CUSTOM)
+    return fail(NLSG_ERR_INVALID_ARG, "cfg.objective must be NLSG_OBJ_CUSTOM");
+  return nm_create(cfg, obj, out);
+}
+
+static int nm_create(const nlsg_nm_config *cfg, const nlsg_custom_objective *custom, nlsg_nm **out) {
   if (!cfg || !out) return fail(NLSG_ERR_INVALID_ARG, "null argument");
   *out = nullptr;
   if (cfg->struct_size != sizeof(nlsg_nm_config))
     return fail(NLSG_ERR_INVALID_ARG, "nlsg_nm_config size mismatch (%u vs %zu)", cfg->struct_size,
                 sizeof(nlsg_nm_config));
-  if (cfg->objective < 0 || cfg->objective > NLSG_OBJ_RASTRIGIN)
+  if (!custom && (cfg->objective < 0 || cfg->objective > NLSG_OBJ_RASTRIGIN))
     return fail(NLSG_ERR_INVALID_ARG, "unknown objective %d", cfg->objective);
   if (cfg->dim < 1 || cfg->batch < 1) return fail(NLSG_ERR_INVALID_ARG, "dim and batch must be >= 1");
   if (cfg->dim > 128)
@@ -112,6 +135,16 @@ int nlsg_nm_create(const nlsg_nm_config *cfg, nlsg_nm **out) {
   if (he == hipSuccess) he = prepare<NLSG_OBJ_SPHERE>(e->lds);
   if (he == hipSuccess) he = prepare<NLSG_OBJ_STYBLINSKI_TANG>(e->lds);
   if (he == hipSuccess) he = prepare<NLSG_OBJ_RASTRIGIN>(e->lds);
+  if (he == hipSuccess && custom) {
+    const int rc2 = rtc_build_nm(custom, &e->rtc);
+    if (rc2) {
+      nlsg_nm_destroy(e);
+      return rc2;
+    }
+    // the module API's counterpart of prepare<>(): allow the simplex-sized dynamic LDS
+    he = hipFuncSetAttribute(reinterpret_cast<const void *>(e->rtc.solve),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(e->lds));
+  }
   if (he != hipSuccess) {
     nlsg_nm_destroy(e);
     return fail(he == hipErrorOutOfMemory ? NLSG_ERR_OOM : NLSG_ERR_HIP,
@@ -140,6 +173,7 @@ int nlsg_nm_destroy(nlsg_nm *e) {
   if (!e) return NLSG_OK;
   hipSetDevice(e->cfg.device);
   if (e->stream) hipStreamSynchronize(e->stream);
+  rtc_release(&e->rtc);
   hipFree(e->p.x);
   hipFree(e->p.prob);
   hipFree(e->upper_dev);

@@ -20,6 +20,12 @@ struct PsoRtcKernels {
 // Compiles de_init / de_generation / de_turn kernels for the objective, CHUNKS = chunks, VEC = vec.
 int rtc_build_de(const nlsg_custom_objective *obj, int chunks, bool vec, DeRtcKernels *out);
 void rtc_release(DeRtcKernels *k);
+struct NmRtcKernels {
+  hipModule_t mod = nullptr;
+  hipFunction_t solve = nullptr;
+};
+int rtc_build_nm(const nlsg_custom_objective *obj, NmRtcKernels *out);
+void rtc_release(NmRtcKernels *k);
 // pso_init / pso_move kernels; type = nlsg_pso_type.
 int rtc_build_pso(const nlsg_custom_objective *obj, int chunks, bool vec, int type, PsoRtcKernels *out);
 void rtc_release(PsoRtcKernels *k);

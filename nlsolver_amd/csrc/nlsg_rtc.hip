@@ -171,6 +171,22 @@ int rtc_build_pso(const nlsg_custom_objective *obj, int chunks, bool vec, int ty
   return NLSG_OK;
 }
 
+int rtc_build_nm(const nlsg_custom_objective *obj, NmRtcKernels *out) {
+  std::vector<hipFunction_t> f;
+  NmRtcKernels k;
+  const int rc = rtc_compile(obj, "nlsg_nm_kernels.h",
+                             {"nlsg::nm_solve_kernel<" + std::to_string(static_cast<int>(NLSG_OBJ_CUSTOM)) + ">"},
+                             &k.mod, &f);
+  if (rc) return rc;
+  k.solve = f[0];
+  *out = k;
+  return NLSG_OK;
+}
+void rtc_release(NmRtcKernels *k) {
+  if (k && k->mod) hipModuleUnload(k->mod);
+  if (k) *k = NmRtcKernels();
+}
+
 void rtc_release(DeRtcKernels *k) {
   if (k && k->mod) hipModuleUnload(k->mod);
   if (k) *k = DeRtcKernels();

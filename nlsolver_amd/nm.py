@@ -23,14 +23,23 @@ class NMEngine:
         cfg.struct_size = C.sizeof(NMConfig)
         cfg.device = device
         cfg.stream = None if stream is None else (stream or 1)
-        cfg.objective = _capi.OBJECTIVES[objective] if isinstance(objective, str) else objective
+        from .de import CustomObjective, rtc_library_path
+        custom = objective if isinstance(objective, CustomObjective) else None
+        cfg.objective = (_capi.OBJ_CUSTOM if custom else
+                         _capi.OBJECTIVES[objective] if isinstance(objective, str) else objective)
         cfg.minimize, cfg.bounded = int(bool(minimize)), int(bool(bounded))
         cfg.batch, cfg.dim = batch, dim
         cfg.step, cfg.alpha, cfg.gamma, cfg.rho, cfg.sigma, cfg.eps = step, alpha, gamma, rho, sigma, eps
         cfg.max_iter, cfg.no_change_best_tol, cfg.restarts = max_iter, no_change_best_tol, restarts
         self.cfg = cfg
         self._h = C.c_void_p()
-        check(lib().nlsg_nm_create(C.byref(cfg), C.byref(self._h)))
+        if custom:
+            check(lib().nlsg_rtc_load(rtc_library_path().encode()))
+            obj = _capi.CustomObjectiveC(custom.term_body.encode(), custom.finish_body.encode(),
+                                         int(custom.chain), 0)
+            check(lib().nlsg_nm_create_custom(C.byref(cfg), C.byref(obj), C.byref(self._h)))
+        else:
+            check(lib().nlsg_nm_create(C.byref(cfg), C.byref(self._h)))
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:

@@ -1,6 +1,7 @@
 // tests/cpp/header_nm_lm.cpp — NelderMead and LevenbergMarquardt through the drop-in header.
 //   nm-host D step max_iter eps no_change restarts x0 x0_step bounded upper lower minimize
 //   nm-device (same arguments; objective = nlsolver::device::Rosenbrock<double>)
+//   nm-device-custom (same arguments; objective = nlsolver::device::Custom<double>, compiled at run time)
 //   lm-host-exp [lambda max_iter f_delta]      reference-style GN functors on the exp model
 //   lm-device m n problems max_iter            device TanhRegression model, batched
 #include <cmath>
@@ -113,6 +114,11 @@ int main(int argc, char **argv) {
   }
   if (argc >= 14 && !std::strcmp(argv[1], "nm-device")) {
     nlsolver::device::Rosenbrock<double> f;
+    return run_nm(f, argv + 2);
+  }
+  if (argc >= 14 && !std::strcmp(argv[1], "nm-device-custom")) {  // the same chain as source text
+    nlsolver::device::Custom<double> f(
+        "double t1 = 1 - xi; double t2 = (xn - xi * xi); return t1 * t1 + 100 * t2 * t2;", true);
     return run_nm(f, argv + 2);
   }
   if (argc >= 2 && !std::strcmp(argv[1], "lm-host-exp")) {

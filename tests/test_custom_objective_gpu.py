@@ -108,3 +108,17 @@ def test_pso_custom_rosenbrock_equals_builtin_bit_for_bit(mod, ptype, D, n):
     assert a[:4] == b[:4] and np.array_equal(a[4], b[4])
     for u, v in zip(a[5], b[5]):
         assert u is None and v is None or np.array_equal(u, v)
+
+
+@pytest.mark.parametrize("n", [4, 16, 64, 128])
+def test_nm_custom_rosenbrock_equals_builtin_bit_for_bit(mod, n):
+    """Nelder-Mead with a run-time compiled objective (nlsg_nm_create_custom), up to the largest
+    simplex (n = 128: 132 KiB of dynamic LDS through the module launch)."""
+    rng = np.random.default_rng(n)
+    x0 = 0.5 + 0.2 * (rng.random((6, n)) - 0.5)
+    out = []
+    for obj in ("rosenbrock", mod.CustomObjective(ROSENBROCK, chain=True)):
+        with mod.NMEngine(obj, 6, n, eps=0.0, max_iter=120, no_change_best_tol=10**9) as eng:
+            x, st, eps = eng.minimize(x0.copy())
+        out.append((x, [(s.f_value, s.iteration, s.function_calls_used) for s in st]))
+    assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]

@@ -238,9 +238,10 @@ def test_lm_host_path_through_header_matches_reference_bit_exact(built, golden, 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["example_2d", "d4_200iters", "d16_bounded", "d8_restarts"])
-def test_nm_device_objective_through_header_matches_oracle(built, oracle, golden, name):
+@pytest.mark.parametrize("mode", ["nm-device", "nm-device-custom"])
+def test_nm_device_objective_through_header_matches_oracle(built, oracle, golden, name, mode):
     g = golden("nm.json")[name]
-    out = subprocess.check_output([os.path.join(built, "header_nm_lm"), "nm-device", *_nm_args(g)],
+    out = subprocess.check_output([os.path.join(built, "header_nm_lm"), mode, *_nm_args(g)],
                                   env=dict(os.environ, NLSG_LIBRARY=LIB), text=True)
     o = json.loads(out)
     assert "device_error" not in o, o
