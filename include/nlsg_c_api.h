@@ -292,6 +292,10 @@ typedef struct {
 /* diag_host / lin_host: d[dim], b[dim] of the quadratic (copied); NULL for the others. */
 int nlsg_bfgs_create(const nlsg_bfgs_config *cfg, const double *diag_host,
                      const double *lin_host, nlsg_bfgs **out);
+/* cfg->objective == NLSG_OBJ_CUSTOM: a user objective (nlsg_custom_objective, as for
+ * nlsg_de_create_custom) minimised with the default finite-difference gradient; dim <= 256. */
+int nlsg_bfgs_create_custom(const nlsg_bfgs_config *cfg, const nlsg_custom_objective *obj,
+                            nlsg_bfgs **out);
 int nlsg_bfgs_destroy(nlsg_bfgs *e);
 /* x0_host: batch*dim start points (row-major). H = I, g = grad(x0) (3212, 3234). */
 int nlsg_bfgs_init(nlsg_bfgs *e, const double *x0_host);

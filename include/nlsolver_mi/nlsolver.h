@@ -298,6 +298,7 @@ class api {
   decltype(&nlsg_pso_destroy) pso_destroy;
   decltype(&nlsg_pso_minimize) pso_minimize;
   decltype(&nlsg_bfgs_create) bfgs_create;
+  decltype(&nlsg_bfgs_create_custom) bfgs_create_custom;
   decltype(&nlsg_bfgs_destroy) bfgs_destroy;
   decltype(&nlsg_bfgs_minimize) bfgs_minimize;
   decltype(&nlsg_lm_create) lm_create;
@@ -334,6 +335,7 @@ class api {
     bind(h, "nlsg_pso_destroy", pso_destroy);
     bind(h, "nlsg_pso_minimize", pso_minimize);
     bind(h, "nlsg_bfgs_create", bfgs_create);
+    bind(h, "nlsg_bfgs_create_custom", bfgs_create_custom);
     bind(h, "nlsg_bfgs_destroy", bfgs_destroy);
     bind(h, "nlsg_bfgs_minimize", bfgs_minimize);
     bind(h, "nlsg_lm_create", lm_create);
@@ -922,7 +924,8 @@ class BFGS {
                   std::is_same_v<Grad, fin_diff<Callable, scalar_t>>)
       return Callable::nlsg_objective == NLSG_OBJ_ROSENBROCK ||
              Callable::nlsg_objective == NLSG_OBJ_SPHERE ||
-             Callable::nlsg_objective == NLSG_OBJ_STYBLINSKI_TANG;
+             Callable::nlsg_objective == NLSG_OBJ_STYBLINSKI_TANG ||
+             Callable::nlsg_objective == NLSG_OBJ_CUSTOM;
     else
       return false;
   }
@@ -933,7 +936,8 @@ class BFGS {
       x = one[0];
       return st[0];
     } else if constexpr (device_fd()) {
-      if (x.size() > 256) return solve_host(x);  // beyond the device coverage: host functor path
+      if constexpr (Callable::nlsg_objective != NLSG_OBJ_CUSTOM)  // (Custom has no host evaluation)
+        if (x.size() > 256) return solve_host(x);  // beyond the device coverage: host functor path
       std::vector<std::vector<scalar_t>> one{x};
       auto st = minimize_batch(one);
       x = one[0];
@@ -970,7 +974,13 @@ class BFGS {
       api.check(api.bfgs_create(&cfg, f.d.data(), f.b.data(), &eng));
     } else {  // fin_diff (nlsolver.h:2849-2855) evaluated on the device
       cfg.objective = Callable::nlsg_objective;
-      api.check(api.bfgs_create(&cfg, nullptr, nullptr, &eng));
+      if constexpr (Callable::nlsg_objective == NLSG_OBJ_CUSTOM) {
+        api.check(api.rtc_load(std::getenv("NLSG_HIPRTC")));
+        nlsg_custom_objective obj{f.term_body.c_str(), f.finish_body.c_str(), f.chain ? 1 : 0, 0};
+        api.check(api.bfgs_create_custom(&cfg, &obj, &eng));
+      } else {
+        api.check(api.bfgs_create(&cfg, nullptr, nullptr, &eng));
+      }
     }
     std::vector<scalar_t> flat(B * n);
     for (size_t p = 0; p < B; p++) std::copy(xs[p].begin(), xs[p].end(), flat.begin() + p * n);

@@ -43,6 +43,17 @@ class BFGSEngine:
         cfg.batch = batch
         cfg.max_iter, cfg.grad_eps, cfg.alpha = max_iter, grad_eps, alpha
         self._h = C.c_void_p()
+        from .de import CustomObjective, rtc_library_path
+        if isinstance(objective, CustomObjective):  # user objective + finite-difference gradient
+            if dim is None:
+                raise TypeError("a custom objective needs dim=")
+            cfg.objective, cfg.dim, cfg.quad_c = _capi.OBJ_CUSTOM, dim, 0.0
+            self.cfg = cfg
+            check(lib().nlsg_rtc_load(rtc_library_path().encode()))
+            obj = _capi.CustomObjectiveC(objective.term_body.encode(), objective.finish_body.encode(),
+                                         int(objective.chain), 0)
+            check(lib().nlsg_bfgs_create_custom(C.byref(cfg), C.byref(obj), C.byref(self._h)))
+            return
         if isinstance(objective, str):  # built-in objective + finite-difference gradient
             if dim is None:
                 raise TypeError("a built-in objective needs dim=")
@@ -127,7 +138,8 @@ class BFGS:
             raise TypeError("x must be a float64 numpy array of shape (n,) or (batch, n); "
                             "it is updated in place")
         xb = x.reshape(1, -1) if x.ndim == 1 else x
-        extra = dict(dim=xb.shape[1]) if isinstance(self.f, str) else {}
+        from .de import CustomObjective
+        extra = dict(dim=xb.shape[1]) if isinstance(self.f, (str, CustomObjective)) else {}
         with BFGSEngine(self.f, xb.shape[0], **extra, **self.args) as eng:
             out, st = eng.minimize(xb)
         xb[...] = out

@@ -4,10 +4,12 @@
 #include <vector>
 
 #include "nlsg_bfgs_kernels.h"
+#include "nlsg_rtc.h"
 
 using namespace nlsg;
 
 struct nlsg_bfgs {
+  BfgsRtcKernels rtc;  // objective == NLSG_OBJ_CUSTOM: finite-difference kernels hiprtc built
   nlsg_bfgs_config cfg;
   BfgsParams p;
   hipStream_t stream = nullptr;
@@ -80,7 +82,12 @@ namespace {
 void launch_iteration(nlsg_bfgs *e, bool timed) {
   const unsigned wave_grid = static_cast<unsigned>((e->p.batch + 3) / 4);
   const unsigned row_grid = static_cast<unsigned>(e->p.batch * e->bpp);
-  BFGS_DISPATCH_MODEL(bfgs_search_kernel, wave_grid, e->p);
+  if (e->p.model == NLSG_OBJ_CUSTOM) {
+    void *args[] = {&e->p};
+    hipModuleLaunchKernel(e->rtc.search, wave_grid, 1, 1, 256, 1, 1, 0, e->stream, args, nullptr);
+  } else {
+    BFGS_DISPATCH_MODEL(bfgs_search_kernel, wave_grid, e->p);
+  }
   if (timed) hipEventRecord(e->ev2, e->stream);
   BFGS_DISPATCH(bfgs_hy_kernel, row_grid, e->p, e->bpp);
   BFGS_DISPATCH(bfgs_update_kernel, row_grid, e->p, e->bpp);
@@ -105,8 +112,26 @@ int bfgs_check_device(int device) {
 
 extern "C" {
 
+static int bfgs_create(const nlsg_bfgs_config *cfg, const double *diag_host, const double *lin_host,
+                       const nlsg_custom_objective *custom, nlsg_bfgs **out);
+
 int nlsg_bfgs_create(const nlsg_bfgs_config *cfg, const double *diag_host, const double *lin_host,
                      nlsg_bfgs **out) {
+  if (cfg && cfg->objective == NLSG_OBJ_CUSTOM)
+    return fail(NLSG_ERR_INVALID_ARG, "NLSG_OBJ_CUSTOM engines are made by nlsg_bfgs_create_custom");
+  return bfgs_create(cfg, diag_host, lin_host, nullptr, out);
+}
+
+int nlsg_bfgs_create_custom(const nlsg_bfgs_config *cfg, const nlsg_custom_objective *obj,
+                            nlsg_bfgs **out) {
+  if (!cfg || !obj) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  if (cfg->objective != NLSG_OBJ_CUSTOM)
+    return fail(NLSG_ERR_INVALID_ARG, "cfg.objective must be NLSG_OBJ_CUSTOM");
+  return bfgs_create(cfg, nullptr, nullptr, obj, out);
+}
+
+static int bfgs_create(const nlsg_bfgs_config *cfg, const double *diag_host, const double *lin_host,
+                       const nlsg_custom_objective *custom, nlsg_bfgs **out) {
   if (!cfg || !out) return fail(NLSG_ERR_INVALID_ARG, "null argument");
   *out = nullptr;
   if (cfg->struct_size != sizeof(nlsg_bfgs_config))
@@ -114,7 +139,7 @@ int nlsg_bfgs_create(const nlsg_bfgs_config *cfg, const double *diag_host, const
                 cfg->struct_size, sizeof(nlsg_bfgs_config));
   const bool quad = cfg->objective == NLSG_OBJ_QUAD_DIAG_RANK1;
   const bool fd = cfg->objective == NLSG_OBJ_ROSENBROCK || cfg->objective == NLSG_OBJ_SPHERE ||
-                  cfg->objective == NLSG_OBJ_STYBLINSKI_TANG;
+                  cfg->objective == NLSG_OBJ_STYBLINSKI_TANG || custom != nullptr;
   if (!quad && !fd) return fail(NLSG_ERR_INVALID_ARG, "unknown objective %d", cfg->objective);
   if (quad && (!diag_host || !lin_host))
     return fail(NLSG_ERR_INVALID_ARG, "the quadratic needs its d and b vectors");
@@ -194,6 +219,13 @@ int nlsg_bfgs_create(const nlsg_bfgs_config *cfg, const double *diag_host, const
   p.alpha = cfg->alpha;
   p.qc = cfg->quad_c;
   p.model = quad ? kBfgsQuad : cfg->objective;
+  if (custom) {
+    const int rc2 = rtc_build_bfgs(custom, e->chunks, e->vec, &e->rtc);
+    if (rc2) {
+      nlsg_bfgs_destroy(e);
+      return rc2;
+    }
+  }
   *out = e;
   return NLSG_OK;
 }
@@ -210,6 +242,7 @@ int nlsg_bfgs_destroy(nlsg_bfgs *e) {
   hipFree(e->p.y);
   hipFree(e->p.t);
   hipFree(e->p.prob);
+  rtc_release(&e->rtc);
   hipFree(e->qd_dev);
   hipFree(e->qb_dev);
   hipFree(e->zero_dev);
@@ -227,7 +260,13 @@ int nlsg_bfgs_init(nlsg_bfgs *e, const double *x0_host) {
   NLSG_HIP(hipMemcpyAsync(e->p.x, x0_host, e->p.batch * e->p.n * sizeof(double),
                           hipMemcpyHostToDevice, e->stream));
   NLSG_HIP(hipStreamSynchronize(e->stream));
-  BFGS_DISPATCH_MODEL(bfgs_init_kernel, static_cast<unsigned>((e->p.batch + 3) / 4), e->p);
+  if (e->p.model == NLSG_OBJ_CUSTOM) {
+    void *args[] = {&e->p};
+    hipModuleLaunchKernel(e->rtc.init, static_cast<unsigned>((e->p.batch + 3) / 4), 1, 1, 256, 1, 1,
+                          0, e->stream, args, nullptr);
+  } else {
+    BFGS_DISPATCH_MODEL(bfgs_init_kernel, static_cast<unsigned>((e->p.batch + 3) / 4), e->p);
+  }
   NLSG_HIP(hipGetLastError());
   e->initialised = true;
   return NLSG_OK;

@@ -20,6 +20,12 @@ struct PsoRtcKernels {
 // Compiles de_init / de_generation / de_turn kernels for the objective, CHUNKS = chunks, VEC = vec.
 int rtc_build_de(const nlsg_custom_objective *obj, int chunks, bool vec, DeRtcKernels *out);
 void rtc_release(DeRtcKernels *k);
+struct BfgsRtcKernels {  // finite-difference model around the user's objective
+  hipModule_t mod = nullptr;
+  hipFunction_t init = nullptr, search = nullptr;
+};
+int rtc_build_bfgs(const nlsg_custom_objective *obj, int chunks, bool vec, BfgsRtcKernels *out);
+void rtc_release(BfgsRtcKernels *k);
 struct NmRtcKernels {
   hipModule_t mod = nullptr;
   hipFunction_t solve = nullptr;

@@ -171,6 +171,26 @@ int rtc_build_pso(const nlsg_custom_objective *obj, int chunks, bool vec, int ty
   return NLSG_OK;
 }
 
+int rtc_build_bfgs(const nlsg_custom_objective *obj, int chunks, bool vec, BfgsRtcKernels *out) {
+  // <CHUNKS, VEC, MODEL>: MODEL = the objective id selects the finite-difference BfgsModel
+  const std::string t = std::to_string(chunks) + ", " + (vec ? "true" : "false") + ", " +
+                        std::to_string(static_cast<int>(NLSG_OBJ_CUSTOM));
+  std::vector<hipFunction_t> f;
+  BfgsRtcKernels k;
+  const int rc = rtc_compile(obj, "nlsg_bfgs_kernels.h",
+                             {"nlsg::bfgs_init_kernel<" + t + ">", "nlsg::bfgs_search_kernel<" + t + ">"},
+                             &k.mod, &f);
+  if (rc) return rc;
+  k.init = f[0];
+  k.search = f[1];
+  *out = k;
+  return NLSG_OK;
+}
+void rtc_release(BfgsRtcKernels *k) {
+  if (k && k->mod) hipModuleUnload(k->mod);
+  if (k) *k = BfgsRtcKernels();
+}
+
 int rtc_build_nm(const nlsg_custom_objective *obj, NmRtcKernels *out) {
   std::vector<hipFunction_t> f;
   NmRtcKernels k;

@@ -103,6 +103,27 @@ int main(int argc, char **argv) {
     }
     return 0;
   }
+  if (argc >= 8 && !std::strcmp(argv[1], "device-fd-custom")) {
+    // the same with the objective given as source text
+    const size_t n = std::strtoull(argv[2], nullptr, 10);
+    nlsolver::device::Custom<double> prob(
+        "double t1 = 1 - xi; double t2 = (xn - xi * xi); return t1 * t1 + 100 * t2 * t2;", true);
+    auto solver = nlsolver::BFGS<decltype(prob), double>(prob, {}, std::strtoull(argv[3], nullptr, 10),
+                                                         std::strtod(argv[4], nullptr),
+                                                         std::strtod(argv[5], nullptr));
+    std::vector<double> x(n);
+    for (size_t i = 0; i < n; i++)
+      x[i] = std::strtod(argv[6], nullptr) + std::strtod(argv[7], nullptr) * static_cast<double>(i);
+    try {
+      auto st = solver.minimize(x);
+      print_status(st, x);
+      std::printf("\n");
+    } catch (const nlsolver::device_error &e) {
+      std::printf("{\"device_error\":\"%s\"}\n", e.what());
+      return 3;
+    }
+    return 0;
+  }
   if (argc >= 8 && !std::strcmp(argv[1], "device-fd")) {
     // the reference's default-gradient call, objective type swapped for the device one:
     // BFGS<Rosenbrock, double>(prob).minimize(x) (example.cpp:171-173)

@@ -122,3 +122,23 @@ def test_nm_custom_rosenbrock_equals_builtin_bit_for_bit(mod, n):
             x, st, eps = eng.minimize(x0.copy())
         out.append((x, [(s.f_value, s.iteration, s.function_calls_used) for s in st]))
     assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
+
+
+@pytest.mark.parametrize("n", [4, 128, 200])
+def test_bfgs_finite_difference_on_custom_objective_equals_builtin(mod, oracle, n):
+    """BFGS with the default finite-difference gradient around a run-time compiled objective
+    (nlsg_bfgs_create_custom): same iterates, value and counters as the built-in model, hence
+    as the tree oracle."""
+    rng = np.random.default_rng(n)
+    x0 = 0.8 + 0.4 * (rng.random((3, n)) - 0.5)
+    kw = dict(max_iter=5, grad_eps=0.0, alpha=1.0)
+    with mod.BFGSEngine("rosenbrock", 3, dim=n, **kw) as eng:
+        xa, sa = eng.minimize(x0.copy())
+    with mod.BFGSEngine(mod.CustomObjective(ROSENBROCK, chain=True), 3, dim=n, **kw) as eng:
+        xb, sb = eng.minimize(x0.copy())
+    assert np.array_equal(xa, xb)
+    for a, b in zip(sa, sb):
+        assert (a.f_value, a.iteration, a.function_calls_used, a.gradient_evals_used) == \
+            (b.f_value, b.iteration, b.function_calls_used, b.gradient_evals_used)
+    ref, xr, _, _ = O.bfgs_fd(oracle, "rosenbrock", x0[0], tree=1, **kw)
+    assert np.array_equal(xb[0], xr) and sb[0].f_value == ref.f_value

@@ -181,13 +181,14 @@ def test_bfgs_device_batch_through_header_matches_oracle(built, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["device-fd", "device-fd-custom"])
 @pytest.mark.parametrize("n", [2, 16, 128])
-def test_bfgs_default_gradient_on_device_objective_through_header(built, oracle, n):
+def test_bfgs_default_gradient_on_device_objective_through_header(built, oracle, n, mode):
     """BFGS<device::Rosenbrock<double>>(f).minimize(x): the default fin_diff gradient runs on the
     GPU (nlsolver.h:1385-1413 restated in the search kernel); bit-exact vs the tree oracle."""
     args = dict(max_iter=8, grad_eps=0.0, alpha=1.0)
     out = subprocess.check_output(
-        [os.path.join(built, "header_bfgs"), "device-fd", str(n), "8", "0.0", "1.0", "0.9", "0.001"],
+        [os.path.join(built, "header_bfgs"), mode, str(n), "8", "0.0", "1.0", "0.9", "0.001"],
         env=dict(os.environ, NLSG_LIBRARY=LIB), text=True)
     o = json.loads(out)
     assert "device_error" not in o, o
