@@ -216,8 +216,8 @@ def main_lm(args):
     """BASELINE configs[3]: Levenberg-Marquardt NLLS m=512, n=64, batch=8192 on one GPU
     (tanh regression, 20 iterations, lambda0 = 10, up = down = 10, f_delta = 0). One step = one
     LM iteration of every problem: residuals + J^T J (fp64 MFMA) + J^T r, damped Cholesky solve,
-    update. Cholesky solver: two kernels per iteration for all problems in lock step (evaluation:
-    one wave per problem; step: one wave per problem); QR solver: one persistent workgroup per
+    update. Cholesky solver: one launch per iteration for all problems in lock step (one wave per
+    problem: step, then evaluation); QR solver: one persistent workgroup per
     problem runs the whole solve. The timed region is the whole solve divided by its iteration
     count; the roofline object describes the evaluation kernel timed on its own."""
     import torch
@@ -247,10 +247,11 @@ def main_lm(args):
         kname, kms = "lm_solve_kernel<qr>", ms
         flops = 2.0 * m * 10 * 256 * evals * batch
     else:
-        # dominant kernel of the split pipeline, timed on its own: ten lower 16 x 16 tiles of
-        # J^T J per 4-row k-step are what the matrix cores execute (the matrix is symmetric)
+        # the iteration kernel's evaluation half, timed on its own (first-launch form: no step):
+        # ten lower 16 x 16 tiles of J^T J per 4-row k-step are what the matrix cores execute
+        # (the matrix is symmetric)
         eng.time_eval_kernel(theta0, 60)  # untimed: clocks back up after the host-side pauses
-        kname, kms = "lm_eval_wave_kernel", eng.time_eval_kernel(theta0, 20) / 20
+        kname, kms = "lm_iter_kernel (evaluation-only launches)", eng.time_eval_kernel(theta0, 20) / 20
         flops = 2.0 * m * 10 * 256 * batch
     tflops = flops / (kms * 1e-3) / 1e12
     hbm_gbps = hbm_eval * (evals if args.lm_solver == "qr" else 1) / (kms * 1e-3) / 1e9
@@ -265,7 +266,7 @@ def main_lm(args):
         "roofline": {"bound": "mfma", "achieved": tflops, "peak": 78.6, "unit": "TFLOP/s",
                      "frac": tflops / 78.6,
                      "traffic": None if args.lm_solver == "qr" else pmc_bytes(
-                         "lm", ["lm_eval_wave_kernel"], batch == 8192),
+                         "lm", ["lm_iter_kernel"], batch == 8192),
                      "kernel": kname,
                      "kernel_ms": kms, "algorithmic_flops_per_launch": flops,
                      "hbm_GBps": hbm_gbps, "hbm_frac": hbm_gbps / 8000.0},

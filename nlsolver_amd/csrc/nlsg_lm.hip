@@ -44,8 +44,9 @@ int upload_theta(nlsg_lm *e, const double *theta_host) {
 }
 
 // QR solver: one persistent workgroup per problem runs the whole solve in one launch.
-// Cholesky solver: split pipeline, all problems in lock step (eval kernel, step kernel); the
-// host polls the number of unfinished problems every few iterations.
+// Cholesky solver: all problems in lock step, one launch per iteration (step k, then evaluation
+// k + 1, one wave per problem); the host polls the number of unfinished problems every few
+// iterations.
 int launch_solve(nlsg_lm *e) {
   const dim3 grid(static_cast<unsigned>(e->p.batch));
   if (e->cfg.solver == NLSG_LM_QR) {
@@ -53,15 +54,14 @@ int launch_solve(nlsg_lm *e) {
                        sizeof(LmShared) + sizeof(LmQrShared), e->stream, e->p);
     return NLSG_OK;
   }
-  hipLaunchKernelGGL(lm_eval_wave_kernel, grid, dim3(64), 0, e->stream, e->p, 1);
+  hipLaunchKernelGGL(lm_iter_kernel, grid, dim3(64), 0, e->stream, e->p, 1);
   uint64_t launched = 0;
   for (;;) {
     // max_iter iterations plus the turn whose stop test fires
     const uint64_t left = e->p.max_iter + 1 - launched;
     const uint64_t chunk = left < 8 ? left : 8;
     for (uint64_t i = 0; i < chunk; i++) {
-      hipLaunchKernelGGL(lm_step_kernel, grid, dim3(64), 0, e->stream, e->p);
-      hipLaunchKernelGGL(lm_eval_wave_kernel, grid, dim3(64), 0, e->stream, e->p, 0);
+      hipLaunchKernelGGL(lm_iter_kernel, grid, dim3(64), 0, e->stream, e->p, 0);
     }
     launched += chunk;
     if (launched >= e->p.max_iter + 1) break;
@@ -266,7 +266,7 @@ int nlsg_lm_time_eval_kernel(nlsg_lm *e, const double *theta0_host, uint32_t rep
   float total = 0.f;
   for (uint32_t r = 0; r < repeats; r++) {
     NLSG_HIP(hipEventRecord(e->ev0, e->stream));
-    hipLaunchKernelGGL(lm_eval_wave_kernel, dim3(static_cast<unsigned>(e->p.batch)), dim3(64), 0,
+    hipLaunchKernelGGL(lm_iter_kernel, dim3(static_cast<unsigned>(e->p.batch)), dim3(64), 0,
                        e->stream, e->p, 1);
     NLSG_HIP(hipEventRecord(e->ev1, e->stream));
     NLSG_HIP(hipEventSynchronize(e->ev1));

@@ -457,30 +457,33 @@ __global__ __launch_bounds__(256) void lm_solve_kernel(LmParams p) {
   }
 }
 
-// ---- split pipeline (Cholesky solver): all problems advance in lock step -----------------
-// lm_eval_wave_kernel  one WAVE per problem: f, g, H at theta. The wave streams its m x 64
+// ---- Cholesky solver: all problems advance in lock step, ONE WAVE per problem, one launch per
+// iteration (lm_iter_kernel = step k, then evaluation k + 1). Running both in one launch lets a
+// wave's latency-bound solve sit beside the other waves' MFMA phases instead of in a kernel of
+// its own, and saves a launch; H and g still travel through global memory between launches.
+// lm_eval_wave         f, g, H at theta. The wave streams its m x 64
 //                      block of A sixteen rows at a time (next sixteen in flight meanwhile),
 //                      scales them into a wave-private LDS tile and feeds all ten lower
 //                      16 x 16 tiles of J^T J from it. No workgroup barrier anywhere: the
 //                      waves of a SIMD drift apart, so one wave's load / tanh phase is covered
 //                      by the others' MFMA phases (fp64 MFMA and fp64 VALU share the DP pipe,
 //                      the bound is their sum).
-// lm_step_kernel       one WAVE per problem: stop tests, damping, Cholesky solve, theta update
+// lm_step_wave         stop tests, damping, Cholesky solve, theta update
 // Same reduction structure as lm_evaluate (rows -> k-steps of 4, f partials per (row/16 % 4,
 // row parity), g partials per row % 4), hence the same bits.
-struct LmWaveShared {
-  double J[16 * kLmJStride];
-  double r[16];
+struct LmWaveShared {  // view of the wave's LDS during the evaluation
+  double *J;           // [16][kLmJStride]
+  double *r;           // [16]
 };
 
-__global__ __launch_bounds__(64, 2) void lm_eval_wave_kernel(LmParams p, int first) {
-  __shared__ LmWaveShared sh;
-  const uint64_t pid = blockIdx.x;
+// theta_lds: the parameters as the step left them in LDS (nullptr: read them from global)
+__device__ inline void lm_eval_wave(const LmParams &p, int first, uint64_t pid, LmWaveShared sh,
+                                    const double *theta_lds) {
   LmProblem *pr = p.prob + pid;
-  if (!first && pr->done) return;
   const int lane = threadIdx.x;
   const int half = lane >> 5, lp = lane & 31, kk = lane >> 4, cc = lane & 15;
-  const double th0 = p.theta[pid * kLmN + 2 * lp], th1 = p.theta[pid * kLmN + 2 * lp + 1];
+  const double *theta = theta_lds ? theta_lds : p.theta + pid * kLmN;
+  const double th0 = theta[2 * lp], th1 = theta[2 * lp + 1];
   // device layout of A: [row group s][problem][16 rows][64], zero padded past m; y alike
   const double *Ap = p.A + pid * (16 * kLmN) + 2 * lp;
   const double *yp = p.y + pid * 16 + 2 * (lp & 7) + half;
@@ -599,21 +602,19 @@ __global__ __launch_bounds__(64, 2) void lm_eval_wave_kernel(LmParams p, int fir
   }
 }
 
-struct LmStepShared {  // per wave
-  double tri[kLmTri];
-  double g[64], upd[64];
+struct LmStepShared {  // view of the wave's LDS during the step
+  double *tri;         // [kLmTri]
+  double *g, *upd;     // [64] each; upd ends up holding the new parameters
 };
 
-__global__ __launch_bounds__(64) void lm_step_kernel(LmParams p) {
-  __shared__ LmStepShared sh;
-  const uint64_t pid = blockIdx.x;
+// false: a stop test fired (the problem is done)
+__device__ inline bool lm_step_wave(const LmParams &p, uint64_t pid, LmStepShared sh) {
   LmProblem *pr = p.prob + pid;
-  if (pr->done) return;
   const int t = threadIdx.x, n = static_cast<int>(p.n);
   const double prev = pr->prev, cur = pr->f;
   if (pr->iter >= p.max_iter || fabs(prev - cur) < p.f_delta || isnan(prev)) {  // :3520-3527
     if (t == 0) pr->done = 1;
-    return;
+    return false;
   }
   {  // all loads in flight before the first LDS write (the pad holds stale, unused values)
     const double *src = p.Hg + pid * kLmTri;
@@ -631,7 +632,31 @@ __global__ __launch_bounds__(64) void lm_step_kernel(LmParams p) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   lm_solve_cholesky_wave(LmRowsTri{sh.tri}, sh.g, sh.upd, n);
-  if (t < n) p.theta[pid * kLmN + t] = p.theta[pid * kLmN + t] - sh.upd[t];  // :3534
+  const double th = p.theta[pid * kLmN + t];
+  const double tn = t < n ? th - sh.upd[t] : th;  // :3534
+  p.theta[pid * kLmN + t] = tn;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  sh.upd[t] = tn;  // handed to the evaluation of the same launch
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  return true;
+}
+
+// One launch per iteration: step k (skipped on the first launch), then evaluation k + 1.
+// LDS of the wave: the step's packed triangle | g | upd, overlaid by the evaluation's Jacobian
+// tile | r (the new parameters wait in `upd`, which the tile does not reach).
+__global__ __launch_bounds__(64, 2) void lm_iter_kernel(LmParams p, int first) {
+  __shared__ __align__(16) double smem[kLmTri + 128];
+  static_assert(16 * kLmJStride + 16 <= kLmTri + 64, "the Jacobian tile must not reach upd");
+  const uint64_t pid = blockIdx.x;
+  const double *theta_lds = nullptr;
+  if (!first) {
+    if (p.prob[pid].done) return;
+    if (!lm_step_wave(p, pid, LmStepShared{smem, smem + kLmTri, smem + kLmTri + 64})) return;
+    theta_lds = smem + kLmTri + 64;
+  }
+  lm_eval_wave(p, first, pid, LmWaveShared{smem, smem + 16 * kLmJStride}, theta_lds);
 }
 
 // host layout -> device layout of A and y (see nlsg_lm_set_data)
