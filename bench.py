@@ -217,8 +217,8 @@ def main_lm(args):
     (tanh regression, 20 iterations, lambda0 = 10, up = down = 10, f_delta = 0). One step = one
     LM iteration of every problem: residuals + J^T J (fp64 MFMA) + J^T r, damped Cholesky solve,
     update. Cholesky solver: one launch per iteration for all problems in lock step (one wave per
-    problem: step, then evaluation); QR solver: one persistent workgroup per
-    problem runs the whole solve. The timed region is the whole solve divided by its iteration
+    problem: step, then evaluation); QR solver: a step kernel (one workgroup per problem) between
+    evaluation launches. The timed region is the whole solve divided by its iteration
     count; the roofline object describes the evaluation kernel timed on its own."""
     import torch
 
@@ -242,19 +242,13 @@ def main_lm(args):
     th, st, lam = eng.minimize(theta0.copy())
     evals = iters + 1
     hbm_eval = (m * 64 * 8 + m * 8) * batch  # A and y streamed once per evaluation
-    if args.lm_solver == "qr":
-        # one persistent kernel runs the whole solve: full-launch figures
-        kname, kms = "lm_solve_kernel<qr>", ms
-        flops = 2.0 * m * 10 * 256 * evals * batch
-    else:
-        # the iteration kernel's evaluation half, timed on its own (first-launch form: no step):
-        # ten lower 16 x 16 tiles of J^T J per 4-row k-step are what the matrix cores execute
-        # (the matrix is symmetric)
-        eng.time_eval_kernel(theta0, 60)  # untimed: clocks back up after the host-side pauses
-        kname, kms = "lm_iter_kernel (evaluation-only launches)", eng.time_eval_kernel(theta0, 20) / 20
-        flops = 2.0 * m * 10 * 256 * batch
+    # the evaluation launch (both solvers share it), timed on its own: ten lower 16 x 16 tiles of
+    # J^T J per 4-row k-step are what the matrix cores execute (the matrix is symmetric)
+    eng.time_eval_kernel(theta0, 60)  # untimed: clocks back up after the host-side pauses
+    kname, kms = "lm_iter_kernel (evaluation-only launches)", eng.time_eval_kernel(theta0, 20) / 20
+    flops = 2.0 * m * 10 * 256 * batch
     tflops = flops / (kms * 1e-3) / 1e12
-    hbm_gbps = hbm_eval * (evals if args.lm_solver == "qr" else 1) / (kms * 1e-3) / 1e9
+    hbm_gbps = hbm_eval / (kms * 1e-3) / 1e9
     print(json.dumps({
         "metric": "LM iterations x problems / s (NLLS m=512 n=64)",
         "value": batch * iters / (ms * 1e-3), "unit": "iteration-problems/s", "n_gpus": 1,
@@ -262,11 +256,12 @@ def main_lm(args):
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"Levenberg-Marquardt tanh-regression NLLS m={m} n={n}, "
                                f"batch={batch} (BASELINE configs[3]), {args.lm_solver} solve",
-                   "max_final_f": max(s.f_value for s in st)},
+                   "max_final_f": max(s.f_value for s in st),
+                   # what an iteration spends outside the evaluation launch (the damped solve)
+                   "solve_ms_per_iteration": ms / iters - kms * evals / iters},
         "roofline": {"bound": "mfma", "achieved": tflops, "peak": 78.6, "unit": "TFLOP/s",
                      "frac": tflops / 78.6,
-                     "traffic": None if args.lm_solver == "qr" else pmc_bytes(
-                         "lm", ["lm_iter_kernel"], batch == 8192),
+                     "traffic": pmc_bytes("lm", ["lm_iter_kernel"], batch == 8192),
                      "kernel": kname,
                      "kernel_ms": kms, "algorithmic_flops_per_launch": flops,
                      "hbm_GBps": hbm_gbps, "hbm_frac": hbm_gbps / 8000.0},

@@ -43,25 +43,26 @@ int upload_theta(nlsg_lm *e, const double *theta_host) {
   return NLSG_OK;
 }
 
-// QR solver: one persistent workgroup per problem runs the whole solve in one launch.
-// Cholesky solver: all problems in lock step, one launch per iteration (step k, then evaluation
-// k + 1, one wave per problem); the host polls the number of unfinished problems every few
-// iterations.
+// All problems in lock step; the host polls the number of unfinished problems every few
+// iterations. Cholesky solver: one launch per iteration (step k, then evaluation k + 1, one wave
+// per problem). QR solver: the step is a kernel of its own (one workgroup per problem) between
+// two evaluation launches.
 int launch_solve(nlsg_lm *e) {
   const dim3 grid(static_cast<unsigned>(e->p.batch));
-  if (e->cfg.solver == NLSG_LM_QR) {
-    hipLaunchKernelGGL(lm_solve_kernel<true>, grid, dim3(256),
-                       sizeof(LmShared) + sizeof(LmQrShared), e->stream, e->p);
-    return NLSG_OK;
-  }
-  hipLaunchKernelGGL(lm_iter_kernel, grid, dim3(64), 0, e->stream, e->p, 1);
+  const bool qr = e->cfg.solver == NLSG_LM_QR;
+  hipLaunchKernelGGL(lm_iter_kernel, grid, dim3(64), 0, e->stream, e->p, 1, 0);
   uint64_t launched = 0;
   for (;;) {
     // max_iter iterations plus the turn whose stop test fires
     const uint64_t left = e->p.max_iter + 1 - launched;
     const uint64_t chunk = left < 8 ? left : 8;
     for (uint64_t i = 0; i < chunk; i++) {
-      hipLaunchKernelGGL(lm_iter_kernel, grid, dim3(64), 0, e->stream, e->p, 0);
+      if (qr) {
+        hipLaunchKernelGGL(lm_qr_step_kernel, grid, dim3(256), sizeof(LmQrShared), e->stream, e->p);
+        hipLaunchKernelGGL(lm_iter_kernel, grid, dim3(64), 0, e->stream, e->p, 0, 0);
+      } else {
+        hipLaunchKernelGGL(lm_iter_kernel, grid, dim3(64), 0, e->stream, e->p, 0, 1);
+      }
     }
     launched += chunk;
     if (launched >= e->p.max_iter + 1) break;
@@ -127,12 +128,8 @@ int nlsg_lm_create(const nlsg_lm_config *cfg, nlsg_lm **out) {
   if (he == hipSuccess) he = hipEventCreate(&e->ev0);
   if (he == hipSuccess) he = hipEventCreate(&e->ev1);
   if (he == hipSuccess)
-    he = hipFuncSetAttribute(reinterpret_cast<const void *>(lm_solve_kernel<false>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, sizeof(LmShared));
-  if (he == hipSuccess)
-    he = hipFuncSetAttribute(reinterpret_cast<const void *>(lm_solve_kernel<true>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize,
-                             sizeof(LmShared) + sizeof(LmQrShared));
+    he = hipFuncSetAttribute(reinterpret_cast<const void *>(lm_qr_step_kernel),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, sizeof(LmQrShared));
   if (he != hipSuccess) {
     nlsg_lm_destroy(e);
     return fail(he == hipErrorOutOfMemory ? NLSG_ERR_OOM : NLSG_ERR_HIP,
@@ -267,7 +264,7 @@ int nlsg_lm_time_eval_kernel(nlsg_lm *e, const double *theta0_host, uint32_t rep
   for (uint32_t r = 0; r < repeats; r++) {
     NLSG_HIP(hipEventRecord(e->ev0, e->stream));
     hipLaunchKernelGGL(lm_iter_kernel, dim3(static_cast<unsigned>(e->p.batch)), dim3(64), 0,
-                       e->stream, e->p, 1);
+                       e->stream, e->p, 1, 0);
     NLSG_HIP(hipEventRecord(e->ev1, e->stream));
     NLSG_HIP(hipEventSynchronize(e->ev1));
     NLSG_HIP(hipGetLastError());

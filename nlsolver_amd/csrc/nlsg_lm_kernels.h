@@ -5,18 +5,20 @@
 // forwardsolve_inplace / backsolve_inplace_t / is_diagonal / get_update_with_hessian
 // nlsolver.h:251-330.
 //
-// One persistent 256-thread workgroup per problem runs the whole solve (problems
-// converge independently; no lock step). Per evaluation the design matrix A (m x 64 fp64,
-// 256 KiB at m = 512) is streamed ONCE from HBM in 64-row blocks:
+// nlsolver.h:251-330, and tinyqr::lm (tinyqr.h:253-310, 437-470) as the alternative solver.
+//
+// All problems advance in lock step, one launch per iteration (see lm_iter_kernel below). Per
+// evaluation the design matrix A (m x 64 fp64, 256 KiB at m = 512) is streamed ONCE from HBM,
+// sixteen rows at a time by the problem's wave:
 //   global -> registers (1 KiB coalesced per wave instruction) -> z = A theta by a 32-lane
 //   butterfly -> tanh, residual, weight -> scaled Jacobian rows -> LDS (row stride 80 doubles:
 //   conflict-free ds_read_b64 for the MFMA operand pattern) -> J^T J on the fp64 matrix
-//   cores: 16 tiles of v_mfma_f64_16x16x4_f64 (4 per wave, A operand shared), J^T r on the
-//   VALU from the same A operand.
+//   cores (v_mfma_f64_16x16x4_f64, the ten lower 16 x 16 tiles), J^T r on the VALU from the
+//   same operands.
 // fp64 MFMA is a k-ordered fma chain (verified on gfx950), so H = 2 * fma-chain over the
 // rows in order; the CPU restatement (oracle_lm.c, order = 1) mirrors every sum.
-// The damped system is solved in LDS: column-parallel Cholesky (same per-element
-// arithmetic as the reference's row order), column-sweep forward/back substitution.
+// The damped system is solved in LDS: one-wave Cholesky (same per-element arithmetic as the
+// reference's row order) with column-sweep substitutions, or wavefront Givens QR.
 #pragma once
 
 #include "nlsg_common.h"
@@ -38,206 +40,25 @@ struct LmProblem {
 };
 
 struct LmParams {
-  const double *A;   // [batch][m][64]
-  const double *y;   // [batch][m]
+  const double *A;   // [row group][batch][16][64] (zero padded), see nlsg_lm_set_data
+  const double *y;   // [row group][batch][16]
   double *theta;     // [batch][64]
   LmProblem *prob;   // [batch]
   const double *zero;
   uint64_t batch, m, n, max_iter;
   uint64_t nstep;    // ceil(m / 16): row groups of the device layout of A and y
   double lambda0, up, down, f_delta;
-  double *Hg;        // [batch][kLmTri] lower triangle of 2 J^T J, packed by rows (split pipeline)
-  double *gg;        // [batch][64] 2 J^T r (split pipeline)
+  double *Hg;        // [batch][kLmTri] lower triangle of 2 J^T J, packed by rows
+  double *gg;        // [batch][64] 2 J^T r
 };
 
-struct LmQrShared {               // extra LDS of the QR solver
-  double Q[64 * kLmHStride];     // the orthogonal factor's transpose, rotated alongside R
-  double c[32], s[32];           // Givens coefficients of the current wavefront step
-};
-
-struct LmShared {
-  double J[64 * kLmJStride];  // scaled Jacobian block
-  double H[64 * kLmHStride];  // 2 J^T J (+ lambda I), then its Cholesky factor
-  double r[64];               // residuals of the block
-  double theta[64], g[64], upd[64], sum[64];
-  double gpart[4][64];
-  double fpart[8];
-  int flag;
-};
-
-// Row accessors of the damped matrix for the Cholesky solve: full rows with a padded stride
-// (persistent kernel) or the packed lower triangle (split pipeline; the solve only reads
-// H[i][j] with j <= i: Cholesky, both substitutions, and is_diagonal by symmetry).
-struct LmRowsFull {
-  double *base;
-  __device__ double &operator()(int i, int j) const { return base[i * kLmHStride + j]; }
-};
+// The damped matrix as the Cholesky solve sees it: the packed lower triangle (the solve only
+// reads H[i][j] with j <= i: Cholesky, both substitutions, and is_diagonal by symmetry).
 struct LmRowsTri {
   double *base;
   __device__ double &operator()(int i, int j) const { return base[i * (i + 1) / 2 + j]; }
 };
 
-// LDS-only workgroup barrier: __syncthreads() also drains vmcnt, which would stall on the
-// global prefetch of the next row block issued just before it.
-__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// 2 J^T J is bitwise symmetric (every element is one k-ordered fma chain of commuting
-// products), so only the 10 lower 16 x 16 tiles are computed. For v_mfma_f64_16x16x4 the A
-// operand of column block b (A[i][k] = J[k][16b+i]) and its B operand (B[k][j] = J[k][16b+j])
-// are the same register, so a role needs one LDS read per distinct block:
-//   role 0: (0,0) (1,0) (3,0)   role 1: (1,1) (3,1)   role 2: (2,0) (2,1) (2,2)   role 3: (3,2) (3,3)
-// Role r also accumulates J^T r for block r (always among its operands).
-template <int ROLE>
-struct LmTiles;
-template <>
-struct LmTiles<0> { static constexpr int n = 3, rb[3] = {0, 1, 3}, cb[3] = {0, 0, 0}; };
-template <>
-struct LmTiles<1> { static constexpr int n = 2, rb[3] = {1, 3, 0}, cb[3] = {1, 1, 0}; };
-template <>
-struct LmTiles<2> { static constexpr int n = 3, rb[3] = {2, 2, 2}, cb[3] = {0, 1, 2}; };
-template <>
-struct LmTiles<3> { static constexpr int n = 2, rb[3] = {3, 3, 0}, cb[3] = {2, 3, 0}; };
-
-template <int ROLE>
-__device__ inline void lm_mfma_block(const double *J, const double *r, v4d (&acc)[3], double &gacc) {
-  using T = LmTiles<ROLE>;
-  const int lane = lane_id();
-  const int kk = lane >> 4, cc = lane & 15;
-  constexpr bool need[4] = {
-      T::rb[0] == 0 || T::cb[0] == 0 || (T::n > 1 && (T::rb[1] == 0 || T::cb[1] == 0)) || (T::n > 2 && (T::rb[2] == 0 || T::cb[2] == 0)),
-      T::rb[0] == 1 || T::cb[0] == 1 || (T::n > 1 && (T::rb[1] == 1 || T::cb[1] == 1)) || (T::n > 2 && (T::rb[2] == 1 || T::cb[2] == 1)),
-      T::rb[0] == 2 || T::cb[0] == 2 || (T::n > 1 && (T::rb[1] == 2 || T::cb[1] == 2)) || (T::n > 2 && (T::rb[2] == 2 || T::cb[2] == 2)),
-      T::rb[0] == 3 || T::cb[0] == 3 || (T::n > 1 && (T::rb[1] == 3 || T::cb[1] == 3)) || (T::n > 2 && (T::rb[2] == 3 || T::cb[2] == 3))};
-#pragma unroll 4
-  for (int ks = 0; ks < 16; ks++) {
-    const double *row = &J[(4 * ks + kk) * kLmJStride];
-    double op[4];
-#pragma unroll
-    for (int b = 0; b < 4; b++) op[b] = need[b] ? row[16 * b + cc] : 0.0;
-    gacc = gacc + op[ROLE] * r[4 * ks + kk];
-#pragma unroll
-    for (int i = 0; i < T::n; i++)
-      acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[T::rb[i]], op[T::cb[i]], acc[i], 0, 0, 0);
-  }
-}
-
-template <int ROLE, bool TO_GLOBAL, typename SH>
-__device__ inline void lm_publish_tiles(const LmParams &p, SH &sh, uint64_t pid, const v4d (&acc)[3]) {
-  using T = LmTiles<ROLE>;
-  const int lane = lane_id();
-  const int kk = lane >> 4, cc = lane & 15;
-#pragma unroll
-  for (int i = 0; i < T::n; i++)
-#pragma unroll
-    for (int rg = 0; rg < 4; rg++) {
-      const int row = 16 * T::rb[i] + kk + 4 * rg, col = 16 * T::cb[i] + cc;
-      const double v = 2 * acc[i][rg];
-      if constexpr (TO_GLOBAL) {
-        if (col <= row) p.Hg[pid * kLmTri + row * (row + 1) / 2 + col] = v;
-      } else {
-        sh.H[row * kLmHStride + col] = v;
-        sh.H[col * kLmHStride + row] = v;  // mirror (diagonal tiles rewrite identical bits)
-      }
-    }
-}
-
-// f, g, H at sh.theta. Every thread returns f. TO_GLOBAL: the lower triangle of H and g go
-// to p.Hg / p.gg (split pipeline) instead of sh.H / sh.g.
-template <bool TO_GLOBAL, typename SH>
-__device__ inline double lm_evaluate(const LmParams &p, SH &sh, uint64_t pid) {
-  const int lane = lane_id();
-  const int w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
-  // odd problems swap the 3-tile and 2-tile roles so every SIMD sees the same MFMA load
-  const int role = w ^ static_cast<int>(pid & 1);
-  const int half = lane >> 5, lp = lane & 31;
-  const double th0 = sh.theta[2 * lp], th1 = sh.theta[2 * lp + 1];
-  v4d acc[3];
-#pragma unroll
-  for (int c = 0; c < 3; c++) acc[c] = v4d{0.0, 0.0, 0.0, 0.0};
-  double gacc = 0.0, facc = 0.0;
-  const uint64_t nblk = (p.m + 63) / 64;
-  // ---- stream 64 rows per block: two rows per wave instruction, 8 instructions per wave;
-  // lane lp < 8 of each half also fetches y of "its" row k = lp
-  double2 a[8];
-  double ysel;
-  auto fetch = [&](uint64_t blk) {
-    const uint64_t s = blk * 4 + w;  // rows 16 s .. 16 s + 15 (zero padded past m)
-    const bool in = s < p.nstep;
-    const double *Ab = p.A + (s * p.batch + pid) * (16 * kLmN);
-#pragma unroll
-    for (int k = 0; k < 8; k++)
-      a[k] = *reinterpret_cast<const double2 *>(in ? Ab + (2 * k + half) * kLmN + 2 * lp : p.zero);
-    ysel = *(in ? p.y + (s * p.batch + pid) * 16 + 2 * (lp & 7) + half : p.zero);
-  };
-  fetch(0);
-  for (uint64_t blk = 0; blk < nblk; blk++) {
-    // z = A theta for the wave's 16 rows: one 32-lane butterfly per load instruction
-    double z[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      z[k] = a[k].x * th0 + a[k].y * th1;
-      butterfly_levels<16>([&](auto off) { z[k] = z[k] + lane_xor<decltype(off)::value>(z[k]); });
-    }
-    // tanh / residual / weight ONCE per row: lane lp < 8 of each half takes row k = lp
-    // (instead of all 32 lanes of the half repeating the same transcendental 8 times)
-    double zsel = z[0];
-#pragma unroll
-    for (int k = 1; k < 8; k++) zsel = ((lp & 7) == k) ? z[k] : zsel;
-    const double tsel = det_tanh(zsel);
-    const double rsel = ysel - tsel;
-    const double wsel = 1 - tsel * tsel;
-    if (lp < 8) sh.r[2 * (8 * w + lp) + half] = rsel;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const int rb = 2 * (8 * w + k) + half;
-      const double r = __shfl(rsel, 32 * half + k, 64);
-      const double wgt = __shfl(wsel, 32 * half + k, 64);
-      facc = facc + r * r;
-      double2 jv;
-      jv.x = -(wgt * a[k].x);
-      jv.y = -(wgt * a[k].y);
-      *reinterpret_cast<double2 *>(&sh.J[rb * kLmJStride + 2 * lp]) = jv;
-    }
-    // the next block's rows travel from HBM while this one is on the matrix cores
-    if (blk + 1 < nblk) fetch(blk + 1);
-    lds_barrier();
-    // ---- J^T J on the matrix cores, J^T r on the VALU (same operand)
-    switch (role) {
-      case 0: lm_mfma_block<0>(sh.J, sh.r, acc, gacc); break;
-      case 1: lm_mfma_block<1>(sh.J, sh.r, acc, gacc); break;
-      case 2: lm_mfma_block<2>(sh.J, sh.r, acc, gacc); break;
-      default: lm_mfma_block<3>(sh.J, sh.r, acc, gacc); break;
-    }
-    lds_barrier();
-  }
-  // ---- publish H = 2 J^T J, g = 2 J^T r, f
-  switch (role) {
-    case 0: lm_publish_tiles<0, TO_GLOBAL>(p, sh, pid, acc); break;
-    case 1: lm_publish_tiles<1, TO_GLOBAL>(p, sh, pid, acc); break;
-    case 2: lm_publish_tiles<2, TO_GLOBAL>(p, sh, pid, acc); break;
-    default: lm_publish_tiles<3, TO_GLOBAL>(p, sh, pid, acc); break;
-  }
-  sh.gpart[lane >> 4][16 * role + (lane & 15)] = gacc;
-  if (lp == 0) sh.fpart[2 * w + half] = facc;
-  __syncthreads();
-  if (threadIdx.x < 64) {
-    const int j = threadIdx.x;
-    const double gj = 2 * (((sh.gpart[0][j] + sh.gpart[1][j]) + sh.gpart[2][j]) + sh.gpart[3][j]);
-    if constexpr (TO_GLOBAL)
-      p.gg[pid * kLmN + j] = gj;
-    else
-      sh.g[j] = gj;
-  }
-  double f = 0.0;
-#pragma unroll
-  for (int k = 0; k < 8; k++) f = f + sh.fpart[k];
-  __syncthreads();
-  return f;
-}
-
-// get_update_with_hessian (nlsolver.h:310-330) on the n x n leading block of sh.H.
-// Runs in ONE wave (lane = matrix row, n <= 64): no workgroup barriers inside; values
-// cross lanes through LDS (a wave's DS instructions execute in order) or a lane broadcast.
 // value of lane `src` (wave-uniform index) through scalar registers
 __device__ inline double lane_broadcast(double v, int src) {
   const uint64_t b = __double_as_longlong(v);
@@ -344,7 +165,14 @@ __device__ inline void lm_solve_cholesky_wave(Rows H, const double *g, double *u
 // exactly the sequence of updates the serial loop applies (columns left of j are skipped:
 // they only hold annihilated entries that the cleanup pass zeroes and nothing reads).
 // sh.H is the working R (row-major, = the transposed-input layout of qr_decomposition).
-__device__ inline void lm_solve_qr(LmShared &sh, LmQrShared &qs, int n) {
+struct LmQrShared {                // LDS of the QR step (one workgroup per problem)
+  double H[64 * kLmHStride];       // working R (row-major)
+  double Q[64 * kLmHStride];       // the orthogonal factor's transpose, rotated alongside R
+  double g[64], upd[64];
+  double c[32], s[32];             // Givens coefficients of the current wavefront step
+};
+
+__device__ inline void lm_solve_qr(LmQrShared &qs, int n) {
   const int t = threadIdx.x, lane = lane_id();
   const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
   for (int e = t; e < n * n; e += 256) {
@@ -358,7 +186,7 @@ __device__ inline void lm_solve_qr(LmShared &sh, LmQrShared &qs, int n) {
     const int count = jhi - jlo + 1;
     if (t < count) {  // givens_rotation, tinyqr.h:86-97
       const int j = jlo + t, i = n - 1 - (step - 2 * j);
-      const double a = sh.H[(i - 1) * kLmHStride + j], b = sh.H[i * kLmHStride + j];
+      const double a = qs.H[(i - 1) * kLmHStride + j], b = qs.H[i * kLmHStride + j];
       double c, sv;
       if (fabs(b) > fabs(a)) {
         const double r = a / b;
@@ -377,7 +205,7 @@ __device__ inline void lm_solve_qr(LmShared &sh, LmQrShared &qs, int n) {
       const int j = jlo + r, i = n - 1 - (step - 2 * j);
       const double c = qs.c[r], sv = qs.s[r];
       if (lane >= j && lane < n) {
-        double *lo = &sh.H[(i - 1) * kLmHStride + lane], *up = &sh.H[i * kLmHStride + lane];
+        double *lo = &qs.H[(i - 1) * kLmHStride + lane], *up = &qs.H[i * kLmHStride + lane];
         const double t1 = *lo, t2 = *up;
         *lo = c * t1 + sv * t2;
         *up = -sv * t1 + c * t2;
@@ -394,7 +222,7 @@ __device__ inline void lm_solve_qr(LmShared &sh, LmQrShared &qs, int n) {
   // cleanup with lm()'s tol = 1e-12 (tinyqr.h:278-282, 465) on the entries back_solve reads
   for (int e = t; e < n * n; e += 256) {
     const int i = e / n, j = e % n;
-    if (j >= i && fabs(sh.H[i * kLmHStride + j]) < 1e-12) sh.H[i * kLmHStride + j] = 0.0;
+    if (j >= i && fabs(qs.H[i * kLmHStride + j]) < 1e-12) qs.H[i * kLmHStride + j] = 0.0;
   }
   __syncthreads();
   // back_solve (tinyqr.h:437-459): Q^T y lazily per row, then the triangular sweep with the
@@ -402,58 +230,14 @@ __device__ inline void lm_solve_qr(LmShared &sh, LmQrShared &qs, int n) {
   if (t < 64) {
     double ytmp = 0;
     if (t < n)
-      for (int j = 0; j < n; j++) ytmp += qs.Q[t * kLmHStride + j] * sh.g[j];
+      for (int j = 0; j < n; j++) ytmp += qs.Q[t * kLmHStride + j] * qs.g[j];
     double temp = 0.0, u = 0.0;
     for (int j = n - 1; j >= 0; j--) {
-      if (t == j) u = (ytmp - temp) / sh.H[j * kLmHStride + j];
+      if (t == j) u = (ytmp - temp) / qs.H[j * kLmHStride + j];
       const double uj = lane_broadcast(u, j);
-      if (t < j) temp += sh.H[t * kLmHStride + j] * uj;
+      if (t < j) temp += qs.H[t * kLmHStride + j] * uj;
     }
-    if (t < n) sh.upd[t] = u;
-  }
-}
-
-template <bool QR>
-__global__ __launch_bounds__(256) void lm_solve_kernel(LmParams p) {
-  extern __shared__ __align__(16) unsigned char lm_smem[];
-  LmShared &sh = *reinterpret_cast<LmShared *>(lm_smem);
-  LmQrShared &qs = *reinterpret_cast<LmQrShared *>(lm_smem + sizeof(LmShared));  // QR only
-  const uint64_t pid = blockIdx.x;
-  const int t = threadIdx.x;
-  const int n = static_cast<int>(p.n);
-  if (t < 64) sh.theta[t] = p.theta[pid * kLmN + t];
-  __syncthreads();
-  double lambda = p.lambda0;
-  uint64_t iter = 0, fcalls = 1;
-  double cur = lm_evaluate<false>(p, sh, pid);  // g, H, f at x0 (:3513-3516)
-  double prev = 0.0;
-  for (;;) {
-    const double delta = fabs(prev - cur);
-    if (iter >= p.max_iter || delta < p.f_delta || isnan(prev)) break;  // :3520-3527
-    if (t < n) sh.H[t * kLmHStride + t] += lambda;                      // :3529-3531
-    __syncthreads();
-    if (QR) {
-      lm_solve_qr(sh, qs, n);
-      if (t < n) sh.theta[t] = sh.theta[t] - sh.upd[t];  // always accepted, :3534
-    } else if (t < 64) {  // wave 0 solves the damped system and applies the step
-      lm_solve_cholesky_wave(LmRowsFull{sh.H}, sh.g, sh.upd, n);
-      if (t < n) sh.theta[t] = sh.theta[t] - sh.upd[t];
-    }
-    __syncthreads();
-    prev = cur;
-    cur = lm_evaluate<false>(p, sh, pid);
-    fcalls++;
-    iter++;
-    lambda = cur < prev ? lambda / p.down : lambda * p.up;  // :3541-3542
-  }
-  if (t < 64) p.theta[pid * kLmN + t] = sh.theta[t];
-  if (t == 0) {
-    LmProblem *pr = p.prob + pid;
-    pr->f = cur;
-    pr->lambda = lambda;
-    pr->iter = iter;
-    pr->fcalls = fcalls;
-    pr->done = 1;
+    if (t < n) qs.upd[t] = u;
   }
 }
 
@@ -469,8 +253,8 @@ __global__ __launch_bounds__(256) void lm_solve_kernel(LmParams p) {
 //                      by the others' MFMA phases (fp64 MFMA and fp64 VALU share the DP pipe,
 //                      the bound is their sum).
 // lm_step_wave         stop tests, damping, Cholesky solve, theta update
-// Same reduction structure as lm_evaluate (rows -> k-steps of 4, f partials per (row/16 % 4,
-// row parity), g partials per row % 4), hence the same bits.
+// Reductions: rows -> k-steps of 4, f partials per (row/16 % 4, row parity), g partials per
+// row % 4 -- the order oracle_lm.c's order-1 evaluation mirrors.
 struct LmWaveShared {  // view of the wave's LDS during the evaluation
   double *J;           // [16][kLmJStride]
   double *r;           // [16]
@@ -646,17 +430,51 @@ __device__ inline bool lm_step_wave(const LmParams &p, uint64_t pid, LmStepShare
 // One launch per iteration: step k (skipped on the first launch), then evaluation k + 1.
 // LDS of the wave: the step's packed triangle | g | upd, overlaid by the evaluation's Jacobian
 // tile | r (the new parameters wait in `upd`, which the tile does not reach).
-__global__ __launch_bounds__(64, 2) void lm_iter_kernel(LmParams p, int first) {
+// `with_step` = 0: evaluation only (the first launch, and every launch of the QR pipeline, whose
+// step is lm_qr_step_kernel).
+__global__ __launch_bounds__(64, 2) void lm_iter_kernel(LmParams p, int first, int with_step) {
   __shared__ __align__(16) double smem[kLmTri + 128];
   static_assert(16 * kLmJStride + 16 <= kLmTri + 64, "the Jacobian tile must not reach upd");
   const uint64_t pid = blockIdx.x;
   const double *theta_lds = nullptr;
   if (!first) {
     if (p.prob[pid].done) return;
-    if (!lm_step_wave(p, pid, LmStepShared{smem, smem + kLmTri, smem + kLmTri + 64})) return;
-    theta_lds = smem + kLmTri + 64;
+    if (with_step) {
+      if (!lm_step_wave(p, pid, LmStepShared{smem, smem + kLmTri, smem + kLmTri + 64})) return;
+      theta_lds = smem + kLmTri + 64;
+    }
   }
   lm_eval_wave(p, first, pid, LmWaveShared{smem, smem + 16 * kLmJStride}, theta_lds);
+}
+
+// ---- QR solver (tinyqr::lm on the damped matrix): the step as a kernel of its own, one
+// workgroup per problem (R and Q, 33 KiB each, live in LDS; the Givens wavefronts want four
+// waves), between two evaluation launches. Stop tests, damping, QR solve, theta update.
+__global__ __launch_bounds__(256) void lm_qr_step_kernel(LmParams p) {
+  extern __shared__ __align__(16) unsigned char lm_smem[];
+  LmQrShared &qs = *reinterpret_cast<LmQrShared *>(lm_smem);
+  const uint64_t pid = blockIdx.x;
+  LmProblem *pr = p.prob + pid;
+  if (pr->done) return;
+  const int t = threadIdx.x, n = static_cast<int>(p.n);
+  const double prev = pr->prev, cur = pr->f;
+  if (pr->iter >= p.max_iter || fabs(prev - cur) < p.f_delta || isnan(prev)) {  // :3520-3527
+    __syncthreads();  // every thread has read `done` before it flips
+    if (t == 0) pr->done = 1;
+    return;
+  }
+  const double *tri = p.Hg + pid * kLmTri;
+  for (int e = t; e < 64 * 64; e += 256) {  // the full symmetric matrix from its lower triangle
+    const int i = e >> 6, j = e & 63;
+    const int hi = i > j ? i : j, lo = i > j ? j : i;
+    qs.H[i * kLmHStride + j] = tri[hi * (hi + 1) / 2 + lo];
+  }
+  if (t < 64) qs.g[t] = p.gg[pid * kLmN + t];
+  __syncthreads();
+  if (t < n) qs.H[t * kLmHStride + t] += pr->lambda;  // :3529-3531
+  __syncthreads();
+  lm_solve_qr(qs, n);
+  if (t < n) p.theta[pid * kLmN + t] = p.theta[pid * kLmN + t] - qs.upd[t];  // :3534
 }
 
 // host layout -> device layout of A and y (see nlsg_lm_set_data)
