@@ -298,3 +298,42 @@ def test_generations_with_acceptances_bit_exact(eng_mod, oracle, pop, D, strateg
             assert np.array_equal(P, ref.population) and np.array_equal(S, ref.scores), f"gen {g}"
             accepted += int(T[:, 4].sum())
     assert accepted > 0 or D > 600  # (64 agents in 1024-D accept nothing in 10 generations)
+
+
+def _sweep_cases(n=36, seed=20261003):
+    rng = np.random.default_rng(seed)
+    cases = []
+    for _ in range(n):
+        pop = int(rng.choice([4, 5, 7, 31, 100, 255, 256, 257, 1023, 1024, 1025, 2049, 3000]))
+        D = int(rng.choice([1, 2, 3, 17, 64, 127, 128, 129, 255, 256, 300]))
+        cases.append((pop, D, int(rng.integers(0, 2)), bool(rng.integers(0, 2)),
+                      float(rng.choice([0.0, 1e-300, 10e-4])), float(rng.choice([0.1, 0.5, 0.9])),
+                      float(rng.choice([0.4, 0.8])), int(rng.integers(1, 2**31)),
+                      str(rng.choice(["rosenbrock", "sphere", "styblinski_tang"]))))
+    return cases
+
+
+@pytest.mark.parametrize("pop,D,strategy,minimize,eps,CR,F,seed,obj", _sweep_cases())
+def test_randomised_configuration_sweep_bit_exact(eng_mod, oracle, pop, D, strategy, minimize, eps,
+                                                  CR, F, seed, obj):
+    """Populations around the tile / block boundaries (4 agents per block, 1024 scores per tile),
+    odd and multi-chunk dimensions, both strategies, std_err on and off, minimise / maximise:
+    state after 6 turns (or at the stop) equals the oracle's."""
+    kw = dict(strategy=strategy, minimize=minimize, eps=eps, CR=CR, F=F, seed=seed, max_iter=6,
+              best_val_no_change=4)
+    x0 = np.full(D, 1.5)
+    ref = O.DESyncRun(oracle, obj, pop, D, x0, **kw)
+    for _ in range(8):
+        ref.step()
+    with eng_mod.DEEngine(obj, pop, D, **kw) as eng:
+        eng.init(x0)
+        eng.step(8)
+        P, S = eng.download()
+        st = eng.status()
+        bx, bf, bi = eng.best()
+    assert (st.done, st.iteration, st.function_calls_used, st.best_index) == \
+        (ref.s.done, ref.s.iter, ref.s.fcalls, ref.s.best_id)
+    assert np.array_equal(P, ref.population) and np.array_equal(S, ref.scores)
+    if eps > 0:
+        assert st.std_err == ref.s.std_err
+    assert np.array_equal(bx, ref.best_x)

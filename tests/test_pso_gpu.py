@@ -138,3 +138,33 @@ def test_pso_config5_shard_size_properties(mod, oracle):
         eng.init(-2.048, 2.048)
         eng.step(2)
         check_state(eng, ref, "config5 shard")
+
+
+def _sweep_cases(n=24, seed=20261004):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        out.append((int(rng.choice([1, 3, 4, 5, 63, 255, 256, 257, 1023, 1025, 2050])),
+                    int(rng.choice([1, 2, 3, 31, 127, 128, 129, 256, 300])),
+                    int(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2)),
+                    float(rng.choice([0.0, 1e-300, 10e-4])), int(rng.integers(1, 2**31)),
+                    str(rng.choice(["rosenbrock", "sphere", "styblinski_tang"]))))
+    return out
+
+
+@pytest.mark.parametrize("n,D,type_,bounded,minimize,eps,seed,obj", _sweep_cases())
+def test_pso_randomised_configuration_sweep_bit_exact(mod, oracle, n, D, type_, bounded, minimize,
+                                                      eps, seed, obj):
+    """Swarm sizes around the block / tile boundaries, odd and multi-chunk dimensions, both types,
+    bounded or not, minimise / maximise, std_err on and off: 6 turns equal the oracle's."""
+    kw = dict(type=type_, bounded=bounded, minimize=minimize, eps=eps, seed=seed, max_iter=5,
+              best_val_no_change=1000)
+    ref = O.PSOSyncRun(oracle, obj, n, D, -1.5, 2.5, **kw)
+    with mod.PSOEngine(obj, n, D, **kw) as eng:
+        eng.init(-1.5, 2.5)
+        for t in range(6):
+            eng.step(1)
+            ref.step(1)
+        check_state(eng, ref, "after 6 turns")
+        bx, bf, bi = eng.best()
+        assert np.array_equal(bx, ref.gbest_x) and bf == ref.s.gbest_val and bi == ref.s.gbest_idx
