@@ -98,9 +98,15 @@ __device__ inline void lm_solve_cholesky_wave(Rows H, const double *g, double *u
 #pragma unroll
       for (int q = 0; q < 4; q++) x[q] = H(t, k + q);  // lanes t < j0: in-buffer, unused
 #pragma unroll
-      for (int q = 0; q < 4; q++)
+      for (int c = 0; c < 4; c++) {
+        // L[j0+c][k..k+3]: a wave-uniform LDS address (one broadcast read per value on the
+        // otherwise idle LDS port instead of two scalar lane reads on the VALU port)
+        double l[4];
 #pragma unroll
-        for (int c = 0; c < 4; c++) s4[c] += x[q] * lane_broadcast(x[q], min(j0 + c, 63));
+        for (int q = 0; q < 4; q++) l[q] = H(min(j0 + c, 63), k + q);
+#pragma unroll
+        for (int q = 0; q < 4; q++) s4[c] += x[q] * l[q];
+      }
     }
     double hd[4];
 #pragma unroll
