@@ -215,6 +215,10 @@ typedef struct {
 orc_status orc_lm_solve(const orc_nlls *q, double *x, double *lambda, double up, double down,
                         size_t max_iter, double f_delta, int solver, int order, double *f_log,
                         size_t f_cap);
+/* the reference's default LevenbergMarquardt<Callable>(f) (Grad = fin_diff, Hess = fin_diff_h,
+ * nlsolver.h:1385-1517, 3428-3545) on a built-in objective; every probe is a counted call */
+orc_status orc_lm_fd(int obj, double *x, size_t n, double *lambda, double up, double down,
+                     size_t max_iter, double f_delta, int order, double *f_log, size_t f_cap);
 
 /* --------------------------------------------------------------------- NM --- */
 /* NelderMead::solve (nlsolver.h:2166-2299) and the minimize/maximize wrappers with

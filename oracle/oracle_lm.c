@@ -332,3 +332,107 @@ orc_status orc_lm_solve(const orc_nlls *q, double *x, double *lambda, double up,
   free(Xc);
   return st;
 }
+
+/* ---- the reference's DEFAULT LevenbergMarquardt<Callable>(f): Grad = fin_diff, Hess = fin_diff_h,
+ * i.e. finite_difference_gradient<.,.,1> (nlsolver.h:1385-1413) and
+ * finite_difference_hessian<.,.,1> (1413-1517), every probe counted as a function call
+ * (3479-3510), on a built-in objective (oracle_objective.c). order = 0: sequential sums (the
+ * reference arithmetic); order = 1: the kernel's lane tree and back-substitution order. */
+typedef struct {
+  int obj, order;
+  size_t n, fcalls;
+  double *f_log;
+  size_t f_cap, nlog;
+} fd_ctx;
+static double fd_f(fd_ctx *c, const double *x) {
+  const double v = c->order ? orc_objective_tree(c->obj, x, c->n) : orc_objective_seq(c->obj, x, c->n);
+  c->fcalls++;
+  if (c->f_log && c->nlog < c->f_cap) c->f_log[c->nlog] = v;
+  c->nlog++;
+  return v;
+}
+static void fd_gradient(fd_ctx *c, double *x, double *g) { /* accuracy 1, :1385-1413 */
+  const double eps = 2.220446049250313e-16 * 10e7;
+  static const double coeff[4] = {1, -8, 8, -1}, coeff2[4] = {-2, -1, 1, 2};
+  const double dd_val = 12 * eps;
+  for (size_t d = 0; d < c->n; d++) {
+    double acc = 0.0;
+    for (int s = 0; s < 4; s++) {
+      const double tmp = x[d];
+      x[d] += coeff2[s] * eps;
+      acc += coeff[s] * fd_f(c, x);
+      x[d] = tmp;
+    }
+    g[d] = acc / dd_val;
+  }
+}
+static void fd_hessian(fd_ctx *c, double *x, double *hess) { /* accuracy 1, :1446-1515, literal */
+  const double eps = pow(2.220446049250313e-16, 1.0 / 4.0);
+  const double denom = (600.0 * eps * eps), two_eps = 2 * eps, three_eps = 3 * eps, four_eps = 4 * eps;
+  const size_t p = c->n;
+  for (size_t i = 0; i < p; i++) {
+    const double temp_i = x[i];
+    for (size_t j = 0; j < p; j++) {
+      double result = 0.0, temp = 0.0;
+      const double temp_j = x[j];
+      x[i] += eps;      x[j] -= two_eps;   temp += fd_f(c, x);
+      x[i] += eps;      x[j] += eps;       temp += fd_f(c, x);
+      x[i] -= four_eps; x[j] += two_eps;   temp += fd_f(c, x);
+      x[i] += eps;      x[j] += eps;       temp += fd_f(c, x);
+      result -= 63 * temp;
+      temp = 0.0;
+      x[j] -= four_eps;                    temp += fd_f(c, x);
+      x[i] -= eps;      x[j] += eps;       temp += fd_f(c, x);
+      x[i] += three_eps; x[j] += three_eps; temp += fd_f(c, x);
+      x[i] += eps;      x[j] -= eps;       temp += fd_f(c, x);
+      result += 63 * temp;
+      temp = 0.0;
+      x[j] -= three_eps;                   temp += fd_f(c, x);
+      x[i] -= four_eps; x[j] += four_eps;  temp += fd_f(c, x);
+      x[j] -= four_eps;                    temp -= fd_f(c, x);
+      x[i] += four_eps; x[j] += four_eps;  temp -= fd_f(c, x);
+      result += 44 * temp;
+      temp = 0.0;
+      x[i] -= three_eps; x[j] -= three_eps; temp += fd_f(c, x);
+      x[i] += two_eps;  x[j] += two_eps;   temp += fd_f(c, x);
+      x[j] -= two_eps;                     temp -= fd_f(c, x);
+      x[i] -= two_eps;  x[j] += two_eps;   temp -= fd_f(c, x);
+      result += 74 * temp;
+      x[i] = temp_i;
+      x[j] = temp_j;
+      hess[i * p + j] = result / denom;
+    }
+  }
+}
+orc_status orc_lm_fd(int obj, double *x, size_t n, double *lambda, double up, double down,
+                     size_t max_iter, double f_delta, int order, double *f_log, size_t f_cap) {
+  double *g = (double *)malloc(n * sizeof(double)), *H = (double *)malloc(n * n * sizeof(double));
+  double *upd = (double *)malloc(n * sizeof(double));
+  fd_ctx c = {obj, order, n, 0, f_log, f_cap, 0};
+  size_t iter = 0, gc = 0, hc = 0;
+  fd_gradient(&c, x, g); /* g_lam, h_lam, f_lam at x0 (:3513-3516) */
+  gc++;
+  fd_hessian(&c, x, H);
+  hc++;
+  double prev = 0.0, cur = fd_f(&c, x);
+  for (;;) {
+    const double delta = fabs(prev - cur);
+    if (iter >= max_iter || delta < f_delta || isnan(prev)) break; /* :3520-3527 */
+    for (size_t i = 0; i < n; i++) H[i * n + i] += *lambda;          /* :3529-3531 */
+    orc_update_with_hessian_order(upd, H, g, n, order);
+    for (size_t i = 0; i < n; i++) x[i] -= upd[i]; /* :3534 */
+    prev = cur;
+    cur = fd_f(&c, x);
+    iter++;
+    fd_gradient(&c, x, g);
+    gc++;
+    fd_hessian(&c, x, H);
+    hc++;
+    *lambda = cur < prev ? *lambda / down : *lambda * up; /* :3541-3542 */
+  }
+  orc_status st = {cur, iter, c.fcalls, gc, hc};
+  free(g);
+  free(H);
+  free(upd);
+  return st;
+}

@@ -125,6 +125,18 @@ def bfgs_fd(lib, obj, x0, *, max_iter=100, grad_eps=5e-3, alpha=1.0, tree=0, log
     return st, x, (flog[:min(cnt.f_count, log_cap)] if log_cap else None), cnt.f_count
 
 
+def lm_fd(lib, obj, x0, *, lam=10.0, up=10.0, down=10.0, max_iter=100, f_delta=1e-12, order=0,
+          log_cap=0):
+    """Oracle LevenbergMarquardt with the default finite-difference functors on a built-in
+    objective; returns (status, x, lambda_after, f_log or None)."""
+    x = np.ascontiguousarray(x0, dtype=np.float64).copy()
+    lam_c = C.c_double(lam)
+    flog = np.zeros(log_cap) if log_cap else None
+    st = lib.orc_lm_fd(OBJ[obj], _ptr(x), x.size, C.byref(lam_c), up, down, max_iter, f_delta, order,
+                       _ptr(flog) if log_cap else None, log_cap)
+    return st, x, lam_c.value, flog
+
+
 def load():
     if not os.path.exists(LIB):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
@@ -177,6 +189,9 @@ def load():
     lib.orc_bfgs_quad.restype = Status
     lib.orc_bfgs_quad.argtypes = [C.POINTER(Quad), pd, sz, sz, f64, f64, C.c_int,
                                   C.POINTER(BfgsCounters)]
+    lib.orc_lm_fd.restype = Status
+    lib.orc_lm_fd.argtypes = [C.c_int, pd, sz, C.POINTER(C.c_double), f64, f64, sz, f64, C.c_int, pd,
+                              sz]
     lib.orc_bfgs_fd.restype = Status
     lib.orc_bfgs_fd.argtypes = [C.c_int, pd, sz, sz, f64, f64, C.c_int, C.POINTER(BfgsCounters)]
     lib.orc_update_inverse_hessian.argtypes = [pd, pd, pd, pd, f64, sz, C.c_int]

@@ -47,6 +47,20 @@ def main():
     }
     write("bfgs_fd.json", g6fd)
 
+    # LevenbergMarquardt with its DEFAULT functors (fin_diff, fin_diff_h: nlsolver.h:1385-1517,
+    # 3428-3545) on built-in objectives; all objective values counted.
+    # args: objective n max_iter lambda f_delta x0 x0_step trace_cap
+    g8fd = {
+        "rosenbrock_n2_example_start": run("lm-fd", 0, 2, 100, 10, 1e-12, 2, 5, 64),
+        "rosenbrock_n4_near_minimum": run("lm-fd", 0, 4, 30, 10, 1e-12, 0.9, 0.02, 64),
+        "rosenbrock_n4_indefinite_nan": run("lm-fd", 0, 4, 20, 10, 1e-12, -1.2, 0.7, 64),
+        "rosenbrock_n16_6iters": run("lm-fd", 0, 16, 6, 10, 0, 0.95, 0.002, 64),
+        "sphere_n5": run("lm-fd", 1, 5, 50, 10, 1e-12, 3, -0.5, 64),
+        "styblinski_tang_n8": run("lm-fd", 2, 8, 30, 10, 1e-12, -2.5, 0.1, 64),
+        "sphere_n64_3iters_lambda1": run("lm-fd", 1, 64, 3, 1, 0, 1, 0.01, 64),
+    }
+    write("lm_fd.json", g8fd)
+
     # G8/G9 — LevenbergMarquardt (nlsolver.h:3428-3545) with Gauss-Newton functors, its
     # Cholesky solve (251-330) and tinyqr (291-310, 437-470).
     seed = 12374563468
