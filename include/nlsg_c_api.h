@@ -334,7 +334,12 @@ typedef struct {
   uint32_t struct_size;
   int32_t device;
   void *stream;
-  int32_t objective;      /* nlsg_nlls_objective                                     */
+  int32_t objective;      /* nlsg_nlls_objective (Gauss-Newton functors on the device), or
+                           * NLSG_OBJ_ROSENBROCK / SPHERE / STYBLINSKI_TANG / CUSTOM: the
+                           * reference's default functors, Grad = fin_diff and Hess =
+                           * fin_diff_h at accuracy 1 (nlsolver.h:3494-3511, 1385-1413,
+                           * 1446-1515), every probe evaluated on the device; Cholesky only;
+                           * m is ignored and there is no nlsg_lm_set_data            */
   int32_t solver;         /* nlsg_lm_solver                                          */
   uint64_t batch;         /* independent problems                                    */
   uint64_t m;             /* residuals per problem                                   */
@@ -345,6 +350,9 @@ typedef struct {
 } nlsg_lm_config;
 
 int nlsg_lm_create(const nlsg_lm_config *cfg, nlsg_lm **out);
+/* cfg->objective == NLSG_OBJ_CUSTOM, as nlsg_de_create_custom: LevenbergMarquardt with the
+ * default functors on a user objective compiled at run time */
+int nlsg_lm_create_custom(const nlsg_lm_config *cfg, const nlsg_custom_objective *obj, nlsg_lm **out);
 int nlsg_lm_destroy(nlsg_lm *e);
 /* design matrices A [batch][m][n] row-major and targets y [batch][m] (copied to HBM) */
 int nlsg_lm_set_data(nlsg_lm *e, const double *a_host, const double *y_host);

@@ -302,6 +302,7 @@ class api {
   decltype(&nlsg_bfgs_destroy) bfgs_destroy;
   decltype(&nlsg_bfgs_minimize) bfgs_minimize;
   decltype(&nlsg_lm_create) lm_create;
+  decltype(&nlsg_lm_create_custom) lm_create_custom;
   decltype(&nlsg_lm_destroy) lm_destroy;
   decltype(&nlsg_lm_set_data) lm_set_data;
   decltype(&nlsg_lm_minimize) lm_minimize;
@@ -339,6 +340,7 @@ class api {
     bind(h, "nlsg_bfgs_destroy", bfgs_destroy);
     bind(h, "nlsg_bfgs_minimize", bfgs_minimize);
     bind(h, "nlsg_lm_create", lm_create);
+    bind(h, "nlsg_lm_create_custom", lm_create_custom);
     bind(h, "nlsg_lm_destroy", lm_destroy);
     bind(h, "nlsg_lm_set_data", lm_set_data);
     bind(h, "nlsg_lm_minimize", lm_minimize);
@@ -1351,8 +1353,29 @@ class LevenbergMarquardt {
                               Grad g = Grad(), Hess h = Hess())
       : f(f), g(g), h(h), lambda(lambda), upward_mult(upward_mult), downward_mult(downward_mult),
         max_iter(max_iter), f_delta(f_delta) {}
+  // Device coverage of the default functors (fin_diff + fin_diff_h on a built-in objective,
+  // nlsolver.h:3494-3511): the objectives whose arithmetic is deterministic on the device, up
+  // to 64 parameters.
+  static constexpr bool device_fd() {
+    if constexpr (device::is_device_objective<Callable>::value &&
+                  std::is_same_v<Grad, fin_diff<Callable, scalar_t>> &&
+                  std::is_same_v<Hess, fin_diff_h<Callable, scalar_t>>)
+      return Callable::nlsg_objective == NLSG_OBJ_ROSENBROCK ||
+             Callable::nlsg_objective == NLSG_OBJ_SPHERE ||
+             Callable::nlsg_objective == NLSG_OBJ_STYBLINSKI_TANG ||
+             Callable::nlsg_objective == NLSG_OBJ_CUSTOM;
+    else
+      return false;
+  }
   solver_status<scalar_t> minimize(std::vector<scalar_t> &x) {
     if constexpr (device::has_nlls_objective<Callable>::value) {
+      std::vector<std::vector<scalar_t>> one{x};
+      auto st = minimize_batch(one);
+      x = one[0];
+      return st[0];
+    } else if constexpr (device_fd()) {
+      if constexpr (Callable::nlsg_objective != NLSG_OBJ_CUSTOM)  // (Custom has no host evaluation)
+        if (x.size() > 64) return solve_host(x);  // beyond the device coverage: host functor path
       std::vector<std::vector<scalar_t>> one{x};
       auto st = minimize_batch(one);
       x = one[0];
@@ -1368,19 +1391,27 @@ class LevenbergMarquardt {
   }
   // Extension (BASELINE config 4): one start per problem of the model, all solved by one launch.
   std::vector<solver_status<scalar_t>> minimize_batch(std::vector<std::vector<scalar_t>> &thetas) {
-    static_assert(device::has_nlls_objective<Callable>::value,
-                  "minimize_batch needs a device NLLS model");
+    static_assert(device::has_nlls_objective<Callable>::value || device_fd(),
+                  "minimize_batch needs a device NLLS model, or Rosenbrock / Sphere / "
+                  "StyblinskiTang with the default finite-difference functors");
     static_assert(std::is_same_v<scalar_t, double>, "the device path computes in fp64");
     const device::api &api = device::api::get();
-    const size_t B = thetas.size(), n = f.n;
-    if (B != f.problems()) throw device_error("one start per problem of the model is required");
+    const size_t B = thetas.size();
     nlsg_lm_config cfg{};
     cfg.struct_size = sizeof(cfg);
     if (const char *d = std::getenv("NLSG_DEVICE")) cfg.device = std::atoi(d);
-    cfg.objective = Callable::nlsg_nlls_objective;
     cfg.solver = NLSG_LM_CHOLESKY;
     cfg.batch = B;
-    cfg.m = f.m;
+    size_t n = 0;
+    if constexpr (device::has_nlls_objective<Callable>::value) {
+      if (B != f.problems()) throw device_error("one start per problem of the model is required");
+      cfg.objective = Callable::nlsg_nlls_objective;
+      cfg.m = f.m;
+      n = f.n;
+    } else {  // the objective itself, differentiated by fin_diff / fin_diff_h on the device
+      cfg.objective = Callable::nlsg_objective;
+      n = B ? thetas[0].size() : 0;
+    }
     cfg.n = n;
     cfg.lambda = lambda;
     cfg.up = upward_mult;
@@ -1388,11 +1419,22 @@ class LevenbergMarquardt {
     cfg.max_iter = max_iter;
     cfg.f_delta = f_delta;
     nlsg_lm *eng = nullptr;
-    api.check(api.lm_create(&cfg, &eng));
+    bool made = false;
+    if constexpr (device::is_device_objective<Callable>::value) {
+      if constexpr (Callable::nlsg_objective == NLSG_OBJ_CUSTOM) {
+        api.check(api.rtc_load(std::getenv("NLSG_HIPRTC")));
+        nlsg_custom_objective obj{f.term_body.c_str(), f.finish_body.c_str(), f.chain ? 1 : 0, 0};
+        api.check(api.lm_create_custom(&cfg, &obj, &eng));
+        made = true;
+      }
+    }
+    if (!made) api.check(api.lm_create(&cfg, &eng));
     std::vector<scalar_t> flat(B * n), lam(B);
     for (size_t p = 0; p < B; p++) std::copy(thetas[p].begin(), thetas[p].end(), flat.begin() + p * n);
     std::vector<nlsg_status> st(B);
-    int rc = api.lm_set_data(eng, f.A.data(), f.y.data());
+    int rc = 0;
+    if constexpr (device::has_nlls_objective<Callable>::value)
+      rc = api.lm_set_data(eng, f.A.data(), f.y.data());
     if (!rc) rc = api.lm_minimize(eng, flat.data(), st.data(), lam.data());
     const std::string msg = rc ? api.last_error() : "";
     api.lm_destroy(eng);

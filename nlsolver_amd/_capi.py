@@ -122,6 +122,8 @@ SYMBOLS = {
                                         C.POINTER(C.c_void_p)]),
     "nlsg_bfgs_create_custom": (C.c_int, [C.POINTER(BFGSConfig), C.POINTER(CustomObjectiveC),
                                           C.POINTER(C.c_void_p)]),
+    "nlsg_lm_create_custom": (C.c_int, [C.POINTER(LMConfig), C.POINTER(CustomObjectiveC),
+                                        C.POINTER(C.c_void_p)]),
     "nlsg_comm_load": (C.c_int, [C.c_char_p]),
     "nlsg_comm_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
     "nlsg_de_comm_attach": (C.c_int, [_H, C.POINTER(C.c_ubyte), C.c_int32, C.c_int32]),

@@ -1,9 +1,12 @@
 // nlsolver_amd/csrc/nlsg_lm.hip — host side of the batched LM engine + C-ABI.
+#include <cfloat>
+#include <cmath>
 #include <cstdlib>
 #include <new>
 #include <vector>
 
 #include "nlsg_lm_kernels.h"
+#include "nlsg_rtc.h"
 
 using namespace nlsg;
 
@@ -16,6 +19,7 @@ struct nlsg_lm {
   unsigned long long *count_dev = nullptr;
   bool has_data = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  LmRtcKernels rtc;  // objective == NLSG_OBJ_CUSTOM: the kernel hiprtc built for it
 };
 
 namespace {
@@ -47,17 +51,49 @@ int upload_theta(nlsg_lm *e, const double *theta_host) {
 // iterations. Cholesky solver: one launch per iteration (step k, then evaluation k + 1, one wave
 // per problem). QR solver: the step is a kernel of its own (one workgroup per problem) between
 // two evaluation launches.
+bool lm_fd_objective(int objective) {
+  return objective == NLSG_OBJ_ROSENBROCK || objective == NLSG_OBJ_SPHERE ||
+         objective == NLSG_OBJ_STYBLINSKI_TANG || objective == NLSG_OBJ_CUSTOM;
+}
+
+// finite-difference model: step k + evaluation k + 1 (first: the evaluation at x0 only)
+void launch_fd_iter(nlsg_lm *e, int first) {
+  const dim3 grid(static_cast<unsigned>(e->p.batch));
+  const unsigned lds = (64 * lm_fd_chunks(e->p.n) + 128) * sizeof(double);
+  if (e->cfg.objective == NLSG_OBJ_CUSTOM) {
+    void *args[] = {&e->p, &first};
+    hipModuleLaunchKernel(e->rtc.iter, grid.x, 1, 1, 64, 1, 1, lds, e->stream, args, nullptr);
+    return;
+  }
+  switch (e->cfg.objective) {
+    case NLSG_OBJ_ROSENBROCK:
+      hipLaunchKernelGGL(lm_fd_iter_kernel<NLSG_OBJ_ROSENBROCK>, grid, dim3(64), lds, e->stream, e->p, first);
+      break;
+    case NLSG_OBJ_SPHERE:
+      hipLaunchKernelGGL(lm_fd_iter_kernel<NLSG_OBJ_SPHERE>, grid, dim3(64), lds, e->stream, e->p, first);
+      break;
+    default:
+      hipLaunchKernelGGL(lm_fd_iter_kernel<NLSG_OBJ_STYBLINSKI_TANG>, grid, dim3(64), lds, e->stream, e->p, first);
+      break;
+  }
+}
+
 int launch_solve(nlsg_lm *e) {
   const dim3 grid(static_cast<unsigned>(e->p.batch));
-  const bool qr = e->cfg.solver == NLSG_LM_QR;
-  hipLaunchKernelGGL(lm_iter_kernel, grid, dim3(64), 0, e->stream, e->p, 1, 0);
+  const bool qr = e->cfg.solver == NLSG_LM_QR, fd = e->p.fd != 0;
+  if (fd)
+    launch_fd_iter(e, 1);
+  else
+    hipLaunchKernelGGL(lm_iter_kernel, grid, dim3(64), 0, e->stream, e->p, 1, 0);
   uint64_t launched = 0;
   for (;;) {
     // max_iter iterations plus the turn whose stop test fires
     const uint64_t left = e->p.max_iter + 1 - launched;
     const uint64_t chunk = left < 8 ? left : 8;
     for (uint64_t i = 0; i < chunk; i++) {
-      if (qr) {
+      if (fd) {
+        launch_fd_iter(e, 0);
+      } else if (qr) {
         hipLaunchKernelGGL(lm_qr_step_kernel, grid, dim3(256), sizeof(LmQrShared), e->stream, e->p);
         hipLaunchKernelGGL(lm_iter_kernel, grid, dim3(64), 0, e->stream, e->p, 0, 0);
       } else {
@@ -79,19 +115,40 @@ int launch_solve(nlsg_lm *e) {
 }
 }  // namespace
 
+static int lm_create(const nlsg_lm_config *cfg, const nlsg_custom_objective *custom, nlsg_lm **out);
+
 extern "C" {
 
 int nlsg_lm_create(const nlsg_lm_config *cfg, nlsg_lm **out) {
+  if (cfg && cfg->objective == NLSG_OBJ_CUSTOM)
+    return fail(NLSG_ERR_INVALID_ARG, "NLSG_OBJ_CUSTOM engines are made by nlsg_lm_create_custom");
+  return lm_create(cfg, nullptr, out);
+}
+
+int nlsg_lm_create_custom(const nlsg_lm_config *cfg, const nlsg_custom_objective *obj, nlsg_lm **out) {
+  if (!cfg || !obj) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  if (cfg->objective != NLSG_OBJ_CUSTOM)
+    return fail(NLSG_ERR_INVALID_ARG, "cfg.objective must be NLSG_OBJ_CUSTOM");
+  return lm_create(cfg, obj, out);
+}
+
+}  // extern "C"
+
+static int lm_create(const nlsg_lm_config *cfg, const nlsg_custom_objective *custom, nlsg_lm **out) {
   if (!cfg || !out) return fail(NLSG_ERR_INVALID_ARG, "null argument");
   *out = nullptr;
   if (cfg->struct_size != sizeof(nlsg_lm_config))
     return fail(NLSG_ERR_INVALID_ARG, "nlsg_lm_config size mismatch (%u vs %zu)", cfg->struct_size,
                 sizeof(nlsg_lm_config));
-  if (cfg->objective != NLSG_OBJ_TANH_REGRESSION)
+  const bool fd = lm_fd_objective(cfg->objective);
+  if (cfg->objective != NLSG_OBJ_TANH_REGRESSION && !fd)
     return fail(NLSG_ERR_INVALID_ARG, "unknown objective %d", cfg->objective);
   if (cfg->solver != NLSG_LM_CHOLESKY && cfg->solver != NLSG_LM_QR)
     return fail(NLSG_ERR_INVALID_ARG, "unknown solver %d", cfg->solver);
-  if (cfg->n < 1 || cfg->n > kLmN || cfg->m < 1 || cfg->batch < 1)
+  if (fd && cfg->solver != NLSG_LM_CHOLESKY)
+    return fail(NLSG_ERR_UNSUPPORTED,
+                "the finite-difference model runs the reference's own solve (Cholesky) only");
+  if (cfg->n < 1 || cfg->n > kLmN || (!fd && cfg->m < 1) || cfg->batch < 1)
     return fail(NLSG_ERR_INVALID_ARG, "need 1 <= n <= 64, m >= 1, batch >= 1");
   if (cfg->batch > 0x7fffffffull) return fail(NLSG_ERR_UNSUPPORTED, "batch too large");
   int rc = lm_check_device(cfg->device);
@@ -112,15 +169,18 @@ int nlsg_lm_create(const nlsg_lm_config *cfg, nlsg_lm **out) {
   }
   LmParams &p = e->p;
   std::memset(&p, 0, sizeof p);
-  const uint64_t B = cfg->batch, m = cfg->m;
+  const uint64_t B = cfg->batch, m = fd ? 0 : cfg->m;  // no design matrix behind an objective
   hipError_t he = hipSuccess;
   const uint64_t nstep = (m + 15) / 16;
   p.nstep = nstep;
-  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&e->A_dev), nstep * B * 16 * kLmN * 8);
-  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&e->y_dev), nstep * B * 16 * 8);
+  if (he == hipSuccess && nstep)
+    he = hipMalloc(reinterpret_cast<void **>(&e->A_dev), nstep * B * 16 * kLmN * 8);
+  if (he == hipSuccess && nstep)
+    he = hipMalloc(reinterpret_cast<void **>(&e->y_dev), nstep * B * 16 * 8);
   if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p.theta), B * kLmN * 8);
   if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p.prob), B * sizeof(LmProblem));
   if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p.Hg), B * kLmTri * 8);
+  if (he == hipSuccess) he = hipMemset(p.Hg, 0, B * kLmTri * 8);  // rows past n are never written
   if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p.gg), B * kLmN * 8);
   if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&e->count_dev), 8);
   if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&e->zero_dev), 16);
@@ -135,6 +195,13 @@ int nlsg_lm_create(const nlsg_lm_config *cfg, nlsg_lm **out) {
     return fail(he == hipErrorOutOfMemory ? NLSG_ERR_OOM : NLSG_ERR_HIP,
                 "device setup failed: %s", hipGetErrorString(he));
   }
+  if (custom) {
+    const int rc2 = rtc_build_lm(custom, &e->rtc);
+    if (rc2) {
+      nlsg_lm_destroy(e);
+      return rc2;
+    }
+  }
   p.A = e->A_dev;
   p.y = e->y_dev;
   p.zero = e->zero_dev;
@@ -146,9 +213,14 @@ int nlsg_lm_create(const nlsg_lm_config *cfg, nlsg_lm **out) {
   p.up = cfg->up;
   p.down = cfg->down;
   p.f_delta = cfg->f_delta;
+  p.fd = fd ? 1 : 0;
+  p.eps_h = std::pow(DBL_EPSILON, 1.0 / 4.0);  // fin_diff_h's step (:1454)
+  e->has_data = fd;  // the model is the objective itself
   *out = e;
   return NLSG_OK;
 }
+
+extern "C" {
 
 int nlsg_lm_destroy(nlsg_lm *e) {
   if (!e) return NLSG_OK;
@@ -164,6 +236,7 @@ int nlsg_lm_destroy(nlsg_lm *e) {
   hipFree(e->zero_dev);
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
+  rtc_release(&e->rtc);
   if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
   delete e;
   return NLSG_OK;
@@ -171,6 +244,7 @@ int nlsg_lm_destroy(nlsg_lm *e) {
 
 int nlsg_lm_set_data(nlsg_lm *e, const double *a_host, const double *y_host) {
   if (!e || !a_host || !y_host) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  if (e->p.fd) return fail(NLSG_ERR_STATE, "this engine minimises a built-in objective: no data");
   NLSG_HIP(hipSetDevice(e->cfg.device));
   const uint64_t B = e->p.batch, m = e->p.m, n = e->p.n;
   // host layout [problem][m][n] -> device layout [row group][problem][16][64] (zero padded):
@@ -216,7 +290,9 @@ int nlsg_lm_minimize(nlsg_lm *e, double *theta_inout_host, nlsg_status *status_h
       nlsg_status &st = status_host[b];
       st.f_value = pr[b].f;
       st.iteration = pr[b].iter;
-      st.function_calls_used = pr[b].fcalls;  // f, grad and hess are evaluated together
+      // f, grad and hess are evaluated together; behind the default functors every probe of
+      // fin_diff (4 n) and fin_diff_h (16 n^2) is a call of the objective
+      st.function_calls_used = pr[b].fcalls * (e->p.fd ? 1 + 4 * n + 16 * n * n : 1);
       st.gradient_evals_used = pr[b].fcalls;
       st.hessian_evals_used = pr[b].fcalls;
       st.best_index = b;
@@ -256,6 +332,7 @@ int nlsg_lm_time_solve(nlsg_lm *e, const double *theta0_host, uint32_t repeats, 
 // for every problem) on the engine's stream, HIP events around each launch.
 int nlsg_lm_time_eval_kernel(nlsg_lm *e, const double *theta0_host, uint32_t repeats, float *ms_total) {
   if (!e || !theta0_host || !ms_total) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  if (e->p.fd) return fail(NLSG_ERR_UNSUPPORTED, "Gauss-Newton model only");
   if (!e->has_data) return fail(NLSG_ERR_STATE, "nlsg_lm_set_data has not been called");
   NLSG_HIP(hipSetDevice(e->cfg.device));
   int rc = upload_theta(e, theta0_host);

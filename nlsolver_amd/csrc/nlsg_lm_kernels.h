@@ -36,7 +36,8 @@ constexpr int kLmTri = 33 * 64;  // packed lower triangle of a 64 x 64 matrix (2
 struct LmProblem {
   double f, lambda, prev;
   uint64_t iter, fcalls;
-  int32_t done, pad;
+  int32_t done;
+  int32_t upper;  // finite-difference model: an upper off-diagonal of H exceeds eps * 1e12
 };
 
 struct LmParams {
@@ -50,6 +51,8 @@ struct LmParams {
   double lambda0, up, down, f_delta;
   double *Hg;        // [batch][kLmTri] lower triangle of 2 J^T J, packed by rows
   double *gg;        // [batch][64] 2 J^T r
+  double eps_h;      // finite-difference model: step of fin_diff_h, pow(DBL_EPSILON, 1/4)
+  int32_t fd, pad;   // 1: the functors are the reference's defaults on a built-in objective
 };
 
 // The damped matrix as the Cholesky solve sees it: the packed lower triangle (the solve only
@@ -57,6 +60,15 @@ struct LmParams {
 struct LmRowsTri {
   double *base;
   __device__ double &operator()(int i, int j) const { return base[i * (i + 1) / 2 + j]; }
+};
+// The same for an LDS image that ends with row n - 1: the solve's masked reads (rows >= n,
+// columns past the diagonal) are folded back inside it.
+struct LmRowsTriShort {
+  double *base;
+  int last;  // n - 1
+  __device__ double &operator()(int i, int j) const {
+    return base[min(i, last) * (min(i, last) + 1) / 2 + min(j, last)];
+  }
 };
 
 // value of lane `src` (wave-uniform index) through scalar registers
@@ -68,13 +80,16 @@ __device__ inline double lane_broadcast(double v, int src) {
 }
 
 template <typename Rows>
-__device__ inline void lm_solve_cholesky_wave(Rows H, const double *g, double *upd, int n) {
+__device__ inline void lm_solve_cholesky_wave(Rows H, const double *g, double *upd, int n,
+                                              bool off_upper = false) {
   const int t = lane_id();
   const bool row = t < n;
-  // is_diagonal (:295-307): any off-diagonal above eps * 1e12 (positive values only); the
-  // matrix is bitwise symmetric (fma chains of commuting products), so the lower triangle
-  // decides. Reads past the lane's own row end stay inside the buffer and are masked.
-  bool off = false;
+  // is_diagonal (:295-307): any off-diagonal above eps * 1e12 (positive values only). The
+  // Gauss-Newton matrix is bitwise symmetric (fma chains of commuting products), so the lower
+  // triangle decides; a finite-difference Hessian is not, and its evaluation hands over the
+  // verdict on the upper triangle (`off_upper`). Reads past the lane's own row end stay inside
+  // the buffer and are masked.
+  bool off = off_upper;
   for (int j0 = 0; j0 < n; j0 += 8) {
     double h[8];
 #pragma unroll
@@ -266,6 +281,25 @@ struct LmWaveShared {  // view of the wave's LDS during the evaluation
   double *r;           // [16]
 };
 
+// the iteration's bookkeeping after an evaluation (one lane)
+__device__ inline void lm_publish_state(const LmParams &p, LmProblem *pr, int first, double f) {
+  if (first) {  // g, H, f at x0 (:3513-3516)
+    pr->prev = 0.0;
+    pr->f = f;
+    pr->lambda = p.lambda0;
+    pr->iter = 0;
+    pr->fcalls = 1;
+    pr->done = 0;
+  } else {  // :3535-3542
+    const double prev = pr->f;
+    pr->prev = prev;
+    pr->f = f;
+    pr->fcalls += 1;
+    pr->iter += 1;
+    pr->lambda = f < prev ? pr->lambda / p.down : pr->lambda * p.up;
+  }
+}
+
 // theta_lds: the parameters as the step left them in LDS (nullptr: read them from global)
 __device__ inline void lm_eval_wave(const LmParams &p, int first, uint64_t pid, LmWaveShared sh,
                                     const double *theta_lds) {
@@ -373,23 +407,7 @@ __device__ inline void lm_eval_wave(const LmParams &p, int first, uint64_t pid, 
     f = f + __shfl(facc[w], 0, 64);
     f = f + __shfl(facc[w], 32, 64);
   }
-  if (lane == 0) {
-    if (first) {  // g, H, f at x0 (:3513-3516)
-      pr->prev = 0.0;
-      pr->f = f;
-      pr->lambda = p.lambda0;
-      pr->iter = 0;
-      pr->fcalls = 1;
-      pr->done = 0;
-    } else {  // :3535-3542
-      const double prev = pr->f;
-      pr->prev = prev;
-      pr->f = f;
-      pr->fcalls += 1;
-      pr->iter += 1;
-      pr->lambda = f < prev ? pr->lambda / p.down : pr->lambda * p.up;
-    }
-  }
+  if (lane == 0) lm_publish_state(p, pr, first, f);
 }
 
 struct LmStepShared {  // view of the wave's LDS during the step
@@ -397,8 +415,11 @@ struct LmStepShared {  // view of the wave's LDS during the step
   double *g, *upd;     // [64] each; upd ends up holding the new parameters
 };
 
-// false: a stop test fired (the problem is done)
-__device__ inline bool lm_step_wave(const LmParams &p, uint64_t pid, LmStepShared sh) {
+// false: a stop test fired (the problem is done). FD = the finite-difference model: the LDS image
+// of the triangle ends with row n - 1 (`chunks` x 64 doubles), and is_diagonal also needs the
+// evaluation's verdict on the upper triangle.
+template <bool FD>
+__device__ inline bool lm_step_wave(const LmParams &p, uint64_t pid, LmStepShared sh, int chunks = 33) {
   LmProblem *pr = p.prob + pid;
   const int t = threadIdx.x, n = static_cast<int>(p.n);
   const double prev = pr->prev, cur = pr->f;
@@ -406,8 +427,11 @@ __device__ inline bool lm_step_wave(const LmParams &p, uint64_t pid, LmStepShare
     if (t == 0) pr->done = 1;
     return false;
   }
-  {  // all loads in flight before the first LDS write (the pad holds stale, unused values)
-    const double *src = p.Hg + pid * kLmTri;
+  const double *src = p.Hg + pid * kLmTri;
+  if constexpr (FD) {
+    for (int q = 0; q < chunks; q++) sh.tri[64 * q + t] = src[64 * q + t];
+    sh.g[t] = p.gg[pid * kLmN + t];
+  } else {  // all loads in flight before the first LDS write (the pad holds stale, unused values)
     double h[33];
 #pragma unroll
     for (int q = 0; q < 33; q++) h[q] = src[64 * q + t];
@@ -421,7 +445,10 @@ __device__ inline bool lm_step_wave(const LmParams &p, uint64_t pid, LmStepShare
   if (t < n) sh.tri[t * (t + 1) / 2 + t] += pr->lambda;  // :3529-3531
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  lm_solve_cholesky_wave(LmRowsTri{sh.tri}, sh.g, sh.upd, n);
+  if constexpr (FD)
+    lm_solve_cholesky_wave(LmRowsTriShort{sh.tri, n - 1}, sh.g, sh.upd, n, pr->upper != 0);
+  else
+    lm_solve_cholesky_wave(LmRowsTri{sh.tri}, sh.g, sh.upd, n);
   const double th = p.theta[pid * kLmN + t];
   const double tn = t < n ? th - sh.upd[t] : th;  // :3534
   p.theta[pid * kLmN + t] = tn;
@@ -446,11 +473,196 @@ __global__ __launch_bounds__(64, 2) void lm_iter_kernel(LmParams p, int first, i
   if (!first) {
     if (p.prob[pid].done) return;
     if (with_step) {
-      if (!lm_step_wave(p, pid, LmStepShared{smem, smem + kLmTri, smem + kLmTri + 64})) return;
+      if (!lm_step_wave<false>(p, pid, LmStepShared{smem, smem + kLmTri, smem + kLmTri + 64})) return;
       theta_lds = smem + kLmTri + 64;
     }
   }
   lm_eval_wave(p, first, pid, LmWaveShared{smem, smem + 16 * kLmJStride}, theta_lds);
+}
+
+// ---- The reference's default functors on a built-in objective: when the
+// caller gives LevenbergMarquardt no Grad / Hess, solve() builds them from finite differences
+// (nlsolver.h:3494-3511 -> fin_diff :1385-1413 and fin_diff_h :1446-1515, both at accuracy 1):
+// f (1 probe), the gradient (4 n probes), the Hessian (16 n^2 probes) per evaluation, one wave
+// per problem.
+//
+// A point of n <= 64 coordinates fills at most 32 lanes, so the wave evaluates P = 64 / G
+// probe points at once, each in a group of G lanes (G = 4, 8, 16 or 32 for n <= 8, 16, 32, 64;
+// lane g of a group holds x[2g], x[2g+1]). group_objective is wave_objective restricted to a
+// group: the same per-lane partial and the levels G/2 .. 1 of the same butterfly; the levels
+// it drops only ever add the zeros of the unused lanes, so every probe value has the bits the
+// full-wave tree (oracle order 1) gives.
+//
+// fin_diff_h moves x[i] and x[j] through a fixed sequence of += / -= steps between its sixteen
+// probes of an entry. The sequence is replayed literally on two wave-uniform scalars (one when
+// i == j, where both names are the same element); group k % P captures the pair at probe k,
+// 16 / P passes evaluate all sixteen, and the weighted sums are taken in the reference's order
+// from the broadcast values. The result is not symmetric; Cholesky and the substitutions read
+// the lower triangle only (:251-294), is_diagonal reads both (:295-307): the lower triangle goes
+// to Hg, the upper one is reduced to its verdict.
+template <int OBJ, int G>
+__device__ inline double group_objective(double x0, double x1, uint64_t D) {
+  using O = Objective<OBJ>;
+  const uint64_t e0 = 2 * static_cast<uint64_t>(lane_id() & (G - 1));
+  const uint64_t nt = O::n_terms(D);
+  double xn = 0.0;
+  if (O::kChain) xn = lane_down1(x0);  // x[e0+2]; only read where e0 + 2 < D, inside the group
+  double acc = 0.0;
+  if (e0 < nt) acc = acc + O::term(x0, x1);
+  if (e0 + 1 < nt) acc = acc + O::term(x1, xn);
+  if constexpr (G > 1)
+    butterfly_levels<G / 2>([&](auto off) { acc = acc + lane_xor<decltype(off)::value>(acc); });
+  return O::finish(acc, D);
+}
+
+template <int OBJ, int G>
+__device__ inline void lm_fd_eval_groups(const LmParams &p, int first, uint64_t pid,
+                                         const double *theta_lds) {
+  constexpr int P = 64 / G;                  // probe points per pass
+  constexpr int HP = P >= 16 ? 1 : 16 / P;   // passes per Hessian entry
+  LmProblem *pr = p.prob + pid;
+  const int lane = threadIdx.x, n = static_cast<int>(p.n);
+  const int g = lane & (G - 1), gi = lane / G;
+  const double *theta = theta_lds ? theta_lds : p.theta + pid * kLmN;
+  const double x0 = theta[2 * g], x1 = theta[2 * g + 1];  // zero past n
+  const double f = lane_broadcast(group_objective<OBJ, G>(x0, x1, n), 0);
+  {  // fin_diff<1>: coeff {1,-8,8,-1}, coeff2 {-2,-1,1,2}, eps = DBL_EPSILON * 10e7; probe
+     // q = 4 d + s of the 4 n probes runs in group q % P of pass q / P
+    constexpr double eps = 2.220446049250313e-16 * 10e7;
+    constexpr double dd_val = 12 * eps;
+    double gl = 0.0, acc = 0.0;
+    for (int q0 = 0; q0 < 4 * n; q0 += P) {
+      const int q = q0 + gi, d = q >> 2, sq = q & 3;
+      const double c2 = sq == 0 ? -2.0 : sq == 1 ? -1.0 : sq == 2 ? 1.0 : 2.0;
+      const double xp0 = d == 2 * g ? x0 + c2 * eps : x0;
+      const double xp1 = d == 2 * g + 1 ? x1 + c2 * eps : x1;
+      const double fv = group_objective<OBJ, G>(xp0, xp1, n);
+#pragma unroll
+      for (int u = 0; u < P; u++) {
+        const int qu = q0 + u, su = qu & 3;  // wave-uniform
+        if (qu < 4 * n) {
+          const double fq = lane_broadcast(fv, u * G);
+          const double c = su == 0 ? 1.0 : su == 1 ? -8.0 : su == 2 ? 8.0 : -1.0;
+          acc = (su == 0 ? 0.0 : acc) + c * fq;
+          if (su == 3 && lane == (qu >> 2)) gl = acc / dd_val;
+        }
+      }
+    }
+    p.gg[pid * kLmN + lane] = gl;
+  }
+  // fin_diff_h<1>
+  const double e1 = p.eps_h, e2 = 2 * e1, e3 = 3 * e1, e4 = 4 * e1;
+  const double denom = (600.0 * e1 * e1);
+  bool upper = false;
+  for (int i = 0; i < n; i++) {
+    const double ti = lane_broadcast((i & 1) ? x1 : x0, i >> 1);
+    const bool mi0 = 2 * g == i, mi1 = 2 * g + 1 == i;
+    double hrow = 0.0;
+    for (int j = 0; j < n; j++) {
+      const bool mj0 = 2 * g == j, mj1 = 2 * g + 1 == j;
+      const bool same = i == j;
+      double xi = ti, xj = lane_broadcast((j & 1) ? x1 : x0, j >> 1);
+      double ci[HP], cj[HP];  // the pair this lane's group probes in each pass
+#pragma unroll
+      for (int h = 0; h < HP; h++) ci[h] = cj[h] = 0.0;
+      auto add_i = [&](double d) { xi = xi + d; xj = same ? xi : xj; };
+      auto sub_i = [&](double d) { xi = xi - d; xj = same ? xi : xj; };
+      auto add_j = [&](double d) { xj = xj + d; xi = same ? xj : xi; };
+      auto sub_j = [&](double d) { xj = xj - d; xi = same ? xj : xi; };
+      auto at = [&](auto k) {  // probe k is taken here
+        constexpr int K = decltype(k)::value;
+        const bool mine = gi == K % P;
+        ci[K / P] = mine ? xi : ci[K / P];
+        cj[K / P] = mine ? xj : cj[K / P];
+      };
+      add_i(e1); sub_j(e2); at(int_c<0>{});
+      add_i(e1); add_j(e1); at(int_c<1>{});
+      sub_i(e4); add_j(e2); at(int_c<2>{});
+      add_i(e1); add_j(e1); at(int_c<3>{});
+      sub_j(e4); at(int_c<4>{});
+      sub_i(e1); add_j(e1); at(int_c<5>{});
+      add_i(e3); add_j(e3); at(int_c<6>{});
+      add_i(e1); sub_j(e1); at(int_c<7>{});
+      sub_j(e3); at(int_c<8>{});
+      sub_i(e4); add_j(e4); at(int_c<9>{});
+      sub_j(e4); at(int_c<10>{});
+      add_i(e4); add_j(e4); at(int_c<11>{});
+      sub_i(e3); sub_j(e3); at(int_c<12>{});
+      add_i(e2); add_j(e2); at(int_c<13>{});
+      sub_j(e2); at(int_c<14>{});
+      sub_i(e2); add_j(e2); at(int_c<15>{});
+      double fv[HP];
+#pragma unroll
+      for (int h = 0; h < HP; h++) {
+        const double xp0 = mj0 ? cj[h] : mi0 ? ci[h] : x0;
+        const double xp1 = mj1 ? cj[h] : mi1 ? ci[h] : x1;
+        fv[h] = group_objective<OBJ, G>(xp0, xp1, n);
+      }
+      auto probe = [&](auto k) {
+        constexpr int K = decltype(k)::value;
+        return lane_broadcast(fv[K / P], (K % P) * G);
+      };
+      double result = 0.0, temp = 0.0;
+      temp = temp + probe(int_c<0>{});
+      temp = temp + probe(int_c<1>{});
+      temp = temp + probe(int_c<2>{});
+      temp = temp + probe(int_c<3>{});
+      result = result - 63 * temp;
+      temp = 0.0;
+      temp = temp + probe(int_c<4>{});
+      temp = temp + probe(int_c<5>{});
+      temp = temp + probe(int_c<6>{});
+      temp = temp + probe(int_c<7>{});
+      result = result + 63 * temp;
+      temp = 0.0;
+      temp = temp + probe(int_c<8>{});
+      temp = temp + probe(int_c<9>{});
+      temp = temp - probe(int_c<10>{});
+      temp = temp - probe(int_c<11>{});
+      result = result + 44 * temp;
+      temp = 0.0;
+      temp = temp + probe(int_c<12>{});
+      temp = temp + probe(int_c<13>{});
+      temp = temp - probe(int_c<14>{});
+      temp = temp - probe(int_c<15>{});
+      result = result + 74 * temp;
+      const double hij = result / denom;
+      hrow = lane == j ? hij : hrow;
+    }
+    if (lane <= i) p.Hg[pid * kLmTri + i * (i + 1) / 2 + lane] = hrow;
+    upper |= lane > i && lane < n && hrow > 2.220446049250313e-16 * 1e12;
+  }
+  const bool any_upper = __ballot(upper) != 0ull;
+  if (lane == 0) {
+    pr->upper = any_upper ? 1 : 0;
+    lm_publish_state(p, pr, first, f);
+  }
+}
+
+// LDS of the wave: `chunks` x 64 doubles of the triangle (rows 0 .. n-1) | g | upd
+__host__ __device__ inline int lm_fd_chunks(uint64_t n) {
+  return static_cast<int>((n * (n + 1) / 2 + 63) / 64);
+}
+template <int OBJ>
+__global__ __launch_bounds__(64) void lm_fd_iter_kernel(LmParams p, int first) {
+  extern __shared__ __align__(16) double lm_fd_smem[];
+  const uint64_t pid = blockIdx.x;
+  const double *theta_lds = nullptr;
+  if (!first) {
+    if (p.prob[pid].done) return;
+    const int chunks = lm_fd_chunks(p.n);
+    double *g = lm_fd_smem + 64 * chunks;
+    if (!lm_step_wave<true>(p, pid, LmStepShared{lm_fd_smem, g, g + 64}, chunks)) return;
+    theta_lds = g + 64;
+  }
+  if (p.n <= 8)
+    lm_fd_eval_groups<OBJ, 4>(p, first, pid, theta_lds);
+  else if (p.n <= 16)
+    lm_fd_eval_groups<OBJ, 8>(p, first, pid, theta_lds);
+  else if (p.n <= 32)
+    lm_fd_eval_groups<OBJ, 16>(p, first, pid, theta_lds);
+  else
+    lm_fd_eval_groups<OBJ, 32>(p, first, pid, theta_lds);
 }
 
 // ---- QR solver (tinyqr::lm on the damped matrix): the step as a kernel of its own, one

@@ -32,6 +32,12 @@ struct NmRtcKernels {
 };
 int rtc_build_nm(const nlsg_custom_objective *obj, NmRtcKernels *out);
 void rtc_release(NmRtcKernels *k);
+struct LmRtcKernels {  // finite-difference model (default functors) around the user's objective
+  hipModule_t mod = nullptr;
+  hipFunction_t iter = nullptr;
+};
+int rtc_build_lm(const nlsg_custom_objective *obj, LmRtcKernels *out);
+void rtc_release(LmRtcKernels *k);
 // pso_init / pso_move kernels; type = nlsg_pso_type.
 int rtc_build_pso(const nlsg_custom_objective *obj, int chunks, bool vec, int type, PsoRtcKernels *out);
 void rtc_release(PsoRtcKernels *k);

@@ -207,6 +207,22 @@ void rtc_release(NmRtcKernels *k) {
   if (k) *k = NmRtcKernels();
 }
 
+int rtc_build_lm(const nlsg_custom_objective *obj, LmRtcKernels *out) {
+  std::vector<hipFunction_t> f;
+  LmRtcKernels k;
+  const int rc = rtc_compile(obj, "nlsg_lm_kernels.h",
+                             {"nlsg::lm_fd_iter_kernel<" + std::to_string(static_cast<int>(NLSG_OBJ_CUSTOM)) + ">"},
+                             &k.mod, &f);
+  if (rc) return rc;
+  k.iter = f[0];
+  *out = k;
+  return NLSG_OK;
+}
+void rtc_release(LmRtcKernels *k) {
+  if (k && k->mod) hipModuleUnload(k->mod);
+  if (k) *k = LmRtcKernels();
+}
+
 void rtc_release(DeRtcKernels *k) {
   if (k && k->mod) hipModuleUnload(k->mod);
   if (k) *k = DeRtcKernels();

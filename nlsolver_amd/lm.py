@@ -1,5 +1,6 @@
 """Host-side mirror of the reference's LevenbergMarquardt class, batched, for NLLS models
-whose Gauss-Newton functors live on the device.
+whose Gauss-Newton functors live on the device, and for built-in objectives minimised through the
+reference's default functors (finite-difference gradient and Hessian, nlsolver.h:3494-3511).
 
 Reference interface (nlsolver.h:3428-3463):
     LevenbergMarquardt<Callable, scalar_t, Grad, Hess>(f, lambda = 10, upward_mult = 10,
@@ -32,21 +33,43 @@ class TanhRegression:
 
 
 class LMEngine:
+    """model: a TanhRegression, or the name / id of a built-in objective ("rosenbrock", "sphere",
+    "styblinski_tang") or a CustomObjective, with batch= and n= (default functors: fin_diff +
+    fin_diff_h)."""
+
     def __init__(self, model, *, lam=10.0, up=10.0, down=10.0, max_iter=100, f_delta=1e-12,
-                 solver=_capi.LM_CHOLESKY, device=0, stream=None):
-        B, m, n = model.A.shape
+                 solver=_capi.LM_CHOLESKY, device=0, stream=None, batch=None, n=None):
+        from .de import CustomObjective, rtc_library_path
+        custom = model if isinstance(model, CustomObjective) else None
+        fd = custom is not None or isinstance(model, (str, int))
+        if fd:
+            if batch is None or n is None:
+                raise TypeError("an objective needs batch= and n=")
+            B, m = batch, 0
+            objective = (_capi.OBJ_CUSTOM if custom else
+                         _capi.OBJECTIVES[model] if isinstance(model, str) else model)
+        else:
+            B, m, n = model.A.shape
+            objective = model.nlsg_nlls_objective
         cfg = LMConfig()
         cfg.struct_size = C.sizeof(LMConfig)
         cfg.device = device
         cfg.stream = None if stream is None else (stream or 1)
-        cfg.objective, cfg.solver = model.nlsg_nlls_objective, solver
+        cfg.objective, cfg.solver = objective, solver
         cfg.batch, cfg.m, cfg.n = B, m, n
         cfg.lambda_, cfg.up, cfg.down, cfg.max_iter, cfg.f_delta = lam, up, down, max_iter, f_delta
         self.cfg = cfg
         self._h = C.c_void_p()
-        check(lib().nlsg_lm_create(C.byref(cfg), C.byref(self._h)))
-        check(lib().nlsg_lm_set_data(self._h, model.A.ctypes.data_as(_capi.pd),
-                                     model.y.ctypes.data_as(_capi.pd)))
+        if custom:
+            check(lib().nlsg_rtc_load(rtc_library_path().encode()))
+            obj = _capi.CustomObjectiveC(custom.term_body.encode(), custom.finish_body.encode(),
+                                         int(custom.chain), 0)
+            check(lib().nlsg_lm_create_custom(C.byref(cfg), C.byref(obj), C.byref(self._h)))
+        else:
+            check(lib().nlsg_lm_create(C.byref(cfg), C.byref(self._h)))
+        if not fd:
+            check(lib().nlsg_lm_set_data(self._h, model.A.ctypes.data_as(_capi.pd),
+                                         model.y.ctypes.data_as(_capi.pd)))
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
@@ -86,12 +109,14 @@ class LMEngine:
 
 
 class LevenbergMarquardt:
-    """Drop-in for nlsolver::LevenbergMarquardt on a device NLLS model; x: (n,) or (batch, n)."""
+    """Drop-in for nlsolver::LevenbergMarquardt on a device NLLS model or a built-in objective
+    (by name); x: (n,) or (batch, n)."""
 
     def __init__(self, f, lam=10.0, upward_mult=10.0, downward_mult=10.0, max_iter=100,
                  f_delta=1e-12, g=None, h=None, *, solver=_capi.LM_CHOLESKY, device=0):
         if g is not None or h is not None:
-            raise TypeError("device NLLS models carry their Gauss-Newton functors; pass g=h=None")
+            raise TypeError("device models carry their functors (Gauss-Newton for NLLS models, "
+                            "the reference's finite-difference defaults for objectives)")
         self.f = f
         self.args = dict(lam=lam, up=upward_mult, down=downward_mult, max_iter=max_iter,
                          f_delta=f_delta, solver=solver, device=device)
@@ -100,7 +125,8 @@ class LevenbergMarquardt:
         if not isinstance(x, np.ndarray) or x.dtype != np.float64 or x.ndim not in (1, 2):
             raise TypeError("x must be a float64 numpy array of shape (n,) or (batch, n)")
         xb = x.reshape(1, -1) if x.ndim == 1 else x
-        with LMEngine(self.f, **self.args) as eng:
+        shape = {} if hasattr(self.f, "A") else dict(batch=xb.shape[0], n=xb.shape[1])
+        with LMEngine(self.f, **self.args, **shape) as eng:
             out, st, lam = eng.minimize(xb)
         xb[...] = out
         self.lambdas = lam  # the reference keeps lambda as a member across calls (:3436)

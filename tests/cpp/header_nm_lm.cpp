@@ -4,6 +4,7 @@
 //   nm-device-custom (same arguments; objective = nlsolver::device::Custom<double>, compiled at run time)
 //   lm-host-exp [lambda max_iter f_delta]      reference-style GN functors on the exp model
 //   lm-device m n problems max_iter            device TanhRegression model, batched
+//   lm-device-fd n lambda max_iter f_delta x0 x0_step   default functors on device::Rosenbrock
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -107,6 +108,36 @@ struct ExpHess {
   }
 };
 
+template <typename F>
+static int run_lm_fd_with(F &f, int argc, char **argv) {
+  // lm-device-fd n lambda max_iter f_delta x0 x0_step: default functors on a device objective
+  const size_t n = std::strtoull(argv[2], nullptr, 10);
+  auto solver = nlsolver::LevenbergMarquardt<F, double>(
+      f, std::strtod(argv[3], nullptr), 10, 10, std::strtoull(argv[4], nullptr, 10),
+      std::strtod(argv[5], nullptr));
+  std::vector<double> x(n);
+  for (size_t i = 0; i < n; i++)
+    x[i] = std::strtod(argv[6], nullptr) + (argc > 7 ? std::strtod(argv[7], nullptr) : 0.0) * static_cast<double>(i);
+  try {
+    auto st = solver.minimize(x);
+    print_status(st, x);
+    std::printf("\n");
+  } catch (const nlsolver::device_error &e) {
+    std::printf("{\"device_error\":\"%s\"}\n", e.what());
+    return 3;
+  }
+  return 0;
+}
+static int run_lm_fd(int argc, char **argv) {
+  if (!std::strcmp(argv[1], "lm-device-fd-custom")) {
+    nlsolver::device::Custom<double> f(
+        "double t1 = 1 - xi; double t2 = (xn - xi * xi); return t1 * t1 + 100 * t2 * t2;", true);
+    return run_lm_fd_with(f, argc, argv);
+  }
+  nlsolver::device::Rosenbrock<double> f;
+  return run_lm_fd_with(f, argc, argv);
+}
+
 int main(int argc, char **argv) {
   if (argc >= 14 && !std::strcmp(argv[1], "nm-host")) {
     RosenbrockND f;
@@ -179,6 +210,8 @@ int main(int argc, char **argv) {
     }
     return 0;
   }
-  std::fprintf(stderr, "usage: header_nm_lm nm-host|nm-device|lm-host-exp|lm-host-findiff|lm-device ...\n");
+  if (argc >= 7 && (!std::strcmp(argv[1], "lm-device-fd") || !std::strcmp(argv[1], "lm-device-fd-custom")))
+    return run_lm_fd(argc, argv);
+  std::fprintf(stderr, "usage: header_nm_lm nm-host|nm-device|lm-host-exp|lm-host-findiff|lm-device|lm-device-fd ...\n");
   return 2;
 }

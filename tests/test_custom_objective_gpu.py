@@ -142,3 +142,35 @@ def test_bfgs_finite_difference_on_custom_objective_equals_builtin(mod, oracle, 
             (b.f_value, b.iteration, b.function_calls_used, b.gradient_evals_used)
     ref, xr, _, _ = O.bfgs_fd(oracle, "rosenbrock", x0[0], tree=1, **kw)
     assert np.array_equal(xb[0], xr) and sb[0].f_value == ref.f_value
+
+
+@pytest.mark.parametrize("n", [2, 7, 16])
+def test_lm_default_functors_on_custom_objective_equals_builtin(mod, oracle, n):
+    """LevenbergMarquardt with the default fin_diff / fin_diff_h functors around a run-time
+    compiled objective (nlsg_lm_create_custom): same iterates as the built-in, hence the oracle."""
+    rng = np.random.default_rng(n)
+    x0 = 0.8 + 0.4 * (rng.random((4, n)) - 0.5)
+    kw = dict(lam=10.0, max_iter=6, f_delta=0.0)
+    with mod.lm.LMEngine("rosenbrock", batch=4, n=n, **kw) as eng:
+        xa, sa, la = eng.minimize(x0.copy())
+    with mod.lm.LMEngine(mod.CustomObjective(ROSENBROCK, chain=True), batch=4, n=n, **kw) as eng:
+        xb, sb, lb = eng.minimize(x0.copy())
+    assert np.array_equal(xa, xb, equal_nan=True) and np.array_equal(la, lb, equal_nan=True)
+    for a, b in zip(sa, sb):
+        assert (a.iteration, a.function_calls_used) == (b.iteration, b.function_calls_used)
+        assert np.array_equal(a.f_value, b.f_value, equal_nan=True)
+    ref, xr, lam_r, _ = O.lm_fd(oracle, "rosenbrock", x0[0], order=1, **kw)
+    assert np.array_equal(xb[0], xr, equal_nan=True) and lb[0] == lam_r
+
+
+def test_lm_custom_objective_quartic(mod):
+    """An objective the library does not ship: f = sum (x_i^2 - 1)^2 + 0.1 x_i, minimised by the
+    damped Newton iteration from its finite-difference model."""
+    obj = mod.CustomObjective("double t = xi * xi - 1; return t * t + 0.1 * xi;")
+    x0 = np.full((2, 5), 1.3)
+    x0[1] = -0.7
+    solver = mod.lm.LevenbergMarquardt(obj, 1.0, 10.0, 10.0, 60, 1e-14)
+    st = solver.minimize(x0)
+    # stationary points of t^2 + 0.1 x: 4 x (x^2 - 1) + 0.1 = 0
+    r = 4 * x0 * (x0 * x0 - 1) + 0.1
+    assert np.max(np.abs(r)) < 1e-4, (x0, st[0].f_value)

@@ -283,3 +283,29 @@ def test_lm_device_model_through_header_matches_oracle(built, oracle):
             (ref.iteration, ref.function_calls_used, ref.gradient_evals_used, ref.hessian_evals_used)
         assert hx(o["f"]) == ref.f_value
         assert np.array_equal(np.array([hx(v) for v in o["x"]]), xr)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["lm-device-fd", "lm-device-fd-custom"])
+@pytest.mark.parametrize("n,iters", [(2, 12), (5, 8), (16, 4)])
+def test_lm_default_functors_on_device_objective_through_header(built, oracle, n, iters, mode):
+    """LevenbergMarquardt<device::Rosenbrock<double>, double>(f).minimize(x): fin_diff and
+    fin_diff_h (nlsolver.h:3494-3511) evaluated on the GPU; bit-exact vs the tree oracle."""
+    out = subprocess.check_output(
+        [os.path.join(built, "header_nm_lm"), mode, str(n), "10", str(iters), "0.0",
+         "0.8", "0.01"], env=dict(os.environ, NLSG_LIBRARY=LIB), text=True)
+    o = json.loads(out)
+    assert "device_error" not in o, o
+    x0 = 0.8 + 0.01 * np.arange(n, dtype=np.float64)
+    ref, xr, _, _ = O.lm_fd(oracle, "rosenbrock", x0, lam=10.0, max_iter=iters, f_delta=0.0, order=1)
+    assert (o["iters"], o["fcalls"], o["gcalls"], o["hcalls"]) == \
+        (ref.iteration, ref.function_calls_used, ref.gradient_evals_used, ref.hessian_evals_used)
+    assert hx(o["f"]) == ref.f_value
+    assert np.array_equal(np.array([hx(v) for v in o["x"]]), xr)
+
+
+def test_lm_device_objective_without_library_fails_loudly(built):
+    r = subprocess.run([os.path.join(built, "header_nm_lm"), "lm-device-fd", "4", "10", "5", "0.0",
+                        "0.8", "0.01"], env=dict(os.environ, NLSG_LIBRARY="/nonexistent/lib.so"),
+                       capture_output=True, text=True)
+    assert r.returncode == 3 and "device_error" in r.stdout, (r.returncode, r.stdout, r.stderr)

@@ -103,3 +103,80 @@ def test_lm_qr_and_cholesky_agree_to_rounding(mod, oracle):
     with mod.LMEngine(mod.TanhRegression(A, y), **kw) as eng:
         tc, sc, _ = eng.minimize(t0.copy())
     assert np.allclose(tq, tc, rtol=1e-8, atol=1e-10) and not np.array_equal(tq, tc)
+
+
+# ---- default functors (fin_diff + fin_diff_h) on built-in objectives, SURVEY.md §8f N2
+def fd_starts(oracle, objective, batch, n, scale):
+    x0 = np.zeros((batch, n))
+    for b in range(batch):
+        k = oracle.orc_ctr_key(SEED, 1000 + b)
+        u = np.array([oracle.orc_u01(oracle.orc_ctr_key(k, j)) for j in range(n)])
+        x0[b] = scale * (2 * u - 1)
+    return x0
+
+
+@pytest.mark.parametrize("objective,n,scale", [("rosenbrock", 2, 2.0), ("rosenbrock", 4, 1.5),
+                                               ("rosenbrock", 7, 1.2), ("rosenbrock", 16, 1.0),
+                                               ("sphere", 1, 3.0), ("sphere", 5, 3.0),
+                                               ("styblinski_tang", 8, 4.0),
+                                               ("styblinski_tang", 33, 4.0)])
+@pytest.mark.parametrize("kw", [dict(lam=10.0, max_iter=12, f_delta=1e-12),
+                                dict(lam=1.0, up=4.0, down=3.0, max_iter=5, f_delta=0.0)])
+def test_lm_default_functors_bit_exact_vs_oracle(mod, oracle, objective, n, scale, kw):
+    """fin_diff / fin_diff_h probes through the wave's objective tree (oracle order 1): parameters,
+    objective value, damping, iteration and probe counts agree exactly, NaN runs included."""
+    batch = 6
+    x0 = fd_starts(oracle, objective, batch, n, scale)
+    with mod.lm.LMEngine(objective, batch=batch, n=n, **kw) as eng:
+        x, st, lam = eng.minimize(x0.copy())
+    for b in range(batch):
+        ref, xr, lam_r, _ = O.lm_fd(oracle, objective, x0[b], order=1, **kw)
+        assert np.array_equal(x[b], xr, equal_nan=True), (b, x[b], xr)
+        assert np.array_equal(st[b].f_value, ref.f_value, equal_nan=True)
+        assert np.array_equal(lam[b], lam_r, equal_nan=True)
+        assert st[b].iteration == ref.iteration
+        assert st[b].function_calls_used == ref.function_calls_used
+        assert st[b].gradient_evals_used == ref.gradient_evals_used
+        assert st[b].hessian_evals_used == ref.hessian_evals_used
+
+
+def test_lm_default_functors_n64(mod, oracle):
+    x0 = fd_starts(oracle, "sphere", 3, 64, 2.0)
+    kw = dict(lam=1.0, max_iter=3, f_delta=0.0)
+    with mod.lm.LMEngine("sphere", batch=3, n=64, **kw) as eng:
+        x, st, lam = eng.minimize(x0.copy())
+    for b in range(3):
+        ref, xr, lam_r, _ = O.lm_fd(oracle, "sphere", x0[b], order=1, **kw)
+        assert np.array_equal(x[b], xr) and st[b].f_value == ref.f_value and lam[b] == lam_r
+        assert st[b].function_calls_used == ref.function_calls_used == 4 * (1 + 4 * 64 + 16 * 64 * 64)
+
+
+def test_lm_default_functors_match_reference_runs(mod, golden):
+    """The committed runs of the reference's LevenbergMarquardt with its default functors
+    (tests/golden/lm_fd.json). The reference sums the objective sequentially, the wave in a
+    tree; fin_diff_h divides differences of those sums by 600 eps^2 ~ 9e-6, so the paths agree
+    to ~1e-6, not to rounding; the probe and iteration counts agree exactly."""
+    from tests.test_oracle_golden import hx
+    names = {0: "rosenbrock", 1: "sphere", 2: "styblinski_tang"}
+    for name, g in golden("lm_fd.json").items():
+        x = hx(g["x0"]) + hx(g["x0_step"]) * np.arange(g["n"], dtype=np.float64)
+        solver = mod.lm.LevenbergMarquardt(names[g["objective"]], hx(g["lambda"]), 10.0, 10.0,
+                                           g["max_iter"], hx(g["f_delta"]))
+        st = solver.minimize(x)
+        f_ref, x_ref = hx(g["f"]), np.array([hx(v) for v in g["x"]])
+        if np.isnan(f_ref):
+            assert np.isnan(st.f_value), name
+            continue
+        assert st.iteration == g["iters"], name
+        assert st.function_calls_used == g["fcalls"], name
+        assert st.gradient_evals_used == g["gcalls"] and st.hessian_evals_used == g["hcalls"], name
+        assert np.allclose(x, x_ref, rtol=1e-5, atol=1e-6), name
+        assert abs(st.f_value - f_ref) <= 1e-6 * max(1.0, abs(f_ref)), name
+
+
+def test_lm_default_functors_reject_qr_and_data(mod):
+    from nlsolver_amd._capi import LM_QR, NlsgError
+    with pytest.raises(NlsgError):
+        mod.lm.LMEngine("rosenbrock", batch=1, n=4, solver=LM_QR)
+    with pytest.raises(NlsgError):
+        mod.lm.LMEngine("rastrigin", batch=1, n=4)
