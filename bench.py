@@ -212,6 +212,48 @@ def main_bfgs_fd(args):
     eng.close()
 
 
+def main_lm_fd(args):
+    """LevenbergMarquardt with the reference's DEFAULT functors (fin_diff + fin_diff_h,
+    nlsolver.h:3494-3511) on the device: Rosenbrock-16D, batch = 8192 independent starts, 10
+    iterations. One step = one LM iteration of every problem = 1 + 4 n + 16 n^2 = 4161 objective
+    evaluations per problem, several probe points per wave."""
+    import torch
+
+    import nlsolver_amd
+    n, iters = 16, 10
+    batch = 8192 if args.pop_per_gpu == POP_PER_GPU else args.pop_per_gpu
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    rng = np.random.default_rng(12374563468 % 2**32)
+    x0 = 0.8 + 0.4 * (rng.random((batch, n)) - 0.5)
+    eng = nlsolver_amd.lm.LMEngine("rosenbrock", batch=batch, n=n, lam=10.0, max_iter=iters,
+                                   f_delta=0.0, device=local_rank)
+    x, st, lam = eng.minimize(x0.copy())
+    reps = 5
+    ms = eng.time_solve(x0, reps) / reps
+    fcalls = sum(s.function_calls_used for s in st)
+    assert all(s.iteration == iters for s in st)
+    print(json.dumps({
+        "metric": "LM iterations x problems / s (Rosenbrock-16D, finite-difference gradient and Hessian)",
+        "value": batch * iters / (ms * 1e-3), "unit": "iteration-problems/s", "n_gpus": 1,
+        "steps": iters, "warmup": iters, "ms_per_step": ms / iters, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"Levenberg-Marquardt, default fin_diff / fin_diff_h functors, "
+                               f"Rosenbrock-{n}D, batch={batch} independent starts",
+                   "objective_calls_per_s": fcalls / (ms * 1e-3),
+                   "finite_final_f": int(np.sum(np.isfinite([s.f_value for s in st])))},
+        "roofline": {"bound": "valu", "achieved": None, "peak": None, "unit": None,
+                     "frac": None, "traffic": None, "kernel": "lm_fd_iter_kernel",
+                     "kernel_ms": ms / (iters + 1),
+                     "note": "fp64 VALU issue bound (objective probes, 8 per wave pass); "
+                             "not roofline-graded"},
+        **({} if args.no_cpu_baseline else {"cpu_baseline": ref_baseline(
+            ["bench-lm-fd", n, 16384, iters], "iterations_per_s", "iteration-problems/s",
+            f"reference LevenbergMarquardt, default functors, Rosenbrock-{n}D, 16384 starts x "
+            f"{iters} iterations")})}))
+    eng.close()
+
+
 def main_lm(args):
     """BASELINE configs[3]: Levenberg-Marquardt NLLS m=512, n=64, batch=8192 on one GPU
     (tanh regression, 20 iterations, lambda0 = 10, up = down = 10, f_delta = 0). One step = one
@@ -403,7 +445,7 @@ def main():
     ap.add_argument("--lm-solver", choices=["cholesky", "qr"], default="cholesky",
                     help="lm workload: damped-system solver (cholesky = the reference class's "
                          "get_update_with_hessian; qr = tinyqr::lm, as BASELINE configs[3] words it)")
-    ap.add_argument("--workload", choices=["de", "pso-accel", "pso-vanilla", "bfgs", "bfgs-fd", "lm", "nm"],
+    ap.add_argument("--workload", choices=["de", "pso-accel", "pso-vanilla", "bfgs", "bfgs-fd", "lm", "lm-fd", "nm"],
                     default="de",
                     help="de = the headline benchmark (BASELINE metric); pso-* = config 5's "
                          "per-GPU shard (secondary, same JSON shape)")
@@ -412,6 +454,8 @@ def main():
         return main_bfgs(args)
     if args.workload == "bfgs-fd":
         return main_bfgs_fd(args)
+    if args.workload == "lm-fd":
+        return main_lm_fd(args)
     if args.workload == "lm":
         return main_lm(args)
     if args.workload == "nm":
