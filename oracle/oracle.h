@@ -233,6 +233,14 @@ orc_status orc_nm_run(int obj, int minimize, int bound, double *x, size_t n, con
                       double sigma, double *eps, size_t max_iter, size_t no_change_best_tol,
                       size_t restarts, int order, orc_eval_log *log);
 
+/* ---- simulated annealing (oracle_sann.c), SANN::solve nlsolver.h:2777-2814 ---- */
+orc_status orc_sann_serial(int obj, int minimize, double *x, size_t D, orc_xorshift *gen,
+                           size_t max_iter, size_t temp_iter, double temp_max, double *f_log,
+                           size_t f_cap);
+orc_status orc_sann_sync(int obj, int minimize, double *x, size_t D, uint64_t seed, uint64_t chain,
+                         size_t max_iter, size_t temp_iter, double temp_max, double *f_log,
+                         size_t f_cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -137,6 +137,29 @@ def lm_fd(lib, obj, x0, *, lam=10.0, up=10.0, down=10.0, max_iter=100, f_delta=1
     return st, x, lam_c.value, flog
 
 
+def sann_serial(lib, obj, x0, *, minimize=True, max_iter=5000, temp_iter=10, temp_max=10.0,
+                log_cap=0):
+    """Oracle SANN in the reference's arithmetic and draw order (fresh xorshift generator);
+    returns (status, x, next draw of the generator, f_log or None)."""
+    x = np.ascontiguousarray(x0, dtype=np.float64).copy()
+    gen = XorShift()
+    lib.orc_xorshift_init(C.byref(gen))
+    flog = np.zeros(log_cap) if log_cap else None
+    st = lib.orc_sann_serial(OBJ[obj], int(minimize), _ptr(x), x.size, C.byref(gen), max_iter,
+                             temp_iter, temp_max, _ptr(flog) if log_cap else None, log_cap)
+    return st, x, lib.orc_xorshift_next(C.byref(gen)), flog
+
+
+def sann_sync(lib, obj, x0, seed, chain, *, minimize=True, max_iter=5000, temp_iter=10,
+              temp_max=10.0, log_cap=0):
+    """Oracle SANN as the GPU runs it (counter-keyed draws, deterministic math, objective tree)."""
+    x = np.ascontiguousarray(x0, dtype=np.float64).copy()
+    flog = np.zeros(log_cap) if log_cap else None
+    st = lib.orc_sann_sync(OBJ[obj], int(minimize), _ptr(x), x.size, seed, chain, max_iter,
+                           temp_iter, temp_max, _ptr(flog) if log_cap else None, log_cap)
+    return st, x, flog
+
+
 def load():
     if not os.path.exists(LIB):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
@@ -189,6 +212,10 @@ def load():
     lib.orc_bfgs_quad.restype = Status
     lib.orc_bfgs_quad.argtypes = [C.POINTER(Quad), pd, sz, sz, f64, f64, C.c_int,
                                   C.POINTER(BfgsCounters)]
+    lib.orc_sann_serial.restype = Status
+    lib.orc_sann_serial.argtypes = [C.c_int, C.c_int, pd, sz, C.POINTER(XorShift), sz, sz, f64, pd, sz]
+    lib.orc_sann_sync.restype = Status
+    lib.orc_sann_sync.argtypes = [C.c_int, C.c_int, pd, sz, u64, u64, sz, sz, f64, pd, sz]
     lib.orc_lm_fd.restype = Status
     lib.orc_lm_fd.argtypes = [C.c_int, pd, sz, C.POINTER(C.c_double), f64, f64, sz, f64, C.c_int, pd,
                               sz]

@@ -61,6 +61,19 @@ def main():
     }
     write("lm_fd.json", g8fd)
 
+    # N4 — SANN (nlsolver.h:2744-2815) with the reference's xorshift generator.
+    # args: objective n max_iter temp_iter temp_max x0 x0_step minimize trace_cap
+    gsann = {
+        "rosenbrock_n2_default_schedule": run("sann", 0, 2, 200, 10, 10, 2, 5, 1, 64),
+        "rosenbrock_n8": run("sann", 0, 8, 300, 10, 10, 0.5, 0.1, 1, 64),
+        "sphere_n16_hot": run("sann", 1, 16, 100, 5, 50, 3, -0.25, 1, 64),
+        "styblinski_tang_n6": run("sann", 2, 6, 400, 10, 10, -1, 0.5, 1, 64),
+        "sphere_n4_maximize": run("sann", 1, 4, 60, 10, 10, 1, 0.5, 0, 64),
+        "rosenbrock_n130_ragged": run("sann", 0, 130, 40, 10, 10, 0.4, 0.001, 1, 64),
+        "temp_iter_1_no_moves": run("sann", 0, 4, 25, 1, 10, 0.3, 0.2, 1, 64),
+    }
+    write("sann.json", gsann)
+
     # G8/G9 — LevenbergMarquardt (nlsolver.h:3428-3545) with Gauss-Newton functors, its
     # Cholesky solve (251-330) and tinyqr (291-310, 437-470).
     seed = 12374563468
