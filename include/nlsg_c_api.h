@@ -401,6 +401,42 @@ int nlsg_nm_minimize(nlsg_nm *e, double *x_inout_host, const double *upper_host,
                      const double *lower_host, nlsg_status *status_host, double *eps_out_host);
 int nlsg_nm_time_solve(nlsg_nm *e, const double *x0_host, uint32_t repeats, float *ms_total);
 
+/* ========================================================================== */
+/* Batched simulated annealing — replaces SANN::solve (nlsolver.h:2777-2814)   */
+/* with rnorm (2479-2485) and the minimize / maximize wrappers (2766-2773), for */
+/* `batch` independent chains (one per wave). Draws are keyed */
+/* by (seed, chain, step, slot) instead of coming from one sequential generator */
+/* (oracle: orc_sann_sync).                                                     */
+/* ========================================================================== */
+typedef struct nlsg_sann nlsg_sann;
+
+typedef struct {
+  uint32_t struct_size;
+  int32_t device;
+  void *stream;
+  int32_t objective;         /* nlsg_objective                                       */
+  int32_t minimize;          /* 1: minimize(), 0: maximize() (f_multiplier, :2779)   */
+  uint64_t batch;            /* independent chains                                   */
+  uint64_t dim;              /* <= 1024                                              */
+  uint64_t chain_lo;         /* global id of chain 0 (keys the draws; batch sharding)*/
+  uint64_t max_iter;         /* ctor arg max_iter = 5000 (:2760)                     */
+  uint64_t temperature_iter; /* ctor arg temperature_iter = 10 (:2761)               */
+  double temperature_max;    /* ctor arg temperature_max = 10.0 (:2761)              */
+  uint64_t seed;
+} nlsg_sann_config;
+
+int nlsg_sann_create(const nlsg_sann_config *cfg, nlsg_sann **out);
+/* cfg->objective == NLSG_OBJ_CUSTOM, as nlsg_de_create_custom */
+int nlsg_sann_create_custom(const nlsg_sann_config *cfg, const nlsg_custom_objective *obj,
+                            nlsg_sann **out);
+int nlsg_sann_destroy(nlsg_sann *e);
+/* x [batch][dim] in: starts, out: best points (:2808). One status per chain: f_value =
+ * f_multiplier * f(x) as the reference returns it (:2790), iteration = max_iter,
+ * function_calls_used = 1 + max_iter * (temperature_iter - 1). Synchronises. */
+int nlsg_sann_minimize(nlsg_sann *e, double *x_inout_host, nlsg_status *status_host);
+/* The same solve bracketed by hipEvents (starts restored from x0 each time). */
+int nlsg_sann_time_solve(nlsg_sann *e, const double *x0_host, uint32_t repeats, float *ms_total);
+
 #ifdef __cplusplus
 }
 #endif

@@ -90,6 +90,13 @@ class NMConfig(C.Structure):
                 ("eps", f64), ("max_iter", u64), ("no_change_best_tol", u64), ("restarts", u64)]
 
 
+class SANNConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("device", i32), ("stream", C.c_void_p),
+                ("objective", i32), ("minimize", i32), ("batch", u64), ("dim", u64),
+                ("chain_lo", u64), ("max_iter", u64), ("temperature_iter", u64),
+                ("temperature_max", f64), ("seed", u64)]
+
+
 # every symbol include/nlsg_c_api.h declares: name -> (restype, argtypes)
 _H = C.c_void_p
 SYMBOLS = {
@@ -161,6 +168,12 @@ SYMBOLS = {
     "nlsg_nm_destroy": (C.c_int, [_H]),
     "nlsg_nm_minimize": (C.c_int, [_H, pd, pd, pd, C.POINTER(Status), pd]),
     "nlsg_nm_time_solve": (C.c_int, [_H, pd, C.c_uint32, C.POINTER(C.c_float)]),
+    "nlsg_sann_create": (C.c_int, [C.POINTER(SANNConfig), C.POINTER(_H)]),
+    "nlsg_sann_create_custom": (C.c_int, [C.POINTER(SANNConfig), C.POINTER(CustomObjectiveC),
+                                          C.POINTER(C.c_void_p)]),
+    "nlsg_sann_destroy": (C.c_int, [_H]),
+    "nlsg_sann_minimize": (C.c_int, [_H, pd, C.POINTER(Status)]),
+    "nlsg_sann_time_solve": (C.c_int, [_H, pd, C.c_uint32, C.POINTER(C.c_float)]),
 }
 
 _lib = None

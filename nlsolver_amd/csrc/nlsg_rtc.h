@@ -38,6 +38,12 @@ struct LmRtcKernels {  // finite-difference model (default functors) around the 
 };
 int rtc_build_lm(const nlsg_custom_objective *obj, LmRtcKernels *out);
 void rtc_release(LmRtcKernels *k);
+struct SannRtcKernels {
+  hipModule_t mod = nullptr;
+  hipFunction_t anneal = nullptr;
+};
+int rtc_build_sann(const nlsg_custom_objective *obj, int chunks, bool vec, SannRtcKernels *out);
+void rtc_release(SannRtcKernels *k);
 // pso_init / pso_move kernels; type = nlsg_pso_type.
 int rtc_build_pso(const nlsg_custom_objective *obj, int chunks, bool vec, int type, PsoRtcKernels *out);
 void rtc_release(PsoRtcKernels *k);

@@ -207,6 +207,21 @@ void rtc_release(NmRtcKernels *k) {
   if (k) *k = NmRtcKernels();
 }
 
+int rtc_build_sann(const nlsg_custom_objective *obj, int chunks, bool vec, SannRtcKernels *out) {
+  std::vector<hipFunction_t> f;
+  SannRtcKernels k;
+  const int rc = rtc_compile(obj, "nlsg_sann_kernels.h",
+                             {"nlsg::sann_anneal_kernel<" + targs(chunks, vec) + ">"}, &k.mod, &f);
+  if (rc) return rc;
+  k.anneal = f[0];
+  *out = k;
+  return NLSG_OK;
+}
+void rtc_release(SannRtcKernels *k) {
+  if (k && k->mod) hipModuleUnload(k->mod);
+  if (k) *k = SannRtcKernels();
+}
+
 int rtc_build_lm(const nlsg_custom_objective *obj, LmRtcKernels *out) {
   std::vector<hipFunction_t> f;
   LmRtcKernels k;

@@ -1,0 +1,246 @@
+// nlsolver_amd/csrc/nlsg_sann.hip — host side of the batched simulated-annealing engine + C-ABI.
+#include <cstdlib>
+#include <new>
+#include <vector>
+
+#include "nlsg_rtc.h"
+#include "nlsg_sann_kernels.h"
+
+using namespace nlsg;
+
+struct nlsg_sann {
+  nlsg_sann_config cfg;
+  SannParams p;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  double *zero_dev = nullptr;
+  int chunks = 0;
+  SannRtcKernels rtc;  // objective == NLSG_OBJ_CUSTOM: the kernel hiprtc built for it
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+
+int sann_check_device(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return fail(NLSG_ERR_NO_DEVICE, "no HIP device visible");
+  if (device < 0 || device >= n)
+    return fail(NLSG_ERR_INVALID_ARG, "device %d out of range (0..%d)", device, n - 1);
+  hipDeviceProp_t prop;
+  NLSG_HIP(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(NLSG_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only",
+                device, prop.gcnArchName);
+  return NLSG_OK;
+}
+
+#define SANN_FOR_CHUNKS(OBJ, chunks, CALL) \
+  switch (chunks) {                        \
+    case 1: CALL(OBJ, 1); break;           \
+    case 2: CALL(OBJ, 2); break;           \
+    case 4: CALL(OBJ, 4); break;           \
+    case 8: CALL(OBJ, 8); break;           \
+    default: break;                        \
+  }
+#define SANN_FOR_OBJ(obj, chunks, CALL)                                                  \
+  switch (obj) {                                                                         \
+    case NLSG_OBJ_ROSENBROCK: SANN_FOR_CHUNKS(NLSG_OBJ_ROSENBROCK, chunks, CALL); break; \
+    case NLSG_OBJ_SPHERE: SANN_FOR_CHUNKS(NLSG_OBJ_SPHERE, chunks, CALL); break;         \
+    case NLSG_OBJ_STYBLINSKI_TANG:                                                       \
+      SANN_FOR_CHUNKS(NLSG_OBJ_STYBLINSKI_TANG, chunks, CALL);                           \
+      break;                                                                             \
+    case NLSG_OBJ_RASTRIGIN: SANN_FOR_CHUNKS(NLSG_OBJ_RASTRIGIN, chunks, CALL); break;   \
+    default: break;                                                                      \
+  }
+
+void launch_anneal(nlsg_sann *e, uint64_t iter_begin, uint64_t iter_end) {
+  const dim3 grid(static_cast<unsigned>((e->p.batch + 3) / 4)), block(256);
+  const bool vec = e->p.D % 2 == 0;
+  if (e->cfg.objective == NLSG_OBJ_CUSTOM) {
+    void *args[] = {&e->p, &iter_begin, &iter_end};
+    hipModuleLaunchKernel(e->rtc.anneal, grid.x, 1, 1, 256, 1, 1, 0, e->stream, args, nullptr);
+    return;
+  }
+#define CALL(OBJ, C)                                                                            \
+  if (vec)                                                                                      \
+    hipLaunchKernelGGL((sann_anneal_kernel<OBJ, C, true>), grid, block, 0, e->stream, e->p,     \
+                       iter_begin, iter_end);                                                   \
+  else                                                                                          \
+    hipLaunchKernelGGL((sann_anneal_kernel<OBJ, C, false>), grid, block, 0, e->stream, e->p,    \
+                       iter_begin, iter_end)
+  SANN_FOR_OBJ(e->cfg.objective, e->chunks, CALL)
+#undef CALL
+}
+
+// The whole schedule; long schedules are cut into launches of a bounded number of trial points so
+// that no single kernel runs for seconds (the chain's state waits in HBM between launches).
+void launch_solve(nlsg_sann *e) {
+  const uint64_t max_iter = e->cfg.max_iter;
+  const uint64_t per_iter = e->p.inner ? e->p.inner : 1;
+  uint64_t span = (1u << 16) / per_iter;
+  if (span == 0) span = 1;
+  uint64_t it = 0;
+  do {  // max_iter == 0 still scores the start (:2781)
+    const uint64_t end = max_iter - it < span ? max_iter : it + span;
+    launch_anneal(e, it, end);
+    it = end;
+  } while (it < max_iter);
+}
+
+}  // namespace
+
+static int sann_create(const nlsg_sann_config *cfg, const nlsg_custom_objective *custom,
+                       nlsg_sann **out);
+
+extern "C" {
+
+int nlsg_sann_create(const nlsg_sann_config *cfg, nlsg_sann **out) {
+  if (cfg && cfg->objective == NLSG_OBJ_CUSTOM)
+    return fail(NLSG_ERR_INVALID_ARG, "NLSG_OBJ_CUSTOM engines are made by nlsg_sann_create_custom");
+  return sann_create(cfg, nullptr, out);
+}
+
+int nlsg_sann_create_custom(const nlsg_sann_config *cfg, const nlsg_custom_objective *obj,
+                            nlsg_sann **out) {
+  if (!cfg || !obj) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  if (cfg->objective != NLSG_OBJ_CUSTOM)
+    return fail(NLSG_ERR_INVALID_ARG, "cfg.objective must be NLSG_OBJ_CUSTOM");
+  return sann_create(cfg, obj, out);
+}
+
+}  // extern "C"
+
+static int sann_create(const nlsg_sann_config *cfg, const nlsg_custom_objective *custom,
+                       nlsg_sann **out) {
+  if (!cfg || !out) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  *out = nullptr;
+  if (cfg->struct_size != sizeof(nlsg_sann_config))
+    return fail(NLSG_ERR_INVALID_ARG, "nlsg_sann_config size mismatch (%u vs %zu)",
+                cfg->struct_size, sizeof(nlsg_sann_config));
+  if (!custom && (cfg->objective < 0 || cfg->objective > NLSG_OBJ_RASTRIGIN))
+    return fail(NLSG_ERR_INVALID_ARG, "unknown objective %d", cfg->objective);
+  if (cfg->dim < 1 || cfg->batch < 1) return fail(NLSG_ERR_INVALID_ARG, "dim and batch must be >= 1");
+  if (cfg->dim > 1024)
+    return fail(NLSG_ERR_UNSUPPORTED, "dim %llu > 1024 (one wave holds a chain's three points)",
+                (unsigned long long)cfg->dim);
+  if (cfg->batch > 0x7fffffffull) return fail(NLSG_ERR_UNSUPPORTED, "batch too large");
+  int rc = sann_check_device(cfg->device);
+  if (rc) return rc;
+  NLSG_HIP(hipSetDevice(cfg->device));
+  nlsg_sann *e = new (std::nothrow) nlsg_sann();
+  if (!e) return fail(NLSG_ERR_OOM, "host allocation failed");
+  e->cfg = *cfg;
+  if (cfg->stream) {
+    e->stream = static_cast<hipStream_t>(cfg->stream);
+  } else {
+    hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (he != hipSuccess) {
+      delete e;
+      return fail(NLSG_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(he));
+    }
+    e->own_stream = true;
+  }
+  const uint64_t B = cfg->batch, D = cfg->dim;
+  e->chunks = D <= 128 ? 1 : D <= 256 ? 2 : D <= 512 ? 4 : 8;
+  SannParams &p = e->p;
+  std::memset(&p, 0, sizeof p);
+  hipError_t he = hipSuccess;
+  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p.x), B * D * 8);
+  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p.p), B * D * 8);
+  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p.prob), B * sizeof(SannProblem));
+  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&e->zero_dev), 16);
+  if (he == hipSuccess) he = hipMemset(e->zero_dev, 0, 16);
+  if (he == hipSuccess) he = hipEventCreate(&e->ev0);
+  if (he == hipSuccess) he = hipEventCreate(&e->ev1);
+  if (he != hipSuccess) {
+    nlsg_sann_destroy(e);
+    return fail(he == hipErrorOutOfMemory ? NLSG_ERR_OOM : NLSG_ERR_HIP,
+                "device setup failed: %s", hipGetErrorString(he));
+  }
+  if (custom) {
+    const int rc2 = rtc_build_sann(custom, e->chunks, D % 2 == 0, &e->rtc);
+    if (rc2) {
+      nlsg_sann_destroy(e);
+      return rc2;
+    }
+  }
+  p.zero = e->zero_dev;
+  p.batch = B;
+  p.D = D;
+  p.seed = cfg->seed;
+  p.chain_lo = cfg->chain_lo;
+  p.inner = cfg->temperature_iter ? cfg->temperature_iter - 1 : 0;  // for (j = 1; j < t_iter; j++)
+  p.temp_max = cfg->temperature_max;
+  p.fmul = cfg->minimize ? 1.0 : -1.0;
+  *out = e;
+  return NLSG_OK;
+}
+
+extern "C" {
+
+int nlsg_sann_destroy(nlsg_sann *e) {
+  if (!e) return NLSG_OK;
+  hipSetDevice(e->cfg.device);
+  if (e->stream) hipStreamSynchronize(e->stream);
+  rtc_release(&e->rtc);
+  hipFree(e->p.x);
+  hipFree(e->p.p);
+  hipFree(e->p.prob);
+  hipFree(e->zero_dev);
+  if (e->ev0) hipEventDestroy(e->ev0);
+  if (e->ev1) hipEventDestroy(e->ev1);
+  if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
+  delete e;
+  return NLSG_OK;
+}
+
+int nlsg_sann_minimize(nlsg_sann *e, double *x_inout_host, nlsg_status *status_host) {
+  if (!e || !x_inout_host) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  NLSG_HIP(hipSetDevice(e->cfg.device));
+  const uint64_t B = e->p.batch, D = e->p.D;
+  NLSG_HIP(hipMemcpy(e->p.x, x_inout_host, B * D * 8, hipMemcpyHostToDevice));
+  launch_solve(e);
+  NLSG_HIP(hipGetLastError());
+  NLSG_HIP(hipStreamSynchronize(e->stream));
+  NLSG_HIP(hipMemcpy(x_inout_host, e->p.x, B * D * 8, hipMemcpyDeviceToHost));
+  if (status_host) {
+    std::vector<SannProblem> pr(B);
+    NLSG_HIP(hipMemcpy(pr.data(), e->p.prob, B * sizeof(SannProblem), hipMemcpyDeviceToHost));
+    for (uint64_t b = 0; b < B; b++) {
+      nlsg_status &st = status_host[b];
+      st.f_value = pr[b].best;
+      st.iteration = pr[b].iter;
+      st.function_calls_used = pr[b].fcalls;
+      st.gradient_evals_used = 0;
+      st.hessian_evals_used = 0;
+      st.best_index = b;
+      st.val_no_change = 0;
+      st.std_err = 0.0;
+      st.done = 1;
+      st.reserved = 0;
+    }
+  }
+  return NLSG_OK;
+}
+
+int nlsg_sann_time_solve(nlsg_sann *e, const double *x0_host, uint32_t repeats, float *ms_total) {
+  if (!e || !x0_host || !ms_total) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  NLSG_HIP(hipSetDevice(e->cfg.device));
+  float total = 0.f;
+  for (uint32_t r = 0; r < repeats; r++) {
+    NLSG_HIP(hipMemcpy(e->p.x, x0_host, e->p.batch * e->p.D * 8, hipMemcpyHostToDevice));
+    NLSG_HIP(hipEventRecord(e->ev0, e->stream));
+    launch_solve(e);
+    NLSG_HIP(hipEventRecord(e->ev1, e->stream));
+    NLSG_HIP(hipEventSynchronize(e->ev1));
+    NLSG_HIP(hipGetLastError());
+    float ms = 0.f;
+    NLSG_HIP(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+    total += ms;
+  }
+  *ms_total = total;
+  return NLSG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,113 @@
+// nlsolver_amd/csrc/nlsg_sann_kernels.h — gfx950 kernel of the batched simulated-annealing engine
+// ("batched SANN chains").
+//
+// Replaces (reference file:line): SANN::solve nlsolver.h:2777-2814 with rnorm 2479-2485, for
+// `batch` independent chains. One wave per chain, the chain's three points (current p, trial
+// ptry, best x) in registers in the lane layout of the other engines (element 128 c + 2 l + k
+// in lane l); a chain never touches memory between its first load and its last store, so the
+// kernel is bound by the fp64 VALU (two counter draws, log, cos, sqrt per coordinate and step:
+// the arithmetic of the Accelerated-PSO move) and the objective's reduction latency.
+//
+// The reference draws from one sequential generator; here every draw is keyed by (seed, chain,
+// step, slot) like in the population engines: kc = key(seed, chain), inner step
+// s = iter * (temperature_iter - 1) + (j - 1) has ks = key(kc, s); coordinate e takes draws 2e
+// (log) and 2e + 1 (cos) of ks, the acceptance test draw 2 D. oracle_sann.c's orc_sann_sync
+// executes the same chain on the CPU.
+#pragma once
+
+#include "nlsg_common.h"
+#include "nlsg_math.h"
+
+namespace nlsg {
+
+struct SannProblem {
+  double best;  // f_multiplier * f at x (:2781, 2809)
+  uint64_t iter, fcalls;
+};
+
+struct SannParams {
+  double *x;          // [batch][D] in: start, out: best point (:2808)
+  double *p;          // [batch][D] current point of the chain between launches
+  SannProblem *prob;  // [batch]
+  const double *zero;
+  uint64_t batch, D, seed, chain_lo;
+  uint64_t inner;     // trial points per temperature: temperature_iter - 1 (0 if that is 0), :2795
+  double temp_max, fmul;
+};
+
+// outer iterations [iter_begin, iter_end) of every chain; iter_begin == 0 also scores the start
+template <int OBJ, int CHUNKS, bool VEC>
+__global__ __launch_bounds__(256) void sann_anneal_kernel(SannParams p, uint64_t iter_begin,
+                                                          uint64_t iter_end) {
+  const uint64_t chain = static_cast<uint64_t>(blockIdx.x) * 4 +
+                         __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+  if (chain >= p.batch) return;
+  const int lane = lane_id();
+  const uint64_t D = p.D;
+  constexpr double e_minus_1 = 1.7182818;  // :2780
+  double xb[CHUNKS][2], pc[CHUNKS][2], pt[CHUNKS][2];
+  load_row<CHUNKS, VEC>(p.x + chain * D, D, p.zero, xb);
+  double best;
+  uint64_t fcalls;
+  if (iter_begin == 0) {  // :2781-2785
+#pragma unroll
+    for (int c = 0; c < CHUNKS; c++) pc[c][0] = xb[c][0], pc[c][1] = xb[c][1];
+    best = p.fmul * wave_objective<OBJ, CHUNKS>(xb, D);
+    fcalls = 1;
+  } else {
+    load_row<CHUNKS, VEC>(p.p + chain * D, D, p.zero, pc);
+    best = p.prob[chain].best;
+    fcalls = p.prob[chain].fcalls;
+  }
+  const double scale = 1.0 / p.temp_max;
+  const uint64_t kc = ctr_key(p.seed, p.chain_lo + chain);
+  const uint64_t inner = p.inner;
+  for (uint64_t iter = iter_begin; iter < iter_end; iter++) {
+    // temperature annealing schedule (:2793-2794)
+    const double t = p.temp_max / det_log(static_cast<double>(iter) + e_minus_1);
+    const double current_scale = t * scale;
+    for (uint64_t j = 0; j < inner; j++) {
+      const uint64_t ks = ctr_key(kc, iter * inner + j);
+      // draw 2e (+1) of element e = 128 c + 2 lane + k: mix64(ks + G (2e + 1 [+ 1])), with
+      // 2e + 1 = (4 lane + 1) + (256 c + 2 k): one 64-bit multiply per step and lane
+      const uint64_t ks_lane = ks + kGolden * (4 * static_cast<uint64_t>(lane) + 1);
+#pragma unroll
+      for (int c = 0; c < CHUNKS; c++) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+          const uint64_t e = static_cast<uint64_t>(c) * 128 + 2 * static_cast<uint64_t>(lane) + k;
+          const double u1 = u01(mix64(ks_lane + kGolden * static_cast<uint64_t>(256 * c + 2 * k)));
+          const double u2 = u01(mix64(ks_lane + kGolden * static_cast<uint64_t>(256 * c + 2 * k + 1)));
+          // rnorm (:2479-2485): sqrt(-2 log u1) * cos(2 pi_ u2), pi_ = 3.141593
+          const double rn = sqrt(-2 * det_log(u1)) * det_cos(2 * 3.141593 * u2);
+          pt[c][k] = (e < D) ? pc[c][k] + current_scale * rn : 0.0;  // :2800
+        }
+      }
+      const double current_val = p.fmul * wave_objective<OBJ, CHUNKS>(pt, D);
+      fcalls++;
+      const double difference = current_val - best;  // against the best so far (:2804)
+      const bool accept = (difference <= 0.0) ||
+                          (u01(ctr_key(ks, 2 * D)) < det_exp(-difference / t));  // :2805
+      if (accept) {  // wave-uniform
+        const bool better = current_val <= best;
+#pragma unroll
+        for (int c = 0; c < CHUNKS; c++)
+#pragma unroll
+          for (int k = 0; k < 2; k++) {
+            pc[c][k] = pt[c][k];
+            xb[c][k] = better ? pt[c][k] : xb[c][k];
+          }
+        best = better ? current_val : best;
+      }
+    }
+  }
+  store_row<CHUNKS, VEC>(p.x + chain * D, D, xb);
+  store_row<CHUNKS, VEC>(p.p + chain * D, D, pc);
+  if (lane == 0) {
+    p.prob[chain].best = best;
+    p.prob[chain].iter = iter_end;
+    p.prob[chain].fcalls = fcalls;
+  }
+}
+
+}  // namespace nlsg
