@@ -212,6 +212,48 @@ def main_bfgs_fd(args):
     eng.close()
 
 
+def main_sann(args):
+    """Batched simulated annealing: Rosenbrock-128D, 16 384 independent chains, the
+    reference's default temperature_iter = 10 and temperature_max = 10, 100 temperatures. One step
+    = one temperature of every chain = 9 trial points (9 x 128 normal draws + one objective
+    evaluation each), one wave per chain, nothing but registers between the first load and the
+    last store."""
+    import torch
+
+    import nlsolver_amd
+    n, iters, t_iter = 128, 100, 10
+    batch = 16384 if args.pop_per_gpu == POP_PER_GPU else args.pop_per_gpu
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    rng = np.random.default_rng(12374563468 % 2**32)
+    x0 = 0.5 + 1.0 * (rng.random((batch, n)) - 0.5)
+    eng = nlsolver_amd.SANNEngine("rosenbrock", batch, n, max_iter=iters, temperature_iter=t_iter,
+                                  temperature_max=10.0, device=local_rank)
+    x, st = eng.minimize(x0)
+    reps = 3
+    ms = eng.time_solve(x0, reps) / reps
+    trials = sum(s.function_calls_used for s in st)
+    f0 = float(np.mean([((1 - r[:-1]) ** 2 + 100 * (r[1:] - r[:-1] ** 2) ** 2).sum() for r in x0[:256]]))
+    print(json.dumps({
+        "metric": "SANN trial points x chains / s (Rosenbrock-128D)",
+        "value": trials / (ms * 1e-3), "unit": "trial-points/s", "n_gpus": 1, "steps": iters,
+        "warmup": iters, "ms_per_step": ms / iters, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"SANN, Rosenbrock-{n}D, batch={batch} independent chains, "
+                               f"{iters} temperatures x {t_iter - 1} trial points",
+                   "normal_draws_per_s": trials * n / (ms * 1e-3),
+                   "mean_start_f": f0, "mean_best_f": float(np.mean([s.f_value for s in st]))},
+        "roofline": {"bound": "valu", "achieved": None, "peak": None, "unit": None, "frac": None,
+                     "traffic": None, "kernel": "sann_anneal_kernel", "kernel_ms": ms,
+                     "note": "register-resident chains: two counter draws, log, cos, sqrt per "
+                             "coordinate and trial on the fp64 VALU; not roofline-graded"},
+        **({} if args.no_cpu_baseline else {"cpu_baseline": ref_baseline(
+            ["bench-sann", n, 4096, iters, t_iter], "trials_per_s", "trial-points/s",
+            f"reference SANN, Rosenbrock-{n}D, 4096 chains x {iters} temperatures x {t_iter - 1} "
+            "trial points")})}))
+    eng.close()
+
+
 def main_lm_fd(args):
     """LevenbergMarquardt with the reference's DEFAULT functors (fin_diff + fin_diff_h,
     nlsolver.h:3494-3511) on the device: Rosenbrock-16D, batch = 8192 independent starts, 10
@@ -445,7 +487,7 @@ def main():
     ap.add_argument("--lm-solver", choices=["cholesky", "qr"], default="cholesky",
                     help="lm workload: damped-system solver (cholesky = the reference class's "
                          "get_update_with_hessian; qr = tinyqr::lm, as BASELINE configs[3] words it)")
-    ap.add_argument("--workload", choices=["de", "pso-accel", "pso-vanilla", "bfgs", "bfgs-fd", "lm", "lm-fd", "nm"],
+    ap.add_argument("--workload", choices=["de", "pso-accel", "pso-vanilla", "bfgs", "bfgs-fd", "lm", "lm-fd", "nm", "sann"],
                     default="de",
                     help="de = the headline benchmark (BASELINE metric); pso-* = config 5's "
                          "per-GPU shard (secondary, same JSON shape)")
@@ -456,6 +498,8 @@ def main():
         return main_bfgs_fd(args)
     if args.workload == "lm-fd":
         return main_lm_fd(args)
+    if args.workload == "sann":
+        return main_sann(args)
     if args.workload == "lm":
         return main_lm(args)
     if args.workload == "nm":

@@ -310,6 +310,10 @@ class api {
   decltype(&nlsg_nm_create_custom) nm_create_custom;
   decltype(&nlsg_nm_destroy) nm_destroy;
   decltype(&nlsg_nm_minimize) nm_minimize;
+  decltype(&nlsg_sann_create) sann_create;
+  decltype(&nlsg_sann_create_custom) sann_create_custom;
+  decltype(&nlsg_sann_destroy) sann_destroy;
+  decltype(&nlsg_sann_minimize) sann_minimize;
 
   void check(int rc) const {
     if (rc != NLSG_OK)
@@ -348,6 +352,10 @@ class api {
     bind(h, "nlsg_nm_create_custom", nm_create_custom);
     bind(h, "nlsg_nm_destroy", nm_destroy);
     bind(h, "nlsg_nm_minimize", nm_minimize);
+    bind(h, "nlsg_sann_create", sann_create);
+    bind(h, "nlsg_sann_create_custom", sann_create_custom);
+    bind(h, "nlsg_sann_destroy", sann_destroy);
+    bind(h, "nlsg_sann_minimize", sann_minimize);
     if (abi_version() != NLSG_ABI_VERSION)
       throw device_error("libnlsolver_hip.so ABI version mismatch");
   }
@@ -1058,6 +1066,121 @@ class BFGS {
           H[j * n + i] = H[j * n + i] - rho * (s[i] * t[j] + t[i] * s[j] + denom * s[i] * s[j]);
       iter++;
     }
+  }
+};
+
+// ---------------------------------------------------------------------------
+// SANN — nlsolver.h:2744-2815
+// ---------------------------------------------------------------------------
+template <typename Callable, typename RNG, typename scalar_t = double>
+class SANN {
+  RNG &generator;
+  Callable &f;
+  size_t f_evals;  // accumulates across calls, like the reference's member (nlsolver.h:2751)
+  const size_t max_iter, temperature_iter;
+  const scalar_t temperature_max;
+
+ public:
+  // same positional arguments and defaults as nlsolver.h:2759-2761
+  SANN(Callable &f, RNG &generator, const size_t max_iter = 5000,
+       const size_t temperature_iter = 10, const scalar_t temperature_max = 10.0)
+      : generator(generator), f(f), f_evals(0), max_iter(max_iter),
+        temperature_iter(temperature_iter), temperature_max(temperature_max) {}
+  solver_status<scalar_t> minimize(std::vector<scalar_t> &x) { return run<true>(x); }
+  solver_status<scalar_t> maximize(std::vector<scalar_t> &x) { return run<false>(x); }
+  // Extension: `xs.size()` independent chains annealed side by side on the GPU (chain b is
+  // keyed by (seed, b)); the reference runs one chain per call.
+  std::vector<solver_status<scalar_t>> minimize_batch(std::vector<std::vector<scalar_t>> &xs) {
+    return run_device<true>(xs);
+  }
+  std::vector<solver_status<scalar_t>> maximize_batch(std::vector<std::vector<scalar_t>> &xs) {
+    return run_device<false>(xs);
+  }
+
+ private:
+  template <bool minimize>
+  solver_status<scalar_t> run(std::vector<scalar_t> &x) {
+    if constexpr (device::is_device_objective<Callable>::value) {
+      std::vector<std::vector<scalar_t>> one{x};
+      auto st = run_device<minimize>(one);
+      x = one[0];
+      return st[0];
+    } else {
+      return solve_host<minimize>(x);
+    }
+  }
+  template <bool minimize>
+  std::vector<solver_status<scalar_t>> run_device(std::vector<std::vector<scalar_t>> &xs) {
+    static_assert(device::is_device_objective<Callable>::value,
+                  "the batched chains need a device objective");
+    static_assert(std::is_same_v<scalar_t, double>, "the device path computes in fp64");
+    const device::api &api = device::api::get();
+    const size_t B = xs.size(), n = B ? xs[0].size() : 0;
+    nlsg_sann_config cfg{};
+    cfg.struct_size = sizeof(cfg);
+    if (const char *d = std::getenv("NLSG_DEVICE")) cfg.device = std::atoi(d);
+    cfg.objective = Callable::nlsg_objective;
+    cfg.minimize = minimize ? 1 : 0;
+    cfg.batch = B;
+    cfg.dim = n;
+    cfg.max_iter = max_iter;
+    cfg.temperature_iter = temperature_iter;
+    cfg.temperature_max = temperature_max;
+    cfg.seed = device::seed_from(generator);
+    nlsg_sann *eng = nullptr;
+    if constexpr (Callable::nlsg_objective == NLSG_OBJ_CUSTOM) {
+      api.check(api.rtc_load(std::getenv("NLSG_HIPRTC")));
+      nlsg_custom_objective obj{f.term_body.c_str(), f.finish_body.c_str(), f.chain ? 1 : 0, 0};
+      api.check(api.sann_create_custom(&cfg, &obj, &eng));
+    } else {
+      api.check(api.sann_create(&cfg, &eng));
+    }
+    std::vector<scalar_t> flat(B * n);
+    for (size_t b = 0; b < B; b++) std::copy(xs[b].begin(), xs[b].end(), flat.begin() + b * n);
+    std::vector<nlsg_status> st(B);
+    const int rc = api.sann_minimize(eng, flat.data(), st.data());
+    const std::string msg = rc ? api.last_error() : "";
+    api.sann_destroy(eng);
+    if (rc) throw device_error("nlsg error " + std::to_string(rc) + ": " + msg);
+    std::vector<solver_status<scalar_t>> out;
+    for (size_t b = 0; b < B; b++) {
+      std::copy(flat.begin() + b * n, flat.begin() + (b + 1) * n, xs[b].begin());
+      f_evals += st[b].function_calls_used;
+      out.emplace_back(st[b].f_value, st[b].iteration, st[b].function_calls_used);
+    }
+    return out;
+  }
+
+  // Host path for arbitrary callables: SANN::solve (nlsolver.h:2777-2814). Trial points are
+  // normal steps around the current point scaled by the temperature; a trial is compared with
+  // the BEST value so far (not the current point's), accepted when not worse or with
+  // probability exp(-difference / t); the uniform draw is only taken when it is worse.
+  template <bool minimize>
+  solver_status<scalar_t> solve_host(std::vector<scalar_t> &x) {
+    constexpr scalar_t sign = minimize ? 1.0 : -1.0, e_minus_1 = 1.7182818;
+    const size_t n = x.size();
+    scalar_t best = sign * f(x);
+    f_evals++;
+    const scalar_t inv_max = 1.0 / temperature_max;
+    std::vector<scalar_t> current = x, trial = x;
+    for (size_t iter = 0; iter < max_iter; iter++) {
+      const scalar_t t = temperature_max / std::log(static_cast<scalar_t>(iter) + e_minus_1);
+      for (size_t j = 1; j < temperature_iter; j++) {
+        const scalar_t spread = t * inv_max;
+        for (size_t i = 0; i < n; i++) trial[i] = current[i] + spread * rnorm<scalar_t>(generator);
+        const scalar_t value = sign * f(trial);
+        f_evals++;
+        const scalar_t difference = value - best;
+        if (difference <= 0.0 || generator() < std::exp(-difference / t)) {
+          current = trial;
+          if (value <= best) {
+            x = current;
+            best = value;
+          }
+        }
+      }
+    }
+    return solver_status<scalar_t>(best, max_iter, f_evals);
   }
 };
 

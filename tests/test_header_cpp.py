@@ -309,3 +309,53 @@ def test_lm_device_objective_without_library_fails_loudly(built):
                         "0.8", "0.01"], env=dict(os.environ, NLSG_LIBRARY="/nonexistent/lib.so"),
                        capture_output=True, text=True)
     assert r.returncode == 3 and "device_error" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
+SANN_CASES = ["rosenbrock_n2_default_schedule", "rosenbrock_n8", "sphere_n16_hot",
+              "styblinski_tang_n6", "sphere_n4_maximize", "rosenbrock_n130_ragged",
+              "temp_iter_1_no_moves"]
+
+
+@pytest.mark.parametrize("name", SANN_CASES)
+def test_sann_host_path_through_header_matches_reference_bit_exact(built, golden, name):
+    g = golden("sann.json")[name]
+    o = json.loads(subprocess.check_output(
+        [os.path.join(built, "header_sann"), "host", str(g["objective"]), str(g["n"]),
+         str(g["max_iter"]), str(g["temp_iter"]), repr(hx(g["temp_max"])), repr(hx(g["x0"])),
+         repr(hx(g["x0_step"])), str(g["minimize"])], text=True))
+    assert (o["fcalls"], o["iters"]) == (g["fcalls"], g["iters"])
+    assert o["f"] == g["f"] and o["x"] == g["x"] and o["next_draw"] == g["next_draw"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["device", "device-custom"])
+@pytest.mark.parametrize("n,max_iter,temp_iter,minimize", [(2, 150, 10, 1), (16, 40, 6, 1),
+                                                           (130, 12, 10, 0)])
+def test_sann_device_objective_through_header_matches_oracle(built, oracle, mode, n, max_iter,
+                                                             temp_iter, minimize):
+    """SANN<device::Rosenbrock<double>, xorshift<double>>(f, gen, ...).minimize_batch(xs): chains
+    keyed by (two draws of the generator, chain index); bit-exact vs the synchronous oracle."""
+    B = 3
+    out = subprocess.check_output(
+        [os.path.join(built, "header_sann"), mode, str(B), str(n), str(max_iter), str(temp_iter),
+         "10.0", "0.4", "0.01", str(minimize)], env=dict(os.environ, NLSG_LIBRARY=LIB), text=True)
+    res = json.loads(out)
+    assert isinstance(res, list) and len(res) == B, res
+    xs = O.XorShift()
+    oracle.orc_xorshift_init(C.byref(xs))
+    half = [min(int(oracle.orc_xorshift_next(C.byref(xs)) * 2.0**32), 2**32 - 1) for _ in range(2)]
+    seed = (half[0] << 32) | half[1]
+    for b, o in enumerate(res):
+        x0 = 0.4 + 0.01 * (np.arange(n, dtype=np.float64) + b)
+        ref, xr, _ = O.sann_sync(oracle, "rosenbrock", x0, seed, b, minimize=bool(minimize),
+                                 max_iter=max_iter, temp_iter=temp_iter, temp_max=10.0)
+        assert (o["fcalls"], o["iters"]) == (ref.function_calls_used, ref.iteration)
+        assert hx(o["f"]) == ref.f_value
+        assert np.array_equal(np.array([hx(v) for v in o["x"]]), xr)
+
+
+def test_sann_device_objective_without_library_fails_loudly(built):
+    r = subprocess.run([os.path.join(built, "header_sann"), "device", "2", "4", "10", "10", "10.0",
+                        "0.4", "0.01", "1"], env=dict(os.environ, NLSG_LIBRARY="/nonexistent/lib.so"),
+                       capture_output=True, text=True)
+    assert r.returncode == 3 and "device_error" in r.stdout, (r.returncode, r.stdout, r.stderr)
