@@ -241,6 +241,18 @@ orc_status orc_sann_sync(int obj, int minimize, double *x, size_t D, uint64_t se
                          size_t max_iter, size_t temp_iter, double temp_max, double *f_log,
                          size_t f_cap);
 
+/* ---- Nelder-Mead / PSO hybrid (oracle_nmpso.c), NelderMeadPSO nlsolver.h:3546-3920 ---- */
+orc_status orc_nmpso_serial(int obj, int minimize, int bound, double *x, size_t n,
+                            const double *upper, const double *lower, orc_xorshift *gen, double alpha,
+                            double gamma, double rho, double sigma, double inertia, double cog,
+                            double soc, double eps, size_t max_iter, size_t no_change_best_iter,
+                            double *f_log, size_t f_cap);
+orc_status orc_nmpso_sync(int obj, int minimize, int bound, double *x, size_t n, const double *upper,
+                          const double *lower, uint64_t seed, uint64_t instance, double alpha,
+                          double gamma, double rho, double sigma, double inertia, double cog,
+                          double soc, double eps, size_t max_iter, size_t no_change_best_iter,
+                          double *f_log, size_t f_cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -160,6 +160,43 @@ def sann_sync(lib, obj, x0, seed, chain, *, minimize=True, max_iter=5000, temp_i
     return st, x, flog
 
 
+def _hyb_args(x, upper, lower, kw):
+    n = x.size
+    bound = upper is not None
+    up = np.ascontiguousarray(np.broadcast_to(upper, (n,)), dtype=np.float64) if bound else None
+    lo = np.ascontiguousarray(np.broadcast_to(lower, (n,)), dtype=np.float64) if bound else None
+    coefs = [kw.get(k, d) for k, d in (("alpha", 1.0), ("gamma", 2.0), ("rho", 0.5), ("sigma", 0.5),
+                                       ("inertia", 0.8), ("cog", 1.8), ("soc", 1.8))]
+    tail = [kw.get("eps", 1e-6), kw.get("max_iter", 1000), kw.get("no_change", 20)]
+    return bound, up, lo, coefs, tail
+
+
+def nmpso_serial(lib, obj, x0, *, minimize=True, upper=None, lower=None, log_cap=0, **kw):
+    """Oracle NelderMeadPSO in the reference's arithmetic and draw order (fresh xorshift);
+    returns (status, x, next draw, f_log or None)."""
+    x = np.ascontiguousarray(x0, dtype=np.float64).copy()
+    bound, up, lo, coefs, tail = _hyb_args(x, upper, lower, kw)
+    gen = XorShift()
+    lib.orc_xorshift_init(C.byref(gen))
+    flog = np.zeros(log_cap) if log_cap else None
+    st = lib.orc_nmpso_serial(OBJ[obj], int(minimize), int(bound), _ptr(x), x.size,
+                              _ptr(up) if bound else None, _ptr(lo) if bound else None,
+                              C.byref(gen), *coefs, *tail, _ptr(flog) if log_cap else None, log_cap)
+    return st, x, lib.orc_xorshift_next(C.byref(gen)), flog
+
+
+def nmpso_sync(lib, obj, x0, seed, instance, *, minimize=True, upper=None, lower=None, log_cap=0,
+               **kw):
+    """Oracle NelderMeadPSO as the GPU runs it (keyed draws, objective / std_err trees)."""
+    x = np.ascontiguousarray(x0, dtype=np.float64).copy()
+    bound, up, lo, coefs, tail = _hyb_args(x, upper, lower, kw)
+    flog = np.zeros(log_cap) if log_cap else None
+    st = lib.orc_nmpso_sync(OBJ[obj], int(minimize), int(bound), _ptr(x), x.size,
+                            _ptr(up) if bound else None, _ptr(lo) if bound else None, seed, instance,
+                            *coefs, *tail, _ptr(flog) if log_cap else None, log_cap)
+    return st, x, flog
+
+
 def load():
     if not os.path.exists(LIB):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
@@ -212,6 +249,12 @@ def load():
     lib.orc_bfgs_quad.restype = Status
     lib.orc_bfgs_quad.argtypes = [C.POINTER(Quad), pd, sz, sz, f64, f64, C.c_int,
                                   C.POINTER(BfgsCounters)]
+    lib.orc_nmpso_serial.restype = Status
+    lib.orc_nmpso_serial.argtypes = [C.c_int, C.c_int, C.c_int, pd, sz, pd, pd, C.POINTER(XorShift)] + \
+        [f64] * 8 + [sz, sz, pd, sz]
+    lib.orc_nmpso_sync.restype = Status
+    lib.orc_nmpso_sync.argtypes = [C.c_int, C.c_int, C.c_int, pd, sz, pd, pd, u64, u64] + \
+        [f64] * 8 + [sz, sz, pd, sz]
     lib.orc_sann_serial.restype = Status
     lib.orc_sann_serial.argtypes = [C.c_int, C.c_int, pd, sz, C.POINTER(XorShift), sz, sz, f64, pd, sz]
     lib.orc_sann_sync.restype = Status

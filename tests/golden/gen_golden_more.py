@@ -74,6 +74,20 @@ def main():
     }
     write("sann.json", gsann)
 
+    # N4 — NelderMeadPSO (nlsolver.h:3546-3920), unbounded overloads. Even n only: init writes one
+    # element past an n-vector (3713-3716) and the process aborts for odd n (as NelderMead, B1).
+    # args: objective n max_iter eps no_change x0 x0_step minimize trace_cap
+    ghyb = {
+        "rosenbrock_n2_defaults": run("nmpso", 0, 2, 1000, 1e-6, 20, 2, 5, 1, 64),
+        "rosenbrock_n4": run("nmpso", 0, 4, 100, 1e-6, 20, 0.5, 0.1, 1, 64),
+        "rosenbrock_n8_200iters": run("nmpso", 0, 8, 200, 0, 1000, 0.5, 0.1, 1, 64),
+        "rosenbrock_n16": run("nmpso", 0, 16, 100, 1e-6, 20, 0.5, 0.1, 1, 64),
+        "sphere_n6": run("nmpso", 1, 6, 150, 1e-9, 20, 3, -0.4, 1, 64),
+        "styblinski_tang_n4_maximize": run("nmpso", 2, 4, 60, 0, 1000, 0.5, 0.3, 0, 64),
+        "rosenbrock_n130_ragged": run("nmpso", 0, 130, 30, 0, 1000, 0.4, 0.001, 1, 64),
+    }
+    write("nmpso.json", ghyb)
+
     # G8/G9 — LevenbergMarquardt (nlsolver.h:3428-3545) with Gauss-Newton functors, its
     # Cholesky solve (251-330) and tinyqr (291-310, 437-470).
     seed = 12374563468
