@@ -437,6 +437,48 @@ int nlsg_sann_minimize(nlsg_sann *e, double *x_inout_host, nlsg_status *status_h
 /* The same solve bracketed by hipEvents (starts restored from x0 each time). */
 int nlsg_sann_time_solve(nlsg_sann *e, const double *x0_host, uint32_t repeats, float *ms_total);
 
+/* ========================================================================== */
+/* Batched Nelder-Mead / PSO hybrid — replaces NelderMeadPSO::solve             */
+/* (nlsolver.h:3623-3685) with init_solver_state 3686-3738, apply_simplex       */
+/* 3739-3822, apply_pso 3823-3866, update_centroid, shrink, simplex_std_err     */
+/* 3867-3918 and the four minimize / maximize overloads 3583-3620, for `batch`  */
+/* independent instances (one workgroup each). Draws are keyed */
+/* by (seed, instance, iteration, particle rank, slot) (oracle: orc_nmpso_sync). */
+/* ========================================================================== */
+typedef struct nlsg_nmpso nlsg_nmpso;
+
+typedef struct {
+  uint32_t struct_size;
+  int32_t device;
+  void *stream;
+  int32_t objective;   /* nlsg_objective                                              */
+  int32_t minimize;    /* 1: minimize(), 0: maximize()                                */
+  int32_t bounded;     /* 0: minimize(x): bounds -+|2.5 x_i| (3587-3593) seed the PSO
+                        * particles only; 1: minimize(x, lower, upper): they also clamp
+                        * the simplex points and the velocity (by coordinate)          */
+  int32_t reserved;
+  uint64_t batch;      /* independent instances                                       */
+  uint64_t dim;        /* 2 <= dim <= 128; 3 dim + 1 particles per instance           */
+  uint64_t inst_lo;    /* global id of instance 0 (keys the draws; batch sharding)    */
+  double alpha, gamma, rho, sigma;      /* ctor args, defaults 1, 2, 0.5, 0.5 (3564-3566) */
+  double inertia, cognitive, social;    /* 0.8, 1.8, 1.8 (3566-3567)                   */
+  double eps;                           /* 1e-6 (3568)                                 */
+  uint64_t max_iter, no_change_best_iter; /* 1000, 20 (3568-3569)                      */
+  uint64_t seed;
+} nlsg_nmpso_config;
+
+int nlsg_nmpso_create(const nlsg_nmpso_config *cfg, nlsg_nmpso **out);
+/* cfg->objective == NLSG_OBJ_CUSTOM, as nlsg_de_create_custom */
+int nlsg_nmpso_create_custom(const nlsg_nmpso_config *cfg, const nlsg_custom_objective *obj,
+                             nlsg_nmpso **out);
+int nlsg_nmpso_destroy(nlsg_nmpso *e);
+/* x [batch][dim] in: starts, out: best particles; lower/upper [dim] shared by the batch (note
+ * the reference's order: lower first, 3609-3612; NULL when unbounded). One status per
+ * instance (f_value = f_multiplier * f). Synchronises. */
+int nlsg_nmpso_minimize(nlsg_nmpso *e, double *x_inout_host, const double *lower_host,
+                        const double *upper_host, nlsg_status *status_host);
+int nlsg_nmpso_time_solve(nlsg_nmpso *e, const double *x0_host, uint32_t repeats, float *ms_total);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,6 +10,7 @@ Layout:
     lm.py                 LevenbergMarquardt (batched NLLS): mirror of nlsolver.h:3428-3545
     nm.py                 NelderMead (batched starts): mirror of nlsolver.h:2099-2300
     sann.py               SANN (batched chains): mirror of nlsolver.h:2744-2815
+    nmpso.py              NelderMeadPSO (batched instances): mirror of nlsolver.h:3546-3920
     dist.py               population sharding across ranks (torch.distributed / RCCL)
 """
 from ._capi import DE_BEST, DE_RANDOM, PSO_ACCELERATED, PSO_VANILLA, NlsgError  # noqa: F401
@@ -19,3 +20,4 @@ from .bfgs import BFGS, BFGSEngine, QuadDiagRank1  # noqa: F401
 from .lm import LevenbergMarquardt, LMEngine, TanhRegression  # noqa: F401
 from .nm import NelderMead, NMEngine  # noqa: F401
 from .sann import SANN, SANNEngine  # noqa: F401
+from .nmpso import NelderMeadPSO, NMPSOEngine  # noqa: F401

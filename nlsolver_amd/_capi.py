@@ -97,6 +97,15 @@ class SANNConfig(C.Structure):
                 ("temperature_max", f64), ("seed", u64)]
 
 
+class NMPSOConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("device", i32), ("stream", C.c_void_p),
+                ("objective", i32), ("minimize", i32), ("bounded", i32), ("reserved", i32),
+                ("batch", u64), ("dim", u64), ("inst_lo", u64),
+                ("alpha", f64), ("gamma", f64), ("rho", f64), ("sigma", f64),
+                ("inertia", f64), ("cognitive", f64), ("social", f64), ("eps", f64),
+                ("max_iter", u64), ("no_change_best_iter", u64), ("seed", u64)]
+
+
 # every symbol include/nlsg_c_api.h declares: name -> (restype, argtypes)
 _H = C.c_void_p
 SYMBOLS = {
@@ -168,6 +177,12 @@ SYMBOLS = {
     "nlsg_nm_destroy": (C.c_int, [_H]),
     "nlsg_nm_minimize": (C.c_int, [_H, pd, pd, pd, C.POINTER(Status), pd]),
     "nlsg_nm_time_solve": (C.c_int, [_H, pd, C.c_uint32, C.POINTER(C.c_float)]),
+    "nlsg_nmpso_create": (C.c_int, [C.POINTER(NMPSOConfig), C.POINTER(_H)]),
+    "nlsg_nmpso_create_custom": (C.c_int, [C.POINTER(NMPSOConfig), C.POINTER(CustomObjectiveC),
+                                           C.POINTER(C.c_void_p)]),
+    "nlsg_nmpso_destroy": (C.c_int, [_H]),
+    "nlsg_nmpso_minimize": (C.c_int, [_H, pd, pd, pd, C.POINTER(Status)]),
+    "nlsg_nmpso_time_solve": (C.c_int, [_H, pd, C.c_uint32, C.POINTER(C.c_float)]),
     "nlsg_sann_create": (C.c_int, [C.POINTER(SANNConfig), C.POINTER(_H)]),
     "nlsg_sann_create_custom": (C.c_int, [C.POINTER(SANNConfig), C.POINTER(CustomObjectiveC),
                                           C.POINTER(C.c_void_p)]),

@@ -38,6 +38,12 @@ struct LmRtcKernels {  // finite-difference model (default functors) around the 
 };
 int rtc_build_lm(const nlsg_custom_objective *obj, LmRtcKernels *out);
 void rtc_release(LmRtcKernels *k);
+struct HybRtcKernels {
+  hipModule_t mod = nullptr;
+  hipFunction_t solve = nullptr;
+};
+int rtc_build_nmpso(const nlsg_custom_objective *obj, HybRtcKernels *out);
+void rtc_release(HybRtcKernels *k);
 struct SannRtcKernels {
   hipModule_t mod = nullptr;
   hipFunction_t anneal = nullptr;

@@ -207,6 +207,22 @@ void rtc_release(NmRtcKernels *k) {
   if (k) *k = NmRtcKernels();
 }
 
+int rtc_build_nmpso(const nlsg_custom_objective *obj, HybRtcKernels *out) {
+  std::vector<hipFunction_t> f;
+  HybRtcKernels k;
+  const int rc = rtc_compile(obj, "nlsg_nmpso_kernels.h",
+                             {"nlsg::nmpso_solve_kernel<" + std::to_string(static_cast<int>(NLSG_OBJ_CUSTOM)) + ">"},
+                             &k.mod, &f);
+  if (rc) return rc;
+  k.solve = f[0];
+  *out = k;
+  return NLSG_OK;
+}
+void rtc_release(HybRtcKernels *k) {
+  if (k && k->mod) hipModuleUnload(k->mod);
+  if (k) *k = HybRtcKernels();
+}
+
 int rtc_build_sann(const nlsg_custom_objective *obj, int chunks, bool vec, SannRtcKernels *out) {
   std::vector<hipFunction_t> f;
   SannRtcKernels k;

@@ -247,6 +247,7 @@ orc_status orc_nmpso_serial(int obj, int minimize, int bound, double *x, size_t 
                             double gamma, double rho, double sigma, double inertia, double cog,
                             double soc, double eps, size_t max_iter, size_t no_change_best_iter,
                             double *f_log, size_t f_cap);
+size_t orc_nmpso_last_shrinks(void); /* shrink steps of the most recent orc_nmpso_* run */
 orc_status orc_nmpso_sync(int obj, int minimize, int bound, double *x, size_t n, const double *upper,
                           const double *lower, uint64_t seed, uint64_t instance, double alpha,
                           double gamma, double rho, double sigma, double inertia, double cog,

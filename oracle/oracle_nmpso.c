@@ -31,6 +31,9 @@
 
 #include "oracle.h"
 
+static size_t hyb_last_shrinks; /* shrink steps of the most recent run (test coverage aid) */
+size_t orc_nmpso_last_shrinks(void) { return hyb_last_shrinks; }
+
 typedef struct {
   int obj, order; /* order: 0 reference arithmetic, 1 device trees */
   size_t n, fcalls;
@@ -163,6 +166,7 @@ static orc_status hyb_solve(int obj, int minimize, int bound, double *x, size_t 
     for (size_t i = 0; i < total; i++) val[i] = hyb_f(&c, pos + i * n);
   }
   for (size_t i = 0; i < total; i++) order[i] = i;
+  hyb_last_shrinks = 0;
   size_t iter = 0, no_change = 0;
   const double best_val = val[0]; /* H2 */
   for (;;) {
@@ -202,6 +206,7 @@ static orc_status hyb_solve(int obj, int minimize, int bound, double *x, size_t 
           memcpy(pos + worst * n, tc, n * sizeof(double));
           val[worst] = cont_score;
         } else {
+          hyb_last_shrinks++;
           const double *best = pos + order[0] * n; /* shrink (3885-3902) */
           for (size_t i = 1; i < ns; i++) {
             double *cur = pos + order[i] * n;

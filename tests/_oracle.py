@@ -249,6 +249,8 @@ def load():
     lib.orc_bfgs_quad.restype = Status
     lib.orc_bfgs_quad.argtypes = [C.POINTER(Quad), pd, sz, sz, f64, f64, C.c_int,
                                   C.POINTER(BfgsCounters)]
+    lib.orc_nmpso_last_shrinks.restype = sz
+    lib.orc_nmpso_last_shrinks.argtypes = []
     lib.orc_nmpso_serial.restype = Status
     lib.orc_nmpso_serial.argtypes = [C.c_int, C.c_int, C.c_int, pd, sz, pd, pd, C.POINTER(XorShift)] + \
         [f64] * 8 + [sz, sz, pd, sz]

@@ -1,0 +1,128 @@
+"""Parity tests: batched HIP Nelder-Mead / PSO hybrid (one workgroup per instance) vs
+oracle_nmpso.c's synchronous variant (keyed draws, objective and std_err trees): bit-exact best
+particles, values and counters for every instance."""
+import numpy as np
+import pytest
+
+from tests import _oracle as O
+
+pytestmark = pytest.mark.gpu
+SEED = 12374563468
+
+
+@pytest.fixture(scope="module")
+def mod():
+    import torch
+    assert torch.cuda.is_available()
+    import nlsolver_amd
+    return nlsolver_amd
+
+
+def starts(batch, n, base, spread, seed=0):
+    rng = np.random.default_rng(seed + n)
+    return base + spread * (rng.random((batch, n)) - 0.5)
+
+
+def check(mod, oracle, objective, n, batch, x0, minimize=True, bounds=None, **kw):
+    okw = dict(eps=kw.get("eps", 1e-6), max_iter=kw.get("max_iter", 1000),
+               no_change=kw.get("no_change_best_iter", 20))
+    for k in ("alpha", "gamma", "rho", "sigma", "inertia"):
+        if k in kw:
+            okw[k] = kw[k]
+    if "cognitive" in kw:
+        okw["cog"] = kw["cognitive"]
+    if "social" in kw:
+        okw["soc"] = kw["social"]
+    lower, upper = bounds if bounds else (None, None)
+    with mod.NMPSOEngine(objective, batch, n, minimize=minimize, bounded=bounds is not None,
+                         seed=SEED, inst_lo=2, **kw) as eng:
+        x, st = eng.minimize(x0, lower, upper)
+    for b in range(batch):
+        ref, xr, _ = O.nmpso_sync(oracle, objective, x0[b], SEED, 2 + b, minimize=minimize,
+                                  upper=upper, lower=lower, **okw)
+        assert np.array_equal(x[b], xr), (b, x[b], xr)
+        assert st[b].f_value == ref.f_value, (b, st[b].f_value, ref.f_value)
+        assert (st[b].iteration, st[b].function_calls_used) == (ref.iteration, ref.function_calls_used)
+    return st
+
+
+@pytest.mark.parametrize("objective,n,kw", [
+    ("rosenbrock", 2, dict(max_iter=1000, eps=1e-6, no_change_best_iter=20)),
+    ("rosenbrock", 3, dict(max_iter=60, eps=0.0, no_change_best_iter=1000)),
+    ("rosenbrock", 4, dict(max_iter=100, eps=1e-6, no_change_best_iter=20)),
+    ("rosenbrock", 8, dict(max_iter=120, eps=0.0, no_change_best_iter=1000)),
+    ("sphere", 6, dict(max_iter=150, eps=1e-9, no_change_best_iter=20)),
+    ("styblinski_tang", 5, dict(max_iter=60, eps=0.0, no_change_best_iter=1000)),
+    ("rosenbrock", 16, dict(max_iter=80, eps=1e-6, no_change_best_iter=20)),
+    ("rosenbrock", 33, dict(max_iter=40, eps=0.0, no_change_best_iter=1000)),
+    ("rosenbrock", 64, dict(max_iter=30, eps=0.0, no_change_best_iter=1000)),
+    ("rosenbrock", 127, dict(max_iter=12, eps=0.0, no_change_best_iter=1000)),
+    ("sphere", 128, dict(max_iter=12, eps=0.0, no_change_best_iter=1000)),
+])
+def test_hybrid_instances_bit_exact_vs_sync_oracle(mod, oracle, objective, n, kw):
+    check(mod, oracle, objective, n, 5, starts(5, n, 0.5, 1.0), **kw)
+
+
+def test_hybrid_maximize_and_other_coefficients(mod, oracle):
+    x0 = starts(4, 6, 0.5, 1.0)
+    check(mod, oracle, "styblinski_tang", 6, 4, x0, minimize=False, max_iter=50, eps=0.0,
+          no_change_best_iter=1000)
+    check(mod, oracle, "rosenbrock", 6, 4, x0, max_iter=70, eps=0.0, no_change_best_iter=1000,
+          alpha=1.2, gamma=1.8, rho=0.4, sigma=0.6, inertia=0.7, cognitive=1.5, social=1.2)
+
+
+def test_hybrid_bounded_overload(mod, oracle):
+    """minimize(x, lower, upper): simplex points and velocities clamped per coordinate."""
+    x0 = starts(4, 8, 0.2, 0.8)
+    st = check(mod, oracle, "styblinski_tang", 8, 4, x0, bounds=(-1.0, 1.0), max_iter=60, eps=0.0,
+               no_change_best_iter=1000)
+    assert all(np.isfinite(s.f_value) for s in st)
+
+
+def test_hybrid_shrink_path_is_exercised(mod, oracle):
+    """Small simplexes fail their contraction often: the shrink + rescore + re-sort path runs (the
+    oracle counts its shrink steps; the device run agrees with it bit for bit)."""
+    for objective, n in (("styblinski_tang", 4), ("rosenbrock", 2)):
+        x0 = starts(4, n, -1.0, 3.0, seed=11)
+        check(mod, oracle, objective, n, 4, x0, max_iter=300, eps=0.0, no_change_best_iter=10**6)
+        assert oracle.orc_nmpso_last_shrinks() > 10  # of the last instance's oracle run
+
+
+def test_hybrid_instance_ids_are_global(mod):
+    x0 = starts(5, 6, 0.5, 1.0)
+    kw = dict(max_iter=40, eps=0.0, seed=7)
+    with mod.NMPSOEngine("rosenbrock", 5, 6, **kw) as eng:
+        xa, sa = eng.minimize(x0)
+    with mod.NMPSOEngine("rosenbrock", 3, 6, inst_lo=2, **kw) as eng:
+        xb, sb = eng.minimize(x0[2:])
+    assert np.array_equal(xa[2:], xb)
+    assert [s.f_value for s in sa[2:]] == [s.f_value for s in sb]
+
+
+def test_hybrid_converges_on_the_reference_example(mod):
+    """The reference's own pass criterion (within 0.05 of the known minimum on a small problem)."""
+    x = np.array([2.0, 7.0])
+    st = mod.NelderMeadPSO("rosenbrock").minimize(x)
+    assert np.all(np.abs(x - 1.0) <= 0.05), (x, st.f_value)
+
+
+def test_hybrid_one_dimension_is_refused_like_the_reference(mod):
+    from nlsolver_amd._capi import NlsgError
+    st = mod.NelderMeadPSO("sphere").minimize(np.array([2.0]))
+    assert (st.f_value, st.iteration, st.function_calls_used) == (999999, 0, 0)
+    with pytest.raises(NlsgError):
+        mod.NMPSOEngine("sphere", 1, 1)
+    with pytest.raises(NlsgError):
+        mod.NMPSOEngine("sphere", 1, 129)
+
+
+def test_hybrid_custom_objective_equals_builtin(mod):
+    rosen = "double t1 = 1 - xi; double t2 = (xn - xi * xi); return t1 * t1 + 100 * t2 * t2;"
+    for n in (4, 40):
+        x0 = starts(3, n, 0.5, 1.0)
+        out = []
+        for obj in ("rosenbrock", mod.CustomObjective(rosen, chain=True)):
+            with mod.NMPSOEngine(obj, 3, n, max_iter=30, eps=0.0, seed=5) as eng:
+                x, st = eng.minimize(x0)
+            out.append((x, [(s.f_value, s.function_calls_used) for s in st]))
+        assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
