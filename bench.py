@@ -212,6 +212,46 @@ def main_bfgs_fd(args):
     eng.close()
 
 
+def main_nmpso(args):
+    """Batched Nelder-Mead / PSO hybrid: Rosenbrock-32D (97 particles per
+    instance), 4096 independent instances, 100 iterations (eps = 0, no early stop). One step = one
+    iteration of every instance: sort, simplex step on the best 33 particles, PSO move + evaluation
+    of the other 64."""
+    import torch
+
+    import nlsolver_amd
+    n, iters = 32, 100
+    batch = 4096 if args.pop_per_gpu == POP_PER_GPU else args.pop_per_gpu
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    rng = np.random.default_rng(12374563468 % 2**32)
+    x0 = 0.5 + 1.0 * (rng.random((batch, n)) - 0.5)
+    eng = nlsolver_amd.NMPSOEngine("rosenbrock", batch, n, max_iter=iters, eps=0.0,
+                                   no_change_best_iter=2**62, device=local_rank)
+    x, st = eng.minimize(x0)
+    reps = 3
+    ms = eng.time_solve(x0, reps) / reps
+    evals = sum(s.function_calls_used for s in st)
+    assert all(s.iteration == iters for s in st)
+    print(json.dumps({
+        "metric": "NelderMeadPSO objective evaluations x instances / s (Rosenbrock-32D)",
+        "value": evals / (ms * 1e-3), "unit": "particle-evals/s", "n_gpus": 1, "steps": iters,
+        "warmup": iters, "ms_per_step": ms / iters, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"NelderMeadPSO, Rosenbrock-{n}D, batch={batch} independent "
+                               f"instances of {3 * n + 1} particles, {iters} iterations",
+                   "iteration_instances_per_s": batch * iters / (ms * 1e-3),
+                   "mean_best_f": float(np.mean([s.f_value for s in st]))},
+        "roofline": {"bound": "latency", "achieved": None, "peak": None, "unit": None,
+                     "frac": None, "traffic": None, "kernel": "nmpso_solve_kernel", "kernel_ms": ms,
+                     "note": "a chain of data-dependent simplex decisions per iteration around the "
+                             "parallel PSO move; not roofline-graded"},
+        **({} if args.no_cpu_baseline else {"cpu_baseline": ref_baseline(
+            ["bench-nmpso", n, 4096, iters], "evals_per_s", "particle-evals/s",
+            f"reference NelderMeadPSO, Rosenbrock-{n}D, 4096 instances x {iters} iterations")})}))
+    eng.close()
+
+
 def main_sann(args):
     """Batched simulated annealing: Rosenbrock-128D, 16 384 independent chains, the
     reference's default temperature_iter = 10 and temperature_max = 10, 100 temperatures. One step
@@ -487,7 +527,7 @@ def main():
     ap.add_argument("--lm-solver", choices=["cholesky", "qr"], default="cholesky",
                     help="lm workload: damped-system solver (cholesky = the reference class's "
                          "get_update_with_hessian; qr = tinyqr::lm, as BASELINE configs[3] words it)")
-    ap.add_argument("--workload", choices=["de", "pso-accel", "pso-vanilla", "bfgs", "bfgs-fd", "lm", "lm-fd", "nm", "sann"],
+    ap.add_argument("--workload", choices=["de", "pso-accel", "pso-vanilla", "bfgs", "bfgs-fd", "lm", "lm-fd", "nm", "sann", "nmpso"],
                     default="de",
                     help="de = the headline benchmark (BASELINE metric); pso-* = config 5's "
                          "per-GPU shard (secondary, same JSON shape)")
@@ -500,6 +540,8 @@ def main():
         return main_lm_fd(args)
     if args.workload == "sann":
         return main_sann(args)
+    if args.workload == "nmpso":
+        return main_nmpso(args)
     if args.workload == "lm":
         return main_lm(args)
     if args.workload == "nm":

@@ -310,6 +310,10 @@ class api {
   decltype(&nlsg_nm_create_custom) nm_create_custom;
   decltype(&nlsg_nm_destroy) nm_destroy;
   decltype(&nlsg_nm_minimize) nm_minimize;
+  decltype(&nlsg_nmpso_create) nmpso_create;
+  decltype(&nlsg_nmpso_create_custom) nmpso_create_custom;
+  decltype(&nlsg_nmpso_destroy) nmpso_destroy;
+  decltype(&nlsg_nmpso_minimize) nmpso_minimize;
   decltype(&nlsg_sann_create) sann_create;
   decltype(&nlsg_sann_create_custom) sann_create_custom;
   decltype(&nlsg_sann_destroy) sann_destroy;
@@ -352,6 +356,10 @@ class api {
     bind(h, "nlsg_nm_create_custom", nm_create_custom);
     bind(h, "nlsg_nm_destroy", nm_destroy);
     bind(h, "nlsg_nm_minimize", nm_minimize);
+    bind(h, "nlsg_nmpso_create", nmpso_create);
+    bind(h, "nlsg_nmpso_create_custom", nmpso_create_custom);
+    bind(h, "nlsg_nmpso_destroy", nmpso_destroy);
+    bind(h, "nlsg_nmpso_minimize", nmpso_minimize);
     bind(h, "nlsg_sann_create", sann_create);
     bind(h, "nlsg_sann_create_custom", sann_create_custom);
     bind(h, "nlsg_sann_destroy", sann_destroy);
@@ -1181,6 +1189,249 @@ class SANN {
       }
     }
     return solver_status<scalar_t>(best, max_iter, f_evals);
+  }
+};
+
+// ---------------------------------------------------------------------------
+// NelderMeadPSO — nlsolver.h:3546-3920
+// ---------------------------------------------------------------------------
+template <typename Callable, typename RNG, typename scalar_t = double>
+class NelderMeadPSO {
+  RNG &generator;
+  Callable &f;
+  const scalar_t alpha, gamma, rho, sigma, inertia, cognitive_coef, social_coef;
+  scalar_t eps;
+  const size_t max_iter, no_change_best_iter;
+
+ public:
+  // same positional arguments and defaults as nlsolver.h:3563-3569
+  NelderMeadPSO(Callable &f, RNG &generator, const scalar_t alpha = 1, const scalar_t gamma = 2,
+                const scalar_t rho = 0.5, const scalar_t sigma = 0.5, const scalar_t inertia = 0.8,
+                const scalar_t cognitive_coef = 1.8, const scalar_t social_coef = 1.8,
+                const scalar_t eps = 1e-6, const size_t max_iter = 1000,
+                const size_t no_change_best_iter = 20)
+      : generator(generator), f(f), alpha(alpha), gamma(gamma), rho(rho), sigma(sigma),
+        inertia(inertia), cognitive_coef(cognitive_coef), social_coef(social_coef), eps(eps),
+        max_iter(max_iter), no_change_best_iter(no_change_best_iter) {}
+  solver_status<scalar_t> minimize(std::vector<scalar_t> &x) { return unbounded<true>(x); }
+  solver_status<scalar_t> maximize(std::vector<scalar_t> &x) { return unbounded<false>(x); }
+  // note the argument order (lower, upper), nlsolver.h:3609-3612
+  solver_status<scalar_t> minimize(std::vector<scalar_t> &x, const std::vector<scalar_t> &lower,
+                                   const std::vector<scalar_t> &upper) {
+    return run<true, true>(x, upper, lower);
+  }
+  solver_status<scalar_t> maximize(std::vector<scalar_t> &x, const std::vector<scalar_t> &lower,
+                                   const std::vector<scalar_t> &upper) {
+    return run<false, true>(x, upper, lower);
+  }
+  // Extension: `xs.size()` independent instances side by side on the GPU (instance b is keyed
+  // by (seed, b)); the reference solves one per call.
+  std::vector<solver_status<scalar_t>> minimize_batch(std::vector<std::vector<scalar_t>> &xs) {
+    std::vector<scalar_t> none;
+    return run_device<true, false>(xs, none, none);
+  }
+
+ private:
+  template <bool minimize>
+  solver_status<scalar_t> unbounded(std::vector<scalar_t> &x) {
+    std::vector<scalar_t> lower(x.size()), upper(x.size());
+    for (size_t i = 0; i < x.size(); i++) {  // implied bounds, nlsolver.h:3587-3593
+      const scalar_t reach = std::abs(2.5 * x[i]);
+      lower[i] = -reach;
+      upper[i] = reach;
+    }
+    return run<minimize, false>(x, upper, lower);
+  }
+  template <bool minimize, bool bound>
+  solver_status<scalar_t> run(std::vector<scalar_t> &x, const std::vector<scalar_t> &upper,
+                              const std::vector<scalar_t> &lower) {
+    if (x.size() < 2) {  // nlsolver.h:3627-3637
+      std::cout << "You are trying to optimize a one dimensional function; use NelderMead or PSO: "
+                   "the NelderMead-PSO hybrid does not support this."
+                << std::endl;
+      return solver_status<scalar_t>(999999, 0, 0);
+    }
+    if constexpr (device::is_device_objective<Callable>::value) {
+      std::vector<std::vector<scalar_t>> one{x};
+      auto st = run_device<minimize, bound>(one, upper, lower);
+      x = one[0];
+      return st[0];
+    } else {
+      return solve_host<minimize, bound>(x, upper, lower);
+    }
+  }
+  template <bool minimize, bool bound>
+  std::vector<solver_status<scalar_t>> run_device(std::vector<std::vector<scalar_t>> &xs,
+                                                  const std::vector<scalar_t> &upper,
+                                                  const std::vector<scalar_t> &lower) {
+    static_assert(device::is_device_objective<Callable>::value,
+                  "the batched hybrid needs a device objective");
+    static_assert(std::is_same_v<scalar_t, double>, "the device path computes in fp64");
+    const device::api &api = device::api::get();
+    const size_t B = xs.size(), n = B ? xs[0].size() : 0;
+    nlsg_nmpso_config cfg{};
+    cfg.struct_size = sizeof(cfg);
+    if (const char *d = std::getenv("NLSG_DEVICE")) cfg.device = std::atoi(d);
+    cfg.objective = Callable::nlsg_objective;
+    cfg.minimize = minimize ? 1 : 0;
+    cfg.bounded = bound ? 1 : 0;
+    cfg.batch = B;
+    cfg.dim = n;
+    cfg.alpha = alpha;
+    cfg.gamma = gamma;
+    cfg.rho = rho;
+    cfg.sigma = sigma;
+    cfg.inertia = inertia;
+    cfg.cognitive = cognitive_coef;
+    cfg.social = social_coef;
+    cfg.eps = eps;
+    cfg.max_iter = max_iter;
+    cfg.no_change_best_iter = no_change_best_iter;
+    cfg.seed = device::seed_from(generator);
+    nlsg_nmpso *eng = nullptr;
+    if constexpr (Callable::nlsg_objective == NLSG_OBJ_CUSTOM) {
+      api.check(api.rtc_load(std::getenv("NLSG_HIPRTC")));
+      nlsg_custom_objective obj{f.term_body.c_str(), f.finish_body.c_str(), f.chain ? 1 : 0, 0};
+      api.check(api.nmpso_create_custom(&cfg, &obj, &eng));
+    } else {
+      api.check(api.nmpso_create(&cfg, &eng));
+    }
+    std::vector<scalar_t> flat(B * n);
+    for (size_t b = 0; b < B; b++) std::copy(xs[b].begin(), xs[b].end(), flat.begin() + b * n);
+    std::vector<nlsg_status> st(B);
+    const int rc = api.nmpso_minimize(eng, flat.data(), bound ? lower.data() : nullptr,
+                                      bound ? upper.data() : nullptr, st.data());
+    const std::string msg = rc ? api.last_error() : "";
+    api.nmpso_destroy(eng);
+    if (rc) throw device_error("nlsg error " + std::to_string(rc) + ": " + msg);
+    std::vector<solver_status<scalar_t>> out;
+    for (size_t b = 0; b < B; b++) {
+      std::copy(flat.begin() + b * n, flat.begin() + (b + 1) * n, xs[b].begin());
+      out.emplace_back(st[b].f_value, st[b].iteration, st[b].function_calls_used);
+    }
+    return out;
+  }
+
+  // Host path for arbitrary callables: NelderMeadPSO::solve (nlsolver.h:3623-3685) with
+  // init_solver_state 3686-3738, apply_simplex 3739-3822, apply_pso 3823-3866. 3n + 1
+  // particles: every iteration sorts them, runs one Nelder-Mead step on the best n + 1 and a PSO
+  // move on the other 2n. Kept as the reference behaves: the last simplex particle stays at x
+  // (its write of element [n][n] is out of bounds and dropped); the no-change counter compares
+  // with the first particle's initial value, which is never refreshed; the PSO move works on a
+  // copy of the velocity, so velocities keep their initial values; the "better particle of a
+  // pair" is the pair's second one (the first pair: its first). The bounded overloads clamp the
+  // velocity by coordinate (the reference indexes the bounds with the particle's rank, out of
+  // range).
+  template <bool minimize, bool bound>
+  solver_status<scalar_t> solve_host(std::vector<scalar_t> &x, const std::vector<scalar_t> &upper,
+                                     const std::vector<scalar_t> &lower) {
+    constexpr scalar_t sign = minimize ? 1.0 : -1.0;
+    const size_t n = x.size(), n_simplex = n + 1, n_all = 3 * n + 1;
+    size_t calls = 0;
+    auto value = [&](std::vector<scalar_t> &at) {
+      calls++;
+      return sign * f(at);
+    };
+    std::vector<std::vector<scalar_t>> where(n_all, x), speed(n_all, std::vector<scalar_t>(n, 0.0));
+    std::vector<scalar_t> score(n_all);
+    {
+      scalar_t inf_norm = std::abs(x[0]);
+      for (size_t i = 1; i < n; i++) inf_norm = inf_norm < std::abs(x[i]) ? std::abs(x[i]) : inf_norm;
+      const scalar_t a = inf_norm < 1.0 ? 1.0 : inf_norm;
+      const scalar_t spread = a < 10 ? a : 10;
+      for (size_t i = 1; i < n; i++) where[i][i] = x[i] + spread;
+      const auto nn = static_cast<scalar_t>(n);
+      for (size_t i = 0; i < n; i++) where[0][i] = x[i] + ((1.0 - std::sqrt(nn + 1.0)) / nn * spread);
+    }
+    for (size_t i = n_simplex; i < n_all; i++)
+      for (size_t j = 0; j < n; j++) {
+        const scalar_t width = std::abs(upper[j] - lower[j]);
+        where[i][j] = lower[j] + ((upper[j] - lower[j]) * generator());
+        speed[i][j] = -width + (generator() * width);
+      }
+    for (size_t i = 0; i < n_all; i++) score[i] = value(where[i]);
+    std::vector<size_t> rank(n_all);
+    for (size_t i = 0; i < n_all; i++) rank[i] = i;
+    auto by_score = [&](size_t l, size_t r) { return score[l] < score[r]; };
+    auto transform = [&](const std::vector<scalar_t> &pt, const std::vector<scalar_t> &c,
+                         std::vector<scalar_t> &out, scalar_t coef, bool reflect) {
+      for (size_t i = 0; i < n; i++) {
+        scalar_t t = reflect ? c[i] + coef * (c[i] - pt[i]) : c[i] + coef * (pt[i] - c[i]);
+        if constexpr (bound) t = std::clamp(t, lower[i], upper[i]);
+        out[i] = t;
+      }
+    };
+    const scalar_t first_value = score[0];
+    size_t iter = 0, unchanged = 0;
+    std::vector<scalar_t> centroid(n), refl(n), expd(n), cont(n);
+    for (;;) {
+      std::sort(rank.begin(), rank.end(), by_score);
+      const bool same = first_value == score[rank[0]];
+      unchanged = same ? unchanged + 1 : 0;
+      scalar_t mean = 0, dev = 0;
+      for (size_t i = 0; i < n_simplex; i++) mean += score[rank[i]];
+      mean /= static_cast<scalar_t>(n_simplex);
+      for (size_t i = 0; i < n_simplex; i++) dev += std::pow(score[rank[i]] - mean, 2);
+      dev = std::sqrt(dev / static_cast<scalar_t>(n_simplex - 1));
+      if (iter >= max_iter || unchanged >= no_change_best_iter || dev < eps) {
+        x = where[rank[0]];
+        return solver_status<scalar_t>(score[rank[0]], iter, calls);
+      }
+      {  // the simplex step on the best n + 1 particles
+        const scalar_t best_score = score[rank[0]];
+        const size_t worst = rank[n_simplex - 1], second = rank[n_simplex - 2];
+        std::fill(centroid.begin(), centroid.end(), 0.0);
+        for (size_t i = 0; i + 1 < n_simplex; i++)
+          for (size_t j = 0; j < n; j++) centroid[j] += where[rank[i]][j];
+        for (auto &c : centroid) c /= static_cast<scalar_t>(n_simplex - 1);
+        transform(where[worst], centroid, refl, alpha, true);
+        const scalar_t refl_score = value(refl);
+        if (refl_score >= best_score && refl_score < score[second]) {
+          where[worst] = refl;
+          score[worst] = refl_score;
+        } else if (refl_score < best_score) {
+          transform(refl, centroid, expd, gamma, false);
+          const scalar_t expd_score = value(expd);
+          where[worst] = expd_score < refl_score ? expd : refl;
+          score[worst] = expd_score < refl_score ? expd_score : refl_score;
+        } else {
+          const scalar_t worst_score = score[worst];
+          transform(refl_score < worst_score ? refl : where[worst], centroid, cont, rho, false);
+          const scalar_t cont_score = value(cont);
+          if (cont_score < std::min(refl_score, worst_score)) {
+            where[worst] = cont;
+            score[worst] = cont_score;
+          } else {
+            const std::vector<scalar_t> &best = where[rank[0]];
+            for (size_t i = 1; i < n_simplex; i++)
+              for (size_t j = 0; j < n; j++)
+                where[rank[i]][j] = best[j] + sigma * (where[rank[i]][j] - best[j]);
+            for (size_t i = 1; i < n_simplex; i++) score[rank[i]] = value(where[rank[i]]);
+            std::sort(rank.begin(), rank.end(), by_score);
+          }
+        }
+      }
+      {  // the PSO move of the other 2n particles
+        const std::vector<scalar_t> &best = where[rank[0]];
+        size_t partner = rank[n_simplex];
+        bool take_next = false;
+        for (size_t i = n_simplex; i < n_all; i++) {
+          const size_t id = rank[i];
+          if (take_next) partner = rank[i + 1];
+          take_next = ((i - n_simplex) % 2) != 0;
+          const std::vector<scalar_t> pair = where[partner];  // a copy, taken before the move
+          for (size_t j = 0; j < n; j++) {
+            const scalar_t r_p = generator(), r_g = generator();
+            scalar_t step = (inertia * speed[id][j]) + cognitive_coef * r_p * (pair[j] - where[id][j]) +
+                            social_coef * r_g * (best[j] - where[id][j]);
+            if constexpr (bound) step = std::clamp(step, lower[j], upper[j]);
+            where[id][j] += step;
+          }
+          score[id] = value(where[id]);
+        }
+      }
+      iter++;
+    }
   }
 };
 

@@ -359,3 +359,52 @@ def test_sann_device_objective_without_library_fails_loudly(built):
                         "0.4", "0.01", "1"], env=dict(os.environ, NLSG_LIBRARY="/nonexistent/lib.so"),
                        capture_output=True, text=True)
     assert r.returncode == 3 and "device_error" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
+HYBRID_CASES = ["rosenbrock_n2_defaults", "rosenbrock_n4", "rosenbrock_n8_200iters", "rosenbrock_n16",
+                "sphere_n6", "styblinski_tang_n4_maximize", "rosenbrock_n130_ragged"]
+
+
+@pytest.mark.parametrize("name", HYBRID_CASES)
+def test_hybrid_host_path_through_header_matches_reference_bit_exact(built, golden, name):
+    g = golden("nmpso.json")[name]
+    o = json.loads(subprocess.check_output(
+        [os.path.join(built, "header_hybrid"), "host", str(g["objective"]), str(g["n"]),
+         str(g["max_iter"]), repr(hx(g["eps"])), str(g["no_change"]), repr(hx(g["x0"])),
+         repr(hx(g["x0_step"])), str(g["minimize"])], text=True))
+    assert (o["fcalls"], o["iters"]) == (g["fcalls"], g["iters"])
+    assert o["f"] == g["f"] and o["x"] == g["x"] and o["next_draw"] == g["next_draw"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["device", "device-custom"])
+@pytest.mark.parametrize("n,max_iter,eps,no_change", [(2, 1000, 1e-6, 20), (7, 60, 0.0, 1000),
+                                                      (32, 20, 0.0, 1000)])
+def test_hybrid_device_objective_through_header_matches_oracle(built, oracle, mode, n, max_iter, eps,
+                                                               no_change):
+    """NelderMeadPSO<device::Rosenbrock<double>, xorshift<double>>(f, gen, ...).minimize_batch(xs):
+    instances keyed by (two draws of the generator, instance index); bit-exact vs the oracle."""
+    B = 3
+    out = subprocess.check_output(
+        [os.path.join(built, "header_hybrid"), mode, str(B), str(n), str(max_iter), repr(eps),
+         str(no_change), "0.4", "0.03"], env=dict(os.environ, NLSG_LIBRARY=LIB), text=True)
+    res = json.loads(out)
+    assert isinstance(res, list) and len(res) == B, res
+    xs = O.XorShift()
+    oracle.orc_xorshift_init(C.byref(xs))
+    half = [min(int(oracle.orc_xorshift_next(C.byref(xs)) * 2.0**32), 2**32 - 1) for _ in range(2)]
+    seed = (half[0] << 32) | half[1]
+    for b, o in enumerate(res):
+        x0 = 0.4 + 0.03 * (np.arange(n, dtype=np.float64) + b)
+        ref, xr, _ = O.nmpso_sync(oracle, "rosenbrock", x0, seed, b, eps=eps, max_iter=max_iter,
+                                  no_change=no_change)
+        assert (o["fcalls"], o["iters"]) == (ref.function_calls_used, ref.iteration)
+        assert hx(o["f"]) == ref.f_value
+        assert np.array_equal(np.array([hx(v) for v in o["x"]]), xr)
+
+
+def test_hybrid_device_objective_without_library_fails_loudly(built):
+    r = subprocess.run([os.path.join(built, "header_hybrid"), "device", "2", "4", "10", "0.0", "20",
+                        "0.4", "0.01"], env=dict(os.environ, NLSG_LIBRARY="/nonexistent/lib.so"),
+                       capture_output=True, text=True)
+    assert r.returncode == 3 and "device_error" in r.stdout, (r.returncode, r.stdout, r.stderr)
