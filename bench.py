@@ -431,6 +431,23 @@ def main_nm(args):
     eng.close()
 
 
+def rehearsal_device(local_rank):
+    """NLSG_BENCH_REHEARSAL=1: every rank uses GPU 0 and the ranks talk over gloo — the N > 1
+    control flow of this file on a one-GPU box (RCCL refuses two ranks on one device). Numbers
+    from such a run mean nothing; it exists so that the multi-rank path is executed before the
+    scaling run."""
+    if os.environ.get("NLSG_BENCH_REHEARSAL") != "1":
+        return local_rank
+    os.environ["NLSG_DIST_NATIVE"] = "0"  # host-ordered turns over gloo
+    return 0
+
+
+def pg_args(rank, world, device):
+    if os.environ.get("NLSG_BENCH_REHEARSAL") == "1":
+        return dict(backend="gloo", rank=rank, world_size=world)
+    return dict(backend="nccl", rank=rank, world_size=world, device_id=device)
+
+
 def main_pso(args):
     """BASELINE configs[4]: PSO swarm = 2^20 particles x D=256 sharded over 8 GPUs ->
     131072 particles per GPU (weak scaling). One step = best update + stop tests + one
@@ -445,13 +462,14 @@ def main_pso(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = rehearsal_device(local_rank)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     distributed = world > 1 or os.environ.get("NLSG_BENCH_FORCE_DIST") == "1"
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        dist.init_process_group(**pg_args(rank, world, device))
     vanilla = args.workload == "pso-vanilla"
     n = n_local * world
     kw = dict(type=nlsolver_amd.PSO_VANILLA if vanilla else nlsolver_amd.PSO_ACCELERATED,
@@ -482,13 +500,14 @@ def main_pso(args):
     barrier()
     dt = time.perf_counter() - t0
     if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64,
+                         device="cpu" if dist.get_backend() == "gloo" else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert eng.status().iteration == args.warmup + args.steps
+    stepper(200)  # untimed, every rank (a sharded turn is collective): clocks back up after the pauses
     if rank == 0:
         launches = max(min(args.steps, 200), 20)
-        eng.step(200)  # untimed: clocks back up after the host-side pauses
         kern_ms = eng.time_move_kernel(launches) / launches
         bytes_per = (40 if vanilla else 16) * Dp + 24  # rows r/w + cur/pbest values
         achieved = bytes_per * n_local / (kern_ms * 1e-3) / 1e9
@@ -562,6 +581,7 @@ def main():
                          "torch.distributed.run --nproc-per-node N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    local_rank = rehearsal_device(local_rank)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     # NLSG_BENCH_FORCE_DIST=1 exercises the sharded/RCCL path with a single rank (self-test)
@@ -569,7 +589,7 @@ def main():
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        dist.init_process_group(**pg_args(rank, world, device))
 
     pop_local = args.pop_per_gpu
     pop = pop_local * world
@@ -610,7 +630,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64,
+                         device="cpu" if dist.get_backend() == "gloo" else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     st = eng.status()
@@ -636,10 +657,12 @@ def main():
                          "agents_improved_frac": float(np.mean(e2.download()[1] < s0))}
 
     out = None
+    # untimed, every rank (a sharded turn is collective): clocks back up after the host-side
+    # pauses (status, downloads) before rank 0 times the dominant kernel
+    stepper(1000)
     if rank == 0:
         # dominant kernel: de_generation_kernel, timed alone with hipEvents on its stream
         launches = max(args.steps, 20)
-        eng.step(1000)  # untimed: clocks back up after the host-side pauses (status, downloads)
         kern_ms = eng.time_generation_kernel(launches) / launches
         achieved = BYTES_PER_CANDIDATE * pop_local / (kern_ms * 1e-3) / 1e9
         out = {

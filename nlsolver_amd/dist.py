@@ -61,8 +61,14 @@ class ShardedSwarm:
         assert rec == dim + 5
         self.send = torch.zeros(rec, dtype=torch.float64, device=device)
         self.gathered = torch.zeros(self.world * rec, dtype=torch.float64, device=device)
+        # gloo with device buffers (the one-GPU rehearsal of the multi-rank flow): the collective
+        # goes through host memory
+        self._stage = device.type == "cuda" and dist.get_backend() == "gloo"
+        if self._stage:
+            self._send_host = torch.zeros(rec, dtype=torch.float64)
+            self._gathered_host = torch.zeros(self.world * rec, dtype=torch.float64)
         self.native = False
-        if (device.type == "cuda" and hasattr(self.engine, "comm_attach")
+        if (device.type == "cuda" and hasattr(self.engine, "comm_attach") and not self._stage
                 and os.environ.get("NLSG_DIST_NATIVE", "1") != "0"):
             self._attach_native()
 
@@ -98,7 +104,13 @@ class ShardedSwarm:
         (strategy best, PSO: the move needs the exchanged best) keeps the serial order."""
         eng = self.engine
         eng.turn_begin(self.send.data_ptr())
-        if getattr(eng, "can_speculate", lambda: False)():
+        if self._stage:
+            self.torch.cuda.synchronize(self.device)
+            self._send_host.copy_(self.send)
+            self.dist.all_gather_into_tensor(self._gathered_host, self._send_host)
+            self.gathered.copy_(self._gathered_host)
+            eng.turn_end(self.gathered.data_ptr(), self.world)
+        elif getattr(eng, "can_speculate", lambda: False)():
             work = self.dist.all_gather_into_tensor(self.gathered, self.send, async_op=True)
             eng.turn_generation()
             work.wait()
