@@ -104,3 +104,22 @@ def test_sharded_turn_world1_matches_unsharded_engine(mode, port):
         assert case["best"][0] == case["best"][1], case
         assert case["same_pop"] and case["same_scores"] and case["same_best"], case
         assert case["std_err"][0] == case["std_err"][1], case
+
+
+@pytest.mark.parametrize("workload,port", [("de", "29641"), ("pso-accel", "29642")])
+def test_bench_two_rank_flow_rehearsal(workload, port):
+    """bench.py's N > 1 control flow, executed with two ranks on this one GPU over gloo
+    (NLSG_BENCH_REHEARSAL=1; RCCL refuses two ranks on one device): every collective step is
+    entered by every rank, rank 0 prints exactly one JSON line. The number itself means nothing."""
+    env = dict(os.environ, NLSG_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "40", "--warmup", "5", "--pop-per-gpu", "8192",
+           "--workload", workload]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 40 and out["value"] > 0
+    assert out["roofline"]["kernel_ms"] > 0
