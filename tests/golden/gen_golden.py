@@ -57,6 +57,25 @@ def main():
         g3[f"{strat}_pop256_D128"] = run("de", strat, 128, 256, 5, 0, 1000, "4.096", 1)
     write("de_trace.json", g3)
 
+    # G10 — the pass / fail matrix the reference's own test program prints (tests.cpp ->
+    # test_functions.h:390-523: every solver with default arguments from x = (-0.5, -0.5),
+    # "passed" = every coordinate within 0.05 of the known minimum; failures print the result)
+    import re
+    text = subprocess.check_output([os.path.join(ROOT, "oracle", "_ref", "ref_tests")], text=True)
+    text = re.sub(r"\x1b\[[0-9;]*m", "", text)
+    matrix, last = {}, None
+    for line in text.splitlines():
+        m = re.match(r"Solver (.+) on Problem (\S+) (passed|failed)\.", line)
+        if m:
+            last = matrix.setdefault(m.group(2), {}).setdefault(m.group(1), {})
+            last["passed"] = m.group(3) == "passed"
+            continue
+        m = re.match(r"Result: (.*?)\s*\. Expected: (.*)", line)
+        if m and last is not None:
+            last["result"] = [float(v) for v in m.group(1).split()]
+            last["expected"] = [float(v) for v in m.group(2).split()]
+    write("reference_matrix.json", matrix)
+
     more = os.path.join(HERE, "gen_golden_more.py")
     if os.path.exists(more):
         import runpy
