@@ -237,6 +237,27 @@ __device__ inline double wave_objective(const double (&xv)[CHUNKS][2], uint64_t 
 }
 
 
+// The same for a point of at most 2 G coordinates held by a GROUP of G lanes (G a power of two;
+// lane g of the group holds x[2g], x[2g+1]): a wave then evaluates 64 / G points at once. It is
+// wave_objective restricted to the group — the same per-lane partial and the levels G/2 .. 1 of
+// the same butterfly; the levels it drops only ever add the zeros of unused lanes, so the value
+// has the bits of the full-wave tree. All lanes of the group return it.
+template <int OBJ, int G>
+__device__ inline double group_objective(double x0, double x1, uint64_t D) {
+  using O = Objective<OBJ>;
+  const uint64_t e0 = 2 * static_cast<uint64_t>(lane_id() & (G - 1));
+  const uint64_t nt = O::n_terms(D);
+  double xn = 0.0;
+  if (O::kChain) xn = lane_down1(x0);  // x[e0+2]; only read where e0 + 2 < D, inside the group
+  double acc = 0.0;
+  if (e0 < nt) acc = acc + O::term(x0, x1);
+  if (e0 + 1 < nt) acc = acc + O::term(x1, xn);
+  if constexpr (G > 1)
+    butterfly_levels<G / 2>([&](auto off) { acc = acc + lane_xor<decltype(off)::value>(acc); });
+  return O::finish(acc, D);
+}
+
+
 // ---------------------------------------------------------------------------
 // pieces shared by the population engines (DE, PSO)
 // ---------------------------------------------------------------------------

@@ -501,21 +501,6 @@ __global__ __launch_bounds__(64, 2) void lm_iter_kernel(LmParams p, int first, i
 // the lower triangle only (:251-294), is_diagonal reads both (:295-307): the lower triangle goes
 // to Hg, the upper one is reduced to its verdict.
 template <int OBJ, int G>
-__device__ inline double group_objective(double x0, double x1, uint64_t D) {
-  using O = Objective<OBJ>;
-  const uint64_t e0 = 2 * static_cast<uint64_t>(lane_id() & (G - 1));
-  const uint64_t nt = O::n_terms(D);
-  double xn = 0.0;
-  if (O::kChain) xn = lane_down1(x0);  // x[e0+2]; only read where e0 + 2 < D, inside the group
-  double acc = 0.0;
-  if (e0 < nt) acc = acc + O::term(x0, x1);
-  if (e0 + 1 < nt) acc = acc + O::term(x1, xn);
-  if constexpr (G > 1)
-    butterfly_levels<G / 2>([&](auto off) { acc = acc + lane_xor<decltype(off)::value>(acc); });
-  return O::finish(acc, D);
-}
-
-template <int OBJ, int G>
 __device__ inline void lm_fd_eval_groups(const LmParams &p, int first, uint64_t pid,
                                          const double *theta_lds) {
   constexpr int P = 64 / G;                  // probe points per pass

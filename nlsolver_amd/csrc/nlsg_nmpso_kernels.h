@@ -12,9 +12,9 @@
 // iteration: a rank sort of the values (every thread counts the particles that precede its own:
 // no barrier ladder, ties keep their current order), the stop tests, the simplex step on the
 // best n + 1 particles (a chain of data-dependent decisions: thread j owns coordinate j, wave 0
-// evaluates the trial points), then the PSO move of the other 2n particles, one PAIR per wave
-// pass (the second particle of the first pair reads the first one's new position, H4) with the
-// objective evaluated by the same wave.
+// evaluates the trial points), then the PSO move of the other 2n particles: one PAIR per group of
+// lanes (the second particle of the first pair reads the first one's new position, H4), several
+// pairs per wave pass when n < 128, the objective evaluated by the same lanes.
 //
 // Reference behaviour kept literally (oracle_nmpso.c lists the evidence): H1 the last simplex
 // particle keeps x; H2 the no-change counter compares with the first particle's INITIAL value;
@@ -51,6 +51,7 @@ struct HybParams {
 
 struct HybShared {
   double val[kHybMaxParticles + 1];
+  uint64_t key[kHybMaxParticles + 3];  // the values in their current order as ordered integers
   uint32_t order[2][kHybMaxParticles + 1];
   double centroid[kHybMaxN], tr[kHybMaxN], te[kHybMaxN], tc[kHybMaxN];
   double up[kHybMaxN], lo[kHybMaxN];
@@ -58,9 +59,6 @@ struct HybShared {
   uint64_t iter, fcalls, no_change;
   int stop, cur;  // cur: which order[] buffer is current
 };
-
-// value order of the sort: NaN last
-__device__ inline bool hyb_less(double a, double b) { return (a < b) || (b != b && a == a); }
 
 // objective of the point at `pt` (n <= 128 doubles, LDS or global), one wave; all lanes get it
 template <int OBJ>
@@ -72,19 +70,33 @@ __device__ inline double hyb_wave_f(const double *pt, uint64_t n, double fmul) {
   return fmul * wave_objective<OBJ, 1>(xv, n);
 }
 
-// stable rank sort of the particles by value: order[cur] -> order[cur ^ 1]
+// The value order as an integer order: a < b (NaN last, -0 = +0) <=> hyb_key(a) < hyb_key(b)
+__device__ inline uint64_t hyb_key(double v) {
+  if (v != v) return ~0ull;
+  const uint64_t b = static_cast<uint64_t>(__double_as_longlong(v + 0.0));  // -0 -> +0
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+// stable rank sort of the particles by value: order[cur] -> order[cur ^ 1]. The values are first
+// laid out in their current order as ordered integers, so the counting loop reads one LDS word
+// per step that every lane shares (a broadcast) and compares integers, four steps per trip.
 __device__ inline void hyb_sort(HybShared &sh, uint32_t total) {
   const uint32_t *src = sh.order[sh.cur];
   uint32_t *dst = sh.order[sh.cur ^ 1];
+  for (uint32_t q = threadIdx.x; q < total + 3; q += kHybThreads)
+    sh.key[q] = q < total ? hyb_key(sh.val[src[q]]) : ~0ull;  // the pads sort last, behind q
+  __syncthreads();
   for (uint32_t q = threadIdx.x; q < total; q += kHybThreads) {
-    const uint32_t id = src[q];
-    const double v = sh.val[id];
+    const uint64_t v = sh.key[q];
     uint32_t rank = 0;
-    for (uint32_t r = 0; r < total; r++) {
-      const double w = sh.val[src[r]];
-      rank += (hyb_less(w, v) || (!hyb_less(v, w) && r < q)) ? 1u : 0u;
+    for (uint32_t r = 0; r < total; r += 4) {
+#pragma unroll
+      for (uint32_t u = 0; u < 4; u++) {
+        const uint64_t w = sh.key[r + u];
+        rank += (w < v || (w == v && r + u < q)) ? 1u : 0u;
+      }
     }
-    dst[rank] = id;
+    dst[rank] = src[q];
   }
   __syncthreads();
   if (threadIdx.x == 0) sh.cur ^= 1;
@@ -106,6 +118,113 @@ __device__ inline double hyb_std_err_wave(const HybShared &sh, uint32_t count) {
   }
   return sqrt(wave_sum(acc) / static_cast<double>(count - 1));
 }
+
+// ---- group-packed vector work: a particle of n coordinates fills n / 2 lanes, so a wave handles
+// 64 / G particles at once, one per group of G lanes (G = 4 .. 64 for n <= 8 .. 128; lane g of a
+// group holds coordinates 2g, 2g + 1). group_objective gives each the bits of the full-wave tree.
+
+// values of `count` particles (row_of(i) = particle id of the i-th), 64 / G per wave pass
+template <int OBJ, int G, typename RowOf>
+__device__ inline void hyb_eval_rows(const HybParams &p, HybShared &sh, const double *pos,
+                                     uint32_t n, uint32_t count, RowOf row_of) {
+  constexpr int P = 64 / G;
+  const int lane = lane_id(), g = lane & (G - 1), gi = lane / G;
+  const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+  const uint32_t j0 = 2 * g, j1 = 2 * g + 1;
+  for (uint32_t i0 = wid * P; i0 < count; i0 += kHybWaves * P) {
+    const uint32_t i = i0 + gi;
+    const bool live = i < count;
+    const uint32_t id = row_of(live ? i : 0);
+    const double *row = pos + id * n;
+    const double x0 = j0 < n ? row[j0] : 0.0, x1 = j1 < n ? row[j1] : 0.0;
+    const double f = p.fmul * group_objective<OBJ, G>(x0, x1, n);
+    if (live && g == 0) sh.val[id] = f;
+  }
+}
+
+// apply_pso (3823-3866): the 2n particles behind the simplex, one PAIR per group and pass
+template <int OBJ, int G>
+__device__ inline void hyb_pso_move(const HybParams &p, HybShared &sh, double *pos,
+                                    const double *vel, uint32_t n, uint32_t ns, uint64_t kc) {
+  constexpr int P = 64 / G;
+  const int lane = lane_id(), g = lane & (G - 1), gi = lane / G;
+  const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+  const uint32_t *ord = sh.order[sh.cur];
+  const double *best = pos + ord[0] * n;
+  const uint64_t kit = ctr_key(kc, sh.iter + 1);
+  const uint32_t j0 = 2 * g, j1 = 2 * g + 1;
+  const bool in0 = j0 < n, in1 = j1 < n;
+  const double bb[2] = {in0 ? best[j0] : 0.0, in1 ? best[j1] : 0.0};
+  const double lo[2] = {in0 ? sh.lo[j0] : 0.0, in1 ? sh.lo[j1] : 0.0};
+  const double up[2] = {in0 ? sh.up[j0] : 0.0, in1 ? sh.up[j1] : 0.0};
+  for (uint32_t m0 = wid * P; m0 < n; m0 += kHybWaves * P) {
+    const bool live = m0 + gi < n;
+    const uint32_t m = live ? m0 + gi : 0;  // idle groups shadow pair 0 and store nothing
+    const uint32_t id_a = ord[ns + 2 * m], id_b = ord[ns + 2 * m + 1];
+    double *ra = pos + id_a * n, *rb = pos + id_b * n;
+    const double *va = vel + id_a * n, *vb = vel + id_b * n;
+    double a[2] = {in0 ? ra[j0] : 0.0, in1 ? ra[j1] : 0.0};
+    double b[2] = {in0 ? rb[j0] : 0.0, in1 ? rb[j1] : 0.0};
+    const double wa[2] = {in0 ? va[j0] : 0.0, in1 ? va[j1] : 0.0};
+    const double wb[2] = {in0 ? vb[j0] : 0.0, in1 ? vb[j1] : 0.0};
+    // draws 2j, 2j+1 of coordinate j = 2g + k: mix64(kp + G64 (2j + 1 [+ 1])), 2j + 1 = 4g + 2k + 1
+    const uint64_t goff = kGolden * (4 * static_cast<uint64_t>(g) + 1);
+    // first of the pair: its "pairwise best" is itself (pair 0) or its partner (H4)
+    {
+      const uint64_t kp_lane = ctr_key(kit, 2 * m) + goff;
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const double r_p = u01(mix64(kp_lane + kGolden * static_cast<uint64_t>(2 * k)));
+        const double r_g = u01(mix64(kp_lane + kGolden * static_cast<uint64_t>(2 * k + 1)));
+        const double pair = m == 0 ? a[k] : b[k];
+        double temp = (p.inertia * wa[k]) + p.cog * r_p * (pair - a[k]) +
+                      p.soc * r_g * (bb[k] - a[k]);
+        if (p.bounded) temp = temp < lo[k] ? lo[k] : (up[k] < temp ? up[k] : temp);
+        a[k] = a[k] + temp;
+      }
+    }
+    // second of the pair: the first one's NEW position (pair 0) or itself
+    {
+      const uint64_t kp_lane = ctr_key(kit, 2 * m + 1) + goff;
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const double r_p = u01(mix64(kp_lane + kGolden * static_cast<uint64_t>(2 * k)));
+        const double r_g = u01(mix64(kp_lane + kGolden * static_cast<uint64_t>(2 * k + 1)));
+        const double pair = m == 0 ? a[k] : b[k];
+        double temp = (p.inertia * wb[k]) + p.cog * r_p * (pair - b[k]) +
+                      p.soc * r_g * (bb[k] - b[k]);
+        if (p.bounded) temp = temp < lo[k] ? lo[k] : (up[k] < temp ? up[k] : temp);
+        b[k] = b[k] + temp;
+      }
+    }
+    const double fa = p.fmul * group_objective<OBJ, G>(in0 ? a[0] : 0.0, in1 ? a[1] : 0.0, n);
+    const double fb = p.fmul * group_objective<OBJ, G>(in0 ? b[0] : 0.0, in1 ? b[1] : 0.0, n);
+    if (live) {
+      if (in0) ra[j0] = a[0], rb[j0] = b[0];
+      if (in1) ra[j1] = a[1], rb[j1] = b[1];
+      if (g == 0) {
+        sh.val[id_a] = fa;
+        sh.val[id_b] = fb;
+      }
+    }
+  }
+}
+
+// lanes per particle: the smallest power of two >= n / 2, at least 4
+#define NLSG_HYB_GROUPS(n, CALL) \
+  do {                           \
+    if ((n) <= 8) {              \
+      CALL(4);                   \
+    } else if ((n) <= 16) {      \
+      CALL(8);                   \
+    } else if ((n) <= 32) {      \
+      CALL(16);                  \
+    } else if ((n) <= 64) {      \
+      CALL(32);                  \
+    } else {                     \
+      CALL(64);                  \
+    }                            \
+  } while (0)
 
 template <int OBJ>
 __global__ __launch_bounds__(kHybThreads) void nmpso_solve_kernel(HybParams p) {
@@ -172,10 +291,9 @@ __global__ __launch_bounds__(kHybThreads) void nmpso_solve_kernel(HybParams p) {
     }
   }
   __syncthreads();  // block-scope visibility of the rows written above
-  for (uint32_t i = wid; i < total; i += kHybWaves) {
-    const double f = hyb_wave_f<OBJ>(pos + i * n, n, p.fmul);
-    if (lane == 0) sh.val[i] = f;
-  }
+#define HYB_EVAL_ALL(G) hyb_eval_rows<OBJ, G>(p, sh, pos, n, total, [](uint32_t i) { return i; })
+  NLSG_HYB_GROUPS(n, HYB_EVAL_ALL);
+#undef HYB_EVAL_ALL
   for (uint32_t i = t; i < total; i += kHybThreads) sh.order[0][i] = i;
   __syncthreads();
   if (t == 0) {
@@ -205,7 +323,15 @@ __global__ __launch_bounds__(kHybThreads) void nmpso_solve_kernel(HybParams p) {
       double *wrow = pos + worst * n;
       if (t < static_cast<int>(n)) {  // update_centroid (3867-3884): particles in sorted order
         double c = 0.0;
-        for (uint32_t i = 0; i < ns - 1; i++) c = c + pos[ord[i] * n + t];
+        uint32_t i = 0;
+        for (; i + 8 <= ns - 1; i += 8) {  // eight loads in flight, added in the reference's order
+          double v[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) v[u] = pos[ord[i + u] * n + t];
+#pragma unroll
+          for (int u = 0; u < 8; u++) c = c + v[u];
+        }
+        for (; i < ns - 1; i++) c = c + pos[ord[i] * n + t];
         c = c / static_cast<double>(ns - 1);
         sh.centroid[t] = c;
         double r = c + p.alpha * (c - wrow[t]);  // reflect
@@ -268,10 +394,10 @@ __global__ __launch_bounds__(kHybThreads) void nmpso_solve_kernel(HybParams p) {
             cur[j] = best[j] + p.sigma * (cur[j] - best[j]);
           }
           __syncthreads();
-          for (uint32_t i = 1 + wid; i < ns; i += kHybWaves) {
-            const double f = hyb_wave_f<OBJ>(pos + ord[i] * n, n, p.fmul);
-            if (lane == 0) sh.val[ord[i]] = f;
-          }
+#define HYB_EVAL_SHRUNK(G) \
+  hyb_eval_rows<OBJ, G>(p, sh, pos, n, ns - 1, [ord](uint32_t i) { return ord[1 + i]; })
+          NLSG_HYB_GROUPS(n, HYB_EVAL_SHRUNK);
+#undef HYB_EVAL_SHRUNK
           calls += ns - 1;
           __syncthreads();
           hyb_sort(sh, total);
@@ -280,70 +406,10 @@ __global__ __launch_bounds__(kHybThreads) void nmpso_solve_kernel(HybParams p) {
       if (t == 0) sh.fcalls += calls;
       __syncthreads();
     }
-    // ---- apply_pso (3823-3866): the 2n particles behind the simplex, one pair per wave pass
-    {
-      const uint32_t *ord = sh.order[sh.cur];
-      const double *best = pos + ord[0] * n;
-      const uint64_t kit = ctr_key(kc, sh.iter + 1);
-      const uint32_t j0 = 2 * lane, j1 = 2 * lane + 1;
-      const double b0 = j0 < n ? best[j0] : 0.0, b1 = j1 < n ? best[j1] : 0.0;
-      const double lo0 = j0 < n ? sh.lo[j0] : 0.0, lo1 = j1 < n ? sh.lo[j1] : 0.0;
-      const double up0 = j0 < n ? sh.up[j0] : 0.0, up1 = j1 < n ? sh.up[j1] : 0.0;
-      for (uint32_t m = wid; m < n; m += kHybWaves) {
-        const uint32_t id_a = ord[ns + 2 * m], id_b = ord[ns + 2 * m + 1];
-        double *ra = pos + id_a * n, *rb = pos + id_b * n;
-        const double *va = vel + id_a * n, *vb = vel + id_b * n;
-        double a[2], b[2], wa[2], wb[2];
-        a[0] = j0 < n ? ra[j0] : 0.0;
-        a[1] = j1 < n ? ra[j1] : 0.0;
-        b[0] = j0 < n ? rb[j0] : 0.0;
-        b[1] = j1 < n ? rb[j1] : 0.0;
-        wa[0] = j0 < n ? va[j0] : 0.0;
-        wa[1] = j1 < n ? va[j1] : 0.0;
-        wb[0] = j0 < n ? vb[j0] : 0.0;
-        wb[1] = j1 < n ? vb[j1] : 0.0;
-        const double bb[2] = {b0, b1}, lo[2] = {lo0, lo1}, up[2] = {up0, up1};
-        // first of the pair: its "pairwise best" is itself (pair 0) or its partner (H4)
-        {
-          const uint64_t kp_lane = ctr_key(kit, 2 * m) + kGolden * (4 * static_cast<uint64_t>(lane) + 1);
-#pragma unroll
-          for (int k = 0; k < 2; k++) {
-            const double r_p = u01(mix64(kp_lane + kGolden * static_cast<uint64_t>(2 * k)));
-            const double r_g = u01(mix64(kp_lane + kGolden * static_cast<uint64_t>(2 * k + 1)));
-            const double pair = m == 0 ? a[k] : b[k];
-            double temp = (p.inertia * wa[k]) + p.cog * r_p * (pair - a[k]) +
-                          p.soc * r_g * (bb[k] - a[k]);
-            if (p.bounded) temp = temp < lo[k] ? lo[k] : (up[k] < temp ? up[k] : temp);
-            a[k] = a[k] + temp;
-          }
-        }
-        // second of the pair: the first one's NEW position (pair 0) or itself
-        {
-          const uint64_t kp_lane =
-              ctr_key(kit, 2 * m + 1) + kGolden * (4 * static_cast<uint64_t>(lane) + 1);
-#pragma unroll
-          for (int k = 0; k < 2; k++) {
-            const double r_p = u01(mix64(kp_lane + kGolden * static_cast<uint64_t>(2 * k)));
-            const double r_g = u01(mix64(kp_lane + kGolden * static_cast<uint64_t>(2 * k + 1)));
-            const double pair = m == 0 ? a[k] : b[k];
-            double temp = (p.inertia * wb[k]) + p.cog * r_p * (pair - b[k]) +
-                          p.soc * r_g * (bb[k] - b[k]);
-            if (p.bounded) temp = temp < lo[k] ? lo[k] : (up[k] < temp ? up[k] : temp);
-            b[k] = b[k] + temp;
-          }
-        }
-        double xa[1][2] = {{j0 < n ? a[0] : 0.0, j1 < n ? a[1] : 0.0}};
-        double xb[1][2] = {{j0 < n ? b[0] : 0.0, j1 < n ? b[1] : 0.0}};
-        const double fa = p.fmul * wave_objective<OBJ, 1>(xa, n);
-        const double fb = p.fmul * wave_objective<OBJ, 1>(xb, n);
-        if (j0 < n) ra[j0] = a[0], rb[j0] = b[0];
-        if (j1 < n) ra[j1] = a[1], rb[j1] = b[1];
-        if (lane == 0) {
-          sh.val[id_a] = fa;
-          sh.val[id_b] = fb;
-        }
-      }
-    }
+    // ---- apply_pso (3823-3866)
+#define HYB_MOVE(G) hyb_pso_move<OBJ, G>(p, sh, pos, vel, n, ns, kc)
+    NLSG_HYB_GROUPS(n, HYB_MOVE);
+#undef HYB_MOVE
     __syncthreads();  // every wave has read sh.iter (the iteration's key) before it moves on
     if (t == 0) {
       sh.fcalls += 2 * n;
