@@ -48,7 +48,9 @@ struct SannRtcKernels {
   hipModule_t mod = nullptr;
   hipFunction_t anneal = nullptr;
 };
-int rtc_build_sann(const nlsg_custom_objective *obj, int chunks, bool vec, SannRtcKernels *out);
+// group != 0: the packed kernel (several chains per wave) with `group` lanes per chain
+int rtc_build_sann(const nlsg_custom_objective *obj, int chunks, bool vec, int group,
+                   SannRtcKernels *out);
 void rtc_release(SannRtcKernels *k);
 // pso_init / pso_move kernels; type = nlsg_pso_type.
 int rtc_build_pso(const nlsg_custom_objective *obj, int chunks, bool vec, int type, PsoRtcKernels *out);

@@ -223,11 +223,15 @@ void rtc_release(HybRtcKernels *k) {
   if (k) *k = HybRtcKernels();
 }
 
-int rtc_build_sann(const nlsg_custom_objective *obj, int chunks, bool vec, SannRtcKernels *out) {
+int rtc_build_sann(const nlsg_custom_objective *obj, int chunks, bool vec, int group,
+                   SannRtcKernels *out) {
   std::vector<hipFunction_t> f;
   SannRtcKernels k;
-  const int rc = rtc_compile(obj, "nlsg_sann_kernels.h",
-                             {"nlsg::sann_anneal_kernel<" + targs(chunks, vec) + ">"}, &k.mod, &f);
+  const std::string name =
+      group ? "nlsg::sann_anneal_groups_kernel<" + std::to_string(static_cast<int>(NLSG_OBJ_CUSTOM)) +
+                  ", " + std::to_string(group) + ">"
+            : "nlsg::sann_anneal_kernel<" + targs(chunks, vec) + ">";
+  const int rc = rtc_compile(obj, "nlsg_sann_kernels.h", {name}, &k.mod, &f);
   if (rc) return rc;
   k.anneal = f[0];
   *out = k;

@@ -15,6 +15,7 @@ struct nlsg_sann {
   bool own_stream = false;
   double *zero_dev = nullptr;
   int chunks = 0;
+  int group = 0;  // lanes per chain when several chains share a wave (dim <= 64), else 0
   SannRtcKernels rtc;  // objective == NLSG_OBJ_CUSTOM: the kernel hiprtc built for it
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -54,12 +55,49 @@ int sann_check_device(int device) {
     default: break;                                                                      \
   }
 
+template <int OBJ>
+void launch_groups(nlsg_sann *e, dim3 grid, uint64_t iter_begin, uint64_t iter_end) {
+  const dim3 block(256);
+  switch (e->group) {
+    case 4:
+      hipLaunchKernelGGL((sann_anneal_groups_kernel<OBJ, 4>), grid, block, 0, e->stream, e->p,
+                         iter_begin, iter_end);
+      break;
+    case 8:
+      hipLaunchKernelGGL((sann_anneal_groups_kernel<OBJ, 8>), grid, block, 0, e->stream, e->p,
+                         iter_begin, iter_end);
+      break;
+    case 16:
+      hipLaunchKernelGGL((sann_anneal_groups_kernel<OBJ, 16>), grid, block, 0, e->stream, e->p,
+                         iter_begin, iter_end);
+      break;
+    default:
+      hipLaunchKernelGGL((sann_anneal_groups_kernel<OBJ, 32>), grid, block, 0, e->stream, e->p,
+                         iter_begin, iter_end);
+      break;
+  }
+}
+
 void launch_anneal(nlsg_sann *e, uint64_t iter_begin, uint64_t iter_end) {
-  const dim3 grid(static_cast<unsigned>((e->p.batch + 3) / 4)), block(256);
+  // waves: one per chain, or one per 64 / group chains
+  const uint64_t per_wave = e->group ? 64 / e->group : 1;
+  const uint64_t waves = (e->p.batch + per_wave - 1) / per_wave;
+  const dim3 grid(static_cast<unsigned>((waves + 3) / 4)), block(256);
   const bool vec = e->p.D % 2 == 0;
   if (e->cfg.objective == NLSG_OBJ_CUSTOM) {
     void *args[] = {&e->p, &iter_begin, &iter_end};
     hipModuleLaunchKernel(e->rtc.anneal, grid.x, 1, 1, 256, 1, 1, 0, e->stream, args, nullptr);
+    return;
+  }
+  if (e->group) {
+    switch (e->cfg.objective) {
+      case NLSG_OBJ_ROSENBROCK: launch_groups<NLSG_OBJ_ROSENBROCK>(e, grid, iter_begin, iter_end); break;
+      case NLSG_OBJ_SPHERE: launch_groups<NLSG_OBJ_SPHERE>(e, grid, iter_begin, iter_end); break;
+      case NLSG_OBJ_STYBLINSKI_TANG:
+        launch_groups<NLSG_OBJ_STYBLINSKI_TANG>(e, grid, iter_begin, iter_end);
+        break;
+      default: launch_groups<NLSG_OBJ_RASTRIGIN>(e, grid, iter_begin, iter_end); break;
+    }
     return;
   }
 #define CALL(OBJ, C)                                                                            \
@@ -143,6 +181,7 @@ static int sann_create(const nlsg_sann_config *cfg, const nlsg_custom_objective 
   }
   const uint64_t B = cfg->batch, D = cfg->dim;
   e->chunks = D <= 128 ? 1 : D <= 256 ? 2 : D <= 512 ? 4 : 8;
+  e->group = D <= 8 ? 4 : D <= 16 ? 8 : D <= 32 ? 16 : D <= 64 ? 32 : 0;
   SannParams &p = e->p;
   std::memset(&p, 0, sizeof p);
   hipError_t he = hipSuccess;
@@ -159,7 +198,7 @@ static int sann_create(const nlsg_sann_config *cfg, const nlsg_custom_objective 
                 "device setup failed: %s", hipGetErrorString(he));
   }
   if (custom) {
-    const int rc2 = rtc_build_sann(custom, e->chunks, D % 2 == 0, &e->rtc);
+    const int rc2 = rtc_build_sann(custom, e->chunks, D % 2 == 0, e->group, &e->rtc);
     if (rc2) {
       nlsg_sann_destroy(e);
       return rc2;

@@ -110,4 +110,81 @@ __global__ __launch_bounds__(256) void sann_anneal_kernel(SannParams p, uint64_t
   }
 }
 
+// The same for chains of at most 64 coordinates: a chain fills D / 2 lanes, so a wave anneals
+// 64 / G chains at once, one per group of G lanes (G = 4, 8, 16, 32 for D <= 8, 16, 32, 64; lane g
+// of a group holds coordinates 2g, 2g + 1). Acceptance is per group (selects instead of the
+// wave-uniform branch); group_objective gives every trial the bits of the full-wave tree, so a
+// chain's history does not depend on how it was packed.
+template <int OBJ, int G>
+__global__ __launch_bounds__(256) void sann_anneal_groups_kernel(SannParams p, uint64_t iter_begin,
+                                                                 uint64_t iter_end) {
+  constexpr int P = 64 / G;
+  const int lane = lane_id(), g = lane & (G - 1), gi = lane / G;
+  const uint64_t wave = static_cast<uint64_t>(blockIdx.x) * 4 +
+                        __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+  if (wave * P >= p.batch) return;
+  const bool live = wave * P + gi < p.batch;
+  const uint64_t chain = live ? wave * P + gi : wave * P;  // idle groups shadow a live chain
+  const uint64_t D = p.D;
+  constexpr double e_minus_1 = 1.7182818;  // :2780
+  const uint32_t j0 = 2 * g, j1 = 2 * g + 1;
+  const bool in0 = j0 < D, in1 = j1 < D;
+  double *xrow = p.x + chain * D, *prow = p.p + chain * D;
+  double xb[2] = {in0 ? xrow[j0] : 0.0, in1 ? xrow[j1] : 0.0};
+  double pc[2], best;
+  uint64_t fcalls;
+  if (iter_begin == 0) {  // :2781-2785
+    pc[0] = xb[0];
+    pc[1] = xb[1];
+    best = p.fmul * group_objective<OBJ, G>(xb[0], xb[1], D);
+    fcalls = 1;
+  } else {
+    pc[0] = in0 ? prow[j0] : 0.0;
+    pc[1] = in1 ? prow[j1] : 0.0;
+    best = p.prob[chain].best;
+    fcalls = p.prob[chain].fcalls;
+  }
+  const double scale = 1.0 / p.temp_max;
+  const uint64_t kc = ctr_key(p.seed, p.chain_lo + chain);
+  const uint64_t inner = p.inner;
+  const uint64_t goff = kGolden * (4 * static_cast<uint64_t>(g) + 1);
+  for (uint64_t iter = iter_begin; iter < iter_end; iter++) {
+    const double t = p.temp_max / det_log(static_cast<double>(iter) + e_minus_1);
+    const double current_scale = t * scale;
+    for (uint64_t j = 0; j < inner; j++) {
+      const uint64_t ks = ctr_key(kc, iter * inner + j);
+      const uint64_t ks_lane = ks + goff;
+      double pt[2];
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const double u1 = u01(mix64(ks_lane + kGolden * static_cast<uint64_t>(2 * k)));
+        const double u2 = u01(mix64(ks_lane + kGolden * static_cast<uint64_t>(2 * k + 1)));
+        const double rn = sqrt(-2 * det_log(u1)) * det_cos(2 * 3.141593 * u2);
+        pt[k] = ((k ? in1 : in0)) ? pc[k] + current_scale * rn : 0.0;
+      }
+      const double current_val = p.fmul * group_objective<OBJ, G>(pt[0], pt[1], D);
+      fcalls++;
+      const double difference = current_val - best;
+      const bool accept = (difference <= 0.0) ||
+                          (u01(ctr_key(ks, 2 * D)) < det_exp(-difference / t));
+      const bool better = accept && current_val <= best;
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        pc[k] = accept ? pt[k] : pc[k];
+        xb[k] = better ? pt[k] : xb[k];
+      }
+      best = better ? current_val : best;
+    }
+  }
+  if (live) {
+    if (in0) xrow[j0] = xb[0], prow[j0] = pc[0];
+    if (in1) xrow[j1] = xb[1], prow[j1] = pc[1];
+    if (g == 0) {
+      p.prob[chain].best = best;
+      p.prob[chain].iter = iter_end;
+      p.prob[chain].fcalls = fcalls;
+    }
+  }
+}
+
 }  // namespace nlsg
