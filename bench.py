@@ -357,9 +357,14 @@ def main_lm(args):
     y = np.tanh(np.einsum("bmn,bn->bm", A, star))
     theta0 = 0.5 * star + 0.1 * (2 * rng.random((batch, n)) - 1)
     from nlsolver_amd import _capi
-    eng = nlsolver_amd.LMEngine(nlsolver_amd.TanhRegression(A, y), lam=10.0, max_iter=iters,
+    model = nlsolver_amd.TanhRegression(A, y)
+    t_up = time.perf_counter()
+    eng = nlsolver_amd.LMEngine(model, lam=10.0, max_iter=iters,
                                 f_delta=0.0, device=local_rank,
                                 solver=_capi.LM_QR if args.lm_solver == "qr" else _capi.LM_CHOLESKY)
+    # the boundary hands over HOST buffers (A: 2 GiB at batch 8192): engine creation = allocation
+    # + pageable-memory upload + device repack; reported beside `value`, never inside it
+    upload_s = time.perf_counter() - t_up
     eng.time_solve(theta0, 1)  # warm-up
     reps = 3
     ms = eng.time_solve(theta0, reps) / reps
@@ -382,7 +387,10 @@ def main_lm(args):
                                f"batch={batch} (BASELINE configs[3]), {args.lm_solver} solve",
                    "max_final_f": max(s.f_value for s in st),
                    # what an iteration spends outside the evaluation launch (the damped solve)
-                   "solve_ms_per_iteration": ms / iters - kms * evals / iters},
+                   "solve_ms_per_iteration": ms / iters - kms * evals / iters,
+                   # host buffers in, host buffers out: data upload + one whole solve
+                   "upload_s": upload_s, "upload_GBps": (A.nbytes + y.nbytes) / upload_s / 1e9,
+                   "pcie_inclusive_value": batch * iters / (upload_s + ms * 1e-3)},
         "roofline": {"bound": "mfma", "achieved": tflops, "peak": 78.6, "unit": "TFLOP/s",
                      "frac": tflops / 78.6,
                      "traffic": pmc_bytes("lm", ["lm_iter_kernel"], batch == 8192),
