@@ -94,20 +94,6 @@ void launch_iteration(nlsg_bfgs *e, bool timed) {
   if (timed) hipEventRecord(e->ev3, e->stream);
 }
 
-int bfgs_check_device(int device) {
-  int n = 0;
-  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
-    return fail(NLSG_ERR_NO_DEVICE, "no HIP device visible");
-  if (device < 0 || device >= n)
-    return fail(NLSG_ERR_INVALID_ARG, "device %d out of range (0..%d)", device, n - 1);
-  hipDeviceProp_t prop;
-  NLSG_HIP(hipGetDeviceProperties(&prop, device));
-  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-    return fail(NLSG_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only",
-                device, prop.gcnArchName);
-  return NLSG_OK;
-}
-
 }  // namespace
 
 extern "C" {
@@ -151,7 +137,7 @@ static int bfgs_create(const nlsg_bfgs_config *cfg, const double *diag_host, con
   if (cfg->dim > 1024)
     return fail(NLSG_ERR_UNSUPPORTED, "dim %llu > 1024 is not covered by the device path",
                 (unsigned long long)cfg->dim);
-  int rc = bfgs_check_device(cfg->device);
+  int rc = check_device(cfg->device);
   if (rc) return rc;
   NLSG_HIP(hipSetDevice(cfg->device));
   nlsg_bfgs *e = new (std::nothrow) nlsg_bfgs();

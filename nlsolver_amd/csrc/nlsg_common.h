@@ -51,7 +51,23 @@ inline int fail(int code, const char *fmt, ...) {
                           "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
                           __FILE__, __LINE__);                                  \
   } while (0)
+// every engine's first question: is `device` a gfx950 this process can see?
+inline int check_device(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return fail(NLSG_ERR_NO_DEVICE, "no HIP device visible");
+  if (device < 0 || device >= n)
+    return fail(NLSG_ERR_INVALID_ARG, "device %d out of range (0..%d)", device, n - 1);
+  hipDeviceProp_t prop;
+  NLSG_HIP(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(NLSG_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only",
+                device, prop.gcnArchName);
+  return NLSG_OK;
+}
+
 #endif  // !__HIPCC_RTC__
+
 
 // ---------------------------------------------------------------------------
 // counter-based RNG: random access into splitmix64 streams

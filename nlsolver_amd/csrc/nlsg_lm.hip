@@ -23,20 +23,6 @@ struct nlsg_lm {
 };
 
 namespace {
-int lm_check_device(int device) {
-  int n = 0;
-  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
-    return fail(NLSG_ERR_NO_DEVICE, "no HIP device visible");
-  if (device < 0 || device >= n)
-    return fail(NLSG_ERR_INVALID_ARG, "device %d out of range (0..%d)", device, n - 1);
-  hipDeviceProp_t prop;
-  NLSG_HIP(hipGetDeviceProperties(&prop, device));
-  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-    return fail(NLSG_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only",
-                device, prop.gcnArchName);
-  return NLSG_OK;
-}
-
 int upload_theta(nlsg_lm *e, const double *theta_host) {
   const uint64_t B = e->p.batch, n = e->p.n;
   std::vector<double> padded(B * kLmN, 0.0);
@@ -151,7 +137,7 @@ static int lm_create(const nlsg_lm_config *cfg, const nlsg_custom_objective *cus
   if (cfg->n < 1 || cfg->n > kLmN || (!fd && cfg->m < 1) || cfg->batch < 1)
     return fail(NLSG_ERR_INVALID_ARG, "need 1 <= n <= 64, m >= 1, batch >= 1");
   if (cfg->batch > 0x7fffffffull) return fail(NLSG_ERR_UNSUPPORTED, "batch too large");
-  int rc = lm_check_device(cfg->device);
+  int rc = check_device(cfg->device);
   if (rc) return rc;
   NLSG_HIP(hipSetDevice(cfg->device));
   nlsg_lm *e = new (std::nothrow) nlsg_lm();

@@ -19,20 +19,6 @@ struct nlsg_nm {
 };
 
 namespace {
-int nm_check_device(int device) {
-  int n = 0;
-  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
-    return fail(NLSG_ERR_NO_DEVICE, "no HIP device visible");
-  if (device < 0 || device >= n)
-    return fail(NLSG_ERR_INVALID_ARG, "device %d out of range (0..%d)", device, n - 1);
-  hipDeviceProp_t prop;
-  NLSG_HIP(hipGetDeviceProperties(&prop, device));
-  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-    return fail(NLSG_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only",
-                device, prop.gcnArchName);
-  return NLSG_OK;
-}
-
 template <int OBJ>
 hipError_t prepare(size_t lds) {
   return hipFuncSetAttribute(reinterpret_cast<const void *>(nm_solve_kernel<OBJ>),
@@ -104,7 +90,7 @@ static int nm_create(const nlsg_nm_config *cfg, const nlsg_custom_objective *cus
     return fail(NLSG_ERR_UNSUPPORTED, "dim %llu > 128: the simplex no longer fits the 160 KiB LDS",
                 (unsigned long long)cfg->dim);
   if (cfg->batch > 0x7fffffffull) return fail(NLSG_ERR_UNSUPPORTED, "batch too large");
-  int rc = nm_check_device(cfg->device);
+  int rc = check_device(cfg->device);
   if (rc) return rc;
   NLSG_HIP(hipSetDevice(cfg->device));
   nlsg_nm *e = new (std::nothrow) nlsg_nm();

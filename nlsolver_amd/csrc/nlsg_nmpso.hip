@@ -20,20 +20,6 @@ struct nlsg_nmpso {
 
 namespace {
 
-int hyb_check_device(int device) {
-  int n = 0;
-  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
-    return fail(NLSG_ERR_NO_DEVICE, "no HIP device visible");
-  if (device < 0 || device >= n)
-    return fail(NLSG_ERR_INVALID_ARG, "device %d out of range (0..%d)", device, n - 1);
-  hipDeviceProp_t prop;
-  NLSG_HIP(hipGetDeviceProperties(&prop, device));
-  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-    return fail(NLSG_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only",
-                device, prop.gcnArchName);
-  return NLSG_OK;
-}
-
 void launch(nlsg_nmpso *e) {
   const dim3 grid(static_cast<unsigned>(e->p.batch)), block(kHybThreads);
   if (e->cfg.objective == NLSG_OBJ_CUSTOM) {
@@ -104,7 +90,7 @@ static int hyb_create(const nlsg_nmpso_config *cfg, const nlsg_custom_objective 
   if (cfg->dim > kHybMaxN)
     return fail(NLSG_ERR_UNSUPPORTED, "dim %llu > %d", (unsigned long long)cfg->dim, kHybMaxN);
   if (cfg->batch > 0x7fffffffull) return fail(NLSG_ERR_UNSUPPORTED, "batch too large");
-  int rc = hyb_check_device(cfg->device);
+  int rc = check_device(cfg->device);
   if (rc) return rc;
   NLSG_HIP(hipSetDevice(cfg->device));
   nlsg_nmpso *e = new (std::nothrow) nlsg_nmpso();

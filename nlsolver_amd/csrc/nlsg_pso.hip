@@ -28,20 +28,6 @@ struct nlsg_pso {
 
 namespace {
 
-int pso_check_device(int device) {
-  int n = 0;
-  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
-    return fail(NLSG_ERR_NO_DEVICE, "no HIP device visible");
-  if (device < 0 || device >= n)
-    return fail(NLSG_ERR_INVALID_ARG, "device %d out of range (0..%d)", device, n - 1);
-  hipDeviceProp_t prop;
-  NLSG_HIP(hipGetDeviceProperties(&prop, device));
-  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-    return fail(NLSG_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only",
-                device, prop.gcnArchName);
-  return NLSG_OK;
-}
-
 #define PSO_FOR_CHUNKS(OBJ, chunks, CALL) \
   switch (chunks) {                       \
     case 1: CALL(OBJ, 1); break;          \
@@ -192,7 +178,7 @@ static int pso_create(const nlsg_pso_config *cfg, const nlsg_custom_objective *c
                 (unsigned long long)cfg->n_particles);
   if (cfg->shard_n > (1ull << 32))
     return fail(NLSG_ERR_UNSUPPORTED, "shard_n > 2^32 particles per engine");
-  int rc = pso_check_device(cfg->device);
+  int rc = check_device(cfg->device);
   if (rc) return rc;
   NLSG_HIP(hipSetDevice(cfg->device));
 

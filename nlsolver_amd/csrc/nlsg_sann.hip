@@ -22,20 +22,6 @@ struct nlsg_sann {
 
 namespace {
 
-int sann_check_device(int device) {
-  int n = 0;
-  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
-    return fail(NLSG_ERR_NO_DEVICE, "no HIP device visible");
-  if (device < 0 || device >= n)
-    return fail(NLSG_ERR_INVALID_ARG, "device %d out of range (0..%d)", device, n - 1);
-  hipDeviceProp_t prop;
-  NLSG_HIP(hipGetDeviceProperties(&prop, device));
-  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-    return fail(NLSG_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only",
-                device, prop.gcnArchName);
-  return NLSG_OK;
-}
-
 #define SANN_FOR_CHUNKS(OBJ, chunks, CALL) \
   switch (chunks) {                        \
     case 1: CALL(OBJ, 1); break;           \
@@ -163,7 +149,7 @@ static int sann_create(const nlsg_sann_config *cfg, const nlsg_custom_objective 
     return fail(NLSG_ERR_UNSUPPORTED, "dim %llu > 1024 (one wave holds a chain's three points)",
                 (unsigned long long)cfg->dim);
   if (cfg->batch > 0x7fffffffull) return fail(NLSG_ERR_UNSUPPORTED, "batch too large");
-  int rc = sann_check_device(cfg->device);
+  int rc = check_device(cfg->device);
   if (rc) return rc;
   NLSG_HIP(hipSetDevice(cfg->device));
   nlsg_sann *e = new (std::nothrow) nlsg_sann();
