@@ -58,6 +58,38 @@ def cpu_baseline():
                       f"OpenMP {threads} threads"}
 
 
+def host_threads():
+    """Cores this process may really use: the affinity mask, capped by the cgroup CPU quota (a GPU
+    box shows all host cores but grants a share of them) and by 16, the share of a one-GPU box."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
+
+
+def cpu_baseline_all_cores():
+    """SURVEY §8(d)'s second CPU figure: the batched CPU restatement (oracle's synchronous DE, the
+    algorithm the GPU runs) with OpenMP over agents on all of this host's cores."""
+    from tests import _oracle as O
+    lib = O.load()
+    threads = host_threads()
+    gens = 1500
+    run = O.DESyncRun(lib, "rosenbrock", POP_PER_GPU, D, np.full(D, 4.096), eps=0.0,
+                      max_iter=10**9, best_val_no_change=10**9)
+    run.step(5, threads=threads)
+    t0 = time.perf_counter()
+    run.step(gens, threads=threads)
+    dt = time.perf_counter() - t0
+    return {"value": POP_PER_GPU * gens / dt, "unit": "candidate-evals/s", "cores": threads,
+            "kind": "port",
+            "sample": f"oracle synchronous DE (keyed draws) Rosenbrock-{D}D pop={POP_PER_GPU}, "
+                      f"{gens} generations ({dt:.1f} s), OpenMP over agents, {threads} threads"}
+
+
 def ref_baseline(cmd, key, unit, sample):
     """Times the unmodified reference (oracle/_ref/ref_driver <cmd>) on this host, 1 thread."""
     drv = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
@@ -701,6 +733,10 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
+            try:
+                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores()
+            except Exception as exc:  # the checker library is optional here; never lose the line
+                out["cpu_baseline_all_cores"] = {"error": str(exc)[:200]}
     if distributed:
         dist.barrier()  # no rank tears its communicator down while another is still measuring
     eng.close()
