@@ -26,10 +26,10 @@ hipError_t prepare(size_t lds) {
 }
 
 void launch(nlsg_nm *e) {
-  const dim3 grid(static_cast<unsigned>(e->p.batch)), block(kNmThreads);
+  const dim3 grid(static_cast<unsigned>(e->p.batch)), block(nm_block_threads(e->p.n));
   if (e->cfg.objective == NLSG_OBJ_CUSTOM) {
     void *args[] = {&e->p};
-    hipModuleLaunchKernel(e->rtc.solve, grid.x, 1, 1, kNmThreads, 1, 1,
+    hipModuleLaunchKernel(e->rtc.solve, grid.x, 1, 1, block.x, 1, 1,
                           static_cast<unsigned>(e->lds), e->stream, args, nullptr);
     return;
   }

@@ -18,8 +18,15 @@
 
 namespace nlsg {
 
-constexpr int kNmThreads = 1024;
-constexpr int kNmWaves = kNmThreads / 64;
+constexpr int kNmThreads = 1024;  // the largest workgroup (n = 128: 16 waves)
+// threads of the workgroup of an n-dimensional simplex: one wave per four vertices (the waves
+// share the vertex evaluations of the initial scoring and of a shrink; everything else is one
+// wave's or n threads' work), so that a batch of small simplexes fills the chip with many small
+// workgroups instead of a few mostly idle large ones
+__host__ __device__ inline int nm_block_threads(uint64_t n) {
+  const uint64_t waves = (n + 1 + 3) / 4;
+  return 64 * static_cast<int>(waves < 1 ? 1 : (waves > kNmThreads / 64 ? kNmThreads / 64 : waves));
+}
 
 struct NmProblem {
   double f, eps;
@@ -53,6 +60,8 @@ __device__ inline double nm_wave_f(const double *pt, uint64_t n, double fmul) {
 
 template <int OBJ>
 __global__ __launch_bounds__(kNmThreads) void nm_solve_kernel(NmParams p) {
+  // the workgroup is sized by the host to the simplex (nm_block_threads): 64 .. kNmThreads
+  const uint64_t nthreads = blockDim.x, nwaves = blockDim.x >> 6;
   extern __shared__ __align__(16) unsigned char nm_smem[];
   const uint64_t n = p.n, nv = p.n + 1;
   double *S = reinterpret_cast<double *>(nm_smem);  // [nv][n]
@@ -65,7 +74,7 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_kernel(NmParams p) {
   const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
   const int lane = lane_id();
 
-  for (uint64_t j = t; j < n; j += kNmThreads) {
+  for (uint64_t j = t; j < n; j += nthreads) {
     x0[j] = p.x[pid * n + j];
     up[j] = p.bounded ? p.upper[j] : 0.0;
     lo[j] = p.bounded ? p.lower[j] : 0.0;
@@ -91,7 +100,7 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_kernel(NmParams p) {
       const double a = inf_norm < 1.0 ? 1.0 : inf_norm;
       scale = a < 10 ? a : 10;
     }
-    for (uint64_t e = t; e < nv * n; e += kNmThreads) {
+    for (uint64_t e = t; e < nv * n; e += nthreads) {
       const uint64_t v = e / n, j = e % n;
       double val = x0[j];
       if (v >= 1 && v < n && j == v) val = val + scale;  // vertex n keeps x (the OOB write)
@@ -101,9 +110,9 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_kernel(NmParams p) {
       }
       S[e] = val;
     }
-    for (uint64_t j = t; j < n; j += kNmThreads) centroid[j] = 0.0;  // :2195
+    for (uint64_t j = t; j < n; j += nthreads) centroid[j] = 0.0;  // :2195
     __syncthreads();
-    for (uint64_t v = wid; v < nv; v += kNmWaves) {  // 2184-2186
+    for (uint64_t v = wid; v < nv; v += nwaves) {  // 2184-2186
       const double f = nm_wave_f<OBJ>(S + v * n, n, p.fmul);
       if (lane == 0) scores[v] = f;
     }
@@ -199,7 +208,7 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_kernel(NmParams p) {
       const uint64_t best = ctl->best, worst = ctl->worst, second = ctl->second_worst;
       // ---- centroid of all vertices but the worst (1965-1984), only when it can have changed
       if (ctl->prev_worst != worst || ctl->shrunk) {
-        for (uint64_t j = t; j < n; j += kNmThreads) {  // two branch-free runs: loads pipeline
+        for (uint64_t j = t; j < n; j += nthreads) {  // two branch-free runs: loads pipeline
           double c = 0.0;
 #pragma unroll 8
           for (uint64_t v = 0; v < worst; v++) c += S[v * n + j];
@@ -210,7 +219,7 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_kernel(NmParams p) {
       }
       __syncthreads();
       // ---- reflect (2245): c + alpha (c - p), clamped when bounded
-      for (uint64_t j = t; j < n; j += kNmThreads) {
+      for (uint64_t j = t; j < n; j += nthreads) {
         double v = centroid[j] + p.alpha * (centroid[j] - S[worst * n + j]);
         if (p.bounded) v = v < lo[j] ? lo[j] : (up[j] < v ? up[j] : v);
         tr[j] = v;
@@ -230,10 +239,10 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_kernel(NmParams p) {
       const int action = ctl->action;
       const double ref_score = ctl->ref_score;
       if (action == 0) {  // 2251-2253
-        for (uint64_t j = t; j < n; j += kNmThreads) S[worst * n + j] = tr[j];
+        for (uint64_t j = t; j < n; j += nthreads) S[worst * n + j] = tr[j];
         if (t == 0) scores[worst] = ref_score;
       } else if (action == 1) {  // expand, 2255-2265: c + gamma (reflected - c)
-        for (uint64_t j = t; j < n; j += kNmThreads) {
+        for (uint64_t j = t; j < n; j += nthreads) {
           double v = centroid[j] + p.gamma * (tr[j] - centroid[j]);
           if (p.bounded) v = v < lo[j] ? lo[j] : (up[j] < v ? up[j] : v);
           te[j] = v;
@@ -248,11 +257,11 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_kernel(NmParams p) {
         }
         __syncthreads();
         const bool take_exp = ctl->exp_score < ref_score;
-        for (uint64_t j = t; j < n; j += kNmThreads) S[worst * n + j] = take_exp ? te[j] : tr[j];
+        for (uint64_t j = t; j < n; j += nthreads) S[worst * n + j] = take_exp ? te[j] : tr[j];
         if (t == 0) scores[worst] = take_exp ? ctl->exp_score : ref_score;
       } else {  // contraction, 2266-2297 (B4: the reflect transform for both kinds)
         const bool outside = ref_score < scores[worst];
-        for (uint64_t j = t; j < n; j += kNmThreads) {
+        for (uint64_t j = t; j < n; j += nthreads) {
           const double pt = outside ? tr[j] : S[worst * n + j];
           double v = centroid[j] + p.rho * (centroid[j] - pt);
           if (p.bounded) v = v < lo[j] ? lo[j] : (up[j] < v ? up[j] : v);
@@ -271,7 +280,7 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_kernel(NmParams p) {
         const double worst_score = scores[worst];
         if (cont_score < (outside ? ref_score : worst_score)) {
           __syncthreads();  // every thread has read scores[worst]
-          for (uint64_t j = t; j < n; j += kNmThreads) S[worst * n + j] = tc[j];
+          for (uint64_t j = t; j < n; j += nthreads) S[worst * n + j] = tc[j];
           if (t == 0) scores[worst] = cont_score;
         } else {  // shrink (2009-2035) and rescoring (2288-2294)
           __syncthreads();
@@ -283,11 +292,11 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_kernel(NmParams p) {
             const bool in0 = 2u * lane < n, in1 = 2u * lane + 1 < n;
             const double b0 = in0 ? S[best * n + 2 * lane] : 0.0;
             const double b1 = in1 ? S[best * n + 2 * lane + 1] : 0.0;
-            for (uint64_t v0 = wid; v0 < nv; v0 += 4 * kNmWaves) {
+            for (uint64_t v0 = wid; v0 < nv; v0 += 4 * nwaves) {
               double xv[4][1][2];
 #pragma unroll
               for (int q = 0; q < 4; q++) {
-                const uint64_t v = v0 + kNmWaves * q;
+                const uint64_t v = v0 + nwaves * q;
                 const bool live = v < nv && v != best;
                 double *row = S + (live ? v : best) * n;
                 const double o0 = in0 ? row[2 * lane] : 0.0, o1 = in1 ? row[2 * lane + 1] : 0.0;
@@ -303,7 +312,7 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_kernel(NmParams p) {
               for (int q = 0; q < 4; q++) f[q] = p.fmul * wave_objective<OBJ, 1>(xv[q], n);
 #pragma unroll
               for (int q = 0; q < 4; q++) {
-                const uint64_t v = v0 + kNmWaves * q;
+                const uint64_t v = v0 + nwaves * q;
                 if (lane == 0 && v < nv && v != best) scores[v] = f[q];
               }
             }
@@ -318,12 +327,12 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_kernel(NmParams p) {
     }
     // x = current_simplex.vals[best] (2235); restarts continue from it (2129-2132)
     const uint64_t best = ctl->best;
-    for (uint64_t j = t; j < n; j += kNmThreads) x0[j] = S[best * n + j];
+    for (uint64_t j = t; j < n; j += nthreads) x0[j] = S[best * n + j];
     total_iter += ctl->iter;
     final_f = scores[best];
     __syncthreads();
   }
-  for (uint64_t j = t; j < n; j += kNmThreads) p.x[pid * n + j] = x0[j];
+  for (uint64_t j = t; j < n; j += nthreads) p.x[pid * n + j] = x0[j];
   if (t == 0) {
     NmProblem *pr = p.prob + pid;
     pr->f = final_f;
