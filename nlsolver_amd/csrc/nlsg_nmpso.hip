@@ -21,10 +21,10 @@ struct nlsg_nmpso {
 namespace {
 
 void launch(nlsg_nmpso *e) {
-  const dim3 grid(static_cast<unsigned>(e->p.batch)), block(kHybThreads);
+  const dim3 grid(static_cast<unsigned>(e->p.batch)), block(hyb_block_threads(e->p.n));
   if (e->cfg.objective == NLSG_OBJ_CUSTOM) {
     void *args[] = {&e->p};
-    hipModuleLaunchKernel(e->rtc.solve, grid.x, 1, 1, kHybThreads, 1, 1, 0, e->stream, args, nullptr);
+    hipModuleLaunchKernel(e->rtc.solve, grid.x, 1, 1, block.x, 1, 1, 0, e->stream, args, nullptr);
     return;
   }
   switch (e->cfg.objective) {

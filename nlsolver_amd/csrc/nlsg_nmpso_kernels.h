@@ -28,8 +28,13 @@
 
 namespace nlsg {
 
-constexpr int kHybThreads = 256;
-constexpr int kHybWaves = kHybThreads / 64;
+constexpr int kHybThreads = 256;  // the largest workgroup
+// threads of an instance's workgroup: one per particle (the rank sort's unit of work), in whole
+// waves, at most kHybThreads — small instances then run as many small workgroups
+__host__ __device__ inline int hyb_block_threads(uint64_t n) {
+  const uint64_t waves = (3 * n + 1 + 63) / 64;
+  return 64 * static_cast<int>(waves > kHybThreads / 64 ? kHybThreads / 64 : waves);
+}
 constexpr int kHybMaxN = 128;
 constexpr int kHybMaxParticles = 3 * kHybMaxN + 1;
 
@@ -83,10 +88,10 @@ __device__ inline uint64_t hyb_key(double v) {
 __device__ inline void hyb_sort(HybShared &sh, uint32_t total) {
   const uint32_t *src = sh.order[sh.cur];
   uint32_t *dst = sh.order[sh.cur ^ 1];
-  for (uint32_t q = threadIdx.x; q < total + 3; q += kHybThreads)
+  for (uint32_t q = threadIdx.x; q < total + 3; q += blockDim.x)
     sh.key[q] = q < total ? hyb_key(sh.val[src[q]]) : ~0ull;  // the pads sort last, behind q
   __syncthreads();
-  for (uint32_t q = threadIdx.x; q < total; q += kHybThreads) {
+  for (uint32_t q = threadIdx.x; q < total; q += blockDim.x) {
     const uint64_t v = sh.key[q];
     uint32_t rank = 0;
     for (uint32_t r = 0; r < total; r += 4) {
@@ -131,7 +136,7 @@ __device__ inline void hyb_eval_rows(const HybParams &p, HybShared &sh, const do
   const int lane = lane_id(), g = lane & (G - 1), gi = lane / G;
   const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
   const uint32_t j0 = 2 * g, j1 = 2 * g + 1;
-  for (uint32_t i0 = wid * P; i0 < count; i0 += kHybWaves * P) {
+  for (uint32_t i0 = wid * P; i0 < count; i0 += (blockDim.x >> 6) * P) {
     const uint32_t i = i0 + gi;
     const bool live = i < count;
     const uint32_t id = row_of(live ? i : 0);
@@ -157,7 +162,7 @@ __device__ inline void hyb_pso_move(const HybParams &p, HybShared &sh, double *p
   const double bb[2] = {in0 ? best[j0] : 0.0, in1 ? best[j1] : 0.0};
   const double lo[2] = {in0 ? sh.lo[j0] : 0.0, in1 ? sh.lo[j1] : 0.0};
   const double up[2] = {in0 ? sh.up[j0] : 0.0, in1 ? sh.up[j1] : 0.0};
-  for (uint32_t m0 = wid * P; m0 < n; m0 += kHybWaves * P) {
+  for (uint32_t m0 = wid * P; m0 < n; m0 += (blockDim.x >> 6) * P) {
     const bool live = m0 + gi < n;
     const uint32_t m = live ? m0 + gi : 0;  // idle groups shadow pair 0 and store nothing
     const uint32_t id_a = ord[ns + 2 * m], id_b = ord[ns + 2 * m + 1];
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(kHybThreads) void nmpso_solve_kernel(HybParams p) {
   {
     const double scale = sh.ref_score;
     const double nn = static_cast<double>(n);
-    for (uint32_t e = t; e < ns * n; e += kHybThreads) {
+    for (uint32_t e = t; e < ns * n; e += blockDim.x) {
       const uint32_t i = e / n, j = e % n;
       double v = x0[j];
       if (i == 0) v = x0[j] + ((1.0 - sqrt(nn + 1.0)) / nn * scale);
@@ -274,7 +279,7 @@ __global__ __launch_bounds__(kHybThreads) void nmpso_solve_kernel(HybParams p) {
       vel[e] = 0.0;
     }
     const uint64_t kinit = ctr_key(kc, 0);
-    for (uint32_t r = wid; r < 2 * n; r += kHybWaves) {  // PSO particles, one per wave pass
+    for (uint32_t r = wid; r < 2 * n; r += (blockDim.x >> 6)) {  // PSO particles, one per wave pass
       const uint64_t kp_lane = ctr_key(kinit, r) + kGolden * (4 * static_cast<uint64_t>(lane) + 1);
 #pragma unroll
       for (int k = 0; k < 2; k++) {
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(kHybThreads) void nmpso_solve_kernel(HybParams p) {
 #define HYB_EVAL_ALL(G) hyb_eval_rows<OBJ, G>(p, sh, pos, n, total, [](uint32_t i) { return i; })
   NLSG_HYB_GROUPS(n, HYB_EVAL_ALL);
 #undef HYB_EVAL_ALL
-  for (uint32_t i = t; i < total; i += kHybThreads) sh.order[0][i] = i;
+  for (uint32_t i = t; i < total; i += blockDim.x) sh.order[0][i] = i;
   __syncthreads();
   if (t == 0) {
     sh.best_val0 = sh.val[0];  // read once, never updated (3658, H2)
@@ -388,7 +393,7 @@ __global__ __launch_bounds__(kHybThreads) void nmpso_solve_kernel(HybParams p) {
           if (t == 0) sh.val[worst] = cont_score;
         } else {  // shrink towards the best particle (3885-3902), rescore, re-sort
           const double *best = pos + ord[0] * n;
-          for (uint32_t e = t; e < (ns - 1) * n; e += kHybThreads) {
+          for (uint32_t e = t; e < (ns - 1) * n; e += blockDim.x) {
             const uint32_t i = 1 + e / n, j = e % n;
             double *cur = pos + ord[i] * n;
             cur[j] = best[j] + p.sigma * (cur[j] - best[j]);
