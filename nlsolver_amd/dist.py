@@ -20,6 +20,7 @@ Two drivers of a turn, same results:
     the MI355X box, more than the 50 us generation it orders).
 """
 import os
+import sys
 
 import numpy as np
 
@@ -87,8 +88,17 @@ class ShardedSwarm:
             _capi.check(_capi.lib().nlsg_comm_unique_id(uid))
         t = torch.tensor(list(bytes(uid)), dtype=torch.uint8, device=self.device)
         self.dist.broadcast(t, src=0)
-        self.engine.comm_attach(bytes(t.cpu().tolist()), self.world, self.rank)
-        self.native = True
+        ok = 1
+        try:
+            self.engine.comm_attach(bytes(t.cpu().tolist()), self.world, self.rank)
+        except RuntimeError as exc:
+            ok = 0
+            print(f"nlsolver_amd.dist: rank {self.rank}: library-side communicator failed ({exc}); "
+                  "host-ordered turns instead", file=sys.stderr)
+        # every rank takes the same driver: native only if the attach worked everywhere
+        agreed = torch.tensor([ok], dtype=torch.int32, device=self.device)
+        self.dist.all_reduce(agreed, op=self.dist.ReduceOp.MIN)
+        self.native = bool(agreed.item())
 
     def init(self, *args):
         """DE: init(x0); PSO: init(lower, upper)."""
