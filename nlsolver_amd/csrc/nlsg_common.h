@@ -152,6 +152,31 @@ __device__ inline double lane_first(double v) {
   const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<int>(b >> 32));
   return __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(hi) << 32) | lo));
 }
+// ---- scalar-issue relief. A CU has ONE scalar unit for its four SIMDs: per SIMD it issues at
+// most one scalar instruction every four cycles, the same rate as the SIMD's vector instructions,
+// and wave-uniform 64-bit integer work (the keyed RNG of a whole agent: ~25 scalar instructions
+// per mix64) lands there. Kernels that are otherwise memory bound become bound by it (the DE
+// generation: 419 scalar vs 238 vector instructions per wave). These helpers move uniform
+// integer work to the vector unit: on_valu() hands the compiler the same value in vector
+// registers (what follows is computed per lane, redundantly or — better — one draw per lane),
+// first64() / readlane64() bring results back to scalar registers.
+__device__ inline uint64_t on_valu(uint64_t s) {
+  const uint32_t lo = static_cast<uint32_t>(s), hi = static_cast<uint32_t>(s >> 32);
+  uint32_t vlo, vhi;
+  asm("v_mov_b32 %0, %1" : "=v"(vlo) : "s"(lo));
+  asm("v_mov_b32 %0, %1" : "=v"(vhi) : "s"(hi));
+  return (static_cast<uint64_t>(vhi) << 32) | vlo;
+}
+__device__ inline uint64_t first64(uint64_t v) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<int>(v & 0xffffffffu));
+  const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<int>(v >> 32));
+  return (static_cast<uint64_t>(hi) << 32) | lo;
+}
+__device__ inline uint64_t readlane64(uint64_t v, int src) {  // src wave-uniform
+  const uint32_t lo = __builtin_amdgcn_readlane(static_cast<int>(v & 0xffffffffu), src);
+  const uint32_t hi = __builtin_amdgcn_readlane(static_cast<int>(v >> 32), src);
+  return (static_cast<uint64_t>(hi) << 32) | lo;
+}
 // f(int_c<OFF>) for OFF = FIRST, FIRST/2, ..., 1
 template <int N>
 struct int_c {

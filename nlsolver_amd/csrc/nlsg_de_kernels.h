@@ -113,14 +113,23 @@ __device__ inline void de_fetch_agent(const DeParams &p, const double *__restric
   // every lane reads the 16 zero bytes, and the agent is not processed
   const uint64_t D = valid ? p.D : 0;
   const uint64_t ga = p.shard_lo + a;  // the global agent id keys the RNG
-  const uint64_t ka = ctr_key(kg, ga);
+  // the agent's key and its wave-uniform draws are computed on the vector unit (see on_valu):
+  // lane L takes draw D + L of the agent's stream — lane 0 the crossover's jrand (:2364), lane
+  // 1 + k donor candidate k — so the donor loop below only picks lanes
+  const uint64_t ka = first64(ctr_key(kg, on_valu(ga)));
+  const int lane = lane_id();
+  const uint64_t drawn = clamp_index(u01(ctr_key(ka, p.D + static_cast<uint64_t>(lane))),
+                                     lane == 0 ? p.D : p.shard_n);
   // generate_indices (nlsolver.h:2331-2355): three distinct donors != fixed,
   // by rejection, drawn inside this engine's shard. Wave-uniform (scalar) code.
   const uint64_t fixed = (p.strategy == NLSG_DE_RANDOM) ? ga : best_id;  // :2451-2457
   uint64_t r0 = ~0ull, r1 = ~0ull, r2 = ~0ull;
   int have = 0;
   for (int k = 0; k < kDeMaxTries && have < 3; k++) {
-    const uint64_t cand = p.shard_lo + clamp_index(u01(ctr_key(ka, p.D + 1 + k)), p.shard_n);
+    // (candidate 63 has no lane: after 61 rejections it is drawn the slow way)
+    const uint64_t cand =
+        p.shard_lo + (k < 63 ? readlane64(drawn, k + 1)
+                             : clamp_index(u01(ctr_key(ka, p.D + 1 + k)), p.shard_n));
     const bool used = (cand == fixed) || (have > 0 && cand == r0) || (have > 1 && cand == r1);
     if (!used) {
       if (have == 0) r0 = cand;
@@ -143,14 +152,17 @@ __device__ inline void de_fetch_agent(const DeParams &p, const double *__restric
   c.r0 = r0;
   c.r1 = r1;
   c.r2 = r2;
-  c.jrand = clamp_index(u01(ctr_key(ka, p.D)), p.D);  // :2364
+  c.jrand = readlane64(drawn, 0);  // :2364
   // rows: own (selection survivor; non-crossed coordinates for strategy random), 3 donors,
   // and for strategy best the row of best_id (L2-resident; strategy random reads the zero
   // pad instead so that the instruction stream does not depend on the strategy)
-  load_row<CHUNKS, VEC>(cur + a * p.D, D, p.zero, c.own);
-  load_row<CHUNKS, VEC>(cur + (r0 - p.shard_lo) * p.D, D, p.zero, c.d1);
-  load_row<CHUNKS, VEC>(cur + (r1 - p.shard_lo) * p.D, D, p.zero, c.d2);
-  load_row<CHUNKS, VEC>(cur + (r2 - p.shard_lo) * p.D, D, p.zero, c.d3);
+  // (shard-local indices and D fit 32 bits: one scalar multiply pair per row offset)
+  const uint32_t d32 = static_cast<uint32_t>(p.D);
+  auto row = [&](uint64_t local) { return cur + static_cast<uint64_t>(static_cast<uint32_t>(local)) * d32; };
+  load_row<CHUNKS, VEC>(row(a), D, p.zero, c.own);
+  load_row<CHUNKS, VEC>(row(r0 - p.shard_lo), D, p.zero, c.d1);
+  load_row<CHUNKS, VEC>(row(r1 - p.shard_lo), D, p.zero, c.d2);
+  load_row<CHUNKS, VEC>(row(r2 - p.shard_lo), D, p.zero, c.d3);
   load_row<CHUNKS, VEC>(p.best_x, p.strategy == NLSG_DE_RANDOM ? 0 : D, p.zero, c.keep);
   c.old_score = *(valid ? p.scores[par] + a : p.zero);
 }
@@ -163,12 +175,15 @@ __device__ inline void de_process_agent(const DeParams &p, double *__restrict__ 
   const bool rnd = p.strategy == NLSG_DE_RANDOM;
   // propose_new_agent (nlsolver.h:2357-2375)
   double trial[CHUNKS][2];
+  // ctr_key(ka, e) = mix64(ka + G (e + 1)), e + 1 = (2 lane + 1) + (128 ch + k): one 64-bit
+  // multiply per lane, the rest are compile-time constants
+  const uint64_t ka_lane = c.ka + kGolden * (2 * static_cast<uint64_t>(lane) + 1);
 #pragma unroll
   for (int ch = 0; ch < CHUNKS; ch++) {
 #pragma unroll
     for (int k = 0; k < 2; k++) {
       const uint64_t e = static_cast<uint64_t>(ch) * 128 + 2 * static_cast<uint64_t>(lane) + k;
-      const double u = u01(ctr_key(c.ka, e));
+      const double u = u01(mix64(ka_lane + kGolden * static_cast<uint64_t>(128 * ch + k)));
       const double mut = c.d1[ch][k] + p.F * (c.d2[ch][k] - c.d3[ch][k]);
       trial[ch][k] = (u < p.CR || e == c.jrand) ? mut : (rnd ? c.own[ch][k] : c.keep[ch][k]);
     }
@@ -208,7 +223,7 @@ __device__ inline void de_generation_block(const DeParams &p, int par, uint64_t 
   if (a0 >= p.shard_n) return;
   const double *__restrict__ cur = p.buf[par];
   double *__restrict__ nxt = p.buf[par ^ 1];
-  const uint64_t kg = ctr_key(p.seed, generation);
+  const uint64_t kg = first64(ctr_key(on_valu(p.seed), generation));
   const uint64_t best_id = st->best_id;
   DeAgent<CHUNKS> A;
   de_fetch_agent<CHUNKS, VEC>(p, cur, par, kg, best_id, a0, true, A);
