@@ -3,9 +3,12 @@
 // rnorm (nlsolver.h:2479-2485) needs log and cos; the device library's versions
 // differ from glibc's in the last bits, which would make positions (and then
 // selection indices) diverge from the CPU restatement. These are built from
-// +,-,*,/ and integer ops only, in a fixed operation order (the TU is compiled
-// with -ffp-contract=off), so the CPU restatement, which carries its own copy of
-// the same algorithms, agrees bit for bit; vs libm they are within 1 ulp
+// +,-,*,/, EXPLICIT fused multiply-adds (the Horner chains and the argument reductions: one
+// v_fma_f64 instead of a multiply and an add — the kernels that draw normal variates are bound
+// by exactly these instructions) and integer ops only, in a fixed operation order (the TU is
+// compiled with -ffp-contract=off, so nothing else is ever fused), so the CPU restatement, which
+// carries its own copy of the same algorithms with C's fma(), agrees bit for bit; vs libm they
+// are within 1 ulp
 // (tests/test_oracle_pso_golden.py). Algorithms: argument reduction + the
 // classic minimax kernels (Sun fdlibm coefficient sets).
 #pragma once
@@ -44,8 +47,8 @@ __device__ inline double det_log(double x) {
   const double s = f / (2.0 + f);
   const double z = s * s;
   const double w = z * z;
-  const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
-  const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+  const double t1 = w * __builtin_fma(w, __builtin_fma(w, Lg6, Lg4), Lg2);
+  const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, Lg7, Lg5), Lg3), Lg1);
   const double R = t2 + t1;
   const double dk = static_cast<double>(k);
   return s * (hfsq + R) + dk * ln2_lo - hfsq + f + dk * ln2_hi;
@@ -56,10 +59,10 @@ __device__ inline double det_kernel_cos(double x) {  // |x| <= pi/4
                    C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
                    C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
   const double z = x * x;
-  const double r = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+  const double r = z * __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, C6, C5), C4), C3), C2), C1);
   const double hz = 0.5 * z;
   const double w = 1.0 - hz;
-  return w + (((1.0 - w) - hz) + z * r);
+  return w + __builtin_fma(z, r, (1.0 - w) - hz);
 }
 __device__ inline double det_kernel_sin(double x) {  // |x| <= pi/4
   constexpr double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
@@ -67,8 +70,8 @@ __device__ inline double det_kernel_sin(double x) {  // |x| <= pi/4
                    S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
   const double z = x * x;
   const double v = z * x;
-  const double r = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
-  return x + v * (S1 + z * r);
+  const double r = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, S6, S5), S4), S3), S2);
+  return __builtin_fma(v, __builtin_fma(z, r, S1), x);
 }
 
 // cosine for |y| <= 64 (two-term Cody-Waite reduction by pi/2); NaN outside
@@ -76,8 +79,8 @@ __device__ inline double det_cos(double y) {
   constexpr double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00,
                    pio2_1t = 6.07710050650619224932e-11;
   if (!(y >= -64.0 && y <= 64.0)) return __builtin_nan("");
-  const double fn = floor(y * invpio2 + 0.5);
-  const double r = (y - fn * pio2_1) - fn * pio2_1t;
+  const double fn = floor(__builtin_fma(y, invpio2, 0.5));
+  const double r = __builtin_fma(-fn, pio2_1t, __builtin_fma(-fn, pio2_1, y));
   const int q = static_cast<int>(static_cast<long long>(fn) & 3);
   const double c = det_kernel_cos(r), s = det_kernel_sin(r);
   return q == 0 ? c : q == 1 ? -s : q == 2 ? -c : s;
@@ -92,11 +95,11 @@ __device__ inline double det_exp(double x) {
   if (x != x) return x;
   if (x > 709.0) return __builtin_inf();
   if (x < -708.0) return 0.0;
-  const int k = static_cast<int>(invln2 * x + (x < 0 ? -0.5 : 0.5));
-  const double hi = x - static_cast<double>(k) * ln2HI, lo = static_cast<double>(k) * ln2LO;
+  const int k = static_cast<int>(__builtin_fma(invln2, x, x < 0 ? -0.5 : 0.5));
+  const double hi = __builtin_fma(-static_cast<double>(k), ln2HI, x), lo = static_cast<double>(k) * ln2LO;
   const double r = hi - lo;
   const double t = r * r;
-  const double c = r - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+  const double c = __builtin_fma(-t, __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, P5, P4), P3), P2), P1), r);
   const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
   return y * __longlong_as_double(static_cast<long long>(static_cast<uint64_t>(1023 + k) << 52));
 }

@@ -33,11 +33,11 @@ double orc_exp(double x) {
   if (x != x) return x;
   if (x > 709.0) return INFINITY;
   if (x < -708.0) return 0.0; /* results below the normal range are flushed */
-  const int k = (int)(invln2 * x + (x < 0 ? -0.5 : 0.5));
-  const double hi = x - (double)k * ln2HI, lo = (double)k * ln2LO;
+  const int k = (int)fma(invln2, x, x < 0 ? -0.5 : 0.5);
+  const double hi = fma(-(double)k, ln2HI, x), lo = (double)k * ln2LO;
   const double r = hi - lo;
   const double t = r * r;
-  const double c = r - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+  const double c = fma(-t, fma(t, fma(t, fma(t, fma(t, P5, P4), P3), P2), P1), r);
   const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
   return y * bits2d((uint64_t)(1023 + k) << 52); /* y * 2^k, k in [-1021, 1023] */
 }

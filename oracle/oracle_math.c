@@ -1,6 +1,7 @@
 /* oracle/oracle_math.c — TEST INFRASTRUCTURE, NOT PRODUCT CODE (see oracle.h).
  *
- * Deterministic log / cos built from +,-,*,/ only (no libm), so that the
+ * Deterministic log / cos built from +,-,*,/ and explicit fma() only (no libm
+ * transcendental; fma is exactly specified), so that the
  * synchronous restatements and the HIP kernels — which carry their own copy of
  * the same algorithms in nlsolver_amd/csrc/nlsg_math.h — agree bit for bit.
  * Accuracy ~1 ulp; the serial restatements keep libm, like the reference
@@ -53,8 +54,8 @@ double orc_log(double x) {
   const double s = f / (2.0 + f);
   const double z = s * s;
   const double w = z * z;
-  const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
-  const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+  const double t1 = w * fma(w, fma(w, Lg6, Lg4), Lg2);
+  const double t2 = z * fma(w, fma(w, fma(w, Lg7, Lg5), Lg3), Lg1);
   const double R = t2 + t1;
   const double dk = (double)k;
   return s * (hfsq + R) + dk * ln2_lo - hfsq + f + dk * ln2_hi;
@@ -65,10 +66,10 @@ static double kernel_cos(double x) { /* |x| <= pi/4 */
                       C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
                       C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
   const double z = x * x;
-  const double r = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+  const double r = z * fma(z, fma(z, fma(z, fma(z, fma(z, C6, C5), C4), C3), C2), C1);
   const double hz = 0.5 * z;
   const double w = 1.0 - hz;
-  return w + (((1.0 - w) - hz) + z * r);
+  return w + fma(z, r, (1.0 - w) - hz);
 }
 static double kernel_sin(double x) { /* |x| <= pi/4 */
   static const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
@@ -76,8 +77,8 @@ static double kernel_sin(double x) { /* |x| <= pi/4 */
                       S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
   const double z = x * x;
   const double v = z * x;
-  const double r = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
-  return x + v * (S1 + z * r);
+  const double r = fma(z, fma(z, fma(z, fma(z, S6, S5), S4), S3), S2);
+  return fma(v, fma(z, r, S1), x);
 }
 
 /* cosine for |y| <= 64 (two-term Cody-Waite reduction by pi/2); NaN outside */
@@ -85,8 +86,8 @@ double orc_cos(double y) {
   static const double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00,
                       pio2_1t = 6.07710050650619224932e-11;
   if (!(y >= -64.0 && y <= 64.0)) return NAN;
-  const double fn = floor(y * invpio2 + 0.5);
-  const double r = (y - fn * pio2_1) - fn * pio2_1t;
+  const double fn = floor(fma(y, invpio2, 0.5));
+  const double r = fma(-fn, pio2_1t, fma(-fn, pio2_1, y));
   const int q = (int)((long long)fn & 3);
   switch (q) {
     case 0: return kernel_cos(r);
