@@ -36,6 +36,8 @@ RcclApi &rccl_api();  // nlsg_comm.hip
                           ::nlsg::rccl_api().GetErrorString(r_), __FILE__, __LINE__); \
   } while (0)
 
+constexpr unsigned kStreamOrderEvent = hipEventDisableTiming | hipEventDisableSystemFence;
+
 // One shard's end of the exchange.
 struct ShardComm {
   ncclComm_t comm = nullptr;
@@ -79,9 +81,11 @@ inline int comm_attach(ShardComm **out, const unsigned char *id, int world, int 
   hipError_t he = hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
   if (he == hipSuccess)
     he = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_high);
+  // The events only order two streams of THIS device: no system-scope fence (cache write-back
+  // and invalidate) when they are recorded — with it every generation kernel started ~9 us late.
   for (int i = 0; i < 2 && he == hipSuccess; i++) {
-    he = hipEventCreateWithFlags(&c->pop_ready[i], hipEventDisableTiming);
-    if (he == hipSuccess) he = hipEventCreateWithFlags(&c->head_done[i], hipEventDisableTiming);
+    he = hipEventCreateWithFlags(&c->pop_ready[i], kStreamOrderEvent);
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&c->head_done[i], kStreamOrderEvent);
   }
   if (he == hipSuccess)
     he = hipMalloc(reinterpret_cast<void **>(&c->gathered), world * rec_doubles * sizeof(double));
