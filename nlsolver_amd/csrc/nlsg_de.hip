@@ -22,6 +22,7 @@ struct nlsg_de {
   double *zero_dev = nullptr;
   double *rec = nullptr;  // local record (single-GPU finaliser input)
   int chunks = 0;
+  int group = 0;  // lanes per agent when several agents share a wave (D <= 64), else 0
   bool initialised = false;
   uint64_t k = 0;            // generations launched so far (= index of the next head)
   // strategy random: the head of turn k (scan, stop tests) does not feed generation k+1
@@ -84,11 +85,54 @@ void launch_init(nlsg_de *e) {
 #undef CALL
 }
 
+template <int OBJ>
+void launch_generation_groups(nlsg_de *e, dim3 grid, int par, uint64_t generation, int ignore_done) {
+  const dim3 block(256);
+  switch (e->group) {
+    case 4:
+      hipLaunchKernelGGL((de_generation_groups_kernel<OBJ, 4>), grid, block, 0, e->stream, e->p, par,
+                         generation, ignore_done);
+      break;
+    case 8:
+      hipLaunchKernelGGL((de_generation_groups_kernel<OBJ, 8>), grid, block, 0, e->stream, e->p, par,
+                         generation, ignore_done);
+      break;
+    case 16:
+      hipLaunchKernelGGL((de_generation_groups_kernel<OBJ, 16>), grid, block, 0, e->stream, e->p, par,
+                         generation, ignore_done);
+      break;
+    default:
+      hipLaunchKernelGGL((de_generation_groups_kernel<OBJ, 32>), grid, block, 0, e->stream, e->p, par,
+                         generation, ignore_done);
+      break;
+  }
+}
+
 void launch_generation(nlsg_de *e, int par, uint64_t generation, int ignore_done = 0) {
-  const dim3 grid(static_cast<unsigned>((e->p.shard_n + 3) / 4)), block(256);
+  // waves: one per agent, or one per 64 / group agents
+  const uint64_t per_wave = e->group ? 64 / e->group : 1;
+  const uint64_t waves = (e->p.shard_n + per_wave - 1) / per_wave;
+  const dim3 grid(static_cast<unsigned>((waves + 3) / 4)), block(256);
   if (e->cfg.objective == NLSG_OBJ_CUSTOM) {
     void *args[] = {&e->p, &par, &generation, &ignore_done};
     launch_module(e, e->rtc.generation, grid.x, args);
+    return;
+  }
+  if (e->group) {
+    switch (e->cfg.objective) {
+      case NLSG_OBJ_ROSENBROCK:
+        launch_generation_groups<NLSG_OBJ_ROSENBROCK>(e, grid, par, generation, ignore_done);
+        break;
+      case NLSG_OBJ_SPHERE:
+        launch_generation_groups<NLSG_OBJ_SPHERE>(e, grid, par, generation, ignore_done);
+        break;
+      case NLSG_OBJ_STYBLINSKI_TANG:
+        launch_generation_groups<NLSG_OBJ_STYBLINSKI_TANG>(e, grid, par, generation, ignore_done);
+        break;
+      default:
+        launch_generation_groups<NLSG_OBJ_RASTRIGIN>(e, grid, par, generation, ignore_done);
+        break;
+    }
     return;
   }
 #define CALL(OBJ, C)                                                                          \
@@ -247,6 +291,9 @@ static int de_create(const nlsg_de_config *cfg, const nlsg_custom_objective *cus
   e->cfg = *cfg;
   const uint64_t D = cfg->dim, n = cfg->shard_n;
   e->chunks = D <= 128 ? 1 : D <= 256 ? 2 : D <= 512 ? 4 : 8;
+  e->group = D <= 8 ? 4 : D <= 16 ? 8 : D <= 32 ? 16 : D <= 64 ? 32 : 0;
+  if (const char *g = std::getenv("NLSG_DE_GROUPS"))  // A/B switch: 0 = one agent per wave at any D
+    if (g[0] == '0') e->group = 0;
   if (cfg->stream) {
     e->stream = static_cast<hipStream_t>(cfg->stream);
   } else {
@@ -290,7 +337,8 @@ static int de_create(const nlsg_de_config *cfg, const nlsg_custom_objective *cus
   e->overlap = cfg->strategy == NLSG_DE_RANDOM && cfg->shard_n == cfg->pop && ov && ov[0] == '1';
   const char *fu = std::getenv("NLSG_DE_FUSED_TURN");
   e->fused = cfg->strategy == NLSG_DE_RANDOM && cfg->shard_n == cfg->pop &&
-             !e->overlap && !cfg->trace && !(fu && fu[0] == '0');  // the trace buffer is not double-buffered
+             !e->overlap && !cfg->trace && !(fu && fu[0] == '0') &&  // the trace buffer is not double-buffered
+             !e->group;  // (the packed generation is a kernel of its own)
   if (e->overlap) {
     if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking);
     for (int i = 0; i < 4; i++) {
@@ -317,7 +365,7 @@ static int de_create(const nlsg_de_config *cfg, const nlsg_custom_objective *cus
   p.strategy = cfg->strategy;
   p.vec = (D % 2 == 0) ? 1 : 0;
   if (custom) {
-    const int rc2 = rtc_build_de(custom, e->chunks, p.vec != 0, &e->rtc);
+    const int rc2 = rtc_build_de(custom, e->chunks, p.vec != 0, e->group, &e->rtc);
     if (rc2) {
       nlsg_de_destroy(e);
       return rc2;

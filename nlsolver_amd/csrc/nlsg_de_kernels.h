@@ -208,6 +208,116 @@ __device__ inline void de_process_agent(const DeParams &p, double *__restrict__ 
   }
 }
 
+// ---- agents of at most 64 coordinates: 64 / G agents per wave, one per group of G lanes (G = 4, 8,
+// 16, 32 for D <= 8, 16, 32, 64; lane g of a group holds coordinates 2g, 2g + 1). One agent per
+// wave leaves 64 - D / 2 lanes idle and costs the same 38 us per generation at D = 16 as at
+// D = 64. Everything that is wave-uniform above is group-uniform here and lives in vector
+// registers: the agent's key, its draws (lane g of a group takes draw D + round * G + g of the
+// agent's stream: draw D is jrand, draw D + 1 + k donor candidate k) and the donor picks, which
+// walk the candidates in order with selects instead of branches. group_objective gives the trial
+// the bits of the full-wave tree, so a population's history does not depend on the packing.
+template <int OBJ, int G>
+__device__ inline void de_generation_groups_block(const DeParams &p, int par, uint64_t generation,
+                                                  int ignore_done, uint64_t block) {
+  constexpr int P = 64 / G;
+  const DeState *__restrict__ st = p.state;
+  if (!ignore_done && st->done) return;
+  const uint64_t wave = block * 4 + __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+  if (wave * P >= p.shard_n) return;
+  const int lane = lane_id(), g = lane & (G - 1), gi = lane / G;
+  const bool live = wave * P + gi < p.shard_n;
+  const uint64_t a = live ? wave * P + gi : wave * P;  // idle groups shadow a live agent
+  const uint64_t D = p.D;
+  const double *__restrict__ cur = p.buf[par];
+  double *__restrict__ nxt = p.buf[par ^ 1];
+  const bool rnd = p.strategy == NLSG_DE_RANDOM;
+  const uint64_t kg = first64(ctr_key(on_valu(p.seed), generation));
+  const uint64_t ga = p.shard_lo + a;
+  const uint64_t ka = ctr_key(kg, ga);
+  const uint64_t fixed = rnd ? ga : st->best_id;  // :2451-2457
+  // draws D + round * G + g; cross-lane reads stay inside the group
+  const int base = gi * G;
+  uint64_t drawn = ctr_key(ka, D + static_cast<uint64_t>(g));
+  const uint64_t jrand = clamp_index(u01(__shfl(drawn, base, 64)), D);  // :2364
+  // generate_indices (nlsolver.h:2331-2355): three distinct donors != fixed, by rejection
+  uint64_t r0 = ~0ull, r1 = ~0ull, r2 = ~0ull;
+  int have = 0;
+  for (int k = 0; k < kDeMaxTries; k++) {
+    if (__ballot(have < 3) == 0ull) break;
+    const int pos = k + 1;  // candidate k is draw D + pos: round pos / G, lane pos % G
+    if (pos >= G && (pos & (G - 1)) == 0)
+      drawn = ctr_key(ka, D + static_cast<uint64_t>(pos + g));
+    const uint64_t cand =
+        p.shard_lo + clamp_index(u01(__shfl(drawn, base + (pos & (G - 1)), 64)), p.shard_n);
+    const bool used = (cand == fixed) || (have > 0 && cand == r0) || (have > 1 && cand == r1);
+    const bool take = !used && have < 3;
+    r0 = (take && have == 0) ? cand : r0;
+    r1 = (take && have == 1) ? cand : r1;
+    r2 = (take && have == 2) ? cand : r2;
+    have += take ? 1 : 0;
+  }
+  for (uint64_t cand = p.shard_lo; __ballot(have < 3) != 0ull; cand++) {  // fallback: lowest unused
+    const bool used = (cand == fixed) || (have > 0 && cand == r0) || (have > 1 && cand == r1);
+    const bool take = !used && have < 3;
+    r0 = (take && have == 0) ? cand : r0;
+    r1 = (take && have == 1) ? cand : r1;
+    r2 = (take && have == 2) ? cand : r2;
+    have += take ? 1 : 0;
+  }
+  // rows: own, three donors, and for strategy best the row of best_id
+  const uint32_t j0 = 2 * g, j1 = 2 * g + 1;
+  const bool in0 = j0 < D, in1 = j1 < D;
+  const uint32_t d32 = static_cast<uint32_t>(D);
+  auto row = [&](uint64_t local) { return cur + static_cast<uint64_t>(static_cast<uint32_t>(local)) * d32; };
+  auto load2 = [&](const double *rp, double (&v)[2]) {
+    v[0] = in0 ? rp[j0] : 0.0;
+    v[1] = in1 ? rp[j1] : 0.0;
+  };
+  double own[2], d1[2], d2[2], d3[2], keep[2] = {0.0, 0.0};
+  load2(row(a), own);
+  load2(row(r0 - p.shard_lo), d1);
+  load2(row(r1 - p.shard_lo), d2);
+  load2(row(r2 - p.shard_lo), d3);
+  if (!rnd) load2(p.best_x, keep);
+  const double old_score = p.scores[par][a];
+  // propose_new_agent (nlsolver.h:2357-2375)
+  double trial[2];
+  const uint64_t ka_lane = ka + kGolden * (2 * static_cast<uint64_t>(g) + 1);
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const uint64_t e = 2 * static_cast<uint64_t>(g) + k;
+    const double u = u01(mix64(ka_lane + kGolden * static_cast<uint64_t>(k)));
+    const double mut = d1[k] + p.F * (d2[k] - d3[k]);
+    const double t = (u < p.CR || e == jrand) ? mut : (rnd ? own[k] : keep[k]);
+    trial[k] = (k ? in1 : in0) ? t : 0.0;
+  }
+  const double score = p.fmul * group_objective<OBJ, G>(trial[0], trial[1], D);  // :2463
+  const bool accept = score < old_score;                                         // :2466
+  if (live) {
+    double *out = nxt + static_cast<uint64_t>(static_cast<uint32_t>(a)) * d32;
+    if (in0) out[j0] = accept ? trial[0] : own[0];
+    if (in1) out[j1] = accept ? trial[1] : own[1];
+    if (g == 0) {
+      p.scores[par ^ 1][a] = accept ? score : old_score;
+      if (p.trace != nullptr) {
+        uint64_t *t = p.trace + a * kTraceWords;
+        t[0] = r0;
+        t[1] = r1;
+        t[2] = r2;
+        t[3] = jrand;
+        t[4] = accept ? 1u : 0u;
+      }
+    }
+  }
+}
+
+template <int OBJ, int G>
+__global__ __launch_bounds__(256) void de_generation_groups_kernel(DeParams p, int par,
+                                                                   uint64_t generation,
+                                                                   int ignore_done) {
+  de_generation_groups_block<OBJ, G>(p, par, generation, ignore_done, blockIdx.x);
+}
+
 // One agent per wave. (Two agents per wave — ten gathers in flight — measured -7 % kernel time at
 // pop = 65536 but +9 % at pop = 2^20 and only -2 % per turn; not kept.)
 template <int OBJ, int CHUNKS, bool VEC>

@@ -18,7 +18,9 @@ struct PsoRtcKernels {
 };
 
 // Compiles de_init / de_generation / de_turn kernels for the objective, CHUNKS = chunks, VEC = vec.
-int rtc_build_de(const nlsg_custom_objective *obj, int chunks, bool vec, DeRtcKernels *out);
+// group != 0: the generation is the packed kernel (`group` lanes per agent); no fused turn then
+int rtc_build_de(const nlsg_custom_objective *obj, int chunks, bool vec, int group,
+                 DeRtcKernels *out);
 void rtc_release(DeRtcKernels *k);
 struct BfgsRtcKernels {  // finite-difference model around the user's objective
   hipModule_t mod = nullptr;

@@ -140,13 +140,17 @@ static std::string targs(int chunks, bool vec) {
          (vec ? "true" : "false");
 }
 
-int rtc_build_de(const nlsg_custom_objective *obj, int chunks, bool vec, DeRtcKernels *out) {
+int rtc_build_de(const nlsg_custom_objective *obj, int chunks, bool vec, int group,
+                 DeRtcKernels *out) {
   const std::string t = targs(chunks, vec);
+  const std::string gen =
+      group ? "nlsg::de_generation_groups_kernel<" + std::to_string(static_cast<int>(NLSG_OBJ_CUSTOM)) +
+                  ", " + std::to_string(group) + ">"
+            : "nlsg::de_generation_kernel<" + t + ">";
   std::vector<hipFunction_t> f;
   DeRtcKernels k;
   const int rc = rtc_compile(obj, "nlsg_de_kernels.h",
-                             {"nlsg::de_init_kernel<" + t + ">", "nlsg::de_generation_kernel<" + t + ">",
-                              "nlsg::de_turn_kernel<" + t + ">"},
+                             {"nlsg::de_init_kernel<" + t + ">", gen, "nlsg::de_turn_kernel<" + t + ">"},
                              &k.mod, &f);
   if (rc) return rc;
   k.init = f[0];
