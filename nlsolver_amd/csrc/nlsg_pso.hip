@@ -22,6 +22,7 @@ struct nlsg_pso {
   PsoRtcKernels rtc;          // objective == NLSG_OBJ_CUSTOM: the kernels hiprtc built for it
   double *rec = nullptr;
   int chunks = 0;
+  int group = 0;  // lanes per particle when several particles share a wave (D <= 64), else 0
   bool initialised = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -64,13 +65,57 @@ void launch_init(nlsg_pso *e) {
 #undef CALL
 }
 
+template <int OBJ, int TYPE>
+void launch_move_groups(nlsg_pso *e, dim3 grid, int timing, uint64_t iter_ovr) {
+  const dim3 block(256);
+  switch (e->group) {
+    case 4:
+      hipLaunchKernelGGL((pso_move_groups_kernel<OBJ, 4, TYPE>), grid, block, 0, e->stream, e->p,
+                         timing, iter_ovr);
+      break;
+    case 8:
+      hipLaunchKernelGGL((pso_move_groups_kernel<OBJ, 8, TYPE>), grid, block, 0, e->stream, e->p,
+                         timing, iter_ovr);
+      break;
+    case 16:
+      hipLaunchKernelGGL((pso_move_groups_kernel<OBJ, 16, TYPE>), grid, block, 0, e->stream, e->p,
+                         timing, iter_ovr);
+      break;
+    default:
+      hipLaunchKernelGGL((pso_move_groups_kernel<OBJ, 32, TYPE>), grid, block, 0, e->stream, e->p,
+                         timing, iter_ovr);
+      break;
+  }
+}
+template <int OBJ>
+void launch_move_groups_type(nlsg_pso *e, dim3 grid, int timing, uint64_t iter_ovr) {
+  if (e->cfg.type == NLSG_PSO_ACCELERATED)
+    launch_move_groups<OBJ, NLSG_PSO_ACCELERATED>(e, grid, timing, iter_ovr);
+  else
+    launch_move_groups<OBJ, NLSG_PSO_VANILLA>(e, grid, timing, iter_ovr);
+}
+
 void launch_move(nlsg_pso *e, int timing, uint64_t iter_ovr) {
-  const dim3 grid(static_cast<unsigned>((e->p.shard_n + 3) / 4)), block(256);
+  // waves: one per particle, or one per 64 / group particles
+  const uint64_t per_wave = e->group ? 64 / e->group : 1;
+  const uint64_t waves = (e->p.shard_n + per_wave - 1) / per_wave;
+  const dim3 grid(static_cast<unsigned>((waves + 3) / 4)), block(256);
   const bool vec = e->p.D % 2 == 0;
   const bool accel = e->cfg.type == NLSG_PSO_ACCELERATED;
   if (e->cfg.objective == NLSG_OBJ_CUSTOM) {
     void *args[] = {&e->p, &timing, &iter_ovr};
     hipModuleLaunchKernel(e->rtc.move, grid.x, 1, 1, 256, 1, 1, 0, e->stream, args, nullptr);
+    return;
+  }
+  if (e->group) {
+    switch (e->cfg.objective) {
+      case NLSG_OBJ_ROSENBROCK: launch_move_groups_type<NLSG_OBJ_ROSENBROCK>(e, grid, timing, iter_ovr); break;
+      case NLSG_OBJ_SPHERE: launch_move_groups_type<NLSG_OBJ_SPHERE>(e, grid, timing, iter_ovr); break;
+      case NLSG_OBJ_STYBLINSKI_TANG:
+        launch_move_groups_type<NLSG_OBJ_STYBLINSKI_TANG>(e, grid, timing, iter_ovr);
+        break;
+      default: launch_move_groups_type<NLSG_OBJ_RASTRIGIN>(e, grid, timing, iter_ovr); break;
+    }
     return;
   }
 #define CALL(OBJ, C)                                                                          \
@@ -187,6 +232,9 @@ static int pso_create(const nlsg_pso_config *cfg, const nlsg_custom_objective *c
   e->cfg = *cfg;
   const uint64_t D = cfg->dim, n = cfg->shard_n;
   e->chunks = D <= 128 ? 1 : D <= 256 ? 2 : D <= 512 ? 4 : 8;
+  e->group = D <= 8 ? 4 : D <= 16 ? 8 : D <= 32 ? 16 : D <= 64 ? 32 : 0;
+  if (const char *g = std::getenv("NLSG_PSO_GROUPS"))  // A/B switch: 0 = one particle per wave at any D
+    if (g[0] == '0') e->group = 0;
   if (cfg->stream) {
     e->stream = static_cast<hipStream_t>(cfg->stream);
   } else {
@@ -255,7 +303,7 @@ static int pso_create(const nlsg_pso_config *cfg, const nlsg_custom_objective *c
   p.type = cfg->type;
   p.bounded = cfg->bounded ? 1 : 0;
   if (custom) {
-    const int rc2 = rtc_build_pso(custom, e->chunks, p.D % 2 == 0, cfg->type, &e->rtc);
+    const int rc2 = rtc_build_pso(custom, e->chunks, p.D % 2 == 0, cfg->type, e->group, &e->rtc);
     if (rc2) {
       nlsg_pso_destroy(e);
       return rc2;

@@ -160,6 +160,88 @@ __global__ __launch_bounds__(256) void pso_move_kernel(PsoParams p, int timing, 
   }
 }
 
+// The same move for particles of at most 64 coordinates: 64 / G particles per wave, one per group
+// of G lanes (G = 4, 8, 16, 32 for D <= 8, 16, 32, 64; lane g of a group holds coordinates 2g,
+// 2g + 1). The particle's key lives in vector registers (it differs from group to group) and
+// group_objective scores the new position with the bits of the full-wave tree, so a swarm's
+// history does not depend on the packing.
+template <int OBJ, int G, int TYPE>
+__global__ __launch_bounds__(256) void pso_move_groups_kernel(PsoParams p, int timing,
+                                                              uint64_t iter_ovr) {
+  constexpr int P = 64 / G;
+  const PsoState *__restrict__ st = p.state;
+  if (!timing && st->done) return;
+  const uint64_t wave = static_cast<uint64_t>(blockIdx.x) * 4 +
+                        __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+  if (wave * P >= p.shard_n) return;
+  const int lane = lane_id(), g = lane & (G - 1), gi = lane / G;
+  const bool live = wave * P + gi < p.shard_n;
+  const uint64_t i = live ? wave * P + gi : wave * P;  // idle groups shadow a live particle
+  const uint64_t D = p.D;
+  const uint64_t iter = timing ? iter_ovr : st->iter;
+  const uint64_t kit = first64(ctr_key(on_valu(p.seed), iter + 1));
+  const uint64_t kp = ctr_key(kit, p.shard_lo + i);
+  const uint32_t j0 = 2 * g, j1 = 2 * g + 1;
+  const bool in[2] = {j0 < D, j1 < D};
+  const uint32_t d32 = static_cast<uint32_t>(D);
+  const uint64_t off = static_cast<uint64_t>(static_cast<uint32_t>(i)) * d32;
+  double *row = p.pos + off;
+  auto load2 = [&](const double *rp, bool on, double (&v)[2]) {
+    v[0] = (on && in[0]) ? rp[j0] : 0.0;
+    v[1] = (on && in[1]) ? rp[j1] : 0.0;
+  };
+  double xv[2], gb[2], lo[2], hi[2], vv[2], pb[2];
+  load2(row, true, xv);
+  load2(p.gbest_x, true, gb);
+  load2(p.lower, p.bounded != 0, lo);
+  load2(p.upper, p.bounded != 0, hi);
+  load2(p.vel + off, TYPE == NLSG_PSO_VANILLA, vv);
+  load2(p.pbest_pos + off, TYPE == NLSG_PSO_VANILLA, pb);
+  const double old_pbest = p.pbest_val[i];
+  double inertia = p.inertia;
+  if (TYPE == NLSG_PSO_ACCELERATED)  // :2613 inertia = pow(init_inertia, iter)
+    inertia = iter < p.tab_len ? p.inertia_tab[iter] : pow(p.inertia, static_cast<double>(iter));
+  // draws 2e and 2e+1 of element e = 2g + k: mix64(kp + G64 (2e + 1 [+ 1])), 2e + 1 = 4g + 2k + 1
+  const uint64_t kp_lane = kp + kGolden * (4 * static_cast<uint64_t>(g) + 1);
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const double u1 = u01(mix64(kp_lane + kGolden * static_cast<uint64_t>(2 * k)));
+    const double u2 = u01(mix64(kp_lane + kGolden * static_cast<uint64_t>(2 * k + 1)));
+    double pnew;
+    if (TYPE == NLSG_PSO_ACCELERATED) {
+      const double rn = sqrt(-2 * det_log(u1)) * det_cos(2 * 3.141593 * u2);  // rnorm, :2479-2485
+      pnew = inertia * rn + (1 - p.cog) * xv[k] + p.soc * gb[k];  // :2693-2697
+    } else {
+      vv[k] = (inertia * vv[k]) + p.cog * u1 * (pb[k] - xv[k]) + p.soc * u2 * (gb[k] - xv[k]);
+      pnew = xv[k] + vv[k];  // :2683
+    }
+    if (p.bounded) {  // :2701-2715
+      pnew = pnew < lo[k] ? lo[k] : pnew;
+      pnew = pnew > hi[k] ? hi[k] : pnew;
+    }
+    xv[k] = in[k] ? pnew : 0.0;
+  }
+  const double f = p.fmul * group_objective<OBJ, G>(xv[0], xv[1], D);
+  const bool better = f < old_pbest;  // :2733-2735
+  if (live) {
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const uint32_t j = 2 * g + k;
+      if (in[k]) {
+        row[j] = xv[k];
+        if (TYPE == NLSG_PSO_VANILLA) {
+          p.vel[off + j] = vv[k];
+          if (better) p.pbest_pos[off + j] = xv[k];
+        }
+      }
+    }
+    if (g == 0) {
+      p.cur_val[i] = f;
+      if (better) p.pbest_val[i] = f;
+    }
+  }
+}
+
 // First level of update_best_positions' scan (min / first argmin of the last
 // evaluation) and of std_err(particle_best_values)'s first pass.
 __global__ __launch_bounds__(256) void pso_scan_partial_kernel(PsoParams p) {

@@ -55,7 +55,9 @@ int rtc_build_sann(const nlsg_custom_objective *obj, int chunks, bool vec, int g
                    SannRtcKernels *out);
 void rtc_release(SannRtcKernels *k);
 // pso_init / pso_move kernels; type = nlsg_pso_type.
-int rtc_build_pso(const nlsg_custom_objective *obj, int chunks, bool vec, int type, PsoRtcKernels *out);
+// group != 0: the move is the packed kernel (`group` lanes per particle)
+int rtc_build_pso(const nlsg_custom_objective *obj, int chunks, bool vec, int type, int group,
+                  PsoRtcKernels *out);
 void rtc_release(PsoRtcKernels *k);
 
 }  // namespace nlsg

@@ -160,13 +160,16 @@ int rtc_build_de(const nlsg_custom_objective *obj, int chunks, bool vec, int gro
   return NLSG_OK;
 }
 
-int rtc_build_pso(const nlsg_custom_objective *obj, int chunks, bool vec, int type, PsoRtcKernels *out) {
+int rtc_build_pso(const nlsg_custom_objective *obj, int chunks, bool vec, int type, int group,
+                  PsoRtcKernels *out) {
   const std::string t = targs(chunks, vec);
+  const std::string move =
+      group ? "nlsg::pso_move_groups_kernel<" + std::to_string(static_cast<int>(NLSG_OBJ_CUSTOM)) +
+                  ", " + std::to_string(group) + ", " + std::to_string(type) + ">"
+            : "nlsg::pso_move_kernel<" + t + ", " + std::to_string(type) + ">";
   std::vector<hipFunction_t> f;
   PsoRtcKernels k;
-  const int rc = rtc_compile(obj, "nlsg_pso_kernels.h",
-                             {"nlsg::pso_init_kernel<" + t + ">",
-                              "nlsg::pso_move_kernel<" + t + ", " + std::to_string(type) + ">"},
+  const int rc = rtc_compile(obj, "nlsg_pso_kernels.h", {"nlsg::pso_init_kernel<" + t + ">", move},
                              &k.mod, &f);
   if (rc) return rc;
   k.init = f[0];
