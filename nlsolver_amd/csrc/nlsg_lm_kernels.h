@@ -102,7 +102,10 @@ __device__ inline void lm_solve_cholesky_wave(Rows H, const double *g, double *u
     if (row) upd[t] = gt / H(t, t);
     return;
   }
-  // cholesky (:251-269): every element's sum runs over k in order. Columns are taken four at
+  // cholesky (:251-269): every element's sum runs over k in order, each accumulate-multiply as
+  // one fused multiply-add (the inner loops are bound by exactly these instructions; the oracle's
+  // order-1 solve does the same, the reference's separate multiply and add differ in the last
+  // bits). Columns are taken four at
   // a time so one LDS read of L[t][k] feeds four sums; the other factor L[j][k] is the same
   // read's value in lane j, broadcast through a scalar register (no second LDS read).
   for (int j0 = 0; j0 < n; j0 += 4) {
@@ -120,7 +123,7 @@ __device__ inline void lm_solve_cholesky_wave(Rows H, const double *g, double *u
 #pragma unroll
         for (int q = 0; q < 4; q++) l[q] = H(min(j0 + c, 63), k + q);
 #pragma unroll
-        for (int q = 0; q < 4; q++) s4[c] += x[q] * l[q];
+        for (int q = 0; q < 4; q++) s4[c] = __builtin_fma(x[q], l[q], s4[c]);
       }
     }
     double hd[4];
@@ -138,7 +141,8 @@ __device__ inline void lm_solve_cholesky_wave(Rows H, const double *g, double *u
         if (act && t >= j) H(t, j) = v;
         // the panel's later columns continue their sums with k = j
 #pragma unroll
-        for (int c2 = c + 1; c2 < 4; c2++) s4[c2] += v * lane_broadcast(v, min(j0 + c2, 63));
+        for (int c2 = c + 1; c2 < 4; c2++)
+          s4[c2] = __builtin_fma(v, lane_broadcast(v, min(j0 + c2, 63)), s4[c2]);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -157,7 +161,7 @@ __device__ inline void lm_solve_cholesky_wave(Rows H, const double *g, double *u
       if (j < n) {
         if (t == j) u = (gt - sum) / dg;
         const double uj = lane_broadcast(u, j);
-        if (row && t > j) sum += h[c] * uj;
+        if (row && t > j) sum = __builtin_fma(h[c], uj, sum);
       }
     }
   }
@@ -173,7 +177,7 @@ __device__ inline void lm_solve_cholesky_wave(Rows H, const double *g, double *u
       if (j < n) {
         if (t == j) u = (u - sum) / dg;
         const double uj = lane_broadcast(u, j);
-        if (row && t < j) sum += h[c] * uj;
+        if (row && t < j) sum = __builtin_fma(h[c], uj, sum);
       }
     }
   }

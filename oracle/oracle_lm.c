@@ -51,23 +51,29 @@ double orc_tanh(double x) {
 }
 
 /* ---- linear algebra of the reference LM ------------------------------------- */
-void orc_cholesky(double *A, size_t n) { /* nlsolver.h:251-269 */
+/* order = 1 (the kernel's arithmetic): every accumulate-multiply of the factorisation and of the
+ * two substitutions is ONE fused multiply-add, sums in the same order as below */
+static void cholesky_order(double *A, size_t n, int order) { /* nlsolver.h:251-269 */
   for (size_t i = 0; i < n; ++i) {
     for (size_t j = 0; j < i; ++j) {
       double sum = 0;
-      for (size_t k = 0; k < j; ++k) sum += A[i * n + k] * A[j * n + k];
+      for (size_t k = 0; k < j; ++k)
+        sum = order ? fma(A[i * n + k], A[j * n + k], sum) : sum + A[i * n + k] * A[j * n + k];
       A[i * n + j] = (1.0 / A[j * n + j] * (A[i * n + j] - sum));
     }
     double sum = 0;
-    for (size_t k = 0; k < i; ++k) sum += A[i * n + k] * A[i * n + k];
+    for (size_t k = 0; k < i; ++k)
+      sum = order ? fma(A[i * n + k], A[i * n + k], sum) : sum + A[i * n + k] * A[i * n + k];
     A[i * n + i] = sqrt(A[i * n + i] - sum);
   }
 }
-static void forwardsolve(double *update, const double *L, const double *b, size_t n) { /* :282-294 */
+void orc_cholesky(double *A, size_t n) { cholesky_order(A, n, 0); }
+static void forwardsolve(double *update, const double *L, const double *b, size_t n, int order) { /* :282-294 */
   memset(update, 0, n * sizeof(double));
   for (size_t i = 0; i < n; ++i) {
     double sum = 0.0;
-    for (size_t j = 0; j < i; ++j) sum += L[i * n + j] * update[j];
+    for (size_t j = 0; j < i; ++j)
+      sum = order ? fma(L[i * n + j], update[j], sum) : sum + L[i * n + j] * update[j];
     update[i] = (b[i] - sum) / L[i + i * n];
   }
 }
@@ -79,7 +85,7 @@ static void backsolve_t(const double *U, double *b, size_t n, int order) { /* :2
     if (order == 0)
       for (size_t j = (size_t)i + 1; j < n; ++j) sum += U[j * n + (size_t)i] * b[j];
     else
-      for (size_t j = n; j-- > (size_t)i + 1;) sum += U[j * n + (size_t)i] * b[j];
+      for (size_t j = n; j-- > (size_t)i + 1;) sum = fma(U[j * n + (size_t)i], b[j], sum);
     b[i] = (b[i] - sum) / U[(size_t)i * n + (size_t)i];
   }
 }
@@ -95,8 +101,8 @@ void orc_update_with_hessian_order(double *update, double *hess, const double *g
     for (size_t i = 0; i < n; i++) update[i] = grad[i] / hess[i * n + i];
     return;
   }
-  orc_cholesky(hess, n);
-  forwardsolve(update, hess, grad, n);
+  cholesky_order(hess, n, order);
+  forwardsolve(update, hess, grad, n, order);
   backsolve_t(hess, update, n, order);
 }
 void orc_update_with_hessian(double *update, double *hess, const double *grad, size_t n) {
