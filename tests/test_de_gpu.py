@@ -337,3 +337,24 @@ def test_randomised_configuration_sweep_bit_exact(eng_mod, oracle, pop, D, strat
     if eps > 0:
         assert st.std_err == ref.s.std_err
     assert np.array_equal(bx, ref.best_x)
+
+
+@pytest.mark.parametrize("D,pop", [(3, 37), (8, 1000), (16, 4096), (33, 515), (64, 2048)])
+@pytest.mark.parametrize("strategy", ["random", "best"])
+def test_packing_does_not_change_the_history(eng_mod, monkeypatch, D, pop, strategy):
+    """Agents of at most 64 coordinates share a wave (one per lane group); NLSG_DE_GROUPS=0 keeps one
+    agent per wave. Same populations, scores, donors and acceptances either way."""
+    m = eng_mod
+    strat = m.DE_RANDOM if strategy == "random" else m.DE_BEST
+    out = []
+    for groups in ("1", "0"):
+        monkeypatch.setenv("NLSG_DE_GROUPS", groups)
+        with m.DEEngine("rosenbrock", pop, D, minimize=True, strategy=strat, CR=0.6, F=0.7,
+                        eps=0.0, max_iter=10**9, best_val_no_change=10**9, seed=77, trace=True) as eng:
+            eng.init(np.full(D, 1.5))
+            eng.step(12)
+            st = eng.status()
+            out.append((eng.download(trace=True), (st.iteration, st.f_value, st.best_index)))
+    (pa, sa, ta), (pb, sb, tb) = out[0][0], out[1][0]
+    assert np.array_equal(pa, pb) and np.array_equal(sa, sb) and np.array_equal(ta, tb)
+    assert out[0][1] == out[1][1]

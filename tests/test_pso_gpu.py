@@ -168,3 +168,23 @@ def test_pso_randomised_configuration_sweep_bit_exact(mod, oracle, n, D, type_, 
         check_state(eng, ref, "after 6 turns")
         bx, bf, bi = eng.best()
         assert np.array_equal(bx, ref.gbest_x) and bf == ref.s.gbest_val and bi == ref.s.gbest_idx
+
+
+@pytest.mark.parametrize("D,n", [(3, 37), (8, 1000), (16, 4096), (33, 515), (64, 2048)])
+@pytest.mark.parametrize("type_", ["accelerated", "vanilla"])
+def test_packing_does_not_change_the_history(mod, monkeypatch, D, n, type_):
+    """Particles of at most 64 coordinates share a wave; NLSG_PSO_GROUPS=0 keeps one per wave."""
+    t = mod.PSO_ACCELERATED if type_ == "accelerated" else mod.PSO_VANILLA
+    out = []
+    for groups in ("1", "0"):
+        monkeypatch.setenv("NLSG_PSO_GROUPS", groups)
+        with mod.PSOEngine("rosenbrock", n, D, type=t, bounded=True, eps=0.0, max_iter=10**9,
+                           best_val_no_change=10**9, seed=99) as eng:
+            eng.init(-1.5, 2.0)
+            eng.step(10)
+            st = eng.status()
+            out.append((eng.download(), eng.best(), (st.iteration, st.f_value)))
+    for u, v in zip(out[0][0], out[1][0]):
+        assert (u is None and v is None) or np.array_equal(u, v)
+    assert np.array_equal(out[0][1][0], out[1][1][0]) and out[0][1][1:] == out[1][1][1:]
+    assert out[0][2] == out[1][2]
