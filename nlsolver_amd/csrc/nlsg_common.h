@@ -314,6 +314,26 @@ struct TilePartial {
   double m2;
 };
 
+// ---- single-launch reductions over tiles: every tile block publishes its partial with
+// write-through stores, drains them and takes a ticket; the block whose ticket is the last one
+// reads all partials and finishes (DE head, PSO head). Relaxed agent-scope accesses bypass the
+// non-coherent levels, and the ticket's read-modify-write orders the blocks where it matters; no
+// release / acquire fence (a release would write back every dirty L2 line other blocks hold).
+__device__ inline void sc1_store(double *ptr, double v) {
+  __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline double sc1_load(const double *ptr) {
+  return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// thread 0, after the block's partial stores: true in the block that arrived last of `count`
+__device__ inline bool take_ticket(uint32_t *ticket, uint32_t count) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (t != count - 1) return false;
+  __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return true;
+}
+
 // ---- row access ------------------------------------------------------------
 // Branch-free and select-free on purpose: a load guarded by a runtime condition
 // makes hipcc branch around it and drain vmcnt before the next one, and a select

@@ -389,21 +389,8 @@ __device__ inline void finish_turn(DeState *st, const DeParams &p, uint64_t bi, 
 // ((w0+w1)+w2)+w3 per tile, the same tree over tiles), so which block ends up last does not
 // matter. No release / acquire fence: a release would write back every dirty line that
 // generation blocks of the same launch hold in the XCD's L2.
-__device__ inline void sc1_store(double *ptr, double v) {
-  __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ inline double sc1_load(const double *ptr) {
-  return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // thread 0, after the block's partial stores: true in the block that arrived last
-__device__ inline bool take_ticket(const DeParams &p) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  const uint32_t t = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (t != p.ntiles - 1) return false;
-  __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return true;
-}
+__device__ inline bool take_ticket(const DeParams &p) { return take_ticket(p.ticket, p.ntiles); }
 
 // `rec` == nullptr: one GPU, the launch finishes the turn; else the shard's exchange record
 __device__ inline void de_scan_head_block(const DeParams &p, uint64_t k, uint32_t tile, double *rec) {

@@ -156,8 +156,7 @@ void launch_turn_single(nlsg_pso *e) {
     hipLaunchKernelGGL(pso_finalize_kernel, dim3(1), dim3(256), 0, e->stream, e->p, e->rec, 1,
                        static_cast<uint64_t>(kRecHeader) + e->p.D);
   } else {
-    hipLaunchKernelGGL(pso_scan_partial_kernel, dim3(e->p.ntiles), dim3(256), 0, e->stream, e->p);
-    hipLaunchKernelGGL(pso_head_kernel, dim3(1), dim3(256), 0, e->stream, e->p);
+    hipLaunchKernelGGL(pso_scan_head_kernel, dim3(e->p.ntiles), dim3(256), 0, e->stream, e->p);
   }
   launch_move(e, 0, 0);
 }
@@ -266,6 +265,8 @@ static int pso_create(const nlsg_pso_config *cfg, const nlsg_custom_objective *c
   p.ntiles = static_cast<uint32_t>((n + kTile - 1) / kTile);
   if (he == hipSuccess)
     he = alloc(reinterpret_cast<void **>(&p.part), p.ntiles * sizeof(TilePartial));
+  if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&p.ticket), 8);
+  if (he == hipSuccess) he = hipMemset(p.ticket, 0, 8);
   if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&e->loc), sizeof(ShardLocal));
   if (he == hipSuccess)
     he = alloc(reinterpret_cast<void **>(&e->rec), (kRecHeader + D) * sizeof(double));
@@ -325,6 +326,7 @@ int nlsg_pso_destroy(nlsg_pso *e) {
   hipFree(e->p.gbest_x);
   hipFree(e->p.state);
   hipFree(e->p.part);
+  hipFree(e->p.ticket);
   hipFree(e->lower_dev);
   hipFree(e->upper_dev);
   hipFree(e->zero_dev);

@@ -34,6 +34,7 @@ struct PsoParams {
   const double *inertia_tab;      // pow(inertia, k), k < tab_len (Accelerated, :2613)
   PsoState *state;
   TilePartial *part;
+  uint32_t *ticket;               // arrival counter of pso_scan_head_kernel's blocks
   const double *zero;
   uint64_t tab_len;
   uint32_t ntiles, pad0;
@@ -330,6 +331,48 @@ __global__ __launch_bounds__(256) void pso_head_kernel(PsoParams p) {
   double bv;
   uint64_t bi;
   pso_shard_best(p, mv, mi, bv, bi);
+  if (threadIdx.x == 0) {
+    const bool have = bi != ~0ull;
+    const bool upd = pso_finish_turn(st, p, have, bv, p.shard_lo + bi, __builtin_nan(""));
+    s_row = bi;
+    s_copy = upd ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_copy) return;
+  const double *row = p.pos + s_row * p.D;  // swarm_best_position = positions[best], :2737
+  for (uint64_t d = threadIdx.x; d < p.D; d += 256) p.gbest_x[d] = row[d];
+}
+
+// One GPU, eps <= 0: the tile scan and the head in ONE launch (a dependent launch costs ~5 us on
+// this platform): every tile block publishes its minimum, the block that arrives last finishes
+// the turn (same arithmetic as pso_scan_partial_kernel + pso_head_kernel: min / first index).
+__global__ __launch_bounds__(256) void pso_scan_head_kernel(PsoParams p) {
+  __shared__ double mv[4];
+  __shared__ uint64_t mi[4];
+  __shared__ uint64_t s_row;
+  __shared__ int s_copy, s_last;
+  PsoState *st = p.state;
+  if (st->done) return;
+  const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kTile;
+  double bv = __builtin_inf();
+  uint64_t bi = ~0ull;
+  for (uint64_t i = base + threadIdx.x; i < base + kTile && i < p.shard_n; i += 256)
+    argmin_combine(bv, bi, p.cur_val[i], i);
+  block_argmin_256(bv, bi, mv, mi);
+  if (threadIdx.x == 0) {
+    sc1_store(&p.part[blockIdx.x].minv, bv);
+    __hip_atomic_store(&p.part[blockIdx.x].mini, bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = take_ticket(p.ticket, p.ntiles) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  if (threadIdx.x == 0) pso_apply_pending(st);
+  bv = __builtin_inf();
+  bi = ~0ull;
+  for (uint32_t j = threadIdx.x; j < p.ntiles; j += 256)
+    argmin_combine(bv, bi, sc1_load(&p.part[j].minv),
+                   __hip_atomic_load(&p.part[j].mini, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  block_argmin_256(bv, bi, mv, mi);
   if (threadIdx.x == 0) {
     const bool have = bi != ~0ull;
     const bool upd = pso_finish_turn(st, p, have, bv, p.shard_lo + bi, __builtin_nan(""));
