@@ -146,12 +146,44 @@ void launch_generation(nlsg_de *e, int par, uint64_t generation, int ignore_done
 #undef CALL
 }
 
+template <int OBJ>
+void launch_fused_turn_groups(nlsg_de *e, dim3 grid, int par, uint64_t generation) {
+  const dim3 block(256);
+  switch (e->group) {
+    case 4:
+      hipLaunchKernelGGL((de_turn_groups_kernel<OBJ, 4>), grid, block, 0, e->stream, e->p, par, generation);
+      break;
+    case 8:
+      hipLaunchKernelGGL((de_turn_groups_kernel<OBJ, 8>), grid, block, 0, e->stream, e->p, par, generation);
+      break;
+    case 16:
+      hipLaunchKernelGGL((de_turn_groups_kernel<OBJ, 16>), grid, block, 0, e->stream, e->p, par, generation);
+      break;
+    default:
+      hipLaunchKernelGGL((de_turn_groups_kernel<OBJ, 32>), grid, block, 0, e->stream, e->p, par, generation);
+      break;
+  }
+}
+
 // head k and generation k+1 in one launch (de_turn_kernel)
 void launch_fused_turn(nlsg_de *e, int par, uint64_t generation) {
-  const dim3 grid(static_cast<unsigned>((e->p.shard_n + 3) / 4 + e->p.ntiles)), block(256);
+  const uint64_t per_wave = e->group ? 64 / e->group : 1;
+  const uint64_t waves = (e->p.shard_n + per_wave - 1) / per_wave;
+  const dim3 grid(static_cast<unsigned>((waves + 3) / 4 + e->p.ntiles)), block(256);
   if (e->cfg.objective == NLSG_OBJ_CUSTOM) {
     void *args[] = {&e->p, &par, &generation};
     launch_module(e, e->rtc.turn, grid.x, args);
+    return;
+  }
+  if (e->group) {
+    switch (e->cfg.objective) {
+      case NLSG_OBJ_ROSENBROCK: launch_fused_turn_groups<NLSG_OBJ_ROSENBROCK>(e, grid, par, generation); break;
+      case NLSG_OBJ_SPHERE: launch_fused_turn_groups<NLSG_OBJ_SPHERE>(e, grid, par, generation); break;
+      case NLSG_OBJ_STYBLINSKI_TANG:
+        launch_fused_turn_groups<NLSG_OBJ_STYBLINSKI_TANG>(e, grid, par, generation);
+        break;
+      default: launch_fused_turn_groups<NLSG_OBJ_RASTRIGIN>(e, grid, par, generation); break;
+    }
     return;
   }
 #define CALL(OBJ, C)                                                                        \
@@ -337,8 +369,7 @@ static int de_create(const nlsg_de_config *cfg, const nlsg_custom_objective *cus
   e->overlap = cfg->strategy == NLSG_DE_RANDOM && cfg->shard_n == cfg->pop && ov && ov[0] == '1';
   const char *fu = std::getenv("NLSG_DE_FUSED_TURN");
   e->fused = cfg->strategy == NLSG_DE_RANDOM && cfg->shard_n == cfg->pop &&
-             !e->overlap && !cfg->trace && !(fu && fu[0] == '0') &&  // the trace buffer is not double-buffered
-             !e->group;  // (the packed generation is a kernel of its own)
+             !e->overlap && !cfg->trace && !(fu && fu[0] == '0');  // the trace buffer is not double-buffered
   if (e->overlap) {
     if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking);
     for (int i = 0; i < 4; i++) {

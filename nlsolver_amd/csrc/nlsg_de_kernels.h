@@ -526,6 +526,16 @@ __global__ __launch_bounds__(256) void de_turn_kernel(DeParams p, int par, uint6
   de_generation_block<OBJ, CHUNKS, VEC>(p, par, generation, 0, blockIdx.x - p.ntiles);
 }
 
+// the same turn with the packed generation (agents of at most 64 coordinates, several per wave)
+template <int OBJ, int G>
+__global__ __launch_bounds__(256) void de_turn_groups_kernel(DeParams p, int par, uint64_t generation) {
+  if (blockIdx.x < p.ntiles) {
+    de_scan_head_block(p, generation - 1, blockIdx.x, nullptr);
+    return;
+  }
+  de_generation_groups_block<OBJ, G>(p, par, generation, 0, blockIdx.x - p.ntiles);
+}
+
 // ---- the sharded path ----------------------------------------------------------
 // Finaliser over `world` records (world == 1: the local record): global best
 // (lower value; on ties the incumbent, then the lower global index), counters,

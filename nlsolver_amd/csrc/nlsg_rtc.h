@@ -18,7 +18,7 @@ struct PsoRtcKernels {
 };
 
 // Compiles de_init / de_generation / de_turn kernels for the objective, CHUNKS = chunks, VEC = vec.
-// group != 0: the generation is the packed kernel (`group` lanes per agent); no fused turn then
+// group != 0: generation and fused turn are the packed kernels (`group` lanes per agent)
 int rtc_build_de(const nlsg_custom_objective *obj, int chunks, bool vec, int group,
                  DeRtcKernels *out);
 void rtc_release(DeRtcKernels *k);

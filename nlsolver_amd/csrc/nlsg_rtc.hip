@@ -149,8 +149,11 @@ int rtc_build_de(const nlsg_custom_objective *obj, int chunks, bool vec, int gro
             : "nlsg::de_generation_kernel<" + t + ">";
   std::vector<hipFunction_t> f;
   DeRtcKernels k;
-  const int rc = rtc_compile(obj, "nlsg_de_kernels.h",
-                             {"nlsg::de_init_kernel<" + t + ">", gen, "nlsg::de_turn_kernel<" + t + ">"},
+  const std::string turn =
+      group ? "nlsg::de_turn_groups_kernel<" + std::to_string(static_cast<int>(NLSG_OBJ_CUSTOM)) + ", " +
+                  std::to_string(group) + ">"
+            : "nlsg::de_turn_kernel<" + t + ">";
+  const int rc = rtc_compile(obj, "nlsg_de_kernels.h", {"nlsg::de_init_kernel<" + t + ">", gen, turn},
                              &k.mod, &f);
   if (rc) return rc;
   k.init = f[0];
