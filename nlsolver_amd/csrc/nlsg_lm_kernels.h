@@ -314,7 +314,7 @@ __device__ inline void lm_eval_wave(const LmParams &p, int first, uint64_t pid, 
   const double th0 = theta[2 * lp], th1 = theta[2 * lp + 1];
   // device layout of A: [row group s][problem][16 rows][64], zero padded past m; y alike
   const double *Ap = p.A + pid * (16 * kLmN) + 2 * lp;
-  const double *yp = p.y + pid * 16 + 2 * (lp & 7) + half;
+  const double *yp = p.y + pid * 16 + 2 * (lp >> 2) + half;  // the row whose z this lane ends up with
   const uint64_t stride = p.batch * (16 * kLmN), ystride = p.batch * 16;
   v4d acc[10];
 #pragma unroll
@@ -330,26 +330,36 @@ __device__ inline void lm_eval_wave(const LmParams &p, int first, uint64_t pid, 
     ysel = yp[s * ystride];
   };
   auto step = [&](uint64_t s, double &fw) {
-    // z = A theta for 16 rows: one 32-lane butterfly per load instruction
+    // z = A theta for 16 rows (8 per half): a reduce-scatter over the half's 32 lanes instead of
+    // eight full butterflies — at the levels 16, 8, 4 a lane keeps half of its rows (by bit 4, 3,
+    // 2 of its index) and hands the other half to its partner, then the last row standing takes
+    // the levels 2 and 1. Every sum pairs the same lanes in the same order as the butterfly did
+    // (own + partner's, commutative), so z has the same bits; 9 exchanges instead of 40.
     double z[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-      z[k] = a[k].x * th0 + a[k].y * th1;
-      butterfly_levels<16>([&](auto off) { z[k] = z[k] + lane_xor<decltype(off)::value>(z[k]); });
-    }
-    // tanh / residual / weight once per row: lane lp of each half takes row k = lp & 7
-    double zsel = z[0];
+    for (int k = 0; k < 8; k++) z[k] = __builtin_fma(a[k].y, th1, a[k].x * th0);
+    const bool b4 = (lp & 16) != 0, b3 = (lp & 8) != 0, b2 = (lp & 4) != 0;
+    double y4[4], y2[2];
 #pragma unroll
-    for (int k = 1; k < 8; k++) zsel = ((lp & 7) == k) ? z[k] : zsel;
+    for (int q = 0; q < 4; q++)
+      y4[q] = (b4 ? z[q + 4] : z[q]) + lane_xor<16>(b4 ? z[q] : z[q + 4]);
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+      y2[q] = (b3 ? y4[q + 2] : y4[q]) + lane_xor<8>(b3 ? y4[q] : y4[q + 2]);
+    double zsel = (b2 ? y2[1] : y2[0]) + lane_xor<4>(b2 ? y2[0] : y2[1]);
+    zsel = zsel + lane_xor<2>(zsel);
+    zsel = zsel + lane_xor<1>(zsel);
+    // tanh / residual / weight once per row: the lanes of a half with the same lp >> 2 hold row
+    // k = lp >> 2 (rows 2k + half of the group)
     const double tsel = det_tanh(zsel);
     const double rsel = ysel - tsel;
     const double wsel = 1 - tsel * tsel;
-    if (lp < 8) sh.r[2 * lp + half] = rsel;
+    if ((lp & 3) == 0) sh.r[2 * (lp >> 2) + half] = rsel;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-      const double r = __shfl(rsel, 32 * half + k, 64);
-      const double wgt = __shfl(wsel, 32 * half + k, 64);
-      fw = fw + r * r;
+      const double r = __shfl(rsel, 32 * half + 4 * k, 64);
+      const double wgt = __shfl(wsel, 32 * half + 4 * k, 64);
+      fw = __builtin_fma(r, r, fw);
       double2 jv;
       jv.x = -(wgt * a[k].x);
       jv.y = -(wgt * a[k].y);
@@ -370,7 +380,7 @@ __device__ inline void lm_eval_wave(const LmParams &p, int first, uint64_t pid, 
 #pragma unroll
       for (int b = 0; b < 4; b++) op[b] = row[16 * b + cc];
 #pragma unroll
-      for (int b = 0; b < 4; b++) gacc[b] = gacc[b] + op[b] * rv;
+      for (int b = 0; b < 4; b++) gacc[b] = __builtin_fma(op[b], rv, gacc[b]);
 #pragma unroll
       for (int rb = 0; rb < 4; rb++)
 #pragma unroll

@@ -229,7 +229,7 @@ static void residual_jacobian(const orc_nlls *q, const double *x, double *r, dou
           const double a0 = 2 * l < n ? q->A[i * n + 2 * l] : 0.0, b0 = 2 * l < n ? x[2 * l] : 0.0;
           const double a1 = 2 * l + 1 < n ? q->A[i * n + 2 * l + 1] : 0.0,
                        b1 = 2 * l + 1 < n ? x[2 * l + 1] : 0.0;
-          lane[l] = a0 * b0 + a1 * b1;
+          lane[l] = fma(a1, b1, a0 * b0);
         }
         for (int off = 16; off >= 1; off >>= 1) {
           for (int l = 0; l < 32; l++) tmp[l] = lane[l] + lane[l ^ off];
@@ -269,13 +269,13 @@ static double gn_all(const orc_nlls *q, const double *x, double *g, double *H, d
     double part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (size_t i = 0; i < m; i++) { /* 8 accumulators: idx = 2*((i%64)/16) + i%2 */
       const size_t rb = i % 64;
-      part[2 * (rb / 16) + rb % 2] += r[i] * r[i];
+      part[2 * (rb / 16) + rb % 2] = fma(r[i], r[i], part[2 * (rb / 16) + rb % 2]);
     }
     f = 0.0;
     for (int k = 0; k < 8; k++) f += part[k];
     for (size_t j = 0; j < n; j++) { /* 4 accumulators by i mod 4, then ((a0+a1)+a2)+a3 */
       double a[4] = {0, 0, 0, 0};
-      for (size_t i = 0; i < m; i++) a[i % 4] += J[i * n + j] * r[i];
+      for (size_t i = 0; i < m; i++) a[i % 4] = fma(J[i * n + j], r[i], a[i % 4]);
       g[j] = 2 * (((a[0] + a[1]) + a[2]) + a[3]);
     }
     for (size_t j = 0; j < n; j++) /* fp64 MFMA: one fma chain over the rows, in order */
