@@ -6,12 +6,14 @@
 //   de_scan_head_kernel   best scan, std_err (2037-2052) when eps > 0 can decide, no-change
 //                         counter, stop tests (2429-2447) -- or the shard's exchange record
 //   de_turn_kernel        head k and generation k+1 in one launch (strategy random)
+//   de_generation_groups_kernel / de_turn_groups_kernel   the same for D <= 64: several agents
+//                         per wave, one per group of lanes
 //   de_finalize_kernel    the head's decisions from the records of all shards
 //
 // Data layout in HBM: population row-major [shard_n][D] fp64, two buffers
 // (synchronous generation: donors are read from `cur`, survivors written to
 // `nxt`); scores [shard_n] fp64 updated in place by the owning wave.
-// Mapping: one wave64 per agent; lane l holds elements c*128 + 2l, +1 of each
+// Mapping (D > 64): one wave64 per agent; lane l holds elements c*128 + 2l, +1 of each
 // 128-element chunk c, so every wave-level load/store is one contiguous 1 KiB
 // burst (global_load_dwordx4 / global_store_dwordx4) when D is even. One agent
 // per wave and 4 agents per 256-thread block, dispatched dynamically: measured

@@ -7,7 +7,9 @@
 // Layout: positions (and, Vanilla, velocities + personal-best positions) row-major
 // [shard_n][D] fp64, updated IN PLACE by the wave that owns the particle (particles
 // only interact through the swarm-best vector). One wave64 per particle; lane l
-// holds elements c*128 + 2l, +1 of each 128-element chunk.
+// holds elements c*128 + 2l, +1 of each 128-element chunk (D <= 64: several particles per wave,
+// one per group of lanes, pso_move_groups_kernel). The head of an iteration is one launch
+// (pso_scan_head_kernel) on one GPU with eps <= 0, else scan / local / finalize kernels.
 #pragma once
 
 #include "nlsg_common.h"
