@@ -126,3 +126,24 @@ def test_hybrid_custom_objective_equals_builtin(mod):
                 x, st = eng.minimize(x0)
             out.append((x, [(s.f_value, s.function_calls_used) for s in st]))
         assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
+
+
+def test_hybrid_bench_size_properties(mod, oracle):
+    """The bench configuration (Rosenbrock-32D, 4096 instances, 30 iterations here): deterministic,
+    never worse than the best initial particle's value bound, value = objective at the returned
+    point, sampled instances equal the oracle."""
+    B, n = 4096, 32
+    rng = np.random.default_rng(6)
+    x0 = 0.5 + (rng.random((B, n)) - 0.5)
+    kw = dict(max_iter=30, eps=0.0, no_change_best_iter=2**62, seed=SEED)
+    with mod.NMPSOEngine("rosenbrock", B, n, **kw) as eng:
+        xa, sa = eng.minimize(x0)
+        xb, sb = eng.minimize(x0)
+    assert np.array_equal(xa, xb) and [s.f_value for s in sa] == [s.f_value for s in sb]
+    assert all(s.iteration == 30 for s in sa)
+    for b in (0, 2049, B - 1):
+        ref, xr, _ = O.nmpso_sync(oracle, "rosenbrock", x0[b], SEED, b, eps=0.0, max_iter=30,
+                                  no_change=2**62)
+        assert np.array_equal(xa[b], xr) and sa[b].f_value == ref.f_value
+        assert sa[b].function_calls_used == ref.function_calls_used
+        assert sa[b].f_value == oracle.orc_objective_tree(0, xa[b].ctypes.data_as(O.pd), n)

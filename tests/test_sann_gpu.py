@@ -128,3 +128,26 @@ def test_sann_rejects_bad_configs(mod):
         mod.SANNEngine("rosenbrock", 1, 2000)
     with pytest.raises(NlsgError):
         mod.SANNEngine(17, 1, 4)
+
+
+def test_sann_bench_size_properties(mod, oracle):
+    """The bench configuration (Rosenbrock-128D, 16 384 chains, 40 temperatures here): runs are
+    deterministic, a chain's best never exceeds its start, the reported value is the objective at
+    the returned point, and sampled chains equal the oracle."""
+    B, n = 16384, 128
+    rng = np.random.default_rng(5)
+    x0 = 0.5 + (rng.random((B, n)) - 0.5)
+    kw = dict(max_iter=40, temperature_iter=10, temperature_max=10.0, seed=SEED)
+    with mod.SANNEngine("rosenbrock", B, n, **kw) as eng:
+        xa, sa = eng.minimize(x0)
+        xb, sb = eng.minimize(x0)
+    assert np.array_equal(xa, xb) and [s.f_value for s in sa] == [s.f_value for s in sb]
+    f0 = ((1 - x0[:, :-1]) ** 2 + 100 * (x0[:, 1:] - x0[:, :-1] ** 2) ** 2).sum(axis=1)
+    fa = np.array([s.f_value for s in sa])
+    assert np.all(fa <= f0 * (1 + 1e-12))
+    assert all(s.function_calls_used == 1 + 40 * 9 for s in sa)
+    for b in (0, 4097, B - 1):
+        ref, xr, _ = O.sann_sync(oracle, "rosenbrock", x0[b], SEED, b, max_iter=40, temp_iter=10,
+                                 temp_max=10.0)
+        assert np.array_equal(xa[b], xr) and sa[b].f_value == ref.f_value
+        assert sa[b].f_value == oracle.orc_objective_tree(0, xa[b].ctypes.data_as(O.pd), n)
