@@ -30,17 +30,21 @@ os.environ.setdefault("MASTER_PORT", sys.argv[3])
 torch.cuda.set_device(0)
 device = torch.device("cuda", 0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
-pop, D = 4096, 128
-x0 = np.full(D, 0.6)
 out = []
-for kw in (dict(strategy=nlsolver_amd.DE_RANDOM, eps=0.0, max_iter=9, best_val_no_change=1000),
-           dict(strategy=nlsolver_amd.DE_RANDOM, eps=0.0, max_iter=1000, best_val_no_change=2),
-           dict(strategy=nlsolver_amd.DE_RANDOM, eps=1e-300, max_iter=12, best_val_no_change=1000),
-           dict(strategy=nlsolver_amd.DE_BEST, eps=1e-300, max_iter=7, best_val_no_change=1000)):
+# (pop, D, turns, settings); the last two are soaks: thousands of turns in an accepting regime, the
+# generation on one stream racing ahead of heads, collectives and finalisers on the other
+for pop, D, turns, kw in (
+        (4096, 128, 30, dict(strategy=nlsolver_amd.DE_RANDOM, eps=0.0, max_iter=9, best_val_no_change=1000)),
+        (4096, 128, 30, dict(strategy=nlsolver_amd.DE_RANDOM, eps=0.0, max_iter=1000, best_val_no_change=2)),
+        (4096, 128, 30, dict(strategy=nlsolver_amd.DE_RANDOM, eps=1e-300, max_iter=12, best_val_no_change=1000)),
+        (4096, 128, 30, dict(strategy=nlsolver_amd.DE_BEST, eps=1e-300, max_iter=7, best_val_no_change=1000)),
+        (8192, 128, 3000, dict(strategy=nlsolver_amd.DE_RANDOM, eps=1e-300, max_iter=10**9, best_val_no_change=10**9)),
+        (8192, 32, 3000, dict(strategy=nlsolver_amd.DE_RANDOM, eps=1e-300, max_iter=10**9, best_val_no_change=10**9))):
+    x0 = np.full(D, 0.6)
     kw = dict(kw, CR=0.2, F=0.5, seed=99)
     with nlsolver_amd.DEEngine("rosenbrock", pop, D, **kw) as ref:
         ref.init(x0)
-        ref.step(30)
+        ref.step(turns)
         P0, S0 = ref.download()
         st0 = ref.status()
         bx0, bf0, bi0 = ref.best()
@@ -48,7 +52,7 @@ for kw in (dict(strategy=nlsolver_amd.DE_RANDOM, eps=0.0, max_iter=9, best_val_n
         "rosenbrock", pop, D, shard_lo=lo, shard_n=n, stream=stream, **kw), pop, D, device)
     assert drv.native == native
     drv.init(x0)
-    drv.step(30)
+    drv.step(turns)
     torch.cuda.synchronize()
     P1, S1 = drv.engine.download()
     st1 = drv.engine.status()
@@ -99,7 +103,7 @@ def test_sharded_turn_world1_matches_unsharded_engine(mode, port):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1]
     for case in json.loads(line[7:]):
-        assert case["done"] == [1, 1], case
+        assert case["done"][0] == case["done"][1], case
         assert case["iters"][0] == case["iters"][1] and case["fcalls"][0] == case["fcalls"][1], case
         assert case["best"][0] == case["best"][1], case
         assert case["same_pop"] and case["same_scores"] and case["same_best"], case
