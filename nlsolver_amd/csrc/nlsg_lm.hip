@@ -80,7 +80,7 @@ int launch_solve(nlsg_lm *e) {
       if (fd) {
         launch_fd_iter(e, 0);
       } else if (qr) {
-        hipLaunchKernelGGL(lm_qr_step_kernel, grid, dim3(256), sizeof(LmQrShared), e->stream, e->p);
+        hipLaunchKernelGGL(lm_qr_step_kernel, grid, dim3(kLmQrThreads), sizeof(LmQrShared), e->stream, e->p);
         hipLaunchKernelGGL(lm_iter_kernel, grid, dim3(64), 0, e->stream, e->p, 0, 0);
       } else {
         hipLaunchKernelGGL(lm_iter_kernel, grid, dim3(64), 0, e->stream, e->p, 0, 1);

@@ -31,6 +31,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 constexpr int kLmN = 64;        // parameters are padded to 64 columns
 constexpr int kLmJStride = 80;  // LDS row stride of the Jacobian block (doubles)
 constexpr int kLmHStride = 65;  // LDS row stride of the damped matrix (doubles)
+constexpr int kLmQrThreads = 1024;  // the QR step's workgroup: a wave per two rotations of a wavefront step
 constexpr int kLmTri = 33 * 64;  // packed lower triangle of a 64 x 64 matrix (2080) + pad
 
 struct LmProblem {
@@ -200,7 +201,7 @@ struct LmQrShared {                // LDS of the QR step (one workgroup per prob
 __device__ inline void lm_solve_qr(LmQrShared &qs, int n) {
   const int t = threadIdx.x, lane = lane_id();
   const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
-  for (int e = t; e < n * n; e += 256) {
+  for (int e = t; e < n * n; e += static_cast<int>(blockDim.x)) {
     const int i = e / n, j = e % n;
     qs.Q[i * kLmHStride + j] = (i == j) ? 1.0 : 0.0;  // make_identity, tinyqr.h:205-210
   }
@@ -226,7 +227,9 @@ __device__ inline void lm_solve_qr(LmQrShared &qs, int n) {
       qs.s[t] = sv;
     }
     __syncthreads();
-    for (int r = wid; r < count; r += 4) {  // rotate_matrix on R and Q, tinyqr.h:126-139
+    // a wave per rotation and pass (sixteen waves: at most two passes per wavefront step; with
+    // four waves the eight dependent LDS round trips per wave dominated the step)
+    for (int r = wid; r < count; r += static_cast<int>(blockDim.x >> 6)) {  // rotate_matrix on R and Q, tinyqr.h:126-139
       const int j = jlo + r, i = n - 1 - (step - 2 * j);
       const double c = qs.c[r], sv = qs.s[r];
       if (lane >= j && lane < n) {
@@ -245,7 +248,7 @@ __device__ inline void lm_solve_qr(LmQrShared &qs, int n) {
     __syncthreads();
   }
   // cleanup with lm()'s tol = 1e-12 (tinyqr.h:278-282, 465) on the entries back_solve reads
-  for (int e = t; e < n * n; e += 256) {
+  for (int e = t; e < n * n; e += static_cast<int>(blockDim.x)) {
     const int i = e / n, j = e % n;
     if (j >= i && fabs(qs.H[i * kLmHStride + j]) < 1e-12) qs.H[i * kLmHStride + j] = 0.0;
   }
@@ -667,7 +670,7 @@ __global__ __launch_bounds__(64) void lm_fd_iter_kernel(LmParams p, int first) {
 // ---- QR solver (tinyqr::lm on the damped matrix): the step as a kernel of its own, one
 // workgroup per problem (R and Q, 33 KiB each, live in LDS; the Givens wavefronts want four
 // waves), between two evaluation launches. Stop tests, damping, QR solve, theta update.
-__global__ __launch_bounds__(256) void lm_qr_step_kernel(LmParams p) {
+__global__ __launch_bounds__(kLmQrThreads) void lm_qr_step_kernel(LmParams p) {
   extern __shared__ __align__(16) unsigned char lm_smem[];
   LmQrShared &qs = *reinterpret_cast<LmQrShared *>(lm_smem);
   const uint64_t pid = blockIdx.x;
@@ -681,7 +684,7 @@ __global__ __launch_bounds__(256) void lm_qr_step_kernel(LmParams p) {
     return;
   }
   const double *tri = p.Hg + pid * kLmTri;
-  for (int e = t; e < 64 * 64; e += 256) {  // the full symmetric matrix from its lower triangle
+  for (int e = t; e < 64 * 64; e += static_cast<int>(blockDim.x)) {  // the full symmetric matrix from its lower triangle
     const int i = e >> 6, j = e & 63;
     const int hi = i > j ? i : j, lo = i > j ? j : i;
     qs.H[i * kLmHStride + j] = tri[hi * (hi + 1) / 2 + lo];
