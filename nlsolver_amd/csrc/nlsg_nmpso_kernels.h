@@ -28,9 +28,10 @@
 
 namespace nlsg {
 
-constexpr int kHybThreads = 256;  // the largest workgroup
+constexpr int kHybThreads = 1024;  // the largest workgroup
 // threads of an instance's workgroup: one per particle (the rank sort's unit of work), in whole
-// waves, at most kHybThreads — small instances then run as many small workgroups
+// waves (n = 128: seven), at most kHybThreads — small instances then run as many small workgroups,
+// large ones have enough waves to cover the row loads of the move
 __host__ __device__ inline int hyb_block_threads(uint64_t n) {
   const uint64_t waves = (3 * n + 1 + 63) / 64;
   return 64 * static_cast<int>(waves > kHybThreads / 64 ? kHybThreads / 64 : waves);
