@@ -330,7 +330,14 @@ __global__ __launch_bounds__(kHybThreads) void nmpso_solve_kernel(HybParams p) {
       if (t < static_cast<int>(n)) {  // update_centroid (3867-3884): particles in sorted order
         double c = 0.0;
         uint32_t i = 0;
-        for (; i + 8 <= ns - 1; i += 8) {  // eight loads in flight, added in the reference's order
+        for (; i + 16 <= ns - 1; i += 16) {  // sixteen loads in flight, added in the reference's order
+          double v[16];
+#pragma unroll
+          for (int u = 0; u < 16; u++) v[u] = pos[ord[i + u] * n + t];
+#pragma unroll
+          for (int u = 0; u < 16; u++) c = c + v[u];
+        }
+        for (; i + 8 <= ns - 1; i += 8) {
           double v[8];
 #pragma unroll
           for (int u = 0; u < 8; u++) v[u] = pos[ord[i + u] * n + t];
