@@ -274,10 +274,10 @@ def main_nmpso(args):
                                f"instances of {3 * n + 1} particles, {iters} iterations",
                    "iteration_instances_per_s": batch * iters / (ms * 1e-3),
                    "mean_best_f": float(np.mean([s.f_value for s in st]))},
-        "roofline": {"bound": "latency", "achieved": None, "peak": None, "unit": None,
+        "roofline": {"bound": "valu", "achieved": None, "peak": None, "unit": None,
                      "frac": None, "traffic": None, "kernel": "nmpso_solve_kernel", "kernel_ms": ms,
-                     "note": "a chain of data-dependent simplex decisions per iteration around the "
-                             "parallel PSO move; not roofline-graded"},
+                     "note": "vector-issue bound (the PSO move's keyed draws) once enough instances "
+                             "per CU hide the simplex step's dependent decisions; not roofline-graded"},
         **({} if args.no_cpu_baseline else {"cpu_baseline": ref_baseline(
             ["bench-nmpso", n, 4096, iters], "evals_per_s", "particle-evals/s",
             f"reference NelderMeadPSO, Rosenbrock-{n}D, 4096 instances x {iters} iterations")})}))
