@@ -93,11 +93,12 @@ def test_pso_class_mirror_reaches_reference_quality(mod, golden):
 
 @pytest.mark.parametrize("type_", [O.PSO_ACCELERATED, O.PSO_VANILLA])
 @pytest.mark.parametrize("eps", [0.0, 200.0])
-def test_pso_sharded_path_on_one_gpu_bit_exact(mod, oracle, type_, eps):
+@pytest.mark.parametrize("D", [256, 24])  # one particle per wave / several per wave
+def test_pso_sharded_path_on_one_gpu_bit_exact(mod, oracle, type_, eps, D):
     import torch
     dev = torch.device("cuda", 0)
     stream = torch.cuda.current_stream(dev).cuda_stream
-    n, D, shards, turns = 4096, 256, 4, 6
+    n, shards, turns = 4096, 4, 6
     kw = dict(type=type_, eps=eps, max_iter=1000, best_val_no_change=1000)
     ref = O.PSOSyncRun(oracle, "rosenbrock", n, D, -2.048, 2.048, n_shards=shards, **kw)
     ref.step(turns)
