@@ -7,8 +7,10 @@ mutation/crossover/evaluation/selection over the whole population) on synthetic
 input: x0_i = 4.096, CR=0.9, F=0.8, strategy random, early stops disabled.
 
     python bench.py --gpus N --steps K --warmup W
-(N>1: launched by torch.distributed.run, one rank per GPU, weak scaling: every
-GPU owns 65536 agents.) Rank 0 prints ONE JSON line.
+N > 1: one rank per GPU, weak scaling (every GPU owns 65536 agents). Either an external launcher
+(torch.distributed.run) has set RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*, or — WORLD_SIZE unset —
+this process starts the N ranks itself as fresh child processes before anything touches a GPU
+(launch_ranks) and forwards rank 0's line. Rank 0 prints ONE JSON line.
 """
 import argparse
 import contextlib
@@ -28,6 +30,102 @@ D = 128
 POP_PER_GPU = 65536
 BYTES_PER_CANDIDATE = 5 * D * 8 + 16  # 4 row reads + 1 row write + score r/w
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes
+    of this one (which has not imported torch, let alone touched a GPU — never an exec), wait for
+    them, forward rank 0's JSON line, exit non-zero if any rank failed."""
+    import socket
+    with socket.socket() as sk:  # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    import tempfile
+    procs = []
+    with tempfile.TemporaryFile(mode="w+") as out0:
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]],
+                                          env=env, stdout=out0 if r == 0 else sys.stderr,
+                                          stderr=sys.stderr))
+        # a rank that died leaves its peers inside a collective: give them a grace period, then
+        # end exactly the processes started here
+        failed_at = None
+        while any(p.poll() is None for p in procs):
+            if failed_at is None and any(p.poll() not in (None, 0) for p in procs):
+                failed_at = time.monotonic()
+            if failed_at is not None and time.monotonic() - failed_at > 30.0:
+                for p in procs:
+                    if p.poll() is None:
+                        p.kill()
+            time.sleep(0.05)
+        rcs = [p.returncode for p in procs]
+        out0.seek(0)
+        lines = [l for l in out0.read().splitlines() if l.strip()]
+    for l in lines[:-1]:
+        print(l, file=sys.stderr)
+    if any(rcs) or not lines:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: rank exit codes {rcs}")
+    print(lines[-1])
+
+
+class Ranks:
+    """This process's place in the job: one rank per GPU. world > 1 (or NLSG_BENCH_FORCE_DIST=1)
+    opens a torch.distributed process group — RCCL; gloo under NLSG_BENCH_REHEARSAL=1 — which the
+    sharded workloads use for their exchange and every workload uses for the barrier and the
+    max-over-ranks of the timed region."""
+
+    def __init__(self, args):
+        import torch
+        self.torch = torch
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        if self.world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}")
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+        self.local_rank = rehearsal_device(int(os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(self.local_rank)
+        self.device = torch.device("cuda", self.local_rank)
+        # NLSG_BENCH_FORCE_DIST=1 exercises the sharded/RCCL path with a single rank (self-test)
+        self.distributed = self.world > 1 or os.environ.get("NLSG_BENCH_FORCE_DIST") == "1"
+        self.dist = None
+        if self.distributed:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            dist.init_process_group(**pg_args(self.rank, self.world, self.device))
+            self.dist = dist
+
+    def barrier(self):
+        if self.distributed:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, value):
+        if not self.distributed:
+            return value
+        t = self.torch.tensor([value], dtype=self.torch.float64,
+                              device="cpu" if self.dist.get_backend() == "gloo" else self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def slice_seed(self, base):
+        """Replica workloads (independent problems, no collective): rank r solves problems
+        [r * batch, (r + 1) * batch) of a global batch of world * batch, drawn from its own
+        stream so that no two ranks hold the same problem."""
+        return (base + 7919 * self.rank) % 2**32
+
+    def replicas(self):
+        return (f"replicas x{self.world}: disjoint slices of {self.world} x batch independent "
+                "problems, no data-path collective")
+
+    def close(self):
+        if self.distributed:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
 
 
 def cpu_baseline():
@@ -100,42 +198,55 @@ def ref_baseline(cmd, key, unit, sample):
             "sample": f"{sample} ({r['seconds']:.1f} s), 1 thread (library is single-threaded by design)"}
 
 
+PMC_DIRS = ("profiles/r02", "profiles/r01")  # newest first
+
+
 def pmc_traffic(pop_local):
     """HBM bytes per launch of de_generation_kernel from the committed rocprofv3 PMC passes
-    (profiles/r01/de_pmc_summary.json; separate FETCH_SIZE / WRITE_SIZE runs of this script),
+    (profiles/rNN/de_pmc_summary.json; separate FETCH_SIZE / WRITE_SIZE runs of this script),
     corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE counts half of wide coalesced
     reads on gfx950 (calibrated on de_scan_partial_kernel's known 8 B/agent), WRITE_SIZE exact;
-    both in KiB. None when no profile exists for this population size."""
-    path = os.path.join(ROOT, "profiles", "r01", "de_pmc_summary.json")
+    both in KiB. The figure is read from the committed profile, not measured in this run:
+    `traffic_source` names the file. None when no profile exists for this population size."""
     tag = {65536: "c2b", 1048576: "nsb"}.get(pop_local)
-    if tag is None or not os.path.exists(path):
-        return None
-    prof = json.load(open(path)).get(tag, {})
-    pick = lambda ctr: next((v["mean_KiB"] for k, v in prof.get(ctr, {}).items()
-                             if "de_generation_kernel" in k), None)
-    fetch, write = pick("FETCH_SIZE"), pick("WRITE_SIZE")
-    if fetch is None or write is None:
-        return None
-    return (2.0 * fetch + write) * 1024.0
+    for d in PMC_DIRS:
+        path = os.path.join(ROOT, d, "de_pmc_summary.json")
+        if tag is None or not os.path.exists(path):
+            continue
+        prof = json.load(open(path)).get(tag, {})
+        pick = lambda ctr: next((v["mean_KiB"] for k, v in prof.get(ctr, {}).items()
+                                 if "de_generation_kernel" in k), None)
+        fetch, write = pick("FETCH_SIZE"), pick("WRITE_SIZE")
+        if fetch is not None and write is not None:
+            return {"traffic": (2.0 * fetch + write) * 1024.0,
+                    "traffic_source": f"{d}/de_pmc_summary.json[{tag}] (committed rocprofv3 --pmc "
+                                      "passes of this script; not collected in this run)"}
+    return {"traffic": None, "traffic_source": None}
 
 
 def pmc_bytes(tag, kernels, default_sizes=True):
     """HBM bytes per launch summed over `kernels` (name fragments) from the committed PMC passes
-    of `bench.py --workload <tag>` at its default size (profiles/r01/pmc_summary.json, made by
+    of `bench.py --workload <tag>` at its default size (profiles/rNN/pmc_summary.json, made by
     profiles/summarize_pmc.py): 2 x FETCH_SIZE + WRITE_SIZE KiB, the gfx950 correction of
-    MI355X_MICROARCH.md. None when not profiled or the run is not at the default size."""
-    path = os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")
-    if not default_sizes or not os.path.exists(path):
-        return None
-    prof = json.load(open(path)).get(tag, {})
-    total = 0.0
-    for frag in kernels:
-        f = next((v["mean_KiB"] for k, v in prof.get("FETCH_SIZE", {}).items() if frag in k), None)
-        w = next((v["mean_KiB"] for k, v in prof.get("WRITE_SIZE", {}).items() if frag in k), None)
-        if f is None or w is None:
-            return None
-        total += (2.0 * f + w) * 1024.0
-    return total
+    MI355X_MICROARCH.md. traffic None when not profiled or the run is not at the default size."""
+    for d in PMC_DIRS:
+        path = os.path.join(ROOT, d, "pmc_summary.json")
+        if not default_sizes or not os.path.exists(path):
+            continue
+        prof = json.load(open(path)).get(tag, {})
+        total = 0.0
+        for frag in kernels:
+            f = next((v["mean_KiB"] for k, v in prof.get("FETCH_SIZE", {}).items() if frag in k), None)
+            w = next((v["mean_KiB"] for k, v in prof.get("WRITE_SIZE", {}).items() if frag in k), None)
+            if f is None or w is None:
+                total = None
+                break
+            total += (2.0 * f + w) * 1024.0
+        if total is not None:
+            return {"traffic": total,
+                    "traffic_source": f"{d}/pmc_summary.json[{tag}] (committed rocprofv3 --pmc "
+                                      "passes of this script; not collected in this run)"}
+    return {"traffic": None, "traffic_source": None}
 
 
 def main_bfgs(args):
@@ -150,22 +261,23 @@ def main_bfgs(args):
     import nlsolver_amd
     n = 1024
     batch = 4096 if args.pop_per_gpu == POP_PER_GPU else args.pop_per_gpu
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
+    ranks = Ranks(args)
+    local_rank = ranks.local_rank
     d = np.array([1.0 + 9.0 * i / (n - 1) for i in range(n)])
     b = np.array([math.sin(0.1 * i) for i in range(n)])
-    rng = np.random.default_rng(12374563468 % 2**32)
+    rng = np.random.default_rng(ranks.slice_seed(12374563468 % 2**32))
     x0 = 1.0 + 0.5 * (rng.random((batch, n)) - 0.5)
     steps, warm = min(args.steps, 40), min(args.warmup, 4)
     eng = nlsolver_amd.BFGSEngine(nlsolver_amd.QuadDiagRank1(d, b, 0.01), batch,
-                                  max_iter=10**9, grad_eps=0.0, alpha=1.0, device=local_rank)
+                                  max_iter=10**9, grad_eps=0.0, alpha=1.0, device=local_rank,
+                                  **({"symmetric": True} if args.bfgs_symmetric else {}))
     eng.init(x0)
     eng.step(warm)
-    torch.cuda.synchronize()
+    ranks.barrier()
     t0 = time.perf_counter()
     eng.step(steps)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    ranks.barrier()
+    dt = ranks.max_over_ranks(time.perf_counter() - t0)
     open_ = eng.unfinished()
     # the H-pass figure is taken on iterations 8..11 of a fresh run: dense H for every problem
     # (towards convergence the reset guard re-identities H and the passes skip their reads)
@@ -173,26 +285,35 @@ def main_bfgs(args):
     eng.step(8)
     total_ms, hess_ms = eng.time_steps(4)
     hess_ms /= 4
-    bytes_per_iter = 3 * n * n * 8 * batch  # read H (t = H y) + read & write H (update)
+    # literal: read H (t = H y) + read & write H (update); symmetric: the upper blocks only
+    bytes_per_iter = (eng.hessian_bytes_per_iteration() if args.bfgs_symmetric
+                      else 3 * n * n * 8) * batch
     achieved = bytes_per_iter / (hess_ms * 1e-3) / 1e9
-    print(json.dumps({
-        "metric": "BFGS iterations x problems / s (quadratic dim=1024)",
-        "value": batch * steps / dt, "unit": "iteration-problems/s", "n_gpus": 1, "steps": steps,
-        "warmup": warm, "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"BFGS + More-Thuente, convex quadratic dim={n}, batch={batch} "
-                               "independent starts (BASELINE configs[2])",
-                   "unfinished_problems": open_},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": pmc_bytes("bfgs", ["bfgs_hy_kernel", "bfgs_update_kernel"],
-                                          batch == 4096),
-                     "kernel": "bfgs_hy_kernel + bfgs_update_kernel", "kernel_ms": hess_ms,
-                     "algorithmic_bytes_per_launch": bytes_per_iter},
-        **({} if args.no_cpu_baseline else {"cpu_baseline": ref_baseline(
-            ["bench-bfgs", n, 24], "iterations_per_s", "iteration-problems/s",
-            f"reference BFGS, same quadratic dim={n}, 24 starts x 50 iterations")})}))
+    if ranks.rank == 0:
+        print(json.dumps({
+            "metric": "BFGS iterations x problems / s (quadratic dim=1024)",
+            "value": ranks.world * batch * steps / dt, "unit": "iteration-problems/s",
+            "n_gpus": ranks.world, "steps": steps,
+            "warmup": warm, "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"BFGS + More-Thuente, convex quadratic dim={n}, batch={batch} "
+                                   "independent starts per GPU (BASELINE configs[2]), "
+                                   f"{'symmetric (upper blocks of H)' if args.bfgs_symmetric else 'literal'}"
+                                   " rank-2 update",
+                       "unfinished_problems": open_, "parallelism": ranks.replicas()},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS,
+                         **pmc_bytes("bfgs_sym" if args.bfgs_symmetric else "bfgs",
+                                     ["bfgs_sym_hy_kernel", "bfgs_sym_update_kernel"] if args.bfgs_symmetric
+                                     else ["bfgs_hy_kernel", "bfgs_update_kernel"], batch == 4096),
+                         "kernel": ("bfgs_sym_hy_kernel + bfgs_sym_update_kernel" if args.bfgs_symmetric
+                                    else "bfgs_hy_kernel + bfgs_update_kernel"), "kernel_ms": hess_ms,
+                         "algorithmic_bytes_per_launch": bytes_per_iter},
+            **({} if (args.no_cpu_baseline or ranks.world > 1) else {"cpu_baseline": ref_baseline(
+                ["bench-bfgs", n, 24], "iterations_per_s", "iteration-problems/s",
+                f"reference BFGS, same quadratic dim={n}, 24 starts x 50 iterations")})}))
     eng.close()
+    ranks.close()
 
 
 def main_bfgs_fd(args):
@@ -200,48 +321,59 @@ def main_bfgs_fd(args):
     Rosenbrock-128D, batch = 4096 independent starts, 20 iterations. One step = one BFGS iteration
     of every problem; each gradient costs 4 n = 512 objective evaluations of 128 terms, made by
     the problem's wave one after the other."""
-    import torch
-
     import nlsolver_amd
     n, iters = 128, 20
     batch = 4096 if args.pop_per_gpu == POP_PER_GPU else args.pop_per_gpu
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    rng = np.random.default_rng(12374563468 % 2**32)
+    ranks = Ranks(args)
+    rng = np.random.default_rng(ranks.slice_seed(12374563468 % 2**32))
     x0 = 0.8 + 0.4 * (rng.random((batch, n)) - 0.5)
     eng = nlsolver_amd.BFGSEngine("rosenbrock", batch, dim=n, max_iter=iters, grad_eps=0.0,
-                                  alpha=1.0, device=local_rank)
+                                  alpha=1.0, device=ranks.local_rank)
     eng.init(x0)
     eng.step(2)
-    torch.cuda.synchronize()
+    ranks.barrier()
     eng.init(x0)
-    torch.cuda.synchronize()
+    ranks.barrier()
     t0 = time.perf_counter()
     eng.step(iters + 1)  # the last turn only fires the stop test and evaluates f once
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    ranks.barrier()
+    dt = ranks.max_over_ranks(time.perf_counter() - t0)
     x, st = eng.download()
     fcalls = sum(s.function_calls_used for s in st)
     assert all(s.done and s.iteration == iters for s in st)
-    print(json.dumps({
-        "metric": "BFGS iterations x problems / s (Rosenbrock-128D, finite-difference gradient)",
-        "value": batch * iters / dt, "unit": "iteration-problems/s", "n_gpus": 1, "steps": iters,
-        "warmup": 2, "ms_per_step": dt / iters * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"BFGS + More-Thuente, default fin_diff gradient, Rosenbrock-{n}D, "
-                               f"batch={batch} independent starts",
-                   "objective_calls_per_s": fcalls / dt,
-                   "mean_final_f": float(np.mean([s.f_value for s in st]))},
-        "roofline": {"bound": "latency", "achieved": None, "peak": None, "unit": None,
-                     "frac": None, "traffic": None, "kernel": "bfgs_search_kernel",
-                     "kernel_ms": dt / iters * 1e3,
-                     "note": "4 n dependent objective evaluations per gradient in one wave; "
-                             "not roofline-graded"},
-        **({} if args.no_cpu_baseline else {"cpu_baseline": ref_baseline(
-            ["bench-bfgs-fd", n, 256, iters], "iterations_per_s", "iteration-problems/s",
-            f"reference BFGS, default fin_diff gradient, Rosenbrock-{n}D, 256 starts x {iters} "
-            "iterations")})}))
+    if ranks.rank == 0:
+        print(json.dumps({
+            "metric": "BFGS iterations x problems / s (Rosenbrock-128D, finite-difference gradient)",
+            "value": ranks.world * batch * iters / dt, "unit": "iteration-problems/s",
+            "n_gpus": ranks.world, "steps": iters,
+            "warmup": 2, "ms_per_step": dt / iters * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"BFGS + More-Thuente, default fin_diff gradient, Rosenbrock-{n}D, "
+                                   f"batch={batch} independent starts per GPU",
+                       "objective_calls_per_s": ranks.world * fcalls / dt,
+                       "mean_final_f": float(np.mean([s.f_value for s in st])),
+                       "parallelism": ranks.replicas()},
+            "roofline": {"bound": "latency", "achieved": None, "peak": None, "unit": None,
+                         "frac": None, "traffic": None, "kernel": "bfgs_search_kernel",
+                         "kernel_ms": dt / iters * 1e3,
+                         "note": "4 n dependent objective evaluations per gradient in one wave; "
+                                 "not roofline-graded"},
+            **({} if (args.no_cpu_baseline or ranks.world > 1) else {"cpu_baseline": ref_baseline(
+                ["bench-bfgs-fd", n, 256, iters], "iterations_per_s", "iteration-problems/s",
+                f"reference BFGS, default fin_diff gradient, Rosenbrock-{n}D, 256 starts x {iters} "
+                "iterations")})}))
     eng.close()
+    ranks.close()
+
+
+def timed_solves(ranks, eng, x0, reps):
+    """The contract's bracket around an engine's own event-timed solves (inputs resident, the
+    start points re-uploaded outside the events): barrier + synchronize on both sides, the
+    slowest rank's milliseconds per solve."""
+    ranks.barrier()
+    ms = eng.time_solve(x0, reps) / reps
+    ranks.barrier()
+    return ranks.max_over_ranks(ms)
 
 
 def main_nmpso(args):
@@ -249,39 +381,40 @@ def main_nmpso(args):
     instance), 4096 independent instances, 100 iterations (eps = 0, no early stop). One step = one
     iteration of every instance: sort, simplex step on the best 33 particles, PSO move + evaluation
     of the other 64."""
-    import torch
-
     import nlsolver_amd
     n, iters = 32, 100
     batch = 4096 if args.pop_per_gpu == POP_PER_GPU else args.pop_per_gpu
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    rng = np.random.default_rng(12374563468 % 2**32)
+    ranks = Ranks(args)
+    rng = np.random.default_rng(ranks.slice_seed(12374563468 % 2**32))
     x0 = 0.5 + 1.0 * (rng.random((batch, n)) - 0.5)
     eng = nlsolver_amd.NMPSOEngine("rosenbrock", batch, n, max_iter=iters, eps=0.0,
-                                   no_change_best_iter=2**62, device=local_rank)
+                                   no_change_best_iter=2**62, device=ranks.local_rank,
+                                   inst_lo=ranks.rank * batch)
     x, st = eng.minimize(x0)
-    reps = 3
-    ms = eng.time_solve(x0, reps) / reps
+    ms = timed_solves(ranks, eng, x0, 3)
     evals = sum(s.function_calls_used for s in st)
     assert all(s.iteration == iters for s in st)
-    print(json.dumps({
-        "metric": "NelderMeadPSO objective evaluations x instances / s (Rosenbrock-32D)",
-        "value": evals / (ms * 1e-3), "unit": "particle-evals/s", "n_gpus": 1, "steps": iters,
-        "warmup": iters, "ms_per_step": ms / iters, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"NelderMeadPSO, Rosenbrock-{n}D, batch={batch} independent "
-                               f"instances of {3 * n + 1} particles, {iters} iterations",
-                   "iteration_instances_per_s": batch * iters / (ms * 1e-3),
-                   "mean_best_f": float(np.mean([s.f_value for s in st]))},
-        "roofline": {"bound": "valu", "achieved": None, "peak": None, "unit": None,
-                     "frac": None, "traffic": None, "kernel": "nmpso_solve_kernel", "kernel_ms": ms,
-                     "note": "vector-issue bound (the PSO move's keyed draws) once enough instances "
-                             "per CU hide the simplex step's dependent decisions; not roofline-graded"},
-        **({} if args.no_cpu_baseline else {"cpu_baseline": ref_baseline(
-            ["bench-nmpso", n, 4096, iters], "evals_per_s", "particle-evals/s",
-            f"reference NelderMeadPSO, Rosenbrock-{n}D, 4096 instances x {iters} iterations")})}))
+    if ranks.rank == 0:
+        print(json.dumps({
+            "metric": "NelderMeadPSO objective evaluations x instances / s (Rosenbrock-32D)",
+            "value": ranks.world * evals / (ms * 1e-3), "unit": "particle-evals/s",
+            "n_gpus": ranks.world, "steps": iters,
+            "warmup": iters, "ms_per_step": ms / iters, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"NelderMeadPSO, Rosenbrock-{n}D, batch={batch} independent "
+                                   f"instances of {3 * n + 1} particles per GPU, {iters} iterations",
+                       "iteration_instances_per_s": ranks.world * batch * iters / (ms * 1e-3),
+                       "mean_best_f": float(np.mean([s.f_value for s in st])),
+                       "parallelism": ranks.replicas()},
+            "roofline": {"bound": "valu", "achieved": None, "peak": None, "unit": None,
+                         "frac": None, "traffic": None, "kernel": "nmpso_solve_kernel", "kernel_ms": ms,
+                         "note": "vector-issue bound (the PSO move's keyed draws) once enough instances "
+                                 "per CU hide the simplex step's dependent decisions; not roofline-graded"},
+            **({} if (args.no_cpu_baseline or ranks.world > 1) else {"cpu_baseline": ref_baseline(
+                ["bench-nmpso", n, 4096, iters], "evals_per_s", "particle-evals/s",
+                f"reference NelderMeadPSO, Rosenbrock-{n}D, 4096 instances x {iters} iterations")})}))
     eng.close()
+    ranks.close()
 
 
 def main_sann(args):
@@ -290,40 +423,41 @@ def main_sann(args):
     = one temperature of every chain = 9 trial points (9 x 128 normal draws + one objective
     evaluation each), one wave per chain, nothing but registers between the first load and the
     last store."""
-    import torch
-
     import nlsolver_amd
     n, iters, t_iter = 128, 100, 10
     batch = 16384 if args.pop_per_gpu == POP_PER_GPU else args.pop_per_gpu
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    rng = np.random.default_rng(12374563468 % 2**32)
+    ranks = Ranks(args)
+    rng = np.random.default_rng(ranks.slice_seed(12374563468 % 2**32))
     x0 = 0.5 + 1.0 * (rng.random((batch, n)) - 0.5)
     eng = nlsolver_amd.SANNEngine("rosenbrock", batch, n, max_iter=iters, temperature_iter=t_iter,
-                                  temperature_max=10.0, device=local_rank)
+                                  temperature_max=10.0, device=ranks.local_rank,
+                                  chain_lo=ranks.rank * batch)
     x, st = eng.minimize(x0)
-    reps = 3
-    ms = eng.time_solve(x0, reps) / reps
+    ms = timed_solves(ranks, eng, x0, 3)
     trials = sum(s.function_calls_used for s in st)
     f0 = float(np.mean([((1 - r[:-1]) ** 2 + 100 * (r[1:] - r[:-1] ** 2) ** 2).sum() for r in x0[:256]]))
-    print(json.dumps({
-        "metric": "SANN trial points x chains / s (Rosenbrock-128D)",
-        "value": trials / (ms * 1e-3), "unit": "trial-points/s", "n_gpus": 1, "steps": iters,
-        "warmup": iters, "ms_per_step": ms / iters, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"SANN, Rosenbrock-{n}D, batch={batch} independent chains, "
-                               f"{iters} temperatures x {t_iter - 1} trial points",
-                   "normal_draws_per_s": trials * n / (ms * 1e-3),
-                   "mean_start_f": f0, "mean_best_f": float(np.mean([s.f_value for s in st]))},
-        "roofline": {"bound": "valu", "achieved": None, "peak": None, "unit": None, "frac": None,
-                     "traffic": None, "kernel": "sann_anneal_kernel", "kernel_ms": ms,
-                     "note": "register-resident chains: two counter draws, log, cos, sqrt per "
-                             "coordinate and trial on the fp64 VALU; not roofline-graded"},
-        **({} if args.no_cpu_baseline else {"cpu_baseline": ref_baseline(
-            ["bench-sann", n, 4096, iters, t_iter], "trials_per_s", "trial-points/s",
-            f"reference SANN, Rosenbrock-{n}D, 4096 chains x {iters} temperatures x {t_iter - 1} "
-            "trial points")})}))
+    if ranks.rank == 0:
+        print(json.dumps({
+            "metric": "SANN trial points x chains / s (Rosenbrock-128D)",
+            "value": ranks.world * trials / (ms * 1e-3), "unit": "trial-points/s",
+            "n_gpus": ranks.world, "steps": iters,
+            "warmup": iters, "ms_per_step": ms / iters, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"SANN, Rosenbrock-{n}D, batch={batch} independent chains per GPU, "
+                                   f"{iters} temperatures x {t_iter - 1} trial points",
+                       "normal_draws_per_s": ranks.world * trials * n / (ms * 1e-3),
+                       "mean_start_f": f0, "mean_best_f": float(np.mean([s.f_value for s in st])),
+                       "parallelism": ranks.replicas()},
+            "roofline": {"bound": "valu", "achieved": None, "peak": None, "unit": None, "frac": None,
+                         "traffic": None, "kernel": "sann_anneal_kernel", "kernel_ms": ms,
+                         "note": "register-resident chains: two counter draws, log, cos, sqrt per "
+                                 "coordinate and trial on the fp64 VALU; not roofline-graded"},
+            **({} if (args.no_cpu_baseline or ranks.world > 1) else {"cpu_baseline": ref_baseline(
+                ["bench-sann", n, 4096, iters, t_iter], "trials_per_s", "trial-points/s",
+                f"reference SANN, Rosenbrock-{n}D, 4096 chains x {iters} temperatures x {t_iter - 1} "
+                "trial points")})}))
     eng.close()
+    ranks.close()
 
 
 def main_lm_fd(args):
@@ -331,76 +465,82 @@ def main_lm_fd(args):
     nlsolver.h:3494-3511) on the device: Rosenbrock-16D, batch = 8192 independent starts, 10
     iterations. One step = one LM iteration of every problem = 1 + 4 n + 16 n^2 = 4161 objective
     evaluations per problem, several probe points per wave."""
-    import torch
-
     import nlsolver_amd
     n, iters = 16, 10
     batch = 8192 if args.pop_per_gpu == POP_PER_GPU else args.pop_per_gpu
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    rng = np.random.default_rng(12374563468 % 2**32)
+    ranks = Ranks(args)
+    rng = np.random.default_rng(ranks.slice_seed(12374563468 % 2**32))
     x0 = 0.8 + 0.4 * (rng.random((batch, n)) - 0.5)
     eng = nlsolver_amd.lm.LMEngine("rosenbrock", batch=batch, n=n, lam=10.0, max_iter=iters,
-                                   f_delta=0.0, device=local_rank)
+                                   f_delta=0.0, device=ranks.local_rank)
     x, st, lam = eng.minimize(x0.copy())
-    reps = 5
-    ms = eng.time_solve(x0, reps) / reps
+    ms = timed_solves(ranks, eng, x0, 5)
     fcalls = sum(s.function_calls_used for s in st)
     assert all(s.iteration == iters for s in st)
-    print(json.dumps({
-        "metric": "LM iterations x problems / s (Rosenbrock-16D, finite-difference gradient and Hessian)",
-        "value": batch * iters / (ms * 1e-3), "unit": "iteration-problems/s", "n_gpus": 1,
-        "steps": iters, "warmup": iters, "ms_per_step": ms / iters, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"Levenberg-Marquardt, default fin_diff / fin_diff_h functors, "
-                               f"Rosenbrock-{n}D, batch={batch} independent starts",
-                   "objective_calls_per_s": fcalls / (ms * 1e-3),
-                   "finite_final_f": int(np.sum(np.isfinite([s.f_value for s in st])))},
-        "roofline": {"bound": "valu", "achieved": None, "peak": None, "unit": None,
-                     "frac": None, "traffic": None, "kernel": "lm_fd_iter_kernel",
-                     "kernel_ms": ms / (iters + 1),
-                     "note": "fp64 VALU issue bound (objective probes, 8 per wave pass); "
-                             "not roofline-graded"},
-        **({} if args.no_cpu_baseline else {"cpu_baseline": ref_baseline(
-            ["bench-lm-fd", n, 16384, iters], "iterations_per_s", "iteration-problems/s",
-            f"reference LevenbergMarquardt, default functors, Rosenbrock-{n}D, 16384 starts x "
-            f"{iters} iterations")})}))
+    if ranks.rank == 0:
+        print(json.dumps({
+            "metric": "LM iterations x problems / s (Rosenbrock-16D, finite-difference gradient and Hessian)",
+            "value": ranks.world * batch * iters / (ms * 1e-3), "unit": "iteration-problems/s",
+            "n_gpus": ranks.world,
+            "steps": iters, "warmup": iters, "ms_per_step": ms / iters, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"Levenberg-Marquardt, default fin_diff / fin_diff_h functors, "
+                                   f"Rosenbrock-{n}D, batch={batch} independent starts per GPU",
+                       "objective_calls_per_s": ranks.world * fcalls / (ms * 1e-3),
+                       "finite_final_f": int(np.sum(np.isfinite([s.f_value for s in st]))),
+                       "parallelism": ranks.replicas()},
+            "roofline": {"bound": "valu", "achieved": None, "peak": None, "unit": None,
+                         "frac": None, "traffic": None, "kernel": "lm_fd_iter_kernel",
+                         "kernel_ms": ms / (iters + 1),
+                         "note": "fp64 VALU issue bound (objective probes, 8 per wave pass); "
+                                 "not roofline-graded"},
+            **({} if (args.no_cpu_baseline or ranks.world > 1) else {"cpu_baseline": ref_baseline(
+                ["bench-lm-fd", n, 16384, iters], "iterations_per_s", "iteration-problems/s",
+                f"reference LevenbergMarquardt, default functors, Rosenbrock-{n}D, 16384 starts x "
+                f"{iters} iterations")})}))
     eng.close()
+    ranks.close()
 
 
 def main_lm(args):
     """BASELINE configs[3]: Levenberg-Marquardt NLLS m=512, n=64, batch=8192 on one GPU
     (tanh regression, 20 iterations, lambda0 = 10, up = down = 10, f_delta = 0). One step = one
-    LM iteration of every problem: residuals + J^T J (fp64 MFMA) + J^T r, damped Cholesky solve,
-    update. Cholesky solver: one launch per iteration for all problems in lock step (one wave per
-    problem: step, then evaluation); QR solver: a step kernel (one workgroup per problem) between
-    evaluation launches. The timed region is the whole solve divided by its iteration
-    count; the roofline object describes the evaluation kernel timed on its own."""
-    import torch
-
+    LM iteration of every problem: residuals + J^T J (fp64 MFMA) + J^T r, damped solve, update.
+    Cholesky solver (the reference class's own get_update_with_hessian): one launch per iteration
+    for all problems in lock step (one wave per problem: step, then evaluation); QR solver
+    (tinyqr::lm, as BASELINE words the config): a step kernel between evaluation launches. The
+    line's `value` is the solver --lm-solver names; the other solver is timed in the same run on
+    the same resident data and reported as `config.other_solver`. The timed region is the whole
+    solve divided by its iteration count; the roofline object describes the evaluation kernel
+    (shared by both solvers) timed on its own."""
     import nlsolver_amd
     m, n, iters = 512, 64, 20
     batch = 8192 if args.pop_per_gpu == POP_PER_GPU else args.pop_per_gpu
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    rng = np.random.default_rng(12374563468 % 2**32)
+    ranks = Ranks(args)
+    rng = np.random.default_rng(ranks.slice_seed(12374563468 % 2**32))
     A = (2 * rng.random((batch, m, n)) - 1) / np.sqrt(n)
     star = 2 * rng.random((batch, n)) - 1
     y = np.tanh(np.einsum("bmn,bn->bm", A, star))
     theta0 = 0.5 * star + 0.1 * (2 * rng.random((batch, n)) - 1)
     from nlsolver_amd import _capi
     model = nlsolver_amd.TanhRegression(A, y)
+    solvers = {"cholesky": _capi.LM_CHOLESKY, "qr": _capi.LM_QR}
     t_up = time.perf_counter()
-    eng = nlsolver_amd.LMEngine(model, lam=10.0, max_iter=iters,
-                                f_delta=0.0, device=local_rank,
-                                solver=_capi.LM_QR if args.lm_solver == "qr" else _capi.LM_CHOLESKY)
+    eng = nlsolver_amd.LMEngine(model, lam=10.0, max_iter=iters, f_delta=0.0,
+                                device=ranks.local_rank, solver=solvers[args.lm_solver])
     # the boundary hands over HOST buffers (A: 2 GiB at batch 8192): engine creation = allocation
-    # + pageable-memory upload + device repack; reported beside `value`, never inside it
+    # + upload + device repack; reported beside `value`, never inside it
     upload_s = time.perf_counter() - t_up
     eng.time_solve(theta0, 1)  # warm-up
-    reps = 3
-    ms = eng.time_solve(theta0, reps) / reps
+    ms = timed_solves(ranks, eng, theta0, 3)
     th, st, lam = eng.minimize(theta0.copy())
+    # the other solver on the same resident data
+    other_name = "qr" if args.lm_solver == "cholesky" else "cholesky"
+    eng.set_solver(solvers[other_name])
+    eng.time_solve(theta0, 1)
+    ms_other = timed_solves(ranks, eng, theta0, 3)
+    th_o, st_o, _ = eng.minimize(theta0.copy())
+    eng.set_solver(solvers[args.lm_solver])
     evals = iters + 1
     hbm_eval = (m * 64 * 8 + m * 8) * batch  # A and y streamed once per evaluation
     # the evaluation launch (both solvers share it), timed on its own: ten lower 16 x 16 tiles of
@@ -410,65 +550,78 @@ def main_lm(args):
     flops = 2.0 * m * 10 * 256 * batch
     tflops = flops / (kms * 1e-3) / 1e12
     hbm_gbps = hbm_eval / (kms * 1e-3) / 1e9
-    print(json.dumps({
-        "metric": "LM iterations x problems / s (NLLS m=512 n=64)",
-        "value": batch * iters / (ms * 1e-3), "unit": "iteration-problems/s", "n_gpus": 1,
-        "steps": iters, "warmup": 1, "ms_per_step": ms / iters, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"Levenberg-Marquardt tanh-regression NLLS m={m} n={n}, "
-                               f"batch={batch} (BASELINE configs[3]), {args.lm_solver} solve",
-                   "max_final_f": max(s.f_value for s in st),
-                   # what an iteration spends outside the evaluation launch (the damped solve)
-                   "solve_ms_per_iteration": ms / iters - kms * evals / iters,
-                   # host buffers in, host buffers out: data upload + one whole solve
-                   "upload_s": upload_s, "upload_GBps": (A.nbytes + y.nbytes) / upload_s / 1e9,
-                   "pcie_inclusive_value": batch * iters / (upload_s + ms * 1e-3)},
-        "roofline": {"bound": "mfma", "achieved": tflops, "peak": 78.6, "unit": "TFLOP/s",
-                     "frac": tflops / 78.6,
-                     "traffic": pmc_bytes("lm", ["lm_iter_kernel"], batch == 8192),
-                     "kernel": kname,
-                     "kernel_ms": kms, "algorithmic_flops_per_launch": flops,
-                     "hbm_GBps": hbm_gbps, "hbm_frac": hbm_gbps / 8000.0},
-        **({} if args.no_cpu_baseline else {"cpu_baseline": ref_baseline(
-            ["bench-lm", m, n, 256, iters], "iterations_per_s", "iteration-problems/s",
-            f"reference LevenbergMarquardt + GN functors, m={m} n={n}, 256 problems x {iters} "
-            "iterations")})}))
+    if ranks.rank == 0:
+        print(json.dumps({
+            "metric": "LM iterations x problems / s (NLLS m=512 n=64)",
+            "value": ranks.world * batch * iters / (ms * 1e-3), "unit": "iteration-problems/s",
+            "n_gpus": ranks.world,
+            "steps": iters, "warmup": 1, "ms_per_step": ms / iters, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"Levenberg-Marquardt tanh-regression NLLS m={m} n={n}, "
+                                   f"batch={batch} per GPU (BASELINE configs[3]), {args.lm_solver} solve",
+                       "max_final_f": max(s.f_value for s in st),
+                       # what an iteration spends outside the evaluation launch (the damped solve)
+                       "solve_ms_per_iteration": ms / iters - kms * evals / iters,
+                       "other_solver": {
+                           "solver": other_name,
+                           "value": ranks.world * batch * iters / (ms_other * 1e-3),
+                           "ms_per_step": ms_other / iters,
+                           "solve_ms_per_iteration": ms_other / iters - kms * evals / iters,
+                           "max_final_f": max(s.f_value for s in st_o),
+                           "max_rel_diff_theta": float(np.max(np.abs(th_o - th) /
+                                                              (1e-300 + np.abs(th))))},
+                       # host buffers in, host buffers out: data upload + one whole solve
+                       "upload_s": upload_s, "upload_GBps": (A.nbytes + y.nbytes) / upload_s / 1e9,
+                       "pcie_inclusive_value": batch * iters / (upload_s + ms * 1e-3),
+                       "parallelism": ranks.replicas()},
+            "roofline": {"bound": "mfma", "achieved": tflops, "peak": 78.6, "unit": "TFLOP/s",
+                         "frac": tflops / 78.6,
+                         **pmc_bytes("lm", ["lm_iter_kernel"], batch == 8192),
+                         "kernel": kname,
+                         "kernel_ms": kms, "algorithmic_flops_per_launch": flops,
+                         "hbm_GBps": hbm_gbps, "hbm_frac": hbm_gbps / 8000.0},
+            **({} if (args.no_cpu_baseline or ranks.world > 1) else {"cpu_baseline": ref_baseline(
+                ["bench-lm", m, n, 256, iters], "iterations_per_s", "iteration-problems/s",
+                f"reference LevenbergMarquardt + GN functors, m={m} n={n}, 256 problems x {iters} "
+                "iterations")})}))
     eng.close()
+    ranks.close()
 
 
 def main_nm(args):
     """Batched Nelder-Mead (no BASELINE config names it): Rosenbrock-128D,
     2000 iterations per start, eps = 0, batch = 4096 independent simplexes, one per workgroup, the
     129 x 128 simplex resident in LDS. One step = one simplex iteration of every start."""
-    import torch
-
     import nlsolver_amd
     n, iters = 128, 2000
     batch = 4096 if args.pop_per_gpu == POP_PER_GPU else args.pop_per_gpu
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    rng = np.random.default_rng(7)
+    ranks = Ranks(args)
+    rng = np.random.default_rng(ranks.slice_seed(7))
     x0 = 0.5 + 0.2 * (rng.random((batch, n)) - 0.5)
     eng = nlsolver_amd.NMEngine("rosenbrock", batch, n, eps=0.0, max_iter=iters,
-                                no_change_best_tol=10**9, device=local_rank)
+                                no_change_best_tol=10**9, device=ranks.local_rank)
     eng.time_solve(x0, 1)
-    ms = eng.time_solve(x0, 2) / 2
+    ms = timed_solves(ranks, eng, x0, 2)
     x, st, _ = eng.minimize(x0.copy())
     fcalls = sum(s.function_calls_used for s in st)
-    print(json.dumps({
-        "metric": "Nelder-Mead iterations x starts / s (Rosenbrock-128D)",
-        "value": batch * iters / (ms * 1e-3), "unit": "iteration-starts/s", "n_gpus": 1,
-        "steps": iters, "warmup": 1, "ms_per_step": ms / iters, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"Nelder-Mead Rosenbrock-{n}D, {iters} iterations, batch={batch}",
-                   "objective_calls_per_s": fcalls / (ms * 1e-3)},
-        "roofline": {"bound": "latency", "achieved": None, "peak": None, "unit": None,
-                     "frac": None, "traffic": None, "kernel": "nm_solve_kernel", "kernel_ms": ms,
-                     "note": "LDS-resident, decision chain; not roofline-graded (SURVEY §8d)"},
-        **({} if args.no_cpu_baseline else {"cpu_baseline": ref_baseline(
-            ["bench-nm", n, 400000], "iterations_per_s", "iteration-starts/s",
-            f"reference NelderMead Rosenbrock-{n}D, one start, 400000 iterations")})}))
+    if ranks.rank == 0:
+        print(json.dumps({
+            "metric": "Nelder-Mead iterations x starts / s (Rosenbrock-128D)",
+            "value": ranks.world * batch * iters / (ms * 1e-3), "unit": "iteration-starts/s",
+            "n_gpus": ranks.world,
+            "steps": iters, "warmup": 1, "ms_per_step": ms / iters, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"Nelder-Mead Rosenbrock-{n}D, {iters} iterations, batch={batch} per GPU",
+                       "objective_calls_per_s": ranks.world * fcalls / (ms * 1e-3),
+                       "parallelism": ranks.replicas()},
+            "roofline": {"bound": "latency", "achieved": None, "peak": None, "unit": None,
+                         "frac": None, "traffic": None, "kernel": "nm_solve_kernel", "kernel_ms": ms,
+                         "note": "LDS-resident, decision chain; not roofline-graded (SURVEY §8d)"},
+            **({} if (args.no_cpu_baseline or ranks.world > 1) else {"cpu_baseline": ref_baseline(
+                ["bench-nm", n, 400000], "iterations_per_s", "iteration-starts/s",
+                f"reference NelderMead Rosenbrock-{n}D, one start, 400000 iterations")})}))
     eng.close()
+    ranks.close()
 
 
 def rehearsal_device(local_rank):
@@ -492,35 +645,20 @@ def main_pso(args):
     """BASELINE configs[4]: PSO swarm = 2^20 particles x D=256 sharded over 8 GPUs ->
     131072 particles per GPU (weak scaling). One step = best update + stop tests + one
     position update + evaluation of the whole swarm."""
-    import torch
-    import torch.distributed as dist
-
     import nlsolver_amd
     Dp, n_local = 256, 131072
     if args.pop_per_gpu != POP_PER_GPU:
         n_local = args.pop_per_gpu
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    local_rank = rehearsal_device(local_rank)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    distributed = world > 1 or os.environ.get("NLSG_BENCH_FORCE_DIST") == "1"
-    if distributed:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group(**pg_args(rank, world, device))
+    ranks = Ranks(args)
+    world, rank, local_rank, device = ranks.world, ranks.rank, ranks.local_rank, ranks.device
+    distributed, dist = ranks.distributed, ranks.dist
     vanilla = args.workload == "pso-vanilla"
     n = n_local * world
     kw = dict(type=nlsolver_amd.PSO_VANILLA if vanilla else nlsolver_amd.PSO_ACCELERATED,
               bounded=False, inertia=0.8, cognitive=1.8, social=1.8, eps=0.0, max_iter=10**12,
               best_val_no_change=10**12, device=local_rank)
 
-    def barrier():
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
-
+    drv = None
     if distributed:
         from nlsolver_amd.dist import ShardedPSO
         drv = ShardedPSO(dist, lambda lo, m_, stream: nlsolver_amd.PSOEngine(
@@ -534,16 +672,11 @@ def main_pso(args):
     stepper(300)  # untimed device wake-up (see the DE benchmark), then start over
     eng.init(-2.048, 2.048)
     stepper(args.warmup)
-    barrier()
+    ranks.barrier()
     t0 = time.perf_counter()
     stepper(args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([dt], dtype=torch.float64,
-                         device="cpu" if dist.get_backend() == "gloo" else device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    ranks.barrier()
+    dt = ranks.max_over_ranks(time.perf_counter() - t0)
     assert eng.status().iteration == args.warmup + args.steps
     stepper(200)  # untimed, every rank (a sharded turn is collective): clocks back up after the pauses
     if rank == 0:
@@ -560,20 +693,64 @@ def main_pso(args):
             "config": {"workload": f"Rosenbrock-{Dp}D PSO {'Vanilla' if vanilla else 'Accelerated'}"
                                    f", {n_local} particles per GPU (BASELINE configs[4] shard)",
                        "global_swarm": n, "dim": Dp,
-                       "parallelism": f"swarm-sharded x{world}"},
+                       "parallelism": f"swarm-sharded x{world} (one all-gather of the best record "
+                                      "per iteration)",
+                       "turn_driver": turn_driver(drv), "rccl_ranks": rccl_ranks(drv)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_bytes("pso_vanilla" if vanilla else "pso_accel",
-                                              ["pso_move_kernel"], n_local == 131072),
+                         **pmc_bytes("pso_vanilla" if vanilla else "pso_accel",
+                                     ["pso_move_kernel"], n_local == 131072),
                          "kernel": "pso_move_kernel", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": bytes_per * n_local},
             **({} if (args.no_cpu_baseline or world > 1 or vanilla) else {"cpu_baseline": ref_baseline(
                 ["bench-pso", Dp, 4096, 40], "particle_evals_per_s", "particle-evals/s",
                 f"reference PSO Accelerated Rosenbrock-{Dp}D, 4096 particles x 40 iterations")})}))
-    eng.close()
     if distributed:
-        dist.barrier()
-        dist.destroy_process_group()
+        dist.barrier()  # no rank tears its communicator down while another is still measuring
+    eng.close()
+    ranks.close()
+
+
+def turn_driver(drv):
+    """Who orders a sharded turn: the library over its own RCCL communicator, or this host over
+    torch.distributed (see nlsolver_amd.dist); None for an unsharded engine."""
+    if drv is None:
+        return None
+    return "library (RCCL all-gather issued by the engine)" if drv.native else \
+        "host (torch.distributed all_gather_into_tensor)"
+
+
+def rccl_ranks(drv):
+    """Communicator size as RCCL itself reports it (ncclCommCount on the engine's communicator);
+    None when the exchange does not go through the library's communicator."""
+    if drv is None or not drv.native:
+        return None
+    return drv.comm_ranks()[0]
+
+
+def north_star_pass(steps):
+    """BASELINE north_star's size — pop = 2^20 x 128 fp64 (1 GiB per population buffer: out of
+    reach of the 256 MiB Infinity Cache that holds configs[1]'s working set) — measured in the
+    same process after the configs[1] pass: whole turns and the generation kernel alone, both by
+    HIP events on the engine's stream."""
+    import nlsolver_amd
+    pop = 1 << 20
+    steps = max(20, min(steps, 200))
+    with nlsolver_amd.DEEngine("rosenbrock", pop, D, minimize=True, strategy=nlsolver_amd.DE_RANDOM,
+                               CR=0.9, F=0.8, eps=1e-300, max_iter=10**12,
+                               best_val_no_change=10**12, seed=12374563468) as eng:
+        eng.init(np.full(D, 4.096))
+        eng.step(60)  # untimed
+        turn_ms = eng.time_turns(steps) / steps
+        assert eng.status().iteration == 60 + steps
+        kern_ms = eng.time_generation_kernel(steps) / steps
+    achieved = BYTES_PER_CANDIDATE * pop / (kern_ms * 1e-3) / 1e9
+    return {"pop": pop, "dim": D, "turns_timed": steps, "turn_us": turn_ms * 1e3,
+            "value": pop / (turn_ms * 1e-3), "unit": "candidate-evals/s",
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, **pmc_traffic(pop),
+                         "kernel": "de_generation_kernel", "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": BYTES_PER_CANDIDATE * pop}}
 
 
 def main():
@@ -583,14 +760,22 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--pop-per-gpu", type=int, default=POP_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-north-star", action="store_true",
+                    help="de workload: skip the pop = 2^20 pass after the configs[1] pass")
     ap.add_argument("--lm-solver", choices=["cholesky", "qr"], default="cholesky",
-                    help="lm workload: damped-system solver (cholesky = the reference class's "
-                         "get_update_with_hessian; qr = tinyqr::lm, as BASELINE configs[3] words it)")
+                    help="lm workload: damped-system solver whose rate is the line's value (cholesky "
+                         "= the reference class's get_update_with_hessian; qr = tinyqr::lm, as "
+                         "BASELINE configs[3] words it); the other one is reported beside it")
+    ap.add_argument("--bfgs-symmetric", action="store_true",
+                    help="bfgs workload: the symmetric restatement of the rank-2 update (streams "
+                         "the upper blocks of H only) instead of the reference's literal one")
     ap.add_argument("--workload", choices=["de", "pso-accel", "pso-vanilla", "bfgs", "bfgs-fd", "lm", "lm-fd", "nm", "sann", "nmpso"],
                     default="de",
                     help="de = the headline benchmark (BASELINE metric); pso-* = config 5's "
                          "per-GPU shard (secondary, same JSON shape)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)  # before torch is imported or a GPU is touched
     if args.workload == "bfgs":
         return main_bfgs(args)
     if args.workload == "bfgs-fd":
@@ -608,28 +793,11 @@ def main():
     if args.workload != "de":
         return main_pso(args)
 
-    import torch
-    import torch.distributed as dist
-
     import nlsolver_amd
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with "
-                         "torch.distributed.run --nproc-per-node N")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    local_rank = rehearsal_device(local_rank)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    # NLSG_BENCH_FORCE_DIST=1 exercises the sharded/RCCL path with a single rank (self-test)
-    distributed = world > 1 or os.environ.get("NLSG_BENCH_FORCE_DIST") == "1"
-    if distributed:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group(**pg_args(rank, world, device))
+    ranks = Ranks(args)
+    world, rank, local_rank, device = ranks.world, ranks.rank, ranks.local_rank, ranks.device
+    distributed, dist = ranks.distributed, ranks.dist
 
     pop_local = args.pop_per_gpu
     pop = pop_local * world
@@ -640,11 +808,7 @@ def main():
                   device=local_rank)
     x0 = np.full(D, 4.096)
 
-    def barrier():
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
-
+    drv = None
     if distributed:
         from nlsolver_amd.dist import ShardedDE
         drv = ShardedDE(dist, lambda lo, n, stream: nlsolver_amd.DEEngine(
@@ -664,16 +828,11 @@ def main():
     stepper(2000)
     eng.init(x0)
     stepper(args.warmup)
-    barrier()
+    ranks.barrier()
     t0 = time.perf_counter()
     stepper(args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([dt], dtype=torch.float64,
-                         device="cpu" if dist.get_backend() == "gloo" else device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    ranks.barrier()
+    dt = ranks.max_over_ranks(time.perf_counter() - t0)
     st = eng.status()
     assert st.iteration == args.warmup + args.steps, (st.iteration, args.warmup + args.steps)
     improved = float(np.mean(eng.download()[1] < scores_before))
@@ -682,6 +841,7 @@ def main():
     # F = 0.5, x0 = 0.6): evidence that throughput does not hinge on the acceptance rate
     accepting = None
     if not distributed:
+        torch = ranks.torch
         with nlsolver_amd.DEEngine("rosenbrock", pop, D, **dict(common, CR=0.2, F=0.5)) as e2:
             e2.init(np.full(D, 0.6))
             s0 = e2.download()[1]
@@ -723,26 +883,31 @@ def main():
                        "agents_improved_frac": improved,
                        "accepting_regime": accepting,
                        "parallelism": f"population-sharded x{world} (island donors, "
-                                      "one all-gather of the best record per generation)"},
+                                      "one all-gather of the best record per generation)",
+                       "turn_driver": turn_driver(drv), "rccl_ranks": rccl_ranks(drv)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(pop_local),
+                         **pmc_traffic(pop_local),
                          "kernel": "de_generation_kernel",
                          "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": BYTES_PER_CANDIDATE * pop_local},
         }
+    if distributed:
+        dist.barrier()  # no rank tears its communicator down while another is still measuring
+    eng.close()
+    if rank == 0:
+        if world == 1 and not args.no_north_star and pop_local == POP_PER_GPU:
+            try:
+                out["north_star"] = north_star_pass(args.steps)
+            except Exception as exc:  # never lose the headline line to the second pass
+                out["north_star"] = {"error": str(exc)[:300]}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
             try:
                 out["cpu_baseline_all_cores"] = cpu_baseline_all_cores()
             except Exception as exc:  # the checker library is optional here; never lose the line
                 out["cpu_baseline_all_cores"] = {"error": str(exc)[:200]}
-    if distributed:
-        dist.barrier()  # no rank tears its communicator down while another is still measuring
-    eng.close()
-    if distributed:
-        dist.barrier()
-        dist.destroy_process_group()
+    ranks.close()
     if rank == 0:
         print(json.dumps(out))
 

@@ -199,6 +199,9 @@ int nlsg_comm_load(const char *rccl_path);
 int nlsg_comm_unique_id(unsigned char *id_out_128);
 int nlsg_de_comm_attach(nlsg_de *e, const unsigned char *unique_id_128, int32_t world, int32_t rank);
 int nlsg_de_step_sharded(nlsg_de *e, uint64_t turns);
+/* Size of the attached communicator and this engine's rank in it, read back from RCCL
+ * (ncclCommCount / ncclCommUserRank) — what a run really used, not what it was asked for. */
+int nlsg_de_comm_ranks(nlsg_de *e, int32_t *world_out, int32_t *rank_out);
 
 /* ========================================================================== */
 /* Particle Swarm Optimisation — replaces PSO::solve (nlsolver.h:2593-2624),   */
@@ -258,6 +261,7 @@ int nlsg_pso_turn_end(nlsg_pso *e, const double *gathered_dev, int32_t world);
 /* the same turns ordered by the library (see nlsg_de_comm_attach / nlsg_de_step_sharded) */
 int nlsg_pso_comm_attach(nlsg_pso *e, const unsigned char *unique_id_128, int32_t world, int32_t rank);
 int nlsg_pso_step_sharded(nlsg_pso *e, uint64_t turns);
+int nlsg_pso_comm_ranks(nlsg_pso *e, int32_t *world_out, int32_t *rank_out);
 
 /* ========================================================================== */
 /* Batched BFGS — replaces BFGS::solve (nlsolver.h:3196-3285), the More-Thuente */
@@ -356,6 +360,9 @@ int nlsg_lm_create_custom(const nlsg_lm_config *cfg, const nlsg_custom_objective
 int nlsg_lm_destroy(nlsg_lm *e);
 /* design matrices A [batch][m][n] row-major and targets y [batch][m] (copied to HBM) */
 int nlsg_lm_set_data(nlsg_lm *e, const double *a_host, const double *y_host);
+/* Switch the damped-system solver of an existing engine (the model data stays resident): the
+ * next nlsg_lm_minimize uses it. */
+int nlsg_lm_set_solver(nlsg_lm *e, int32_t solver);
 /* Whole solve() of every problem in one launch: theta [batch][n] in/out, one status per
  * problem (f, iterations, f/grad/hess evaluation counts), final damping per problem
  * (the reference keeps lambda as a mutable member, :3436/3541). NULLs are skipped. */

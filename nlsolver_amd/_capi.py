@@ -144,6 +144,8 @@ SYMBOLS = {
     "nlsg_comm_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
     "nlsg_de_comm_attach": (C.c_int, [_H, C.POINTER(C.c_ubyte), C.c_int32, C.c_int32]),
     "nlsg_de_step_sharded": (C.c_int, [_H, C.c_uint64]),
+    "nlsg_de_comm_ranks": (C.c_int, [_H, C.POINTER(i32), C.POINTER(i32)]),
+    "nlsg_pso_comm_ranks": (C.c_int, [_H, C.POINTER(i32), C.POINTER(i32)]),
     "nlsg_pso_comm_attach": (C.c_int, [_H, C.POINTER(C.c_ubyte), C.c_int32, C.c_int32]),
     "nlsg_pso_step_sharded": (C.c_int, [_H, C.c_uint64]),
     "nlsg_pso_create": (C.c_int, [C.POINTER(PSOConfig), C.POINTER(_H)]),
@@ -170,6 +172,7 @@ SYMBOLS = {
     "nlsg_lm_create": (C.c_int, [C.POINTER(LMConfig), C.POINTER(_H)]),
     "nlsg_lm_destroy": (C.c_int, [_H]),
     "nlsg_lm_set_data": (C.c_int, [_H, pd, pd]),
+    "nlsg_lm_set_solver": (C.c_int, [_H, i32]),
     "nlsg_lm_minimize": (C.c_int, [_H, pd, C.POINTER(Status), pd]),
     "nlsg_lm_time_solve": (C.c_int, [_H, pd, C.c_uint32, C.POINTER(C.c_float)]),
     "nlsg_lm_time_eval_kernel": (C.c_int, [_H, pd, C.c_uint32, C.POINTER(C.c_float)]),

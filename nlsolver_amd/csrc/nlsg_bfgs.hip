@@ -84,7 +84,7 @@ void launch_iteration(nlsg_bfgs *e, bool timed) {
   const unsigned row_grid = static_cast<unsigned>(e->p.batch * e->bpp);
   if (e->p.model == NLSG_OBJ_CUSTOM) {
     void *args[] = {&e->p};
-    hipModuleLaunchKernel(e->rtc.search, wave_grid, 1, 1, 256, 1, 1, 0, e->stream, args, nullptr);
+    launch_module_kernel(e->rtc.search, wave_grid, 256, 0, e->stream, args);
   } else {
     BFGS_DISPATCH_MODEL(bfgs_search_kernel, wave_grid, e->p);
   }
@@ -152,7 +152,7 @@ static int bfgs_create(const nlsg_bfgs_config *cfg, const double *diag_host, con
     return fail(NLSG_ERR_UNSUPPORTED, "batch * dim too large for one launch grid");
   }
   if (cfg->stream) {
-    e->stream = static_cast<hipStream_t>(cfg->stream);
+    e->stream = borrowed_stream(cfg->stream);
   } else {
     hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (he != hipSuccess) {
@@ -248,12 +248,11 @@ int nlsg_bfgs_init(nlsg_bfgs *e, const double *x0_host) {
   NLSG_HIP(hipStreamSynchronize(e->stream));
   if (e->p.model == NLSG_OBJ_CUSTOM) {
     void *args[] = {&e->p};
-    hipModuleLaunchKernel(e->rtc.init, static_cast<unsigned>((e->p.batch + 3) / 4), 1, 1, 256, 1, 1,
-                          0, e->stream, args, nullptr);
+    launch_module_kernel(e->rtc.init, static_cast<unsigned>((e->p.batch + 3) / 4), 256, 0, e->stream, args);
   } else {
     BFGS_DISPATCH_MODEL(bfgs_init_kernel, static_cast<unsigned>((e->p.batch + 3) / 4), e->p);
   }
-  NLSG_HIP(hipGetLastError());
+  NLSG_HIP(launches_status());
   e->initialised = true;
   return NLSG_OK;
 }
@@ -263,7 +262,7 @@ int nlsg_bfgs_step(nlsg_bfgs *e, uint64_t iters) {
   if (!e->initialised) return fail(NLSG_ERR_STATE, "nlsg_bfgs_init has not been called");
   NLSG_HIP(hipSetDevice(e->cfg.device));
   for (uint64_t k = 0; k < iters; k++) launch_iteration(e, false);
-  NLSG_HIP(hipGetLastError());
+  NLSG_HIP(launches_status());
   return NLSG_OK;
 }
 
@@ -356,7 +355,7 @@ int nlsg_bfgs_time_steps(nlsg_bfgs *e, uint64_t iters, float *ms_total, float *m
   }
   NLSG_HIP(hipEventRecord(e->ev1, e->stream));
   NLSG_HIP(hipEventSynchronize(e->ev1));
-  NLSG_HIP(hipGetLastError());
+  NLSG_HIP(launches_status());
   NLSG_HIP(hipEventElapsedTime(ms_total, e->ev0, e->ev1));
   if (ms_hessian) *ms_hessian = hess;
   return NLSG_OK;

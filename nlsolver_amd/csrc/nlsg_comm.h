@@ -24,6 +24,8 @@ struct RcclApi {
                             hipStream_t) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
 };
 
 RcclApi &rccl_api();  // nlsg_comm.hip
@@ -61,6 +63,17 @@ inline void comm_detach(ShardComm *c) {
   delete c;
 }
 
+// what the communicator itself says about its size and this rank (bench.py's `rccl_ranks`)
+inline int comm_query(const ShardComm *c, int32_t *world, int32_t *rank) {
+  if (!c || !c->comm) return fail(NLSG_ERR_STATE, "no communicator is attached");
+  int w = 0, r = 0;
+  NLSG_RCCL(rccl_api().CommCount(c->comm, &w));
+  NLSG_RCCL(rccl_api().CommUserRank(c->comm, &r));
+  if (world) *world = w;
+  if (rank) *rank = r;
+  return NLSG_OK;
+}
+
 // Collective call: every rank of the job attaches with the same id (nlsg_comm_unique_id on one
 // rank, broadcast by the host).
 inline int comm_attach(ShardComm **out, const unsigned char *id, int world, int rank,
@@ -89,25 +102,23 @@ inline int comm_attach(ShardComm **out, const unsigned char *id, int world, int 
   }
   if (he == hipSuccess)
     he = hipMalloc(reinterpret_cast<void **>(&c->gathered), world * rec_doubles * sizeof(double));
-  if (he != hipSuccess) {
-    comm_detach(c);
-    return fail(NLSG_ERR_HIP, "communicator resources: %s", hipGetErrorString(he));
-  }
+  // A rank whose local resources failed still joins the collective initialisation — its peers
+  // are inside ncclCommInitRank and would wait for it for ever — and reports its failure after.
   ncclUniqueId uid;
   static_assert(sizeof(uid) == 128, "ncclUniqueId is 128 bytes");
   std::memcpy(&uid, id, sizeof uid);
   const ncclResult_t r = api.CommInitRank(&c->comm, world, uid, rank);
+  if (r != ncclSuccess) c->comm = nullptr;
+  if (he != hipSuccess) {
+    comm_detach(c);
+    return fail(NLSG_ERR_HIP, "communicator resources: %s", hipGetErrorString(he));
+  }
   if (r != ncclSuccess) {
-    c->comm = nullptr;
     comm_detach(c);
     return fail(NLSG_ERR_HIP, "ncclCommInitRank failed: %s", api.GetErrorString(r));
   }
   *out = c;
   return NLSG_OK;
 }
-
-// HIP 7.0: an event recorded on the hipStreamLegacy handle crashes the next
-// hipStreamWaitEvent on it; the null stream is the same stream and works.
-inline hipStream_t event_stream(hipStream_t s) { return s == hipStreamLegacy ? nullptr : s; }
 
 }  // namespace nlsg

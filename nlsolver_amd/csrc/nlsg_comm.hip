@@ -1,4 +1,6 @@
 // nlsolver_amd/csrc/nlsg_comm.hip — RCCL entry points resolved at run time (see nlsg_comm.h).
+#include <mutex>
+
 #include "nlsg_comm.h"
 
 namespace nlsg {
@@ -13,6 +15,8 @@ using namespace nlsg;
 extern "C" {
 
 int nlsg_comm_load(const char *rccl_path) {
+  static std::mutex load_mutex;  // shards may be attached from several host threads
+  std::lock_guard<std::mutex> hold(load_mutex);
   RcclApi &api = rccl_api();
   if (api.lib) return NLSG_OK;
   const char *path = (rccl_path && rccl_path[0]) ? rccl_path : "librccl.so";
@@ -24,7 +28,10 @@ int nlsg_comm_load(const char *rccl_path) {
   a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(lib, "ncclAllGather"));
   a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
   a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
-  if (!a.GetUniqueId || !a.CommInitRank || !a.AllGather || !a.CommDestroy || !a.GetErrorString) {
+  a.CommCount = reinterpret_cast<decltype(a.CommCount)>(dlsym(lib, "ncclCommCount"));
+  a.CommUserRank = reinterpret_cast<decltype(a.CommUserRank)>(dlsym(lib, "ncclCommUserRank"));
+  if (!a.GetUniqueId || !a.CommInitRank || !a.AllGather || !a.CommDestroy || !a.GetErrorString ||
+      !a.CommCount || !a.CommUserRank) {
     dlclose(lib);
     return fail(NLSG_ERR_UNSUPPORTED, "%s does not export the RCCL entry points", path);
   }

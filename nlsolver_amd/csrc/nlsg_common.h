@@ -66,6 +66,36 @@ inline int check_device(int device) {
   return NLSG_OK;
 }
 
+// A caller's stream handle as the engines use it. The C-ABI spells "the null stream" as
+// hipStreamLegacy ((void *)1, because NULL means "create a private stream"); inside the library
+// that handle is replaced by the null handle itself — the same stream — once, at engine creation:
+// with HIP 7.0 an event recorded on the hipStreamLegacy handle crashes the next
+// hipStreamWaitEvent on it, and RCCL records and waits on the stream it is given.
+inline hipStream_t borrowed_stream(void *handle) {
+  hipStream_t s = static_cast<hipStream_t>(handle);
+  return s == hipStreamLegacy ? nullptr : s;
+}
+
+
+// Launches of run-time compiled kernels (module API). The launch helpers of the engines return
+// nothing — an entry point enqueues many launches and asks once at its end — so a failed module
+// launch is remembered here and reported by launches_status() together with hipGetLastError().
+inline hipError_t &module_launch_error() {
+  static thread_local hipError_t err = hipSuccess;
+  return err;
+}
+inline void launch_module_kernel(hipFunction_t fn, unsigned grid, unsigned block, unsigned lds_bytes,
+                                 hipStream_t stream, void **args) {
+  const hipError_t r = hipModuleLaunchKernel(fn, grid, 1, 1, block, 1, 1, lds_bytes, stream, args, nullptr);
+  if (r != hipSuccess && module_launch_error() == hipSuccess) module_launch_error() = r;
+}
+inline hipError_t launches_status() {
+  const hipError_t m = module_launch_error();
+  module_launch_error() = hipSuccess;
+  const hipError_t r = hipGetLastError();
+  return m != hipSuccess ? m : r;
+}
+
 #endif  // !__HIPCC_RTC__
 
 

@@ -64,7 +64,7 @@ struct Dispatch;  // OBJ x CHUNKS dispatch of a kernel family
 
 // kernels of a run-time compiled objective take the same arguments through the module API
 void launch_module(nlsg_de *e, hipFunction_t fn, unsigned grid, void **args) {
-  hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, 0, e->stream, args, nullptr);
+  launch_module_kernel(fn, grid, 256, 0, e->stream, args);
 }
 
 void launch_init(nlsg_de *e) {
@@ -240,7 +240,7 @@ int read_state(nlsg_de *e, DeState *host) {
   hipLaunchKernelGGL(de_settle_kernel, dim3(1), dim3(1), 0, e->stream, e->p, e->k);
   NLSG_HIP(hipMemcpyAsync(host, e->p.state, sizeof(DeState), hipMemcpyDeviceToHost, e->stream));
   NLSG_HIP(hipStreamSynchronize(e->stream));
-  NLSG_HIP(hipGetLastError());
+  NLSG_HIP(launches_status());
   return NLSG_OK;
 }
 
@@ -327,7 +327,7 @@ static int de_create(const nlsg_de_config *cfg, const nlsg_custom_objective *cus
   if (const char *g = std::getenv("NLSG_DE_GROUPS"))  // A/B switch: 0 = one agent per wave at any D
     if (g[0] == '0') e->group = 0;
   if (cfg->stream) {
-    e->stream = static_cast<hipStream_t>(cfg->stream);
+    e->stream = borrowed_stream(cfg->stream);
   } else {
     hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (he != hipSuccess) {
@@ -452,7 +452,7 @@ int nlsg_de_init(nlsg_de *e, const double *x0_host) {
   launch_init(e);
   e->k = 0;
   if (e->overlap) NLSG_HIP(hipEventRecord(e->ev_gen[0], e->stream));
-  NLSG_HIP(hipGetLastError());
+  NLSG_HIP(launches_status());
   e->initialised = true;
   return NLSG_OK;
 }
@@ -468,7 +468,7 @@ int nlsg_de_step(nlsg_de *e, uint64_t turns) {
     int rc = launch_turn_single(e);
     if (rc) return rc;
   }
-  NLSG_HIP(hipGetLastError());
+  NLSG_HIP(launches_status());
   return NLSG_OK;
 }
 
@@ -564,7 +564,7 @@ int nlsg_de_time_generation_kernel(nlsg_de *e, uint32_t launches, float *ms_tota
     launch_generation(e, (s.parity + static_cast<int>(k)) & 1, s.iter + 1 + k, 1);
   NLSG_HIP(hipEventRecord(e->ev1, e->stream));
   NLSG_HIP(hipEventSynchronize(e->ev1));
-  NLSG_HIP(hipGetLastError());
+  NLSG_HIP(launches_status());
   NLSG_HIP(hipEventElapsedTime(ms_total, e->ev0, e->ev1));
   // The population advanced `launches` generations without best scans; the
   // engine must be re-initialised before it is used for a solve again.
@@ -588,7 +588,7 @@ int nlsg_de_time_turns(nlsg_de *e, uint64_t turns, float *ms_total) {
   if (rcj) return rcj;
   NLSG_HIP(hipEventRecord(e->ev1, e->stream));
   NLSG_HIP(hipEventSynchronize(e->ev1));
-  NLSG_HIP(hipGetLastError());
+  NLSG_HIP(launches_status());
   NLSG_HIP(hipEventElapsedTime(ms_total, e->ev0, e->ev1));
   return NLSG_OK;
 }
@@ -602,7 +602,7 @@ int nlsg_de_turn_begin(nlsg_de *e, double *send_dev) {
   if (!e->initialised) return fail(NLSG_ERR_STATE, "nlsg_de_init has not been called");
   NLSG_HIP(hipSetDevice(e->cfg.device));
   launch_local_summary(e, send_dev, e->stream);
-  NLSG_HIP(hipGetLastError());
+  NLSG_HIP(launches_status());
   return NLSG_OK;
 }
 
@@ -618,7 +618,7 @@ int nlsg_de_turn_finalize(nlsg_de *e, const double *gathered_dev, int32_t world)
   NLSG_HIP(hipSetDevice(e->cfg.device));
   hipLaunchKernelGGL(de_finalize_kernel, dim3(1), dim3(256), 0, e->stream, e->p, gathered_dev,
                      world, static_cast<uint64_t>(kRecHeader) + e->p.D);
-  NLSG_HIP(hipGetLastError());
+  NLSG_HIP(launches_status());
   return NLSG_OK;
 }
 
@@ -628,7 +628,7 @@ int nlsg_de_turn_generation(nlsg_de *e) {
   NLSG_HIP(hipSetDevice(e->cfg.device));
   launch_generation(e, static_cast<int>(e->k & 1), e->k + 1);
   e->k += 1;
-  NLSG_HIP(hipGetLastError());
+  NLSG_HIP(launches_status());
   return NLSG_OK;
 }
 
@@ -646,6 +646,11 @@ int nlsg_de_comm_attach(nlsg_de *e, const unsigned char *unique_id, int32_t worl
                 (unsigned long long)e->p.pop, rank, world);
   NLSG_HIP(hipSetDevice(e->cfg.device));
   return comm_attach(&e->comm, unique_id, world, rank, static_cast<uint64_t>(kRecHeader) + e->p.D);
+}
+
+int nlsg_de_comm_ranks(nlsg_de *e, int32_t *world_out, int32_t *rank_out) {
+  if (!e) return fail(NLSG_ERR_INVALID_ARG, "null engine");
+  return comm_query(e->comm, world_out, rank_out);
 }
 
 // `turns` sharded turns without a host round trip.
@@ -673,10 +678,10 @@ int nlsg_de_step_sharded(nlsg_de *e, uint64_t turns) {
       launch_generation(e, static_cast<int>(k & 1), k + 1);
       e->k = k + 1;
     }
-    NLSG_HIP(hipGetLastError());
+    NLSG_HIP(launches_status());
     return NLSG_OK;
   }
-  hipStream_t S = event_stream(e->stream), C = c->stream;
+  hipStream_t S = e->stream, C = c->stream;  // S is never the hipStreamLegacy handle (borrowed_stream)
   NLSG_HIP(hipEventRecord(c->pop_ready[e->k & 1], S));  // population k exists
   for (uint64_t t = 0; t < turns; t++) {
     const uint64_t k = e->k;
@@ -693,7 +698,7 @@ int nlsg_de_step_sharded(nlsg_de *e, uint64_t turns) {
   }
   // the engine's stream ends behind the last head (status / download / the next call)
   NLSG_HIP(hipStreamWaitEvent(S, c->head_done[(e->k - 1) & 1], 0));
-  NLSG_HIP(hipGetLastError());
+  NLSG_HIP(launches_status());
   return NLSG_OK;
 }
 

@@ -48,7 +48,7 @@ void launch_fd_iter(nlsg_lm *e, int first) {
   const unsigned lds = (64 * lm_fd_chunks(e->p.n) + 128) * sizeof(double);
   if (e->cfg.objective == NLSG_OBJ_CUSTOM) {
     void *args[] = {&e->p, &first};
-    hipModuleLaunchKernel(e->rtc.iter, grid.x, 1, 1, 64, 1, 1, lds, e->stream, args, nullptr);
+    launch_module_kernel(e->rtc.iter, grid.x, 64, lds, e->stream, args);
     return;
   }
   switch (e->cfg.objective) {
@@ -144,7 +144,7 @@ static int lm_create(const nlsg_lm_config *cfg, const nlsg_custom_objective *cus
   if (!e) return fail(NLSG_ERR_OOM, "host allocation failed");
   e->cfg = *cfg;
   if (cfg->stream) {
-    e->stream = static_cast<hipStream_t>(cfg->stream);
+    e->stream = borrowed_stream(cfg->stream);
   } else {
     hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (he != hipSuccess) {
@@ -253,6 +253,17 @@ int nlsg_lm_set_data(nlsg_lm *e, const double *a_host, const double *y_host) {
   return NLSG_OK;
 }
 
+int nlsg_lm_set_solver(nlsg_lm *e, int32_t solver) {
+  if (!e) return fail(NLSG_ERR_INVALID_ARG, "null engine");
+  if (solver != NLSG_LM_CHOLESKY && solver != NLSG_LM_QR)
+    return fail(NLSG_ERR_INVALID_ARG, "unknown solver %d", solver);
+  if (e->p.fd && solver != NLSG_LM_CHOLESKY)
+    return fail(NLSG_ERR_UNSUPPORTED,
+                "the finite-difference model runs the reference's own solve (Cholesky) only");
+  e->cfg.solver = solver;
+  return NLSG_OK;
+}
+
 int nlsg_lm_minimize(nlsg_lm *e, double *theta_inout_host, nlsg_status *status_host,
                      double *lambda_out_host) {
   if (!e || !theta_inout_host) return fail(NLSG_ERR_INVALID_ARG, "null argument");
@@ -262,7 +273,7 @@ int nlsg_lm_minimize(nlsg_lm *e, double *theta_inout_host, nlsg_status *status_h
   if (rc) return rc;
   rc = launch_solve(e);
   if (rc) return rc;
-  NLSG_HIP(hipGetLastError());
+  NLSG_HIP(launches_status());
   NLSG_HIP(hipStreamSynchronize(e->stream));
   const uint64_t B = e->p.batch, n = e->p.n;
   std::vector<double> padded(B * kLmN);
@@ -305,7 +316,7 @@ int nlsg_lm_time_solve(nlsg_lm *e, const double *theta0_host, uint32_t repeats, 
     if (rc) return rc;
     NLSG_HIP(hipEventRecord(e->ev1, e->stream));
     NLSG_HIP(hipEventSynchronize(e->ev1));
-    NLSG_HIP(hipGetLastError());
+    NLSG_HIP(launches_status());
     float ms = 0.f;
     NLSG_HIP(hipEventElapsedTime(&ms, e->ev0, e->ev1));
     total += ms;
@@ -330,7 +341,7 @@ int nlsg_lm_time_eval_kernel(nlsg_lm *e, const double *theta0_host, uint32_t rep
                        e->stream, e->p, 1, 0);
     NLSG_HIP(hipEventRecord(e->ev1, e->stream));
     NLSG_HIP(hipEventSynchronize(e->ev1));
-    NLSG_HIP(hipGetLastError());
+    NLSG_HIP(launches_status());
     float ms = 0.f;
     NLSG_HIP(hipEventElapsedTime(&ms, e->ev0, e->ev1));
     total += ms;

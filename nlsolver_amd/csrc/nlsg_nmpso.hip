@@ -24,7 +24,7 @@ void launch(nlsg_nmpso *e) {
   const dim3 grid(static_cast<unsigned>(e->p.batch)), block(hyb_block_threads(e->p.n));
   if (e->cfg.objective == NLSG_OBJ_CUSTOM) {
     void *args[] = {&e->p};
-    hipModuleLaunchKernel(e->rtc.solve, grid.x, 1, 1, block.x, 1, 1, 0, e->stream, args, nullptr);
+    launch_module_kernel(e->rtc.solve, grid.x, block.x, 0, e->stream, args);
     return;
   }
   switch (e->cfg.objective) {
@@ -97,7 +97,7 @@ static int hyb_create(const nlsg_nmpso_config *cfg, const nlsg_custom_objective 
   if (!e) return fail(NLSG_ERR_OOM, "host allocation failed");
   e->cfg = *cfg;
   if (cfg->stream) {
-    e->stream = static_cast<hipStream_t>(cfg->stream);
+    e->stream = borrowed_stream(cfg->stream);
   } else {
     hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (he != hipSuccess) {
@@ -185,7 +185,7 @@ int nlsg_nmpso_minimize(nlsg_nmpso *e, double *x_inout_host, const double *lower
   const uint64_t B = e->p.batch, n = e->p.n;
   NLSG_HIP(hipMemcpy(e->p.x, x_inout_host, B * n * 8, hipMemcpyHostToDevice));
   launch(e);
-  NLSG_HIP(hipGetLastError());
+  NLSG_HIP(launches_status());
   NLSG_HIP(hipStreamSynchronize(e->stream));
   NLSG_HIP(hipMemcpy(x_inout_host, e->p.x, B * n * 8, hipMemcpyDeviceToHost));
   if (status_host) {
@@ -219,7 +219,7 @@ int nlsg_nmpso_time_solve(nlsg_nmpso *e, const double *x0_host, uint32_t repeats
     launch(e);
     NLSG_HIP(hipEventRecord(e->ev1, e->stream));
     NLSG_HIP(hipEventSynchronize(e->ev1));
-    NLSG_HIP(hipGetLastError());
+    NLSG_HIP(launches_status());
     float ms = 0.f;
     NLSG_HIP(hipEventElapsedTime(&ms, e->ev0, e->ev1));
     total += ms;

@@ -53,7 +53,7 @@ void launch_init(nlsg_pso *e) {
   const bool vec = e->p.D % 2 == 0;
   if (e->cfg.objective == NLSG_OBJ_CUSTOM) {
     void *args[] = {&e->p};
-    hipModuleLaunchKernel(e->rtc.init, grid.x, 1, 1, 256, 1, 1, 0, e->stream, args, nullptr);
+    launch_module_kernel(e->rtc.init, grid.x, 256, 0, e->stream, args);
     return;
   }
 #define CALL(OBJ, C)                                                                        \
@@ -104,7 +104,7 @@ void launch_move(nlsg_pso *e, int timing, uint64_t iter_ovr) {
   const bool accel = e->cfg.type == NLSG_PSO_ACCELERATED;
   if (e->cfg.objective == NLSG_OBJ_CUSTOM) {
     void *args[] = {&e->p, &timing, &iter_ovr};
-    hipModuleLaunchKernel(e->rtc.move, grid.x, 1, 1, 256, 1, 1, 0, e->stream, args, nullptr);
+    launch_module_kernel(e->rtc.move, grid.x, 256, 0, e->stream, args);
     return;
   }
   if (e->group) {
@@ -165,7 +165,7 @@ int read_state(nlsg_pso *e, PsoState *host) {
   hipLaunchKernelGGL(pso_settle_kernel, dim3(1), dim3(1), 0, e->stream, e->p);
   NLSG_HIP(hipMemcpyAsync(host, e->p.state, sizeof(PsoState), hipMemcpyDeviceToHost, e->stream));
   NLSG_HIP(hipStreamSynchronize(e->stream));
-  NLSG_HIP(hipGetLastError());
+  NLSG_HIP(launches_status());
   return NLSG_OK;
 }
 
@@ -235,7 +235,7 @@ static int pso_create(const nlsg_pso_config *cfg, const nlsg_custom_objective *c
   if (const char *g = std::getenv("NLSG_PSO_GROUPS"))  // A/B switch: 0 = one particle per wave at any D
     if (g[0] == '0') e->group = 0;
   if (cfg->stream) {
-    e->stream = static_cast<hipStream_t>(cfg->stream);
+    e->stream = borrowed_stream(cfg->stream);
   } else {
     hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (he != hipSuccess) {
@@ -272,9 +272,22 @@ static int pso_create(const nlsg_pso_config *cfg, const nlsg_custom_objective *c
     he = alloc(reinterpret_cast<void **>(&e->rec), (kRecHeader + D) * sizeof(double));
   // inertia schedule pow(inertia, iter) (:2613) computed with the host libm, as the
   // reference does, so the device uses bit-identical values
-  p.tab_len = std::min<uint64_t>(cfg->max_iter + 1, 1u << 16);
-  std::vector<double> tab(p.tab_len);
-  for (uint64_t k = 0; k < p.tab_len; k++) tab[k] = std::pow(cfg->inertia, static_cast<double>(k));
+  // (max_iter + 1 entries — guarded against wrapping — or up to the first fixed point of the
+  // sequence: 0 after underflow, 1, inf; at most 2^22 entries)
+  const uint64_t want = cfg->max_iter == ~0ull ? ~0ull : cfg->max_iter + 1;
+  const uint64_t cap = std::min<uint64_t>(want, 1u << 22);
+  std::vector<double> tab;
+  tab.reserve(std::min<uint64_t>(cap, 4096));
+  p.tab_fixed = 0;
+  for (uint64_t k = 0; k < cap; k++) {
+    tab.push_back(std::pow(cfg->inertia, static_cast<double>(k)));
+    if (k >= 2 && std::memcmp(&tab[k], &tab[k - 1], 8) == 0 && std::memcmp(&tab[k], &tab[k - 2], 8) == 0 &&
+        (tab[k] == 0.0 || tab[k] == 1.0 || std::isinf(tab[k]))) {
+      p.tab_fixed = 1;
+      break;
+    }
+  }
+  p.tab_len = tab.size();
   if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&e->tab_dev), p.tab_len * sizeof(double));
   if (he == hipSuccess)
     he = hipMemcpy(e->tab_dev, tab.data(), p.tab_len * sizeof(double), hipMemcpyHostToDevice);
@@ -351,7 +364,7 @@ int nlsg_pso_init(nlsg_pso *e, const double *lower_host, const double *upper_hos
   NLSG_HIP(hipStreamSynchronize(e->stream));  // host buffers are borrowed for this call only
   hipLaunchKernelGGL(pso_reset_state_kernel, dim3(1), dim3(1), 0, e->stream, e->p);
   launch_init(e);
-  NLSG_HIP(hipGetLastError());
+  NLSG_HIP(launches_status());
   e->initialised = true;
   return NLSG_OK;
 }
@@ -364,7 +377,7 @@ int nlsg_pso_step(nlsg_pso *e, uint64_t turns) {
                 "sharded engine: use nlsg_pso_turn_begin / nlsg_pso_turn_end around the exchange");
   NLSG_HIP(hipSetDevice(e->cfg.device));
   for (uint64_t t = 0; t < turns; t++) launch_turn_single(e);
-  NLSG_HIP(hipGetLastError());
+  NLSG_HIP(launches_status());
   return NLSG_OK;
 }
 
@@ -443,7 +456,7 @@ int nlsg_pso_time_move_kernel(nlsg_pso *e, uint32_t launches, float *ms_total) {
   for (uint32_t k = 0; k < launches; k++) launch_move(e, 1, s.iter + k);
   NLSG_HIP(hipEventRecord(e->ev1, e->stream));
   NLSG_HIP(hipEventSynchronize(e->ev1));
-  NLSG_HIP(hipGetLastError());
+  NLSG_HIP(launches_status());
   NLSG_HIP(hipEventElapsedTime(ms_total, e->ev0, e->ev1));
   e->initialised = false;  // the swarm moved without best bookkeeping: re-init before solving
   return NLSG_OK;
@@ -458,7 +471,7 @@ int nlsg_pso_turn_begin(nlsg_pso *e, double *send_dev) {
   if (!e->initialised) return fail(NLSG_ERR_STATE, "nlsg_pso_init has not been called");
   NLSG_HIP(hipSetDevice(e->cfg.device));
   launch_local_summary(e, send_dev);
-  NLSG_HIP(hipGetLastError());
+  NLSG_HIP(launches_status());
   return NLSG_OK;
 }
 
@@ -469,7 +482,7 @@ int nlsg_pso_turn_end(nlsg_pso *e, const double *gathered_dev, int32_t world) {
   hipLaunchKernelGGL(pso_finalize_kernel, dim3(1), dim3(256), 0, e->stream, e->p, gathered_dev,
                      world, static_cast<uint64_t>(kRecHeader) + e->p.D);
   launch_move(e, 0, 0);
-  NLSG_HIP(hipGetLastError());
+  NLSG_HIP(launches_status());
   return NLSG_OK;
 }
 
@@ -483,6 +496,11 @@ int nlsg_pso_comm_attach(nlsg_pso *e, const unsigned char *unique_id, int32_t wo
                 (unsigned long long)e->p.n, rank, world);
   NLSG_HIP(hipSetDevice(e->cfg.device));
   return comm_attach(&e->comm, unique_id, world, rank, static_cast<uint64_t>(kRecHeader) + e->p.D);
+}
+
+int nlsg_pso_comm_ranks(nlsg_pso *e, int32_t *world_out, int32_t *rank_out) {
+  if (!e) return fail(NLSG_ERR_INVALID_ARG, "null engine");
+  return comm_query(e->comm, world_out, rank_out);
 }
 
 // `turns` sharded turns without a host round trip. The move needs the exchanged swarm best, so
@@ -502,7 +520,7 @@ int nlsg_pso_step_sharded(nlsg_pso *e, uint64_t turns) {
                        c->world, stride);
     launch_move(e, 0, 0);
   }
-  NLSG_HIP(hipGetLastError());
+  NLSG_HIP(launches_status());
   return NLSG_OK;
 }
 

@@ -39,12 +39,22 @@ struct PsoParams {
   uint32_t *ticket;               // arrival counter of pso_scan_head_kernel's blocks
   const double *zero;
   uint64_t tab_len;
-  uint32_t ntiles, pad0;
+  uint32_t ntiles;
+  int32_t tab_fixed;              // the table ends at a fixed point of pow (0, 1, inf): later k repeat it
   uint64_t n, D, shard_lo, shard_n;
   double inertia, cog, soc, eps, fmul;
   uint64_t max_iter, best_val_no_change, seed;
   int32_t type, bounded;
 };
+
+// inertia = pow(init_inertia, iter) (:2613) as the host libm computes it: from the table, whose
+// last entry repeats for ever when it is a fixed point of the sequence. Only a schedule that is
+// still moving after the table's 2^22 entries (|inertia| within 2e-4 of 1, or negative) falls
+// back to the device's pow, which is not bit-identical to glibc's.
+__device__ inline double pso_inertia_at(const PsoParams &p, uint64_t iter) {
+  if (iter < p.tab_len) return p.inertia_tab[iter];
+  return p.tab_fixed ? p.inertia_tab[p.tab_len - 1] : pow(p.inertia, static_cast<double>(iter));
+}
 
 __global__ void pso_reset_state_kernel(PsoParams p) {
   PsoState *s = p.state;
@@ -121,7 +131,7 @@ __global__ __launch_bounds__(256) void pso_move_kernel(PsoParams p, int timing, 
   const double old_pbest = p.pbest_val[i];
   double inertia = p.inertia;
   if (TYPE == NLSG_PSO_ACCELERATED)  // :2613 inertia = pow(init_inertia, iter)
-    inertia = iter < p.tab_len ? p.inertia_tab[iter] : pow(p.inertia, static_cast<double>(iter));
+    inertia = pso_inertia_at(p, iter);
 
   // draws 2e and 2e+1 of element e = 128 c + 2 lane + k: ctr_key(kp, j) = mix64(kp + G (j + 1))
   // with j + 1 = (4 lane + 1) + (256 c + 2 k [+ 1]) -- one 64-bit multiply per wave, the rest
@@ -203,7 +213,7 @@ __global__ __launch_bounds__(256) void pso_move_groups_kernel(PsoParams p, int t
   const double old_pbest = p.pbest_val[i];
   double inertia = p.inertia;
   if (TYPE == NLSG_PSO_ACCELERATED)  // :2613 inertia = pow(init_inertia, iter)
-    inertia = iter < p.tab_len ? p.inertia_tab[iter] : pow(p.inertia, static_cast<double>(iter));
+    inertia = pso_inertia_at(p, iter);
   // draws 2e and 2e+1 of element e = 2g + k: mix64(kp + G64 (2e + 1 [+ 1])), 2e + 1 = 4g + 2k + 1
   const uint64_t kp_lane = kp + kGolden * (4 * static_cast<uint64_t>(g) + 1);
 #pragma unroll

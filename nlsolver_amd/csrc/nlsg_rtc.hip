@@ -2,6 +2,7 @@
 #include <dlfcn.h>
 #include <hip/hiprtc.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -30,7 +31,15 @@ RtcApi &rtc_api() {
   return api;
 }
 
+// engines may be created from several host threads at once: the table is filled under a lock
+// and published whole (api.lib is set last, by the assignment of the finished copy)
+std::mutex &rtc_mutex() {
+  static std::mutex m;
+  return m;
+}
+
 int rtc_load(const char *path_in) {
+  std::lock_guard<std::mutex> hold(rtc_mutex());
   RtcApi &api = rtc_api();
   if (api.lib) return NLSG_OK;
   const char *path = (path_in && path_in[0]) ? path_in : "libhiprtc.so";
@@ -96,7 +105,11 @@ static int rtc_compile(const nlsg_custom_objective *obj, const char *kernel_head
   if (api.CreateProgram(&prog, src.c_str(), "nlsg_custom_objective.hip", nh, texts.data(),
                         names.data()) != HIPRTC_SUCCESS)
     return fail(NLSG_ERR_HIP, "hiprtcCreateProgram failed");
-  for (const std::string &n : name_exprs) api.AddNameExpression(prog, n.c_str());
+  for (const std::string &n : name_exprs)
+    if (api.AddNameExpression(prog, n.c_str()) != HIPRTC_SUCCESS) {
+      api.DestroyProgram(&prog);
+      return fail(NLSG_ERR_HIP, "hiprtcAddNameExpression(%s) failed", n.c_str());
+    }
   // the flags of csrc/Makefile: device arithmetic must stay bit-reproducible
   const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
                         "-fno-fast-math"};
@@ -111,9 +124,15 @@ static int rtc_compile(const nlsg_custom_objective *obj, const char *kernel_head
     return fail(NLSG_ERR_INVALID_ARG, "custom objective does not compile: %s", log.c_str());
   }
   size_t cs = 0;
-  api.GetCodeSize(prog, &cs);
+  if (api.GetCodeSize(prog, &cs) != HIPRTC_SUCCESS || cs == 0) {
+    api.DestroyProgram(&prog);
+    return fail(NLSG_ERR_HIP, "hiprtcGetCodeSize failed");
+  }
   std::vector<char> code(cs);
-  api.GetCode(prog, code.data());
+  if (api.GetCode(prog, code.data()) != HIPRTC_SUCCESS) {
+    api.DestroyProgram(&prog);
+    return fail(NLSG_ERR_HIP, "hiprtcGetCode failed");
+  }
   hipModule_t mod = nullptr;
   hipError_t he = hipModuleLoadData(&mod, code.data());
   std::vector<hipFunction_t> fns(name_exprs.size(), nullptr);

@@ -72,7 +72,7 @@ void launch_anneal(nlsg_sann *e, uint64_t iter_begin, uint64_t iter_end) {
   const bool vec = e->p.D % 2 == 0;
   if (e->cfg.objective == NLSG_OBJ_CUSTOM) {
     void *args[] = {&e->p, &iter_begin, &iter_end};
-    hipModuleLaunchKernel(e->rtc.anneal, grid.x, 1, 1, 256, 1, 1, 0, e->stream, args, nullptr);
+    launch_module_kernel(e->rtc.anneal, grid.x, 256, 0, e->stream, args);
     return;
   }
   if (e->group) {
@@ -156,7 +156,7 @@ static int sann_create(const nlsg_sann_config *cfg, const nlsg_custom_objective 
   if (!e) return fail(NLSG_ERR_OOM, "host allocation failed");
   e->cfg = *cfg;
   if (cfg->stream) {
-    e->stream = static_cast<hipStream_t>(cfg->stream);
+    e->stream = borrowed_stream(cfg->stream);
   } else {
     hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (he != hipSuccess) {
@@ -226,7 +226,7 @@ int nlsg_sann_minimize(nlsg_sann *e, double *x_inout_host, nlsg_status *status_h
   const uint64_t B = e->p.batch, D = e->p.D;
   NLSG_HIP(hipMemcpy(e->p.x, x_inout_host, B * D * 8, hipMemcpyHostToDevice));
   launch_solve(e);
-  NLSG_HIP(hipGetLastError());
+  NLSG_HIP(launches_status());
   NLSG_HIP(hipStreamSynchronize(e->stream));
   NLSG_HIP(hipMemcpy(x_inout_host, e->p.x, B * D * 8, hipMemcpyDeviceToHost));
   if (status_host) {
@@ -259,7 +259,7 @@ int nlsg_sann_time_solve(nlsg_sann *e, const double *x0_host, uint32_t repeats, 
     launch_solve(e);
     NLSG_HIP(hipEventRecord(e->ev1, e->stream));
     NLSG_HIP(hipEventSynchronize(e->ev1));
-    NLSG_HIP(hipGetLastError());
+    NLSG_HIP(launches_status());
     float ms = 0.f;
     NLSG_HIP(hipEventElapsedTime(&ms, e->ev0, e->ev1));
     total += ms;

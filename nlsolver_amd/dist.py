@@ -73,32 +73,51 @@ class ShardedSwarm:
                 and os.environ.get("NLSG_DIST_NATIVE", "1") != "0"):
             self._attach_native()
 
+    def _agree(self, ok):
+        """True when `ok` holds on EVERY rank (one all-reduce): what a rank does next in the
+        attach sequence must not depend on its local outcome alone, or some ranks would enter a
+        collective the others never reach."""
+        flag = self.torch.tensor([1 if ok else 0], dtype=self.torch.int32, device=self.device)
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
+        return bool(flag.item())
+
     def _attach_native(self):
         """One rank draws the communicator id, torch.distributed broadcasts it, every rank
-        attaches (a collective inside RCCL)."""
+        attaches (a collective inside RCCL). After each local step the ranks agree on its
+        outcome; any failure anywhere puts ALL ranks on host-ordered turns."""
         from . import _capi
         import ctypes as C
         torch = self.torch
-        try:  # the same outcome on every rank (same installation): safe to fall back on
-            _capi.check(_capi.lib().nlsg_comm_load(rccl_library_path().encode()))
-        except RuntimeError:
+
+        def local(step, what):
+            try:
+                step()
+                return True
+            except RuntimeError as exc:
+                print(f"nlsolver_amd.dist: rank {self.rank}: {what} failed ({exc}); "
+                      "host-ordered turns instead", file=sys.stderr)
+                return False
+
+        if not self._agree(local(lambda: _capi.check(_capi.lib().nlsg_comm_load(
+                rccl_library_path().encode())), "loading RCCL")):
             return
         uid = (C.c_ubyte * 128)()
-        if self.rank == 0:
-            _capi.check(_capi.lib().nlsg_comm_unique_id(uid))
+        drew = self.rank != 0 or local(lambda: _capi.check(_capi.lib().nlsg_comm_unique_id(uid)),
+                                       "ncclGetUniqueId")
+        if not self._agree(drew):
+            return
         t = torch.tensor(list(bytes(uid)), dtype=torch.uint8, device=self.device)
         self.dist.broadcast(t, src=0)
-        ok = 1
-        try:
-            self.engine.comm_attach(bytes(t.cpu().tolist()), self.world, self.rank)
-        except RuntimeError as exc:
-            ok = 0
-            print(f"nlsolver_amd.dist: rank {self.rank}: library-side communicator failed ({exc}); "
-                  "host-ordered turns instead", file=sys.stderr)
-        # every rank takes the same driver: native only if the attach worked everywhere
-        agreed = torch.tensor([ok], dtype=torch.int32, device=self.device)
-        self.dist.all_reduce(agreed, op=self.dist.ReduceOp.MIN)
-        self.native = bool(agreed.item())
+        # the engine joins ncclCommInitRank even when its own resources failed (nlsg_comm.h), so
+        # every rank comes back from this call
+        attached = local(lambda: self.engine.comm_attach(bytes(t.cpu().tolist()), self.world,
+                                                         self.rank), "library-side communicator")
+        self.native = self._agree(attached)
+
+    def comm_ranks(self):
+        """(world, rank) read back from the library-side RCCL communicator; None when turns are
+        host-ordered."""
+        return self.engine.comm_ranks() if self.native else None
 
     def init(self, *args):
         """DE: init(x0); PSO: init(lower, upper)."""

@@ -84,6 +84,11 @@ class LMEngine:
     def __exit__(self, *exc):
         self.close()
 
+    def set_solver(self, solver):
+        """LM_CHOLESKY / LM_QR for the next solves; the model data stays on the device."""
+        check(lib().nlsg_lm_set_solver(self._h, solver))
+        self.cfg.solver = solver
+
     def minimize(self, theta):
         theta = np.ascontiguousarray(theta, dtype=np.float64)
         assert theta.shape == (self.cfg.batch, self.cfg.n)

@@ -124,6 +124,12 @@ class PSOEngine:
     def step_sharded(self, turns=1):
         check(lib().nlsg_pso_step_sharded(self._h, turns))
 
+    def comm_ranks(self):
+        """(world, rank) as the attached RCCL communicator reports them."""
+        w, r = C.c_int32(), C.c_int32()
+        check(lib().nlsg_pso_comm_ranks(self._h, C.byref(w), C.byref(r)))
+        return w.value, r.value
+
 
 class PSO:
     """Drop-in for nlsolver::PSO on a device objective (same ctor args/defaults/overloads)."""

@@ -112,3 +112,22 @@ def test_world2_gloo_pso_matches_single_process_oracle(tmp_path, oracle, kw):
         assert got["gval"][0] == ref.s.gbest_val
         if kw["eps"] > 0:
             assert got["gval"][1] == ref.s.std_err
+
+
+def test_bench_self_launch_without_gpu_fails_loudly():
+    """`python bench.py --gpus 2` with no launcher starts its two ranks itself; without a GPU every
+    rank refuses ("no CPU fallback") and the launcher must come back non-zero, with no JSON line,
+    instead of hanging or printing a number."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this is the no-GPU behaviour")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    assert "rank exit codes" in r.stderr and "needs a GPU" in r.stderr
+    assert not r.stdout.strip()

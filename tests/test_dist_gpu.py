@@ -110,20 +110,58 @@ def test_sharded_turn_world1_matches_unsharded_engine(mode, port):
         assert case["std_err"][0] == case["std_err"][1], case
 
 
-@pytest.mark.parametrize("workload,port", [("de", "29641"), ("pso-accel", "29642")])
-def test_bench_two_rank_flow_rehearsal(workload, port):
-    """bench.py's N > 1 control flow, executed with two ranks on this one GPU over gloo
-    (NLSG_BENCH_REHEARSAL=1; RCCL refuses two ranks on one device): every collective step is
-    entered by every rank, rank 0 prints exactly one JSON line. The number itself means nothing."""
+@pytest.mark.parametrize("workload,extra", [
+    ("de", ["--pop-per-gpu", "8192"]), ("pso-accel", ["--pop-per-gpu", "8192"]),
+    ("bfgs", ["--pop-per-gpu", "16"]), ("lm", ["--pop-per-gpu", "64"]), ("nm", ["--pop-per-gpu", "64"])])
+def test_bench_two_rank_flow_rehearsal(workload, extra):
+    """`python3 bench.py --gpus 2` exactly as the driver spells it — no external launcher:
+    bench.py starts its two ranks itself (fresh child processes, before anything touches the GPU).
+    On this one GPU the ranks share device 0 and talk over gloo (NLSG_BENCH_REHEARSAL=1; RCCL
+    refuses two ranks on one device): every collective step is entered by every rank, rank 0 prints
+    exactly one JSON line with n_gpus = 2. The number itself means nothing."""
     env = dict(os.environ, NLSG_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py"),
-           "--gpus", "2", "--steps", "40", "--warmup", "5", "--pop-per-gpu", "8192",
-           "--workload", workload]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "40",
+           "--warmup", "5", "--workload", workload, "--no-cpu-baseline", *extra]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, lines
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["steps"] == 40 and out["value"] > 0
+    assert out["n_gpus"] == 2 and out["value"] > 0
     assert out["roofline"]["kernel_ms"] > 0
+    if workload in ("de", "pso-accel"):
+        assert out["steps"] == 40
+        # host-ordered turns over gloo in the rehearsal: no library-side communicator to read back
+        assert out["config"]["turn_driver"].startswith("host") and out["config"]["rccl_ranks"] is None
+    else:
+        assert out["config"]["parallelism"].startswith("replicas x2")
+
+
+def test_bench_forced_dist_reports_rccl_ranks():
+    """One rank, but through the sharded path and the library's own RCCL communicator
+    (NLSG_BENCH_FORCE_DIST=1): the line carries the communicator size RCCL reports."""
+    env = dict(os.environ, NLSG_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               MASTER_PORT="29651")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "40",
+           "--warmup", "5", "--pop-per-gpu", "8192", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    assert out["config"]["rccl_ranks"] == 1 and out["config"]["turn_driver"].startswith("library")
+
+
+def test_bench_self_launch_propagates_failure():
+    """A rank that dies takes the whole `bench.py --gpus 2` down with a non-zero exit code and no
+    JSON line (here: an impossible shard size)."""
+    env = dict(os.environ, NLSG_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4",
+           "--warmup", "1", "--pop-per-gpu", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
