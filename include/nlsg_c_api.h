@@ -282,7 +282,7 @@ typedef struct {
   int32_t device;
   void *stream;
   int32_t objective;   /* nlsg_grad_objective (analytic gradient functor), or one of */
-                       /* NLSG_OBJ_ROSENBROCK / SPHERE / STYBLINSKI_TANG with the    */
+                       /* NLSG_OBJ_ROSENBROCK / SPHERE / STYBLINSKI_TANG / RASTRIGIN:  */
                        /* reference's default gradient fin_diff (nlsolver.h:         */
                        /* 1385-1413, 2849-2855), evaluated on the device; dim <= 256 */
   int32_t reserved;
@@ -339,7 +339,7 @@ typedef struct {
   int32_t device;
   void *stream;
   int32_t objective;      /* nlsg_nlls_objective (Gauss-Newton functors on the device), or
-                           * NLSG_OBJ_ROSENBROCK / SPHERE / STYBLINSKI_TANG / CUSTOM: the
+                           * NLSG_OBJ_ROSENBROCK / SPHERE / STYBLINSKI_TANG / RASTRIGIN / CUSTOM: the
                            * reference's default functors, Grad = fin_diff and Hess =
                            * fin_diff_h at accuracy 1 (nlsolver.h:3494-3511, 1385-1413,
                            * 1446-1515), every probe evaluated on the device; Cholesky only;

@@ -943,6 +943,7 @@ class BFGS {
       return Callable::nlsg_objective == NLSG_OBJ_ROSENBROCK ||
              Callable::nlsg_objective == NLSG_OBJ_SPHERE ||
              Callable::nlsg_objective == NLSG_OBJ_STYBLINSKI_TANG ||
+             Callable::nlsg_objective == NLSG_OBJ_RASTRIGIN ||
              Callable::nlsg_objective == NLSG_OBJ_CUSTOM;
     else
       return false;
@@ -1737,6 +1738,7 @@ class LevenbergMarquardt {
       return Callable::nlsg_objective == NLSG_OBJ_ROSENBROCK ||
              Callable::nlsg_objective == NLSG_OBJ_SPHERE ||
              Callable::nlsg_objective == NLSG_OBJ_STYBLINSKI_TANG ||
+             Callable::nlsg_objective == NLSG_OBJ_RASTRIGIN ||
              Callable::nlsg_objective == NLSG_OBJ_CUSTOM;
     else
       return false;

@@ -62,6 +62,11 @@ namespace {
         hipLaunchKernelGGL((KERNEL<C, V, NLSG_OBJ_STYBLINSKI_TANG>), dim3(grid), dim3(256), 0,      \
                            e->stream, __VA_ARGS__);                                                 \
       break;                                                                                        \
+    case NLSG_OBJ_RASTRIGIN:                                                                        \
+      if constexpr (C <= 2)                                                                         \
+        hipLaunchKernelGGL((KERNEL<C, V, NLSG_OBJ_RASTRIGIN>), dim3(grid), dim3(256), 0, e->stream, \
+                           __VA_ARGS__);                                                            \
+      break;                                                                                        \
     default: break;                                                                                 \
   }
 #define BFGS_DISPATCH_MODEL(KERNEL, grid, ...)                           \
@@ -125,7 +130,8 @@ static int bfgs_create(const nlsg_bfgs_config *cfg, const double *diag_host, con
                 cfg->struct_size, sizeof(nlsg_bfgs_config));
   const bool quad = cfg->objective == NLSG_OBJ_QUAD_DIAG_RANK1;
   const bool fd = cfg->objective == NLSG_OBJ_ROSENBROCK || cfg->objective == NLSG_OBJ_SPHERE ||
-                  cfg->objective == NLSG_OBJ_STYBLINSKI_TANG || custom != nullptr;
+                  cfg->objective == NLSG_OBJ_STYBLINSKI_TANG || cfg->objective == NLSG_OBJ_RASTRIGIN ||
+                  custom != nullptr;
   if (!quad && !fd) return fail(NLSG_ERR_INVALID_ARG, "unknown objective %d", cfg->objective);
   if (quad && (!diag_host || !lin_host))
     return fail(NLSG_ERR_INVALID_ARG, "the quadratic needs its d and b vectors");

@@ -25,6 +25,7 @@ typedef int int32_t;
 #endif
 
 #include "../../include/nlsg_c_api.h"
+#include "nlsg_math.h"
 
 namespace nlsg {
 
@@ -275,7 +276,7 @@ template <>
 struct Objective<NLSG_OBJ_RASTRIGIN> {
   static constexpr bool kChain = false;
   __device__ static inline double term(double xi, double) {
-    return xi * xi - 10 * cos(2 * 3.14159265358979323846 * xi);  // test_functions.h:74-76
+    return xi * xi - 10 * det_cos_2pi(xi);  // test_functions.h:74-76, deterministic cosine
   }
   __device__ static inline uint64_t n_terms(uint64_t D) { return D; }
   __device__ static inline double finish(double s, uint64_t D) {

@@ -39,7 +39,8 @@ int upload_theta(nlsg_lm *e, const double *theta_host) {
 // two evaluation launches.
 bool lm_fd_objective(int objective) {
   return objective == NLSG_OBJ_ROSENBROCK || objective == NLSG_OBJ_SPHERE ||
-         objective == NLSG_OBJ_STYBLINSKI_TANG || objective == NLSG_OBJ_CUSTOM;
+         objective == NLSG_OBJ_STYBLINSKI_TANG || objective == NLSG_OBJ_RASTRIGIN ||
+         objective == NLSG_OBJ_CUSTOM;
 }
 
 // finite-difference model: step k + evaluation k + 1 (first: the evaluation at x0 only)
@@ -57,6 +58,9 @@ void launch_fd_iter(nlsg_lm *e, int first) {
       break;
     case NLSG_OBJ_SPHERE:
       hipLaunchKernelGGL(lm_fd_iter_kernel<NLSG_OBJ_SPHERE>, grid, dim3(64), lds, e->stream, e->p, first);
+      break;
+    case NLSG_OBJ_RASTRIGIN:
+      hipLaunchKernelGGL(lm_fd_iter_kernel<NLSG_OBJ_RASTRIGIN>, grid, dim3(64), lds, e->stream, e->p, first);
       break;
     default:
       hipLaunchKernelGGL(lm_fd_iter_kernel<NLSG_OBJ_STYBLINSKI_TANG>, grid, dim3(64), lds, e->stream, e->p, first);

@@ -86,6 +86,18 @@ __device__ inline double det_cos(double y) {
   return q == 0 ? c : q == 1 ? -s : q == 2 ? -c : s;
 }
 
+// cos(2 pi x) the way the reference's Rastrigin writes it (test_functions.h:74-76): the product
+// t = (2 M_PI) x is rounded first, then its cosine is taken. Beyond det_cos's range the period
+// is taken off x itself — x - rint(x) is exact — which differs from a cosine of the rounded
+// product by less than the rounding of that product (|x| > 10: 1e-15 absolute on a value
+// added to x^2 > 100).
+__device__ inline double det_cos_2pi(double x) {
+  constexpr double two_pi = 2 * 3.14159265358979323846;
+  double t = two_pi * x;
+  if (!(t >= -64.0 && t <= 64.0)) t = two_pi * (x - rint(x));
+  return det_cos(t);
+}
+
 // exp / tanh for the NLLS residual models (same algorithms as oracle_lm.c orc_exp/orc_tanh)
 __device__ inline double det_exp(double x) {
   constexpr double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,

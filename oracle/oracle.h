@@ -53,6 +53,7 @@ double orc_u01(uint64_t bits); /* (double)bits * 2^-64, cf. nlsolver.h:1358 */
  * arithmetic of the synchronous restatements and the HIP kernels. */
 double orc_log(double x);
 double orc_cos(double y);
+double orc_cos_2pi(double x); /* cos(2 pi x), the device's Rastrigin cosine (nlsg_math.h) */
 
 /* ------------------------------------------------------------ objectives --- */
 enum {

@@ -81,6 +81,14 @@ static double kernel_sin(double x) { /* |x| <= pi/4 */
   return fma(v, fma(z, r, S1), x);
 }
 
+/* cos(2 pi x) as nlsg_math.h det_cos_2pi (the device's Rastrigin term) */
+double orc_cos_2pi(double x) {
+  const double two_pi = 2 * 3.14159265358979323846;
+  double t = two_pi * x;
+  if (!(t >= -64.0 && t <= 64.0)) t = two_pi * (x - rint(x));
+  return orc_cos(t);
+}
+
 /* cosine for |y| <= 64 (two-term Cody-Waite reduction by pi/2); NaN outside */
 double orc_cos(double y) {
   static const double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00,

@@ -107,7 +107,8 @@ def test_bfgs_config3_shape_sample(mod, oracle):
 @pytest.mark.parametrize("obj,n,batch", [("rosenbrock", 2, 6), ("rosenbrock", 5, 4),
                                          ("rosenbrock", 16, 5), ("rosenbrock", 128, 4),
                                          ("rosenbrock", 130, 3), ("rosenbrock", 256, 2),
-                                         ("sphere", 7, 4), ("styblinski_tang", 64, 4)])
+                                         ("sphere", 7, 4), ("styblinski_tang", 64, 4),
+                                         ("rastrigin", 2, 4), ("rastrigin", 48, 3)])
 @pytest.mark.parametrize("kw", [dict(max_iter=6, grad_eps=0.0, alpha=1.0),
                                 dict(max_iter=40, grad_eps=5e-3, alpha=0.5)])
 def test_bfgs_default_finite_difference_gradient_bit_exact(mod, oracle, obj, n, batch, kw):

@@ -79,17 +79,34 @@ def test_other_objectives_and_maximize_bit_exact(eng_mod, oracle, obj, minimize)
         assert np.array_equal(P, ref.population) and np.array_equal(S, ref.scores)
 
 
-def test_rastrigin_scores_within_tolerance(eng_mod, oracle):
-    # cos() differs between libm and the device library in the last bits, so this
-    # objective is tolerance-checked (1e-12) on the initial scoring only.
+@pytest.mark.parametrize("scale", [5.12, 80.0])
+def test_rastrigin_generations_bit_exact(eng_mod, oracle, scale):
+    """Rastrigin's cosine is the deterministic one on both sides (nlsg_math.h det_cos_2pi and its
+    mirror in the oracle's tree evaluation): populations and scores agree bit for bit through
+    the generations like every other objective. scale = 80: |2 pi x| leaves the cosine's direct
+    range and the period is taken off x first."""
     pop, D = 64, 32
-    x0 = x0_for(D, 5.12)
-    ref = O.DESyncRun(oracle, "rastrigin", pop, D, x0)
-    with eng_mod.DEEngine("rastrigin", pop, D) as eng:
+    x0 = x0_for(D, scale)
+    ref = O.DESyncRun(oracle, "rastrigin", pop, D, x0, eps=0.0, best_val_no_change=1000)
+    with eng_mod.DEEngine("rastrigin", pop, D, eps=0.0, best_val_no_change=1000) as eng:
         eng.init(x0)
+        eng.step(6)
         P, S = eng.download()
-    assert np.array_equal(P, ref.population)
-    assert np.allclose(S, ref.scores, rtol=1e-12, atol=0)
+    ref.step(6)
+    assert np.array_equal(P, ref.population) and np.array_equal(S, ref.scores)
+
+
+def test_rastrigin_within_1e12_of_reference_arithmetic(eng_mod, oracle):
+    """...and within 1e-12 of the reference's own arithmetic (sequential sum, libm cosine of the
+    rounded product 2 pi x; test_functions.h:69-78), inside and outside the direct range."""
+    for scale in (5.12, 80.0):
+        pop, D = 64, 32
+        with eng_mod.DEEngine("rastrigin", pop, D) as eng:
+            eng.init(x0_for(D, scale))
+            P, S = eng.download()
+        seq = np.array([oracle.orc_objective_seq(O.OBJ["rastrigin"], np.ascontiguousarray(r).ctypes.data_as(O.pd), D)
+                        for r in P])
+        assert np.allclose(S, seq, rtol=1e-12, atol=0)
 
 
 def test_scores_match_reference_arithmetic_1e12(eng_mod, oracle):

@@ -119,7 +119,8 @@ def fd_starts(oracle, objective, batch, n, scale):
                                                ("rosenbrock", 7, 1.2), ("rosenbrock", 16, 1.0),
                                                ("sphere", 1, 3.0), ("sphere", 5, 3.0),
                                                ("styblinski_tang", 8, 4.0),
-                                               ("styblinski_tang", 33, 4.0)])
+                                               ("styblinski_tang", 33, 4.0),
+                                               ("rastrigin", 2, 4.0), ("rastrigin", 12, 30.0)])
 @pytest.mark.parametrize("kw", [dict(lam=10.0, max_iter=12, f_delta=1e-12),
                                 dict(lam=1.0, up=4.0, down=3.0, max_iter=5, f_delta=0.0)])
 def test_lm_default_functors_bit_exact_vs_oracle(mod, oracle, objective, n, scale, kw):
@@ -179,4 +180,4 @@ def test_lm_default_functors_reject_qr_and_data(mod):
     with pytest.raises(NlsgError):
         mod.lm.LMEngine("rosenbrock", batch=1, n=4, solver=LM_QR)
     with pytest.raises(NlsgError):
-        mod.lm.LMEngine("rastrigin", batch=1, n=4)
+        mod.lm.LMEngine(99, batch=1, n=4)
