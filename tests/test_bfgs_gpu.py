@@ -104,6 +104,40 @@ def test_bfgs_config3_shape_sample(mod, oracle):
     assert len(iters) > 1
 
 
+def test_bfgs_config3_full_batch(mod, oracle):
+    """BASELINE configs[2] at its full size — n = 1024, batch = 4096 independent starts (32 GiB of
+    inverse Hessians: 64-bit offsets, every block of the H passes in use): 18 sampled problems
+    including the first and the LAST index bit for bit against the tree oracle; every problem
+    finished, inside max_iter, no higher than it started (More-Thuente's sufficient decrease),
+    and problems stop at different iterations (done mask)."""
+    n, batch = 1024, 4096
+    d, b, c = O.quad_problem(n)
+    rng = np.random.default_rng(33)
+    x0 = 1.0 + 0.5 * (rng.random((batch, n)) - 0.5)
+    x0[::7] *= 1.0 + rng.random((len(x0[::7]), 1))  # spread the iteration counts
+    kw = dict(max_iter=50, grad_eps=1e-6, alpha=1.0)
+    with mod.BFGSEngine(mod.QuadDiagRank1(d, b, c), batch, **kw) as eng:
+        x, st = eng.minimize(x0.copy())
+    sample = sorted({0, 1, 7, 255, 256, 2047, 2048, 4094, 4095, *rng.integers(0, batch, 9).tolist()})
+    assert len(sample) >= 16
+    for p in sample:
+        ref, xr, _ = O.bfgs_quad(oracle, x0[p], tree=1, **kw)
+        assert (st[p].iteration, st[p].function_calls_used, st[p].gradient_evals_used) == \
+            (ref.iteration, ref.function_calls_used, ref.gradient_evals_used), p
+        assert st[p].f_value == ref.f_value and np.array_equal(x[p], xr), p
+
+    def quad(v):
+        sv = v.sum(axis=1)
+        return 0.5 * (v * v * d).sum(axis=1) + 0.5 * c * sv * sv - (v * b).sum(axis=1)
+
+    f_start, f_end = quad(x0), np.array([s.f_value for s in st])
+    assert all(s.done == 1 and 1 <= s.iteration <= 50 for s in st)
+    assert np.all(f_end <= f_start) and np.allclose(f_end, quad(x), rtol=1e-12, atol=1e-12)
+    assert len({s.iteration for s in st}) > 1
+    # all of them found the one minimiser of the convex quadratic
+    assert np.max(np.abs(x - x[0])) < 1e-4
+
+
 @pytest.mark.parametrize("obj,n,batch", [("rosenbrock", 2, 6), ("rosenbrock", 5, 4),
                                          ("rosenbrock", 16, 5), ("rosenbrock", 128, 4),
                                          ("rosenbrock", 130, 3), ("rosenbrock", 256, 2),

@@ -55,3 +55,35 @@ def test_kernel_order_follows_the_reference_path(oracle, golden, name):
         # simplex down another (equally valid) path; only the quality is comparable
         assert st.iteration == g["iters"]
         assert 0.5 * hx(g["f"]) <= st.f_value <= 2.0 * hx(g["f"])
+
+
+def test_128d_fork_is_a_tie_broken_by_summation_order(oracle, golden):
+    """Where and why the kernel-order run leaves the reference's path on the 128-D golden: the
+    first 261 evaluated values agree to 3e-15. The start is a constant vector, so the vertices of
+    the (shrunk) simplex that differ only in WHICH coordinate moved have mathematically equal
+    values; in floating point they form clusters a few ulp wide whose internal order depends on
+    the order of summation (sequential in the reference, lane tree on the device). The worst /
+    second-worst scan takes the first index of the maximum: it lands on different vertices."""
+    g = golden("nm.json")["d128_2000iters"]
+    D = g["D"]
+    x0 = hx(g["x0"]) + hx(g["x0_step"]) * np.arange(D, dtype=np.float64)
+    kw = dict(step=hx(g["step"]), eps=hx(g["eps"]), max_iter=140, no_change=g["no_change"],
+              restarts=g["restarts"], minimize=True, log_cap=4096)
+    _, _, _, (_, f0) = O.nm_run(oracle, x0, order=0, **kw)
+    _, _, _, (_, f1) = O.nm_run(oracle, x0, order=1, **kw)
+    n = min(len(f0), len(f1))
+    rel = np.abs(f0[:n] - f1[:n]) / np.abs(f0[:n])
+    fork = int(np.nonzero(rel > 1e-9)[0][0])
+    assert fork == 261
+    assert rel[:fork].max() <= 3e-15
+    # the rescored vertices of the first shrink (calls 129 ..): one cluster, < 1e-14 wide ...
+    c0, c1 = f0[129:257], f1[129:257]
+    big0 = c0[np.abs(c0 - np.median(c0)) <= 1e-14 * np.median(c0)]
+    big1 = c1[np.abs(c1 - np.median(c1)) <= 1e-14 * np.median(c1)]
+    assert len(big0) >= 120 and len(big1) >= 120
+    # ... several distinct bit patterns in either arithmetic, and the maximum sits elsewhere
+    assert len(set(big0.tolist())) > 1 and len(set(big1.tolist())) > 1
+    in0 = np.abs(c0 - np.median(c0)) <= 1e-14 * np.median(c0)
+    in1 = np.abs(c1 - np.median(c1)) <= 1e-14 * np.median(c1)
+    assert np.array_equal(in0, in1)
+    assert int(np.argmax(np.where(in0, c0, -np.inf))) != int(np.argmax(np.where(in1, c1, -np.inf)))
