@@ -19,10 +19,28 @@ struct nlsg_nm {
 };
 
 namespace {
-template <int OBJ>
-hipError_t prepare(size_t lds) {
-  return hipFuncSetAttribute(reinterpret_cast<const void *>(nm_solve_kernel<OBJ>),
+template <int OBJ, int CHUNKS>
+hipError_t prepare1(size_t lds) {
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(nm_solve_kernel<OBJ, CHUNKS>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+}
+template <int OBJ>
+hipError_t prepare(size_t lds, int chunks) {
+  switch (chunks) {
+    case 1: return prepare1<OBJ, 1>(lds);
+    case 2: return prepare1<OBJ, 2>(lds);
+    case 4: return prepare1<OBJ, 4>(lds);
+    default: return prepare1<OBJ, 8>(lds);
+  }
+}
+template <int OBJ>
+void launch_obj(nlsg_nm *e, dim3 grid, dim3 block) {
+  switch (nm_chunks(e->p.n)) {
+    case 1: hipLaunchKernelGGL((nm_solve_kernel<OBJ, 1>), grid, block, e->lds, e->stream, e->p); break;
+    case 2: hipLaunchKernelGGL((nm_solve_kernel<OBJ, 2>), grid, block, e->lds, e->stream, e->p); break;
+    case 4: hipLaunchKernelGGL((nm_solve_kernel<OBJ, 4>), grid, block, e->lds, e->stream, e->p); break;
+    default: hipLaunchKernelGGL((nm_solve_kernel<OBJ, 8>), grid, block, e->lds, e->stream, e->p); break;
+  }
 }
 
 void launch(nlsg_nm *e) {
@@ -33,19 +51,10 @@ void launch(nlsg_nm *e) {
     return;
   }
   switch (e->cfg.objective) {
-    case NLSG_OBJ_ROSENBROCK:
-      hipLaunchKernelGGL(nm_solve_kernel<NLSG_OBJ_ROSENBROCK>, grid, block, e->lds, e->stream, e->p);
-      break;
-    case NLSG_OBJ_SPHERE:
-      hipLaunchKernelGGL(nm_solve_kernel<NLSG_OBJ_SPHERE>, grid, block, e->lds, e->stream, e->p);
-      break;
-    case NLSG_OBJ_STYBLINSKI_TANG:
-      hipLaunchKernelGGL(nm_solve_kernel<NLSG_OBJ_STYBLINSKI_TANG>, grid, block, e->lds, e->stream,
-                         e->p);
-      break;
-    default:
-      hipLaunchKernelGGL(nm_solve_kernel<NLSG_OBJ_RASTRIGIN>, grid, block, e->lds, e->stream, e->p);
-      break;
+    case NLSG_OBJ_ROSENBROCK: launch_obj<NLSG_OBJ_ROSENBROCK>(e, grid, block); break;
+    case NLSG_OBJ_SPHERE: launch_obj<NLSG_OBJ_SPHERE>(e, grid, block); break;
+    case NLSG_OBJ_STYBLINSKI_TANG: launch_obj<NLSG_OBJ_STYBLINSKI_TANG>(e, grid, block); break;
+    default: launch_obj<NLSG_OBJ_RASTRIGIN>(e, grid, block); break;
   }
 }
 
@@ -85,8 +94,8 @@ static int nm_create(const nlsg_nm_config *cfg, const nlsg_custom_objective *cus
   if (!custom && (cfg->objective < 0 || cfg->objective > NLSG_OBJ_RASTRIGIN))
     return fail(NLSG_ERR_INVALID_ARG, "unknown objective %d", cfg->objective);
   if (cfg->dim < 1 || cfg->batch < 1) return fail(NLSG_ERR_INVALID_ARG, "dim and batch must be >= 1");
-  if (cfg->dim > 128)
-    return fail(NLSG_ERR_UNSUPPORTED, "dim %llu > 128: the simplex no longer fits the 160 KiB LDS",
+  if (cfg->dim > 1024)
+    return fail(NLSG_ERR_UNSUPPORTED, "dim %llu > 1024 is not covered by the device path",
                 (unsigned long long)cfg->dim);
   if (cfg->batch > 0x7fffffffull) return fail(NLSG_ERR_UNSUPPORTED, "batch too large");
   int rc = check_device(cfg->device);
@@ -110,18 +119,21 @@ static int nm_create(const nlsg_nm_config *cfg, const nlsg_custom_objective *cus
   const uint64_t B = cfg->batch, n = cfg->dim;
   e->lds = nm_lds_bytes(n);
   hipError_t he = hipSuccess;
+  const int chunks = nm_chunks(n);
+  if (he == hipSuccess && chunks > 1)  // the simplexes themselves: past what LDS holds
+    he = hipMalloc(reinterpret_cast<void **>(&p.simplex), B * (n + 1) * n * 8);
   if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p.x), B * n * 8);
   if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p.prob), B * sizeof(NmProblem));
   if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&e->upper_dev), n * 8);
   if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&e->lower_dev), n * 8);
   if (he == hipSuccess) he = hipEventCreate(&e->ev0);
   if (he == hipSuccess) he = hipEventCreate(&e->ev1);
-  if (he == hipSuccess) he = prepare<NLSG_OBJ_ROSENBROCK>(e->lds);
-  if (he == hipSuccess) he = prepare<NLSG_OBJ_SPHERE>(e->lds);
-  if (he == hipSuccess) he = prepare<NLSG_OBJ_STYBLINSKI_TANG>(e->lds);
-  if (he == hipSuccess) he = prepare<NLSG_OBJ_RASTRIGIN>(e->lds);
+  if (he == hipSuccess) he = prepare<NLSG_OBJ_ROSENBROCK>(e->lds, chunks);
+  if (he == hipSuccess) he = prepare<NLSG_OBJ_SPHERE>(e->lds, chunks);
+  if (he == hipSuccess) he = prepare<NLSG_OBJ_STYBLINSKI_TANG>(e->lds, chunks);
+  if (he == hipSuccess) he = prepare<NLSG_OBJ_RASTRIGIN>(e->lds, chunks);
   if (he == hipSuccess && custom) {
-    const int rc2 = rtc_build_nm(custom, &e->rtc);
+    const int rc2 = rtc_build_nm(custom, chunks, &e->rtc);
     if (rc2) {
       nlsg_nm_destroy(e);
       return rc2;
@@ -159,6 +171,7 @@ int nlsg_nm_destroy(nlsg_nm *e) {
   hipSetDevice(e->cfg.device);
   if (e->stream) hipStreamSynchronize(e->stream);
   rtc_release(&e->rtc);
+  hipFree(e->p.simplex);
   hipFree(e->p.x);
   hipFree(e->p.prob);
   hipFree(e->upper_dev);

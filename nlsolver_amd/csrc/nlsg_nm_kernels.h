@@ -7,7 +7,10 @@
 // One persistent 1024-thread workgroup per start (16 waves: the LDS image allows one workgroup
 // per CU, so the waves are what hides latency and shares the vertex rows of a shrink); the (n+1) x n simplex, its scores and the
 // work vectors live in LDS (132 KiB at n = 128 of the 160 KiB a CDNA4 CU has), so an
-// iteration touches no HBM at all. The method is a chain of data-dependent decisions
+// iteration touches no HBM at all. Past n = 128 (CHUNKS > 1, n <= 128 CHUNKS) the simplex rows
+// move to a per-start workspace in global memory (8.4 MB at n = 1024: L2-resident while the
+// workgroup — the only reader and writer of it — runs; a workgroup barrier orders its own
+// accesses), scores and work vectors stay in LDS; same code, same arithmetic. The method is a chain of data-dependent decisions
 // (latency bound): control flow is evaluated by thread 0 and broadcast through
 // LDS, vector work is spread over threads (centroid: thread j sums vertex coordinates in the
 // reference's vertex order), objectives are evaluated one vertex per wave with the fixed
@@ -34,6 +37,7 @@ struct NmProblem {
 };
 
 struct NmParams {
+  double *simplex;      // [batch][n + 1][n] workspace, n > 128 only
   double *x;            // [batch][n] in/out
   const double *upper, *lower;  // [n]
   NmProblem *prob;      // [batch]
@@ -48,28 +52,38 @@ struct NmCtl {  // control block in LDS
   int stop, shrunk, action;
 };
 
-// objective of the point at `pt` (LDS, n <= 128), evaluated by one wave; all lanes get it
-template <int OBJ>
-__device__ inline double nm_wave_f(const double *pt, uint64_t n, double fmul) {
+// the point at `pt` in the lane layout of the other engines (element 128 c + 2 lane + k)
+template <int CHUNKS>
+__device__ inline void nm_load_point(const double *pt, uint64_t n, double (&xv)[CHUNKS][2]) {
   const int lane = lane_id();
-  double xv[1][2];
-  xv[0][0] = (2u * lane < n) ? pt[2 * lane] : 0.0;
-  xv[0][1] = (2u * lane + 1 < n) ? pt[2 * lane + 1] : 0.0;
-  return fmul * wave_objective<OBJ, 1>(xv, n);
+#pragma unroll
+  for (int c = 0; c < CHUNKS; c++) {
+    const uint64_t e0 = static_cast<uint64_t>(c) * 128 + 2 * static_cast<uint64_t>(lane);
+    xv[c][0] = (e0 < n) ? pt[e0] : 0.0;
+    xv[c][1] = (e0 + 1 < n) ? pt[e0 + 1] : 0.0;
+  }
+}
+// objective of the point at `pt` (n <= 128 CHUNKS), evaluated by one wave; all lanes get it
+template <int OBJ, int CHUNKS>
+__device__ inline double nm_wave_f(const double *pt, uint64_t n, double fmul) {
+  double xv[CHUNKS][2];
+  nm_load_point<CHUNKS>(pt, n, xv);
+  return fmul * wave_objective<OBJ, CHUNKS>(xv, n);
 }
 
-template <int OBJ>
+template <int OBJ, int CHUNKS = 1>
 __global__ __launch_bounds__(kNmThreads) void nm_solve_kernel(NmParams p) {
   // the workgroup is sized by the host to the simplex (nm_block_threads): 64 .. kNmThreads
   const uint64_t nthreads = blockDim.x, nwaves = blockDim.x >> 6;
   extern __shared__ __align__(16) unsigned char nm_smem[];
   const uint64_t n = p.n, nv = p.n + 1;
-  double *S = reinterpret_cast<double *>(nm_smem);  // [nv][n]
-  double *scores = S + nv * n;                      // [nv] (padded to even)
+  const uint64_t pid = blockIdx.x;
+  double *const lds0 = reinterpret_cast<double *>(nm_smem);
+  double *S = CHUNKS == 1 ? lds0 : p.simplex + pid * nv * n;  // [nv][n]
+  double *scores = CHUNKS == 1 ? lds0 + nv * n : lds0;  // [nv] (padded to even)
   double *centroid = scores + ((nv + 1) & ~1ull);
   double *tr = centroid + n, *te = tr + n, *tc = te + n, *x0 = tc + n, *up = x0 + n, *lo = up + n;
   NmCtl *ctl = reinterpret_cast<NmCtl *>(lo + n);
-  const uint64_t pid = blockIdx.x;
   const int t = threadIdx.x;
   const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
   const int lane = lane_id();
@@ -113,7 +127,7 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_kernel(NmParams p) {
     for (uint64_t j = t; j < n; j += nthreads) centroid[j] = 0.0;  // :2195
     __syncthreads();
     for (uint64_t v = wid; v < nv; v += nwaves) {  // 2184-2186
-      const double f = nm_wave_f<OBJ>(S + v * n, n, p.fmul);
+      const double f = nm_wave_f<OBJ, CHUNKS>(S + v * n, n, p.fmul);
       if (lane == 0) scores[v] = f;
     }
     __syncthreads();
@@ -226,7 +240,7 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_kernel(NmParams p) {
       }
       __syncthreads();
       if (wid == 0) {
-        const double rs = nm_wave_f<OBJ>(tr, n, p.fmul);
+        const double rs = nm_wave_f<OBJ, CHUNKS>(tr, n, p.fmul);
         if (lane == 0) {
           ctl->ref_score = rs;
           ctl->fcalls++;
@@ -249,7 +263,7 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_kernel(NmParams p) {
         }
         __syncthreads();
         if (wid == 0) {
-          const double es = nm_wave_f<OBJ>(te, n, p.fmul);
+          const double es = nm_wave_f<OBJ, CHUNKS>(te, n, p.fmul);
           if (lane == 0) {
             ctl->exp_score = es;
             ctl->fcalls++;
@@ -269,7 +283,7 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_kernel(NmParams p) {
         }
         __syncthreads();
         if (wid == 0) {
-          const double cs = nm_wave_f<OBJ>(tc, n, p.fmul);
+          const double cs = nm_wave_f<OBJ, CHUNKS>(tc, n, p.fmul);
           if (lane == 0) {
             ctl->cont_score = cs;
             ctl->fcalls++;
@@ -289,29 +303,36 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_kernel(NmParams p) {
           // lane trees overlap (the method spends most iterations here on Rosenbrock-128D:
           // the reference's second-worst rule, SURVEY B3, rarely accepts a reflection).
           {
-            const bool in0 = 2u * lane < n, in1 = 2u * lane + 1 < n;
-            const double b0 = in0 ? S[best * n + 2 * lane] : 0.0;
-            const double b1 = in1 ? S[best * n + 2 * lane + 1] : 0.0;
-            for (uint64_t v0 = wid; v0 < nv; v0 += 4 * nwaves) {
-              double xv[4][1][2];
+            // ROWS rows at a time per wave (register budget: ROWS x CHUNKS x 2 doubles)
+            constexpr int ROWS = CHUNKS == 1 ? 4 : CHUNKS == 2 ? 2 : 1;
+            double bv[CHUNKS][2];
+            nm_load_point<CHUNKS>(S + best * n, n, bv);
+            for (uint64_t v0 = wid; v0 < nv; v0 += ROWS * nwaves) {
+              double xv[ROWS][CHUNKS][2];
 #pragma unroll
-              for (int q = 0; q < 4; q++) {
+              for (int q = 0; q < ROWS; q++) {
                 const uint64_t v = v0 + nwaves * q;
                 const bool live = v < nv && v != best;
                 double *row = S + (live ? v : best) * n;
-                const double o0 = in0 ? row[2 * lane] : 0.0, o1 = in1 ? row[2 * lane + 1] : 0.0;
-                xv[q][0][0] = b0 + p.sigma * (o0 - b0);
-                xv[q][0][1] = b1 + p.sigma * (o1 - b1);
-                if (live && in0) row[2 * lane] = xv[q][0][0];
-                if (live && in1) row[2 * lane + 1] = xv[q][0][1];
-                if (!in0) xv[q][0][0] = 0.0;
-                if (!in1) xv[q][0][1] = 0.0;
+                double ov[CHUNKS][2];
+                nm_load_point<CHUNKS>(row, n, ov);
+#pragma unroll
+                for (int c = 0; c < CHUNKS; c++) {
+                  const uint64_t e0 = static_cast<uint64_t>(c) * 128 + 2 * static_cast<uint64_t>(lane);
+                  const bool in0 = e0 < n, in1 = e0 + 1 < n;
+                  xv[q][c][0] = bv[c][0] + p.sigma * (ov[c][0] - bv[c][0]);
+                  xv[q][c][1] = bv[c][1] + p.sigma * (ov[c][1] - bv[c][1]);
+                  if (live && in0) row[e0] = xv[q][c][0];
+                  if (live && in1) row[e0 + 1] = xv[q][c][1];
+                  if (!in0) xv[q][c][0] = 0.0;
+                  if (!in1) xv[q][c][1] = 0.0;
+                }
               }
-              double f[4];
+              double f[ROWS];
 #pragma unroll
-              for (int q = 0; q < 4; q++) f[q] = p.fmul * wave_objective<OBJ, 1>(xv[q], n);
+              for (int q = 0; q < ROWS; q++) f[q] = p.fmul * wave_objective<OBJ, CHUNKS>(xv[q], n);
 #pragma unroll
-              for (int q = 0; q < 4; q++) {
+              for (int q = 0; q < ROWS; q++) {
                 const uint64_t v = v0 + nwaves * q;
                 if (lane == 0 && v < nv && v != best) scores[v] = f[q];
               }
@@ -342,9 +363,12 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_kernel(NmParams p) {
   }
 }
 
+// chunks of 128 coordinates per point: 1 = simplex in LDS, else in the global workspace
+__host__ __device__ inline int nm_chunks(uint64_t n) { return n <= 128 ? 1 : n <= 256 ? 2 : n <= 512 ? 4 : 8; }
 inline size_t nm_lds_bytes(uint64_t n) {
   const uint64_t nv = n + 1;
-  return (nv * n + ((nv + 1) & ~1ull) + 7 * n) * sizeof(double) + sizeof(NmCtl) + 16;
+  const uint64_t rows = nm_chunks(n) == 1 ? nv * n : 0;
+  return (rows + ((nv + 1) & ~1ull) + 7 * n) * sizeof(double) + sizeof(NmCtl) + 16;
 }
 
 }  // namespace nlsg

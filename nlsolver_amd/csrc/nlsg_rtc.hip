@@ -220,11 +220,12 @@ void rtc_release(BfgsRtcKernels *k) {
   if (k) *k = BfgsRtcKernels();
 }
 
-int rtc_build_nm(const nlsg_custom_objective *obj, NmRtcKernels *out) {
+int rtc_build_nm(const nlsg_custom_objective *obj, int chunks, NmRtcKernels *out) {
   std::vector<hipFunction_t> f;
   NmRtcKernels k;
   const int rc = rtc_compile(obj, "nlsg_nm_kernels.h",
-                             {"nlsg::nm_solve_kernel<" + std::to_string(static_cast<int>(NLSG_OBJ_CUSTOM)) + ">"},
+                             {"nlsg::nm_solve_kernel<" + std::to_string(static_cast<int>(NLSG_OBJ_CUSTOM)) +
+                              ", " + std::to_string(chunks) + ">"},
                              &k.mod, &f);
   if (rc) return rc;
   k.solve = f[0];

@@ -30,6 +30,21 @@ def starts(batch, n, seed):
                                 dict(max_iter=80, eps=0.0, no_change_best_tol=100000, step=0.4,
                                      restarts=2)])
 def test_nm_batch_bit_exact_vs_kernel_order_oracle(mod, oracle, n, batch, kw):
+    nm_bit_exact_case(mod, oracle, n, batch, kw)
+
+
+@pytest.mark.parametrize("n,batch", [(129, 3), (200, 2), (256, 2), (257, 2), (600, 1), (1024, 2)])
+@pytest.mark.parametrize("kw", [dict(max_iter=60, eps=0.0, no_change_best_tol=100000),
+                                dict(max_iter=40, eps=1e-6, no_change_best_tol=20, step=0.4,
+                                     restarts=1)])
+def test_nm_past_the_lds_simplex_bit_exact(mod, oracle, n, batch, kw):
+    """n > 128: the simplex rows live in a per-start global workspace instead of LDS (the
+    reference has no size limit, nlsolver.h:2099-2300); first size past the old cap, ragged
+    chunk counts, the largest size. Same arithmetic, same bits."""
+    nm_bit_exact_case(mod, oracle, n, batch, kw)
+
+
+def nm_bit_exact_case(mod, oracle, n, batch, kw):
     x0 = starts(batch, n, seed=n)
     with mod.NMEngine("rosenbrock", batch, n, **kw) as eng:
         x, st, eps = eng.minimize(x0.copy())
@@ -134,9 +149,9 @@ def test_nm_device_128d_golden_fork_is_the_documented_tie(mod, oracle, golden):
     assert st[0].f_value == ref.f_value and np.array_equal(x[0], xr)
     assert st[0].iteration == g["iters"] == 2000
     assert 0.5 * hx(g["f"]) <= st[0].f_value <= 2.0 * hx(g["f"])
-    # up to the fork the device is ON the reference's path: a run cut before it has the
-    # reference's counts
-    short = dict(kw, max_iter=60)
+    # up to the fork (the 262nd call, in iteration 4) the device is ON the reference's path: a
+    # run cut before it has the reference's counts and value
+    short = dict(kw, max_iter=3)
     with mod.NMEngine("rosenbrock", 1, D, **short) as eng:
         _, st_s, _ = eng.minimize(x0[None].copy())
     sk = dict(short)
