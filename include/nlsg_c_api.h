@@ -373,6 +373,8 @@ int nlsg_lm_time_solve(nlsg_lm *e, const double *theta0_host, uint32_t repeats, 
 /* Measurement aid: `repeats` launches of the evaluation kernel (f, g = 2 J^T r, H = 2 J^T J at
  * theta0 for every problem; the Gauss-Newton functors of nlsolver.h:3513-3516 / 3535-3537). */
 int nlsg_lm_time_eval_kernel(nlsg_lm *e, const double *theta0_host, uint32_t repeats, float *ms_total);
+/* the same for the QR step kernel alone (after one evaluation at theta0) */
+int nlsg_lm_time_qr_kernel(nlsg_lm *e, const double *theta0_host, uint32_t repeats, float *ms_total);
 
 /* ========================================================================== */
 /* Batched Nelder-Mead — replaces NelderMead::solve (nlsolver.h:2166-2299), the  */

@@ -176,6 +176,7 @@ SYMBOLS = {
     "nlsg_lm_minimize": (C.c_int, [_H, pd, C.POINTER(Status), pd]),
     "nlsg_lm_time_solve": (C.c_int, [_H, pd, C.c_uint32, C.POINTER(C.c_float)]),
     "nlsg_lm_time_eval_kernel": (C.c_int, [_H, pd, C.c_uint32, C.POINTER(C.c_float)]),
+    "nlsg_lm_time_qr_kernel": (C.c_int, [_H, pd, C.c_uint32, C.POINTER(C.c_float)]),
     "nlsg_nm_create": (C.c_int, [C.POINTER(NMConfig), C.POINTER(_H)]),
     "nlsg_nm_destroy": (C.c_int, [_H]),
     "nlsg_nm_minimize": (C.c_int, [_H, pd, pd, pd, C.POINTER(Status), pd]),

@@ -84,7 +84,7 @@ int launch_solve(nlsg_lm *e) {
       if (fd) {
         launch_fd_iter(e, 0);
       } else if (qr) {
-        hipLaunchKernelGGL(lm_qr_step_kernel, grid, dim3(kLmQrThreads), sizeof(LmQrShared), e->stream, e->p);
+        hipLaunchKernelGGL(lm_qr_step_kernel<kLmQrThreads>, grid, dim3(kLmQrThreads), sizeof(LmQrShared), e->stream, e->p);
         hipLaunchKernelGGL(lm_iter_kernel, grid, dim3(64), 0, e->stream, e->p, 0, 0);
       } else {
         hipLaunchKernelGGL(lm_iter_kernel, grid, dim3(64), 0, e->stream, e->p, 0, 1);
@@ -178,7 +178,7 @@ static int lm_create(const nlsg_lm_config *cfg, const nlsg_custom_objective *cus
   if (he == hipSuccess) he = hipEventCreate(&e->ev0);
   if (he == hipSuccess) he = hipEventCreate(&e->ev1);
   if (he == hipSuccess)
-    he = hipFuncSetAttribute(reinterpret_cast<const void *>(lm_qr_step_kernel),
+    he = hipFuncSetAttribute(reinterpret_cast<const void *>(lm_qr_step_kernel<kLmQrThreads>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, sizeof(LmQrShared));
   if (he != hipSuccess) {
     nlsg_lm_destroy(e);
@@ -343,6 +343,33 @@ int nlsg_lm_time_eval_kernel(nlsg_lm *e, const double *theta0_host, uint32_t rep
     NLSG_HIP(hipEventRecord(e->ev0, e->stream));
     hipLaunchKernelGGL(lm_iter_kernel, dim3(static_cast<unsigned>(e->p.batch)), dim3(64), 0,
                        e->stream, e->p, 1, 0);
+    NLSG_HIP(hipEventRecord(e->ev1, e->stream));
+    NLSG_HIP(hipEventSynchronize(e->ev1));
+    NLSG_HIP(launches_status());
+    float ms = 0.f;
+    NLSG_HIP(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+    total += ms;
+  }
+  *ms_total = total;
+  return NLSG_OK;
+}
+
+// Times `repeats` launches of the QR step kernel alone (stop tests, damped matrix, Givens QR,
+// back-substitution, update) after one evaluation at theta0 has produced H and g.
+int nlsg_lm_time_qr_kernel(nlsg_lm *e, const double *theta0_host, uint32_t repeats, float *ms_total) {
+  if (!e || !theta0_host || !ms_total) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  if (e->p.fd) return fail(NLSG_ERR_UNSUPPORTED, "Gauss-Newton model only");
+  if (!e->has_data) return fail(NLSG_ERR_STATE, "nlsg_lm_set_data has not been called");
+  NLSG_HIP(hipSetDevice(e->cfg.device));
+  int rc = upload_theta(e, theta0_host);
+  if (rc) return rc;
+  const dim3 grid(static_cast<unsigned>(e->p.batch));
+  hipLaunchKernelGGL(lm_iter_kernel, grid, dim3(64), 0, e->stream, e->p, 1, 0);
+  float total = 0.f;
+  for (uint32_t r = 0; r < repeats; r++) {
+    NLSG_HIP(hipEventRecord(e->ev0, e->stream));
+    hipLaunchKernelGGL(lm_qr_step_kernel<kLmQrThreads>, grid, dim3(kLmQrThreads), sizeof(LmQrShared),
+                       e->stream, e->p);
     NLSG_HIP(hipEventRecord(e->ev1, e->stream));
     NLSG_HIP(hipEventSynchronize(e->ev1));
     NLSG_HIP(launches_status());

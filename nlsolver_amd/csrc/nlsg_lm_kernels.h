@@ -30,8 +30,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 
 constexpr int kLmN = 64;        // parameters are padded to 64 columns
 constexpr int kLmJStride = 80;  // LDS row stride of the Jacobian block (doubles)
-constexpr int kLmHStride = 65;  // LDS row stride of the damped matrix (doubles)
-constexpr int kLmQrThreads = 1024;  // the QR step's workgroup: a wave per two rotations of a wavefront step
+constexpr int kLmQrThreads = 512;  // the QR step's workgroup: each wave follows 32 / 8 column chains
 constexpr int kLmTri = 33 * 64;  // packed lower triangle of a 64 x 64 matrix (2080) + pad
 
 struct LmProblem {
@@ -186,87 +185,208 @@ __device__ inline void lm_solve_cholesky_wave(Rows H, const double *g, double *u
 }
 
 // tinyqr::lm on the damped matrix (tinyqr.h:253-310, 437-470): Givens QR in the reference's
-// rotation order (column j, rows bottom-up), executed as wavefronts: rotation (j, i) runs at
-// step (n-1-i) + 2j, all rotations of a step touch disjoint row pairs, so every element sees
-// exactly the sequence of updates the serial loop applies (columns left of j are skipped:
-// they only hold annihilated entries that the cleanup pass zeroes and nothing reads).
-// sh.H is the working R (row-major, = the transposed-input layout of qr_decomposition).
-struct LmQrShared {                // LDS of the QR step (one workgroup per problem)
-  double H[64 * kLmHStride];       // working R (row-major)
-  double Q[64 * kLmHStride];       // the orthogonal factor's transpose, rotated alongside R
-  double g[64], upd[64];
-  double c[32], s[32];             // Givens coefficients of the current wavefront step
+// rotations (column j, rows bottom-up; same (a, b) -> (c, s), same element updates), executed as
+// wavefronts: rotation (j, i) runs at step (n-1-i) + 2j, all rotations of a step touch disjoint
+// row pairs, so every element sees exactly the sequence of updates the serial loop applies.
+//
+// What is kept, and where (one workgroup per problem):
+//  * no Q. tinyqr::lm only ever uses Q through Q^T y (back_solve, :437-459), so the right-hand
+//    side is rotated along with R as its column 64: w = G_k ... G_1 g. Mathematically the same
+//    vector; the roundings differ from "accumulate Q, then multiply" (oracle order 1 mirrors the
+//    co-rotation; the reference stays within the rounding tolerance test). Halves the LDS image
+//    (33 KiB: four workgroups per CU) and more than halves the rotation work.
+//  * an element update is one rounded product and one fused multiply-add,
+//    lower' = fma(c, lower, s * upper), upper' = fma(c, upper, (-s) * lower) (oracle order 1
+//    mirrors; tinyqr's two products and an add differ in the last bit).
+//  * the eliminations of one column form a CHAIN that climbs one row per step: rotation (j, i)
+//    writes row i-1, and the only rotation that reads that row next is (j, i-1), one step later.
+//    The wave that owns chain j keeps that row in registers (`carry`) between steps: per
+//    rotation one row is read from LDS and one written instead of two and two. Chains are dealt
+//    to the seven APPLY waves by j mod 7; at most 32 are active at a time, so a wave follows at
+//    most five of them (`slot`; chains j and j + 35 share one, never at the same time), each with
+//    its own carry register, LDS offset and live-lane mask kept from step to step.
+//  * the eighth wave computes the Givens pairs, one chain per lane, ONE STEP AHEAD of the apply
+//    waves: the pair of rotation (j, i) needs a = R[i-1][j] and b = R[i][j]. b is the pivot
+//    element of chain j's carried row, a the upper output of chain j-1's previous rotation in
+//    chain j-1's first off-pivot column; the Givens lane of a chain tracks exactly those two
+//    elements of its carried row (`bp`, `bq`, same arithmetic as the apply lanes, same bits) and
+//    hands `a` to its neighbour lane. Everything it reads from LDS was written two steps back, so
+//    step k's rotations and step k+1's Givens pairs run side by side: one barrier per step, and
+//    the ~40 dependent fp64 instructions of a Givens pair are off the apply waves' path.
+// Columns left of a chain's pivot hold annihilated remnants that nothing reads; they are skipped.
+constexpr int kLmQrStride = 65;  // doubles per row: 64 columns + the right-hand side; odd: the
+                                 // Givens lanes' gather (row and column both vary) is conflict-free
+struct LmQrShared {              // LDS of the QR step (one workgroup per problem)
+  double R[64 * kLmQrStride];    // working R (row-major), column 64 = co-rotated right-hand side
+  double scr[64 + kLmQrStride];  // where the apply waves' lanes without a column load and store
+  double2 cs[2][32];             // Givens pairs (c, s) by step parity and chain j mod 32
+  double upd[64];
 };
+static_assert(__builtin_offsetof(LmQrShared, scr) == 64 * kLmQrStride * sizeof(double), "scr follows R");
 
+// value of lane `src` (per-lane index) through the LDS crossbar
+__device__ inline double lane_gather(double v, int src) {
+  const uint64_t b = static_cast<uint64_t>(__double_as_longlong(v));
+  const uint32_t lo = static_cast<uint32_t>(__shfl(static_cast<int>(b & 0xffffffffu), src, 64));
+  const uint32_t hi = static_cast<uint32_t>(__shfl(static_cast<int>(b >> 32), src, 64));
+  return __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(hi) << 32) | lo));
+}
+
+template <int THREADS>
 __device__ inline void lm_solve_qr(LmQrShared &qs, int n) {
+  constexpr int W = THREADS / 64, AW = W - 1, SLOTS = (32 + AW - 1) / AW, SPAN = AW * SLOTS;
+  constexpr int S = kLmQrStride;
+  static_assert(SPAN >= 32, "chains that share a slot must never be active together");
   const int t = threadIdx.x, lane = lane_id();
   const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
-  for (int e = t; e < n * n; e += static_cast<int>(blockDim.x)) {
-    const int i = e / n, j = e % n;
-    qs.Q[i * kLmHStride + j] = (i == j) ? 1.0 : 0.0;  // make_identity, tinyqr.h:205-210
-  }
-  __syncthreads();
-  for (int step = 0; step <= 2 * n - 4; step++) {
-    const int jlo = step - (n - 2) > 0 ? step - (n - 2) : 0;
-    const int jhi = step / 2 < n - 2 ? step / 2 : n - 2;
-    const int count = jhi - jlo + 1;
-    if (t < count) {  // givens_rotation, tinyqr.h:86-97
-      const int j = jlo + t, i = n - 1 - (step - 2 * j);
-      const double a = qs.H[(i - 1) * kLmHStride + j], b = qs.H[i * kLmHStride + j];
-      double c, sv;
-      if (fabs(b) > fabs(a)) {
-        const double r = a / b;
-        sv = 1.0 / sqrt(r * r + 1.0);
-        c = sv * r;
-      } else {
-        const double r = b / a;
-        c = 1.0 / sqrt(r * r + 1.0);
-        sv = c * r;
+  const int last = 2 * n - 4;  // last wavefront step
+  // rotation of chain j at step k: rows i-1, i with i = n-1-(k-2j); exists for 2j <= k <= j+n-2
+
+  if (wid == AW) {
+    // ---- the Givens wave: lane L follows chain L, then chain L + 32
+    int j = lane;                          // current chain (lanes >= 32 never have one)
+    double bp = 0.0, bq = 0.0, cp = 0.0, sp = 0.0;
+    bool had = false;                      // my chain had a rotation at the step just applied
+    int pend = -1;                         // a finished chain whose row-j elements are still to be stored
+    double pend_p = 0.0, pend_q = 0.0;
+    for (int k = -1; k <= last + 1; k++) {  // one phase past the last step: the last chain's store
+      if (pend >= 0) {  // R[j][j], R[j][j+1] of the chain that ended in the previous phase — one
+                        // phase late: the apply lane of column j+1 read the old R[j][j+1] then
+        qs.R[pend * S + pend] = pend_p;
+        qs.R[pend * S + pend + 1] = pend_q;
+        pend = -1;
       }
-      qs.c[t] = c;
-      qs.s[t] = sv;
+      // (1) step k's rotation of my chain, on the two tracked columns j and j+1; its inputs
+      //     were written by step k-1's rotations (complete: barrier)
+      double upq = 0.0;
+      if (had) {
+        const int i = n - 1 - (k - 2 * j);
+        const double t1q = qs.R[(i - 1) * S + j + 1];
+        upq = __builtin_fma(cp, bq, (-sp) * t1q);  // = R[i][j+1] after the step: chain j+1's next a
+        bq = __builtin_fma(cp, t1q, sp * bq);
+        if (i - 1 == j) {  // the chain ended with this step: row j of R is final in these columns
+          pend = j;
+          pend_p = bp;
+          pend_q = bq;
+          j += 32;
+        }
+      }
+      const double a_in = lane_gather(upq, (lane + 31) & 31);
+      // (2) the Givens pair of my chain's rotation at step k+1 (givens_rotation, tinyqr.h:86-97)
+      had = lane < 32 && j <= n - 2 && k + 1 <= last && k + 1 >= 2 * j && k + 1 <= j + n - 2;
+      if (had) {
+        const int i = n - 1 - (k + 1 - 2 * j);
+        double b = bp;
+        if (k + 1 == 2 * j) {  // the chain starts: row n-1
+          b = qs.R[(n - 1) * S + j];
+          bq = qs.R[(n - 1) * S + j + 1];
+        }
+        const double a = j == 0 ? qs.R[(i - 1) * S] : a_in;
+        // both branches of the reference are r = small / large, t = 1 / sqrt(r^2 + 1), {t, t r}:
+        // one division, one square root, one reciprocal — selected, not branched
+        const bool swap = fabs(b) > fabs(a);
+        const double r = (swap ? a : b) / (swap ? b : a);
+        const double tt = 1.0 / sqrt(r * r + 1.0);
+        const double tr = tt * r;
+        cp = swap ? tr : tt;
+        sp = swap ? tt : tr;
+        bp = __builtin_fma(cp, a, sp * b);  // the chain's new pivot element
+        qs.cs[(k + 1) & 1][j & 31] = make_double2(cp, sp);
+      }
+      __syncthreads();
     }
-    __syncthreads();
-    // a wave per rotation and pass (sixteen waves: at most two passes per wavefront step; with
-    // four waves the eight dependent LDS round trips per wave dominated the step)
-    for (int r = wid; r < count; r += static_cast<int>(blockDim.x >> 6)) {  // rotate_matrix on R and Q, tinyqr.h:126-139
-      const int j = jlo + r, i = n - 1 - (step - 2 * j);
-      const double c = qs.c[r], sv = qs.s[r];
-      if (lane >= j && lane < n) {
-        double *lo = &qs.H[(i - 1) * kLmHStride + lane], *up = &qs.H[i * kLmHStride + lane];
-        const double t1 = *lo, t2 = *up;
-        *lo = c * t1 + sv * t2;
-        *up = -sv * t1 + c * t2;
-      }
-      if (lane < n) {
-        double *lo = &qs.Q[(i - 1) * kLmHStride + lane], *up = &qs.Q[i * kLmHStride + lane];
-        const double t1 = *lo, t2 = *up;
-        *lo = c * t1 + sv * t2;
-        *up = -sv * t1 + c * t2;
-      }
+  } else {
+    // ---- an apply wave: rotate_matrix on rows i-1, i (tinyqr.h:126-139), one chain per slot.
+    // The loop below is bound by instruction issue (a CU has one scalar unit for its four
+    // SIMDs), so a slot's per-step state is kept incrementally in vector registers: `off` the
+    // lane's LDS index of R[i-1][col] (minus one row per step), and lanes without a column
+    // (`dead`) are pointed at a per-lane scratch pair instead of being masked off — no exec
+    // juggling around the loads and the store; what they compute is never read.
+    int ts[SLOTS], span[SLOTS], off[SLOTS], dec[SLOTS], jnext[SLOTS];
+    uint32_t csoff[SLOTS];
+    double carry[SLOTS];
+    bool tail[SLOTS];  // lanes that store the chain's final row (all its columns but j+1)
+    const int scratch = 64 * S + lane;  // LmQrShared::scr: [lane] and [lane + S]
+    auto open_chain = [&](int sl, int j) {
+      const bool any = j <= n - 2;
+      ts[sl] = any ? 2 * j : 0x40000000;            // first step
+      span[sl] = any ? n - 2 - j : 0;               // last step - first step
+      const int col = j + 1 + lane;
+      const bool live = col < n || col == 64;
+      off[sl] = live ? (n - 2) * S + col : scratch;  // R[i-1][col] at the chain's first step (i = n-1)
+      dec[sl] = live ? S : 0;
+      tail[sl] = live && lane != 0;
+      csoff[sl] = static_cast<uint32_t>(j & 31);
+      jnext[sl] = j + SPAN;
+    };
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; sl++) {
+      open_chain(sl, AW * sl + wid);
+      carry[sl] = 0.0;
     }
-    __syncthreads();
+    __syncthreads();  // the prologue phase of the Givens wave (k = -1)
+    for (int k = 0; k <= last; k++) {
+      // two passes: every active slot's LDS reads are in flight before the first is used
+      const double2 *csk = qs.cs[k & 1];
+      double2 cs[SLOTS];
+      double t1[SLOTS];
+#pragma unroll
+      for (int sl = 0; sl < SLOTS; sl++) {
+        if (static_cast<uint32_t>(k - ts[sl]) <= static_cast<uint32_t>(span[sl])) {  // wave-uniform
+          cs[sl] = csk[csoff[sl]];
+          t1[sl] = qs.R[off[sl]];
+          if (k == ts[sl]) carry[sl] = qs.R[off[sl] + S];  // the chain starts: row n-1
+        }
+      }
+#pragma unroll
+      for (int sl = 0; sl < SLOTS; sl++) {
+        if (static_cast<uint32_t>(k - ts[sl]) <= static_cast<uint32_t>(span[sl])) {
+          const double c = cs[sl].x, sv = cs[sl].y, t2 = carry[sl];
+          const double lo = __builtin_fma(c, t1[sl], sv * t2);
+          const double up = __builtin_fma(c, t2, (-sv) * t1[sl]);
+          qs.R[off[sl] + S] = up;
+          carry[sl] = lo;
+          if (k == ts[sl] + span[sl]) {
+            // the chain ends: row j of R is final (its columns j, j+1 come from the Givens lane)
+            if (tail[sl]) qs.R[off[sl]] = lo;
+            open_chain(sl, jnext[sl]);
+          } else {
+            off[sl] -= dec[sl];
+          }
+        }
+      }
+      __syncthreads();
+    }
+    __syncthreads();  // the Givens wave's last phase
   }
-  // cleanup with lm()'s tol = 1e-12 (tinyqr.h:278-282, 465) on the entries back_solve reads
-  for (int e = t; e < n * n; e += static_cast<int>(blockDim.x)) {
-    const int i = e / n, j = e % n;
-    if (j >= i && fabs(qs.H[i * kLmHStride + j]) < 1e-12) qs.H[i * kLmHStride + j] = 0.0;
-  }
-  __syncthreads();
-  // back_solve (tinyqr.h:437-459): Q^T y lazily per row, then the triangular sweep with the
-  // inner sums taken from j = n-1 down to i+1 (oracle order 1)
+  // back_solve (tinyqr.h:437-459) on R x = w, with lm()'s cleanup (tol = 1e-12, :278-282, 465)
+  // applied to the entries it reads; inner sums taken from j = n-1 down to i+1 (oracle order 1)
   if (t < 64) {
-    double ytmp = 0;
-    if (t < n)
-      for (int j = 0; j < n; j++) ytmp += qs.Q[t * kLmHStride + j] * qs.g[j];
+    const double w = t < n ? qs.R[t * S + 64] : 0.0;
     double temp = 0.0, u = 0.0;
-    for (int j = n - 1; j >= 0; j--) {
-      if (t == j) u = (ytmp - temp) / qs.H[j * kLmHStride + j];
-      const double uj = lane_broadcast(u, j);
-      if (t < j) temp += qs.H[t * kLmHStride + j] * uj;
+    for (int j0 = ((n - 1) | 3); j0 >= 0; j0 -= 4) {
+      double h[4], d[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int j = min(j0 - q, n - 1);
+        h[q] = qs.R[min(t, j) * S + j];
+        d[q] = qs.R[j * S + j];
+        h[q] = fabs(h[q]) < 1e-12 ? 0.0 : h[q];
+        d[q] = fabs(d[q]) < 1e-12 ? 0.0 : d[q];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int j = j0 - q;
+        if (j < n) {  // wave-uniform
+          if (t == j) u = (w - temp) / d[q];
+          const double uj = lane_broadcast(u, j);
+          if (t < j) temp += h[q] * uj;
+        }
+      }
     }
     if (t < n) qs.upd[t] = u;
   }
+  __syncthreads();
 }
 
 // ---- Cholesky solver: all problems advance in lock step, ONE WAVE per problem, one launch per
@@ -668,9 +788,10 @@ __global__ __launch_bounds__(64) void lm_fd_iter_kernel(LmParams p, int first) {
 }
 
 // ---- QR solver (tinyqr::lm on the damped matrix): the step as a kernel of its own, one
-// workgroup per problem (R and Q, 33 KiB each, live in LDS; the Givens wavefronts want four
-// waves), between two evaluation launches. Stop tests, damping, QR solve, theta update.
-__global__ __launch_bounds__(kLmQrThreads) void lm_qr_step_kernel(LmParams p) {
+// workgroup per problem (R and the co-rotated right-hand side live in LDS, 33 KiB), between two
+// evaluation launches. Stop tests, damping, QR solve, theta update.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void lm_qr_step_kernel(LmParams p) {
   extern __shared__ __align__(16) unsigned char lm_smem[];
   LmQrShared &qs = *reinterpret_cast<LmQrShared *>(lm_smem);
   const uint64_t pid = blockIdx.x;
@@ -684,16 +805,16 @@ __global__ __launch_bounds__(kLmQrThreads) void lm_qr_step_kernel(LmParams p) {
     return;
   }
   const double *tri = p.Hg + pid * kLmTri;
-  for (int e = t; e < 64 * 64; e += static_cast<int>(blockDim.x)) {  // the full symmetric matrix from its lower triangle
+  const double lambda = pr->lambda;
+  for (int e = t; e < 64 * 64; e += THREADS) {  // the full symmetric matrix from its lower triangle
     const int i = e >> 6, j = e & 63;
     const int hi = i > j ? i : j, lo = i > j ? j : i;
-    qs.H[i * kLmHStride + j] = tri[hi * (hi + 1) / 2 + lo];
+    const double v = tri[hi * (hi + 1) / 2 + lo];
+    qs.R[i * kLmQrStride + j] = (i == j && i < n) ? v + lambda : v;  // :3529-3531
   }
-  if (t < 64) qs.g[t] = p.gg[pid * kLmN + t];
+  if (t < 64) qs.R[t * kLmQrStride + 64] = p.gg[pid * kLmN + t];
   __syncthreads();
-  if (t < n) qs.H[t * kLmHStride + t] += pr->lambda;  // :3529-3531
-  __syncthreads();
-  lm_solve_qr(qs, n);
+  lm_solve_qr<THREADS>(qs, n);
   if (t < n) p.theta[pid * kLmN + t] = p.theta[pid * kLmN + t] - qs.upd[t];  // :3534
 }
 

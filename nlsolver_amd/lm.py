@@ -113,6 +113,15 @@ class LMEngine:
         return ms.value
 
 
+    def time_qr_kernel(self, theta0, repeats=1):
+        """Total ms of `repeats` launches of the QR step kernel (after one evaluation at theta0)."""
+        theta0 = np.ascontiguousarray(theta0, dtype=np.float64)
+        ms = C.c_float()
+        check(lib().nlsg_lm_time_qr_kernel(self._h, theta0.ctypes.data_as(_capi.pd), repeats,
+                                           C.byref(ms)))
+        return ms.value
+
+
 class LevenbergMarquardt:
     """Drop-in for nlsolver::LevenbergMarquardt on a device NLLS model or a built-in objective
     (by name); x: (n,) or (batch, n)."""

@@ -170,19 +170,55 @@ static void qr_decomposition_order(const double *X, size_t n, size_t p, double t
 void orc_tinyqr_lm(const double *X, const double *y, size_t n, size_t p, double *beta) {
   orc_tinyqr_lm_order(X, y, n, p, beta, 0);
 }
-/* order = 1: Givens without pow(), and the back-substitution sums taken from j = p-1 down
- * to i+1 (the order in which the kernel's column sweep produces them) */
+/* order = 1 — the device's restatement (nlsg_lm_kernels.h lm_solve_qr): Givens without pow();
+ * Q is never formed: lm() only uses it through Q^T y, so y is rotated along with R (same vector
+ * mathematically, other roundings); an element update is one rounded product and one fma,
+ * lower' = fma(c, lower, s * upper), upper' = fma(c, upper, (-s) * lower); the back-substitution
+ * sums are taken from j = p-1 down to i+1 (the order in which the kernel's column sweep produces
+ * them). Same rotations in the same per-element order as qr_impl. */
+static void tinyqr_lm_corotated(const double *X, const double *y, size_t n, size_t p, double *beta) {
+  double *Rw = (double *)calloc(n * p, sizeof(double));
+  double *w = (double *)malloc(n * sizeof(double));
+  for (size_t i = 0; i < n; i++) {
+    w[i] = y[i];
+    for (size_t j = 0; j < p; j++) Rw[i * p + j] = X[j * n + i];
+  }
+  for (size_t j = 0; j < p; j++)
+    for (size_t i = n - 1; i > j; --i) {
+      double c, s;
+      givens(Rw[(i - 1) * p + j], Rw[i * p + j], &c, &s, 1);
+      double *lower = Rw + (i - 1) * p, *upper = Rw + i * p;
+      for (size_t k = 0; k < p; k++) {
+        const double t1 = lower[k], t2 = upper[k];
+        lower[k] = fma(c, t1, s * t2);
+        upper[k] = fma(c, t2, (-s) * t1);
+      }
+      const double t1 = w[i - 1], t2 = w[i];
+      w[i - 1] = fma(c, t1, s * t2);
+      w[i] = fma(c, t2, (-s) * t1);
+    }
+  for (size_t e = 0; e < n * p; e++) Rw[e] = fabs(Rw[e]) < 1e-12 ? 0.0 : Rw[e]; /* cleanup */
+  for (size_t i = 0; i < p; i++) beta[i] = 0.0;
+  for (size_t i = p; i-- > 0;) {
+    double temp = 0.0;
+    for (size_t j = p; j-- > i + 1;) temp += Rw[i * p + j] * beta[j];
+    beta[i] = (w[i] - temp) / Rw[i * p + i];
+  }
+  free(Rw);
+  free(w);
+}
 void orc_tinyqr_lm_order(const double *X, const double *y, size_t n, size_t p, double *beta,
                          int order) {
+  if (order) {
+    tinyqr_lm_corotated(X, y, n, p, beta);
+    return;
+  }
   double *Q = (double *)malloc(n * p * sizeof(double)), *R = (double *)malloc(p * p * sizeof(double));
   qr_decomposition_order(X, n, p, 1e-12, Q, R, order);
   for (size_t i = 0; i < p; i++) beta[i] = 0.0;
   for (size_t i = p; i-- > 0;) {
     double temp = 0.0;
-    if (order == 0)
-      for (size_t j = i + 1; j < p; ++j) temp += R[j * p + i] * beta[j];
-    else
-      for (size_t j = p; j-- > i + 1;) temp += R[j * p + i] * beta[j];
+    for (size_t j = i + 1; j < p; ++j) temp += R[j * p + i] * beta[j];
     double ytmp = 0;
     for (size_t j = 0; j < n; ++j) ytmp += Q[i * n + j] * y[j];
     beta[i] = (ytmp - temp) / R[i * p + i];
