@@ -176,6 +176,13 @@ __device__ inline double lane_down1(double v) {
   const uint32_t hi = dpp_mov32<0x130, 0xF>(static_cast<uint32_t>(b >> 32), static_cast<uint32_t>(b >> 32));
   return __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(hi) << 32) | lo));
 }
+// lane l-1's value (lane 0 keeps its own): DPP wave_shr:1
+__device__ inline double lane_up1(double v) {
+  const uint64_t b = static_cast<uint64_t>(__double_as_longlong(v));
+  const uint32_t lo = dpp_mov32<0x138, 0xF>(static_cast<uint32_t>(b), static_cast<uint32_t>(b));
+  const uint32_t hi = dpp_mov32<0x138, 0xF>(static_cast<uint32_t>(b >> 32), static_cast<uint32_t>(b >> 32));
+  return __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(hi) << 32) | lo));
+}
 // lane 0's value through scalar registers
 __device__ inline double lane_first(double v) {
   const uint64_t b = static_cast<uint64_t>(__double_as_longlong(v));

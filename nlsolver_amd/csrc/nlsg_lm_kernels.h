@@ -224,14 +224,6 @@ struct LmQrShared {              // LDS of the QR step (one workgroup per proble
 };
 static_assert(__builtin_offsetof(LmQrShared, scr) == 64 * kLmQrStride * sizeof(double), "scr follows R");
 
-// value of lane `src` (per-lane index) through the LDS crossbar
-__device__ inline double lane_gather(double v, int src) {
-  const uint64_t b = static_cast<uint64_t>(__double_as_longlong(v));
-  const uint32_t lo = static_cast<uint32_t>(__shfl(static_cast<int>(b & 0xffffffffu), src, 64));
-  const uint32_t hi = static_cast<uint32_t>(__shfl(static_cast<int>(b >> 32), src, 64));
-  return __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(hi) << 32) | lo));
-}
-
 template <int THREADS>
 __device__ inline void lm_solve_qr(LmQrShared &qs, int n) {
   constexpr int W = THREADS / 64, AW = W - 1, SLOTS = (32 + AW - 1) / AW, SPAN = AW * SLOTS;
@@ -243,13 +235,26 @@ __device__ inline void lm_solve_qr(LmQrShared &qs, int n) {
   // rotation of chain j at step k: rows i-1, i with i = n-1-(k-2j); exists for 2j <= k <= j+n-2
 
   if (wid == AW) {
-    // ---- the Givens wave: lane L follows chain L, then chain L + 32
+    // ---- the Givens wave: lane L follows chain L, then chain L + 32. Its phase is one long
+    // chain of dependent fp64 instructions (two divisions and a square root, IEEE-correct: ~45 of
+    // them, ~1000 cycles with the LDS round trip and the barrier) and it is the workgroup's
+    // critical path (raising its issue priority over the apply waves changed nothing: measured).
     int j = lane;                          // current chain (lanes >= 32 never have one)
     double bp = 0.0, bq = 0.0, cp = 0.0, sp = 0.0;
     bool had = false;                      // my chain had a rotation at the step just applied
     int pend = -1;                         // a finished chain whose row-j elements are still to be stored
     double pend_p = 0.0, pend_q = 0.0;
     for (int k = -1; k <= last + 1; k++) {  // one phase past the last step: the last chain's store
+      // Every LDS read of the phase is issued here, before anything waits: the phase is a chain
+      // of dependent fp64 instructions behind ONE read round trip (what a read returns is only
+      // used where the comments below say so; the addresses are always inside R).
+      const int jr = j < 63 ? j : 62;
+      const int i_k = n - 1 - (k - 2 * jr);
+      const double t1q = qs.R[(had ? i_k - 1 : 0) * S + jr + 1];  // (1): row i-1 of step k, column j+1
+      const double b_start = qs.R[(n - 1) * S + jr];              // (2) if my chain starts: row n-1
+      const double bq_start = qs.R[(n - 1) * S + jr + 1];
+      const int r0 = n - 3 - k;                                   // (2) chain 0: a = R[i-1][0], i = n-2-k
+      const double a_col0 = qs.R[(r0 > 0 ? r0 : 0) * S];
       if (pend >= 0) {  // R[j][j], R[j][j+1] of the chain that ended in the previous phase — one
                         // phase late: the apply lane of column j+1 read the old R[j][j+1] then
         qs.R[pend * S + pend] = pend_p;
@@ -260,28 +265,28 @@ __device__ inline void lm_solve_qr(LmQrShared &qs, int n) {
       //     were written by step k-1's rotations (complete: barrier)
       double upq = 0.0;
       if (had) {
-        const int i = n - 1 - (k - 2 * j);
-        const double t1q = qs.R[(i - 1) * S + j + 1];
         upq = __builtin_fma(cp, bq, (-sp) * t1q);  // = R[i][j+1] after the step: chain j+1's next a
         bq = __builtin_fma(cp, t1q, sp * bq);
-        if (i - 1 == j) {  // the chain ended with this step: row j of R is final in these columns
+        if (i_k - 1 == j) {  // the chain ended with this step: row j of R is final in these columns
           pend = j;
           pend_p = bp;
           pend_q = bq;
           j += 32;
         }
       }
-      const double a_in = lane_gather(upq, (lane + 31) & 31);
+      // chain j's `a` is chain j-1's upq: lane L from lane L-1 (a DPP wave shift), lane 0 from lane 31
+      double a_in = lane_up1(upq);
+      const double a_wrap = lane_broadcast(upq, 31);
+      if (lane == 0) a_in = a_wrap;
       // (2) the Givens pair of my chain's rotation at step k+1 (givens_rotation, tinyqr.h:86-97)
       had = lane < 32 && j <= n - 2 && k + 1 <= last && k + 1 >= 2 * j && k + 1 <= j + n - 2;
       if (had) {
-        const int i = n - 1 - (k + 1 - 2 * j);
         double b = bp;
         if (k + 1 == 2 * j) {  // the chain starts: row n-1
-          b = qs.R[(n - 1) * S + j];
-          bq = qs.R[(n - 1) * S + j + 1];
+          b = b_start;
+          bq = bq_start;
         }
-        const double a = j == 0 ? qs.R[(i - 1) * S] : a_in;
+        const double a = j == 0 ? a_col0 : a_in;
         // both branches of the reference are r = small / large, t = 1 / sqrt(r^2 + 1), {t, t r}:
         // one division, one square root, one reciprocal — selected, not branched
         const bool swap = fabs(b) > fabs(a);
