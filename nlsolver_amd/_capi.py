@@ -68,8 +68,11 @@ OBJ_QUAD_DIAG_RANK1 = 16
 
 class BFGSConfig(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", i32), ("stream", C.c_void_p),
-                ("objective", i32), ("reserved", i32), ("batch", u64), ("dim", u64),
+                ("objective", i32), ("flags", i32), ("batch", u64), ("dim", u64),
                 ("max_iter", u64), ("grad_eps", f64), ("alpha", f64), ("quad_c", f64)]
+
+
+BFGS_SYMMETRIC = 1  # NLSG_BFGS_SYMMETRIC
 
 
 OBJ_TANH_REGRESSION = 32

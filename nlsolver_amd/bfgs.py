@@ -34,9 +34,15 @@ class QuadDiagRank1:
 
 
 class BFGSEngine:
+    """symmetric=True: the rank-2 update restated so that H stays bitwise symmetric and only its
+    upper 128 x 128 blocks are kept and streamed (NLSG_BFGS_SYMMETRIC, include/nlsg_c_api.h):
+    56 % of the memory and traffic at dim = 1024; results agree with the literal update to rounding."""
+
     def __init__(self, objective, batch, *, dim=None, max_iter=100, grad_eps=5e-3, alpha=1.0,
-                 device=0, stream=None):
+                 device=0, stream=None, symmetric=False):
         cfg = BFGSConfig()
+        cfg.flags = _capi.BFGS_SYMMETRIC if symmetric else 0
+        self.symmetric = bool(symmetric)
         cfg.struct_size = C.sizeof(BFGSConfig)
         cfg.device = device
         cfg.stream = None if stream is None else (stream or 1)
@@ -117,6 +123,15 @@ class BFGSEngine:
         check(lib().nlsg_bfgs_minimize(self._h, x.ctypes.data_as(_capi.pd), st))
         return x, list(st)
 
+    def hessian_bytes_per_iteration(self):
+        """Algorithmic HBM bytes of the H passes per iteration and problem: read H (t = H y), read
+        and write H (update + next direction) — the whole matrix, or its upper 128 x 128 blocks."""
+        n = self.cfg.dim
+        if not self.symmetric:
+            return 3 * n * n * 8
+        nb = (n + 127) // 128
+        return 3 * (nb * (nb + 1) // 2) * 128 * 128 * 8
+
     def time_steps(self, iters):
         total, hess = C.c_float(), C.c_float()
         check(lib().nlsg_bfgs_time_steps(self._h, iters, C.byref(total), C.byref(hess)))
@@ -126,12 +141,14 @@ class BFGSEngine:
 class BFGS:
     """Drop-in for nlsolver::BFGS on a device objective; x may be (n,) or (batch, n)."""
 
-    def __init__(self, f, g=None, max_iter=100, grad_eps=5e-3, alpha=1.0, *, device=0):
+    def __init__(self, f, g=None, max_iter=100, grad_eps=5e-3, alpha=1.0, *, device=0,
+                 symmetric=False):
         if g is not None:
             raise TypeError("device objectives carry their analytic gradient or use the default "
                             "finite-difference one; pass g=None")
         self.f = f
-        self.args = dict(max_iter=max_iter, grad_eps=grad_eps, alpha=alpha, device=device)
+        self.args = dict(max_iter=max_iter, grad_eps=grad_eps, alpha=alpha, device=device,
+                         symmetric=symmetric)
 
     def minimize(self, x):
         if not isinstance(x, np.ndarray) or x.dtype != np.float64 or x.ndim not in (1, 2):

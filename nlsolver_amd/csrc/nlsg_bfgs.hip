@@ -19,6 +19,7 @@ struct nlsg_bfgs {
   int chunks = 0;
   bool vec = false, initialised = false;
   uint32_t bpp = 0;  // blocks per problem in the H-streaming kernels
+  bool symmetric = false;  // NLSG_BFGS_SYMMETRIC: upper blocks of H only
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
 };
 
@@ -94,8 +95,16 @@ void launch_iteration(nlsg_bfgs *e, bool timed) {
     BFGS_DISPATCH_MODEL(bfgs_search_kernel, wave_grid, e->p);
   }
   if (timed) hipEventRecord(e->ev2, e->stream);
-  BFGS_DISPATCH(bfgs_hy_kernel, row_grid, e->p, e->bpp);
-  BFGS_DISPATCH(bfgs_update_kernel, row_grid, e->p, e->bpp);
+  if (e->symmetric) {
+    const dim3 blocks(static_cast<unsigned>(e->p.batch * e->p.nstored)), probs(static_cast<unsigned>(e->p.batch));
+    hipLaunchKernelGGL(bfgs_sym_hy_kernel, blocks, dim3(256), 0, e->stream, e->p);
+    hipLaunchKernelGGL(bfgs_sym_reduce_kernel<false>, probs, dim3(256), 0, e->stream, e->p);
+    hipLaunchKernelGGL(bfgs_sym_update_kernel, blocks, dim3(256), 0, e->stream, e->p);
+    hipLaunchKernelGGL(bfgs_sym_reduce_kernel<true>, probs, dim3(256), 0, e->stream, e->p);
+  } else {
+    BFGS_DISPATCH(bfgs_hy_kernel, row_grid, e->p, e->bpp);
+    BFGS_DISPATCH(bfgs_update_kernel, row_grid, e->p, e->bpp);
+  }
   if (timed) hipEventRecord(e->ev3, e->stream);
 }
 
@@ -153,7 +162,9 @@ static int bfgs_create(const nlsg_bfgs_config *cfg, const double *diag_host, con
   e->chunks = n <= 128 ? 1 : n <= 256 ? 2 : n <= 512 ? 4 : 8;
   e->vec = n % 2 == 0;
   e->bpp = static_cast<uint32_t>((n + 4 * kBfgsRowsPerWave - 1) / (4 * kBfgsRowsPerWave));
-  if (B * e->bpp > 0x7fffffffull) {
+  e->symmetric = (cfg->flags & NLSG_BFGS_SYMMETRIC) != 0;
+  const uint32_t nb = static_cast<uint32_t>((n + kBfgsSymB - 1) / kBfgsSymB), nstored = nb * (nb + 1) / 2;
+  if (B * e->bpp > 0x7fffffffull || B * nstored > 0x7fffffffull) {
     delete e;
     return fail(NLSG_ERR_UNSUPPORTED, "batch * dim too large for one launch grid");
   }
@@ -172,7 +183,12 @@ static int bfgs_create(const nlsg_bfgs_config *cfg, const double *diag_host, con
   auto alloc = [&](void **ptr, size_t bytes) { return hipMalloc(ptr, bytes ? bytes : 8); };
   hipError_t he = hipSuccess;
   const size_t vec_bytes = B * n * sizeof(double);
-  if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&p.H), B * n * n * sizeof(double));
+  if (he == hipSuccess && !e->symmetric)
+    he = alloc(reinterpret_cast<void **>(&p.H), B * n * n * sizeof(double));
+  if (he == hipSuccess && e->symmetric)
+    he = alloc(reinterpret_cast<void **>(&p.Hs), B * nstored * kBfgsSymB * kBfgsSymB * sizeof(double));
+  if (he == hipSuccess && e->symmetric)
+    he = alloc(reinterpret_cast<void **>(&p.part), B * nb * nb * kBfgsSymB * sizeof(double));
   if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&p.x), vec_bytes);
   if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&p.g), vec_bytes);
   if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&p.dir), vec_bytes);
@@ -211,6 +227,8 @@ static int bfgs_create(const nlsg_bfgs_config *cfg, const double *diag_host, con
   p.alpha = cfg->alpha;
   p.qc = cfg->quad_c;
   p.model = quad ? kBfgsQuad : cfg->objective;
+  p.nb = nb;
+  p.nstored = nstored;
   if (custom) {
     const int rc2 = rtc_build_bfgs(custom, e->chunks, e->vec, &e->rtc);
     if (rc2) {
@@ -227,6 +245,8 @@ int nlsg_bfgs_destroy(nlsg_bfgs *e) {
   hipSetDevice(e->cfg.device);
   if (e->stream) hipStreamSynchronize(e->stream);
   hipFree(e->p.H);
+  hipFree(e->p.Hs);
+  hipFree(e->p.part);
   hipFree(e->p.x);
   hipFree(e->p.g);
   hipFree(e->p.dir);
@@ -321,8 +341,23 @@ int nlsg_bfgs_download_state(nlsg_bfgs *e, double *g_host, double *h_host) {
   NLSG_HIP(hipStreamSynchronize(e->stream));
   const uint64_t B = e->p.batch, n = e->p.n;
   if (g_host) NLSG_HIP(hipMemcpy(g_host, e->p.g, B * n * sizeof(double), hipMemcpyDeviceToHost));
-  if (h_host)
+  if (h_host && !e->symmetric)
     NLSG_HIP(hipMemcpy(h_host, e->p.H, B * n * n * sizeof(double), hipMemcpyDeviceToHost));
+  if (h_host && e->symmetric) {  // the full matrix from its upper blocks
+    const uint64_t tile = kBfgsSymB * kBfgsSymB;
+    std::vector<double> blk(e->p.nstored * tile);
+    for (uint64_t b = 0; b < B; b++) {
+      NLSG_HIP(hipMemcpy(blk.data(), e->p.Hs + b * e->p.nstored * tile, blk.size() * sizeof(double),
+                         hipMemcpyDeviceToHost));
+      for (uint64_t i = 0; i < n; i++)
+        for (uint64_t j = 0; j < n; j++) {
+          const uint64_t r = i <= j ? i : j, c = i <= j ? j : i;  // (r, c) in the upper triangle
+          const uint32_t I = static_cast<uint32_t>(r / kBfgsSymB), J = static_cast<uint32_t>(c / kBfgsSymB);
+          h_host[(b * n + i) * n + j] = blk[bfgs_sym_block(I, J, e->p.nb) * tile +
+                                            (r % kBfgsSymB) * kBfgsSymB + c % kBfgsSymB];
+        }
+    }
+  }
   return NLSG_OK;
 }
 

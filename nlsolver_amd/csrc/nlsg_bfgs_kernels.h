@@ -23,6 +23,7 @@ namespace nlsg {
 
 struct BfgsProblem {  // per-problem scalars
   double prev_norm, cur_norm, rho, fval;
+  double denom;  // symmetric restatement: rho y^T t + 1 of the current update (bfgs_sym_reduce_kernel)
   uint64_t iter, fcalls, gcalls;
   int32_t done, identity;
 };
@@ -36,6 +37,11 @@ struct BfgsParams {
   uint64_t batch, n, max_iter;
   double grad_eps, alpha, qc;
   int32_t model, pad;  // kBfgsQuad, or the nlsg_objective minimised with a finite-difference gradient
+  // symmetric restatement (NLSG_BFGS_SYMMETRIC): the upper 128 x 128 blocks of H, and the block
+  // partials of the two products (see "symmetric restatement" below)
+  double *Hs;    // [batch][nstored][128][128]
+  double *part;  // [batch][nb][nb][128]
+  uint32_t nb, nstored;
 };
 
 // ---- wave-level vector helpers (vectors replicated in every lane layout) --------
@@ -488,6 +494,51 @@ __global__ __launch_bounds__(256) void bfgs_init_kernel(BfgsParams p) {
   }
 }
 
+typedef double bfgs_v2d __attribute__((ext_vector_type(2)));
+// the blocks of H are touched once per pass: streamed past the caches' retention (nt)
+__device__ inline double2 bfgs_stream_load(const double *p) {
+  const bfgs_v2d v = __builtin_nontemporal_load(reinterpret_cast<const bfgs_v2d *>(p));
+  return make_double2(v.x, v.y);
+}
+__device__ inline void bfgs_stream_store(double *p, double2 v) {
+  bfgs_v2d w;
+  w.x = v.x;
+  w.y = v.y;
+  __builtin_nontemporal_store(w, reinterpret_cast<bfgs_v2d *>(p));
+}
+// a row of H in the lane layout of load_row / store_row, streamed (nt)
+template <int CHUNKS, bool VEC>
+__device__ inline void bfgs_load_h_row(const double *__restrict__ row, uint64_t D,
+                                       const double *__restrict__ zero, double (&v)[CHUNKS][2]) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int c = 0; c < CHUNKS; c++) {
+    const uint64_t e0 = static_cast<uint64_t>(c) * 128 + 2 * static_cast<uint64_t>(lane);
+    if (VEC) {
+      const double2 t = bfgs_stream_load((e0 < D) ? row + e0 : zero);
+      v[c][0] = t.x;
+      v[c][1] = t.y;
+    } else {
+      v[c][0] = __builtin_nontemporal_load((e0 < D) ? row + e0 : zero);
+      v[c][1] = __builtin_nontemporal_load((e0 + 1 < D) ? row + e0 + 1 : zero);
+    }
+  }
+}
+template <int CHUNKS, bool VEC>
+__device__ inline void bfgs_store_h_row(double *__restrict__ row, uint64_t D, const double (&v)[CHUNKS][2]) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int c = 0; c < CHUNKS; c++) {
+    const uint64_t e0 = static_cast<uint64_t>(c) * 128 + 2 * static_cast<uint64_t>(lane);
+    if (VEC) {
+      if (e0 < D) bfgs_stream_store(row + e0, make_double2(v[c][0], v[c][1]));
+    } else {
+      if (e0 < D) __builtin_nontemporal_store(v[c][0], row + e0);
+      if (e0 + 1 < D) __builtin_nontemporal_store(v[c][1], row + e0 + 1);
+    }
+  }
+}
+
 constexpr int kBfgsRowsPerWave = 8;  // rows a wave streams per launch (vector kept in regs)
 
 // t = H y (first loop of update_inverse_hessian, 3139-3142). Block = 4 waves = 32 rows.
@@ -518,7 +569,7 @@ __global__ __launch_bounds__(256) void bfgs_hy_kernel(BfgsParams p, uint32_t blo
     const uint64_t j = row0 + r;
     if (j >= n) break;
     double h[CHUNKS][2];
-    load_row<CHUNKS, VEC>(Hp + j * n, n, p.zero, h);
+    bfgs_load_h_row<CHUNKS, VEC>(Hp + j * n, n, p.zero, h);
     const double v = wave_dot<CHUNKS>(y, h);  // dot(grad_diff, H row), :3140
     if (lane == 0) t[j] = v;
   }
@@ -554,7 +605,7 @@ __global__ __launch_bounds__(256) void bfgs_update_kernel(BfgsParams p,
     if (j >= n) break;
     double h[CHUNKS][2];
     // H = I is never materialised: identity rows are synthesised
-    load_row<CHUNKS, VEC>(Hp + j * n, identity ? 0 : n, p.zero, h);
+    bfgs_load_h_row<CHUNKS, VEC>(Hp + j * n, identity ? 0 : n, p.zero, h);
     const double sj = p.s[pid * n + j], tj = p.t[pid * n + j];
 #pragma unroll
     for (int c = 0; c < CHUNKS; c++) {
@@ -567,10 +618,216 @@ __global__ __launch_bounds__(256) void bfgs_update_kernel(BfgsParams p,
         h[c][k] = (i < n) ? v : 0.0;
       }
     }
-    store_row<CHUNKS, VEC>(Hp + j * n, n, h);
+    bfgs_store_h_row<CHUNKS, VEC>(Hp + j * n, n, h);
     const double dj = -wave_dot<CHUNKS>(h, g);  // :3249-3250 with the updated row
     if (lane == 0) dir[j] = dj;
   }
+}
+
+// ---- symmetric restatement of the rank-2 update (NLSG_BFGS_SYMMETRIC) ----------------------------
+// H is symmetric in exact arithmetic; the reference's literal update is not bitwise symmetric only
+// because of how its last term associates: (denom * s[i]) * s[j] (nlsolver.h:3156-3163). Restated as
+//     H[j][i] -= rho * ((s[i] t[j] + t[i] s[j]) + denom * (s[i] s[j]))
+// both (j, i) and (i, j) get the same bits (the two products of the first bracket commute under
+// the addition, s[i] s[j] commutes), so H stays bitwise symmetric from the identity on and only its
+// upper 128 x 128 blocks need to exist: 36 of 64 at n = 1024 (4.5 MiB instead of 8 per problem),
+// each streamed ONCE per pass — 13.5 MiB per iteration and problem instead of 24.
+//
+// A stored block (I, J), I <= J, T[r][c] = H[128 I + r][128 J + c], serves two row blocks of a
+// product v = H u: directly, v_I += T u_J (a lane-tree dot per row, as in the literal kernels),
+// and — if I < J — transposed, v_J += T^T u_I (per column, rows summed in order by the wave that
+// owns them, then the block's four waves in order). Every (row block K, column block c) pair of
+// the full matrix thus yields one 128-vector partial, written to part[K][c]; v_K is their sum for
+// c = 0 .. nb-1 in order (bfgs_sym_reduce_kernel). Fixed orders throughout: oracle_bfgs.c, tree = 2,
+// restates them and the kernels match it bit for bit; against the literal arithmetic (and the
+// reference) results differ at rounding level (f within 1e-12 on the G6 runs, tested).
+constexpr int kBfgsSymB = 128;
+
+// block (I, J), I <= J, in the packed upper triangle of nb x nb blocks
+__host__ __device__ inline uint32_t bfgs_sym_block(uint32_t I, uint32_t J, uint32_t nb) {
+  return I * nb - I * (I - 1) / 2 + (J - I);
+}
+
+// u[128 blk + 2 lane + k], zero past n
+__device__ inline void bfgs_sym_slice(const double *u, uint64_t n, uint32_t blk, double (&v)[2]) {
+  const uint64_t e = static_cast<uint64_t>(blk) * kBfgsSymB + 2 * static_cast<uint64_t>(lane_id());
+  v[0] = e < n ? u[e] : 0.0;
+  v[1] = e + 1 < n ? u[e + 1] : 0.0;
+}
+
+struct BfgsSymShared {
+  double direct[kBfgsSymB];      // per row of the block: T[r] . u_J
+  double transp[4][kBfgsSymB];   // per wave and column: sum over the wave's rows of T[r][c] u_I[r]
+};
+
+// the block's two partial vectors -> part[I][J] (direct) and part[J][I] (transposed)
+__device__ inline void bfgs_sym_store_partials(const BfgsParams &p, uint64_t pid, uint32_t I, uint32_t J,
+                                               const BfgsSymShared &sh) {
+  const uint32_t t = threadIdx.x;
+  if (t >= kBfgsSymB) return;
+  double *base = p.part + pid * p.nb * p.nb * kBfgsSymB;
+  base[(static_cast<uint64_t>(I) * p.nb + J) * kBfgsSymB + t] = sh.direct[t];
+  if (I != J)
+    base[(static_cast<uint64_t>(J) * p.nb + I) * kBfgsSymB + t] =
+        ((sh.transp[0][t] + sh.transp[1][t]) + sh.transp[2][t]) + sh.transp[3][t];
+}
+
+// t = H y, one workgroup per stored block (first loop of update_inverse_hessian, 3139-3142)
+constexpr int kBfgsSymFlight = 16;  // rows (KiB) a wave keeps in flight
+
+__global__ __launch_bounds__(256) void bfgs_sym_hy_kernel(BfgsParams p) {
+  __shared__ BfgsSymShared sh;
+  const uint64_t pid = blockIdx.x / p.nstored;
+  const BfgsProblem *pr = p.prob + pid;
+  if (pr->done || pr->identity) return;  // H = I: t = y, written by the reduce kernel
+  uint32_t I = 0, rem = blockIdx.x % p.nstored;
+  while (rem >= p.nb - I) {
+    rem -= p.nb - I;
+    I++;
+  }
+  const uint32_t J = I + rem;
+  const uint64_t n = p.n;
+  const int lane = lane_id();
+  const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+  const double *y = p.y + pid * n;
+  double yJ[2], yI[2];
+  bfgs_sym_slice(y, n, J, yJ);
+  bfgs_sym_slice(y, n, I, yI);  // element r of the row block sits in lane r / 2: read per row
+  const double *T = p.Hs + (pid * p.nstored + blockIdx.x % p.nstored) * (kBfgsSymB * kBfgsSymB) +
+                    2 * lane;
+  double tp0 = 0.0, tp1 = 0.0;
+  for (int r0 = 32 * wid; r0 < 32 * wid + 32; r0 += kBfgsSymFlight) {
+    double2 h[kBfgsSymFlight];
+#pragma unroll
+    for (int q = 0; q < kBfgsSymFlight; q++)
+      h[q] = bfgs_stream_load(T + (r0 + q) * kBfgsSymB);
+#pragma unroll
+    for (int q = 0; q < kBfgsSymFlight; q++) {
+      const double yr = lane_broadcast(yI[q & 1], (r0 + q) >> 1);
+      double acc = 0.0;
+      acc = acc + h[q].x * yJ[0];
+      acc = acc + h[q].y * yJ[1];
+      const double d = wave_sum(acc);
+      if (lane == 0) sh.direct[r0 + q] = d;
+      tp0 = tp0 + h[q].x * yr;
+      tp1 = tp1 + h[q].y * yr;
+    }
+  }
+  sh.transp[wid][2 * lane] = tp0;
+  sh.transp[wid][2 * lane + 1] = tp1;
+  __syncthreads();
+  bfgs_sym_store_partials(p, pid, I, J, sh);
+}
+
+// v = sum of the column blocks' partials in order; one workgroup per problem.
+// UPDATE = false: t = H y (or y while H = I), then denom = rho y^T t + 1 (3143-3145, lane-tree dot).
+// UPDATE = true:  d = -H' g, the next search direction (3248-3251).
+template <bool UPDATE>
+__global__ __launch_bounds__(256) void bfgs_sym_reduce_kernel(BfgsParams p) {
+  __shared__ double tl[1024];
+  const uint64_t pid = blockIdx.x;
+  BfgsProblem *pr = p.prob + pid;
+  if (pr->done) return;
+  const uint64_t n = p.n;
+  const double *base = p.part + pid * p.nb * p.nb * kBfgsSymB;
+  double *out = (UPDATE ? p.dir : p.t) + pid * n;
+  for (uint64_t e = threadIdx.x; e < 1024; e += 256) {
+    double acc = 0.0;
+    if (e < n) {
+      if (!UPDATE && pr->identity) {
+        acc = p.y[pid * n + e];
+      } else {
+        const uint64_t K = e / kBfgsSymB, r = e % kBfgsSymB;
+        acc = base[(K * p.nb) * kBfgsSymB + r];
+        for (uint32_t c = 1; c < p.nb; c++) acc = acc + base[(K * p.nb + c) * kBfgsSymB + r];
+      }
+      if (UPDATE) acc = -acc;
+      out[e] = acc;
+    }
+    tl[e] = acc;
+  }
+  if (UPDATE) return;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int lane = lane_id();
+    const double *y = p.y + pid * n;
+    double acc = 0.0;  // wave_dot<8>(y, t): chunks past n add exact zeros
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      const uint64_t e = static_cast<uint64_t>(c) * 128 + 2 * static_cast<uint64_t>(lane);
+      const double y0 = e < n ? y[e] : 0.0, y1 = e + 1 < n ? y[e + 1] : 0.0;
+      acc = acc + y0 * tl[e];
+      acc = acc + y1 * tl[e + 1];
+    }
+    const double dot = wave_sum(acc);
+    if (lane == 0) pr->denom = (dot * pr->rho) + 1.0;
+  }
+}
+
+// rank-2 update of one stored block (3151-3164, restated) fused with its share of the next
+// direction d = -H' g
+__global__ __launch_bounds__(256) void bfgs_sym_update_kernel(BfgsParams p) {
+  __shared__ BfgsSymShared sh;
+  const uint64_t pid = blockIdx.x / p.nstored;
+  const BfgsProblem *pr = p.prob + pid;
+  if (pr->done) return;
+  uint32_t I = 0, rem = blockIdx.x % p.nstored;
+  while (rem >= p.nb - I) {
+    rem -= p.nb - I;
+    I++;
+  }
+  const uint32_t J = I + rem;
+  const uint64_t n = p.n;
+  const int lane = lane_id();
+  const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+  const double *s = p.s + pid * n, *t = p.t + pid * n, *g = p.g + pid * n;
+  double sJ[2], tJ[2], gJ[2], sI[2], tI[2], gI[2];
+  bfgs_sym_slice(s, n, J, sJ);
+  bfgs_sym_slice(t, n, J, tJ);
+  bfgs_sym_slice(g, n, J, gJ);
+  bfgs_sym_slice(s, n, I, sI);  // element r of the row block sits in lane r / 2: read per row
+  bfgs_sym_slice(t, n, I, tI);
+  bfgs_sym_slice(g, n, I, gI);
+  const double rho = pr->rho, denom = pr->denom;
+  const bool identity = pr->identity != 0;
+  double *T = p.Hs + (pid * p.nstored + blockIdx.x % p.nstored) * (kBfgsSymB * kBfgsSymB) + 2 * lane;
+  const uint64_t col = static_cast<uint64_t>(J) * kBfgsSymB + 2 * static_cast<uint64_t>(lane);
+  double tp0 = 0.0, tp1 = 0.0;
+  for (int r0 = 32 * wid; r0 < 32 * wid + 32; r0 += kBfgsSymFlight) {
+    double2 h[kBfgsSymFlight];
+    if (identity) {  // H = I is never materialised: identity blocks are synthesised (wave-uniform)
+#pragma unroll
+      for (int q = 0; q < kBfgsSymFlight; q++) {
+        const uint64_t row = static_cast<uint64_t>(I) * kBfgsSymB + r0 + q;
+        h[q].x = (row < n && row == col) ? 1.0 : 0.0;
+        h[q].y = (row < n && row == col + 1) ? 1.0 : 0.0;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < kBfgsSymFlight; q++)
+        h[q] = bfgs_stream_load(T + (r0 + q) * kBfgsSymB);
+    }
+#pragma unroll
+    for (int q = 0; q < kBfgsSymFlight; q++) {
+      const int src = (r0 + q) >> 1;
+      const double sr = lane_broadcast(sI[q & 1], src), tr = lane_broadcast(tI[q & 1], src);
+      const double gr = lane_broadcast(gI[q & 1], src);
+      h[q].x = h[q].x - rho * ((sJ[0] * tr + tJ[0] * sr) + denom * (sJ[0] * sr));
+      h[q].y = h[q].y - rho * ((sJ[1] * tr + tJ[1] * sr) + denom * (sJ[1] * sr));
+      bfgs_stream_store(T + (r0 + q) * kBfgsSymB, h[q]);
+      double acc = 0.0;
+      acc = acc + h[q].x * gJ[0];
+      acc = acc + h[q].y * gJ[1];
+      const double d = wave_sum(acc);
+      if (lane == 0) sh.direct[r0 + q] = d;
+      tp0 = tp0 + h[q].x * gr;
+      tp1 = tp1 + h[q].y * gr;
+    }
+  }
+  sh.transp[wid][2 * lane] = tp0;
+  sh.transp[wid][2 * lane + 1] = tp1;
+  __syncthreads();
+  bfgs_sym_store_partials(p, pid, I, J, sh);
 }
 
 __global__ void bfgs_count_unfinished_kernel(BfgsParams p, unsigned long long *count) {

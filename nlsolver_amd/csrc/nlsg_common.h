@@ -215,6 +215,11 @@ __device__ inline uint64_t readlane64(uint64_t v, int src) {  // src wave-unifor
   const uint32_t hi = __builtin_amdgcn_readlane(static_cast<int>(v >> 32), src);
   return (static_cast<uint64_t>(hi) << 32) | lo;
 }
+// value of lane `src` (wave-uniform index) through scalar registers
+__device__ inline double lane_broadcast(double v, int src) {
+  return __longlong_as_double(static_cast<long long>(
+      readlane64(static_cast<uint64_t>(__double_as_longlong(v)), src)));
+}
 // f(int_c<OFF>) for OFF = FIRST, FIRST/2, ..., 1
 template <int N>
 struct int_c {

@@ -71,14 +71,6 @@ struct LmRowsTriShort {
   }
 };
 
-// value of lane `src` (wave-uniform index) through scalar registers
-__device__ inline double lane_broadcast(double v, int src) {
-  const uint64_t b = __double_as_longlong(v);
-  const uint32_t lo = __builtin_amdgcn_readlane(static_cast<int>(b & 0xffffffffu), src);
-  const uint32_t hi = __builtin_amdgcn_readlane(static_cast<int>(b >> 32), src);
-  return __longlong_as_double((static_cast<uint64_t>(hi) << 32) | lo);
-}
-
 template <typename Rows>
 __device__ inline void lm_solve_cholesky_wave(Rows H, const double *g, double *upd, int n,
                                               bool off_upper = false) {

@@ -183,10 +183,11 @@ typedef struct {
   uint64_t f_calls, g_calls;
   double *f_log; /* optional: every objective value in call order */
   size_t f_cap, f_count;
+  double *H_out; /* optional: n*n, the inverse Hessian after the last update */
 } orc_bfgs_counters;
 /* BFGS::solve<true> (nlsolver.h:3196-3285) with more_thuente_search (1527-1891) and
  * update_inverse_hessian (3130-3168). tree = 0: the reference's sequential sums;
- * tree = 1: the HIP kernel's lane tree. */
+ * tree = 1: the HIP kernel's lane tree; tree = 2: the symmetric restatement (oracle_bfgs.c). */
 orc_status orc_bfgs_quad(const orc_quad *q, double *x, size_t n, size_t max_iter, double grad_eps,
                          double alpha, int tree, orc_bfgs_counters *cnt);
 /* the same on a built-in objective with the reference's default gradient, fin_diff

@@ -9,6 +9,11 @@
  *   tree = 1  the fixed lane tree the HIP kernel uses (element e -> lane (e%128)/2,
  *             in-lane sequential, 64-lane xor butterfly). The kernel matches it
  *             bit for bit.
+ *   tree = 2  the symmetric restatement (NLSG_BFGS_SYMMETRIC, nlsg_bfgs_kernels.h): vector
+ *             reductions as tree = 1; the update's last term as denom * (s[i] s[j]), which
+ *             keeps H bitwise symmetric; the products H y and H g summed the way the kernels
+ *             stream the upper 128 x 128 blocks (sym_matvec below). Differs from tree = 0 / 1
+ *             at rounding level only.
  */
 #include <math.h>
 #include <stdlib.h>
@@ -283,6 +288,56 @@ static void cvsrch(const ctx_t *c, const model_t *q, const double *x, double f0,
   }
 }
 
+/* v = H u as the symmetric kernels sum it (bfgs_sym_hy_kernel / bfgs_sym_update_kernel +
+ * bfgs_sym_reduce_kernel): the matrix in 128 x 128 blocks, row block K's value = the partials of
+ * its column blocks c = 0 .. nb-1 added in order. c >= K: the stored block (K, c) used directly —
+ * a lane-tree dot of the row with u's slice. c < K: the stored block (c, K) used transposed — per
+ * column, the products of its 128 rows summed in order inside each quarter (a wave's 32 rows),
+ * then the four quarters in order. H must be bitwise symmetric; entries past n are zeros. */
+#define SYMB 128
+static void sym_matvec(const double *H, const double *u, double *out, size_t n) {
+  const size_t nb = (n + SYMB - 1) / SYMB;
+  for (size_t K = 0; K < nb; K++)
+    for (size_t r = 0; r < SYMB && K * SYMB + r < n; r++) {
+      const size_t row = K * SYMB + r;
+      double total = 0.0;
+      for (size_t c = 0; c < nb; c++) {
+        double partial;
+        if (c >= K) {
+          double lane[64], tmp[64];
+          for (int l = 0; l < 64; l++) {
+            double acc = 0.0;
+            for (int k = 0; k < 2; k++) {
+              const size_t col = c * SYMB + 2 * (size_t)l + k;
+              const double h = col < n ? H[row * n + col] : 0.0, uv = col < n ? u[col] : 0.0;
+              acc = acc + h * uv;
+            }
+            lane[l] = acc;
+          }
+          for (int off = 32; off >= 1; off >>= 1) {
+            for (int l = 0; l < 64; l++) tmp[l] = lane[l] + lane[l ^ off];
+            memcpy(lane, tmp, sizeof lane);
+          }
+          partial = lane[0];
+        } else {
+          double q[4];
+          for (int w = 0; w < 4; w++) {
+            double acc = 0.0;
+            for (size_t rr = 32 * (size_t)w; rr < 32 * (size_t)w + 32; rr++) {
+              const size_t srow = c * SYMB + rr; /* a row of the stored block (c, K) */
+              const double h = srow < n ? H[srow * n + row] : 0.0, uv = srow < n ? u[srow] : 0.0;
+              acc = acc + h * uv;
+            }
+            q[w] = acc;
+          }
+          partial = ((q[0] + q[1]) + q[2]) + q[3];
+        }
+        total = c == 0 ? partial : total + partial;
+      }
+      out[row] = total;
+    }
+}
+
 /* update_inverse_hessian, nlsolver.h:3130-3168 (literal, incl. the sign of the
  * s s^T term). */
 void orc_update_inverse_hessian(double *H, const double *s, const double *y, double *t, double rho,
@@ -320,7 +375,12 @@ static orc_status bfgs_solve(const model_t *q, double *x, size_t n, size_t max_i
       fval = model_f(&c, q, x, cnt);
       break;
     }
-    for (size_t j = 0; j < n; j++) dir[j] = -dot_(&c, H + j * n, g); /* :3248-3251 */
+    if (tree == 2) {
+      sym_matvec(H, g, dir, n);
+      for (size_t j = 0; j < n; j++) dir[j] = -dir[j];
+    } else {
+      for (size_t j = 0; j < n; j++) dir[j] = -dot_(&c, H + j * n, g); /* :3248-3251 */
+    }
     const double phi = dot_(&c, g, dir);
     if ((phi > 0) || isnan(phi) || cur_norm > prev_norm) { /* :3253-3260 */
       memset(H, 0, n * n * sizeof(double));
@@ -343,12 +403,18 @@ static orc_status bfgs_solve(const model_t *q, double *x, size_t n, size_t max_i
     double rho = dot_(&c, y, s);
     rho = 1 / rho; /* :3277-3278 */
     /* update_inverse_hessian with this context's summation order */
-    for (size_t i = 0; i < n; i++) t[i] = dot_(&c, y, H + i * n);
+    if (tree == 2)
+      sym_matvec(H, y, t, n);
+    else
+      for (size_t i = 0; i < n; i++) t[i] = dot_(&c, y, H + i * n);
     double denom = dot_(&c, y, t);
     denom = (denom * rho) + 1.0;
     for (size_t j = 0; j < n; j++)
       for (size_t i = 0; i < n; i++)
-        H[j * n + i] = H[j * n + i] - rho * (s[i] * t[j] + t[i] * s[j] + denom * s[i] * s[j]);
+        H[j * n + i] = tree == 2
+                           ? H[j * n + i] - rho * ((s[i] * t[j] + t[i] * s[j]) + denom * (s[i] * s[j]))
+                           : H[j * n + i] - rho * (s[i] * t[j] + t[i] * s[j] + denom * s[i] * s[j]);
+    if (cnt->H_out) memcpy(cnt->H_out, H, n * n * sizeof(double)); /* tests: the last inverse Hessian */
     iter++;
   }
   orc_status st = {fval, iter, cnt->f_calls, cnt->g_calls, 0};

@@ -59,7 +59,8 @@ class Quad(C.Structure):
 
 
 class BfgsCounters(C.Structure):
-    _fields_ = [("f_calls", u64), ("g_calls", u64), ("f_log", pd), ("f_cap", sz), ("f_count", sz)]
+    _fields_ = [("f_calls", u64), ("g_calls", u64), ("f_log", pd), ("f_cap", sz), ("f_count", sz),
+                ("H_out", pd)]
 
 
 class Nlls(C.Structure):
@@ -99,8 +100,10 @@ def quad_problem(n, c=0.01):
     return d, b, c
 
 
-def bfgs_quad(lib, x0, *, max_iter=100, grad_eps=5e-3, alpha=1.0, tree=0, log=False, c=0.01):
-    """Run the oracle's BFGS on the G6 quadratic; returns (status, x, f_log)."""
+def bfgs_quad(lib, x0, *, max_iter=100, grad_eps=5e-3, alpha=1.0, tree=0, log=False, c=0.01,
+              hessian=None):
+    """Run the oracle's BFGS on the G6 quadratic; returns (status, x, f_log). `hessian`: an
+    (n, n) array that receives the inverse Hessian after the last update."""
     x = np.ascontiguousarray(x0, dtype=np.float64).copy()
     n = x.size
     d, b, c = quad_problem(n, c)
@@ -109,6 +112,9 @@ def bfgs_quad(lib, x0, *, max_iter=100, grad_eps=5e-3, alpha=1.0, tree=0, log=Fa
     flog = np.zeros(22 * (max_iter + 1) + 4) if log else None
     if log:
         cnt.f_log, cnt.f_cap = _ptr(flog), flog.size
+    if hessian is not None:
+        assert hessian.shape == (n, n) and hessian.flags.c_contiguous
+        cnt.H_out = _ptr(hessian)
     st = lib.orc_bfgs_quad(C.byref(q), _ptr(x), n, max_iter, grad_eps, alpha, tree, C.byref(cnt))
     return st, x, (flog[:cnt.f_count] if log else None)
 

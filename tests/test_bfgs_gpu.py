@@ -179,3 +179,89 @@ def test_bfgs_finite_difference_close_to_reference(mod, oracle, golden):
 def test_bfgs_finite_difference_rejects_large_dim(mod):
     with pytest.raises(RuntimeError, match="256"):
         mod.BFGSEngine("rosenbrock", 2, dim=300)
+
+
+# ---- NLSG_BFGS_SYMMETRIC: the rank-2 update restated so that H stays bitwise symmetric, upper
+# ---- 128 x 128 blocks only (include/nlsg_c_api.h; oracle tree = 2)
+@pytest.mark.parametrize("n,batch", [(8, 5), (64, 6), (100, 4), (128, 3), (130, 5), (257, 3), (1024, 3)])
+@pytest.mark.parametrize("kw", [dict(max_iter=100, grad_eps=1e-8, alpha=1.0),
+                                dict(max_iter=100, grad_eps=5e-3, alpha=1.0),
+                                dict(max_iter=7, grad_eps=0.0, alpha=0.5)])
+def test_bfgs_symmetric_bit_exact_vs_oracle(mod, oracle, n, batch, kw):
+    d, b, c = O.quad_problem(n)
+    x0 = starts(batch, n, seed=n)
+    with mod.BFGSEngine(mod.QuadDiagRank1(d, b, c), batch, symmetric=True, **kw) as eng:
+        x, st = eng.minimize(x0.copy())
+    for p in range(batch):
+        ref, xr, _ = O.bfgs_quad(oracle, x0[p], tree=2, **kw)
+        assert (st[p].iteration, st[p].function_calls_used, st[p].gradient_evals_used) == \
+            (ref.iteration, ref.function_calls_used, ref.gradient_evals_used), f"problem {p}"
+        assert st[p].f_value == ref.f_value, f"problem {p}"
+        assert np.array_equal(x[p], xr), f"problem {p}"
+        assert st[p].done == 1
+
+
+@pytest.mark.parametrize("n", [96, 130, 300])
+def test_bfgs_symmetric_inverse_hessian_bit_exact_and_symmetric(mod, oracle, n):
+    """The stored upper blocks after k updates, expanded: equal to the oracle's H bit for bit, and
+    the oracle's H (computed on the whole matrix with the restated formula) is bitwise symmetric —
+    which is what makes keeping half of it legitimate."""
+    batch, k = 3, 5
+    d, b, c = O.quad_problem(n)
+    x0 = starts(batch, n, seed=70 + n)
+    kw = dict(max_iter=k, grad_eps=0.0, alpha=1.0)
+    with mod.BFGSEngine(mod.QuadDiagRank1(d, b, c), batch, symmetric=True, **kw) as eng:
+        eng.init(x0)
+        eng.step(k)
+        g, H = eng.download_state()
+    for p in range(batch):
+        Href = np.zeros((n, n))
+        O.bfgs_quad(oracle, x0[p], tree=2, hessian=Href, **kw)
+        assert np.array_equal(Href, Href.T)
+        assert np.array_equal(H[p], Href), p
+
+
+def test_bfgs_symmetric_matches_reference_within_1e12(mod, golden):
+    """Symmetric restatement vs the reference itself (golden, literal update, sequential sums) on
+    the G6 runs: f within 1e-12 relative, and where the stop test is not at the rounding floor
+    (grad_eps = 5e-3) the same iteration / call counts."""
+    g = golden("bfgs.json")
+    for name in ("n8", "n64", "n1024", "n64_default_stop"):
+        c = g[name]
+        n = c["n"]
+        d, b, cc = O.quad_problem(n)
+        x0 = np.full((1, n), float.fromhex(c["x0"]))
+        kw = dict(max_iter=c["max_iter"], grad_eps=float.fromhex(c["grad_eps"]),
+                  alpha=float.fromhex(c["alpha"]))
+        st = mod.BFGS(mod.QuadDiagRank1(d, b, cc), None, kw["max_iter"], kw["grad_eps"],
+                      kw["alpha"], symmetric=True).minimize(x0[0])
+        fref = float.fromhex(c["f"])
+        assert abs(st.f_value - fref) <= 1e-12 * abs(fref), name
+        if kw["grad_eps"] >= 1e-6:
+            assert (st.iteration, st.function_calls_used, st.gradient_evals_used) == \
+                (c["iters"], c["fcalls"], c["gcalls"])
+
+
+def test_bfgs_symmetric_config3_full_batch(mod, oracle):
+    """BASELINE configs[2] at full size with the symmetric restatement (18 GiB of upper blocks
+    instead of 32 GiB): sampled problems incl. the first and the last bit for bit vs oracle tree 2,
+    and every problem within 1e-10 of what the literal engine reaches."""
+    n, batch = 1024, 4096
+    d, b, c = O.quad_problem(n)
+    rng = np.random.default_rng(34)
+    x0 = 1.0 + 0.5 * (rng.random((batch, n)) - 0.5)
+    x0[::7] *= 1.0 + rng.random((len(x0[::7]), 1))
+    kw = dict(max_iter=50, grad_eps=1e-6, alpha=1.0)
+    with mod.BFGSEngine(mod.QuadDiagRank1(d, b, c), batch, symmetric=True, **kw) as eng:
+        x, st = eng.minimize(x0.copy())
+    sample = sorted({0, 1, 255, 2048, 4094, 4095, *rng.integers(0, batch, 6).tolist()})
+    for p in sample:
+        ref, xr, _ = O.bfgs_quad(oracle, x0[p], tree=2, **kw)
+        assert (st[p].iteration, st[p].function_calls_used) == (ref.iteration, ref.function_calls_used), p
+        assert st[p].f_value == ref.f_value and np.array_equal(x[p], xr), p
+    assert all(s.done == 1 and 1 <= s.iteration <= 50 for s in st)
+    with mod.BFGSEngine(mod.QuadDiagRank1(d, b, c), 64, **kw) as eng:
+        x_lit, st_lit = eng.minimize(x0[:64].copy())
+    f_sym = np.array([s.f_value for s in st[:64]])
+    f_lit = np.array([s.f_value for s in st_lit])
+    assert np.allclose(f_sym, f_lit, rtol=1e-10, atol=0)

@@ -63,3 +63,26 @@ def test_survey_anchor(golden):
     g = golden("bfgs.json")
     assert abs(hx(g["n64"]["f"]) - (-3.551897415725755)) < 1e-13
     assert abs(hx(g["n1024"]["f"]) - (-65.308652606191941)) < 1e-10
+
+
+@pytest.mark.parametrize("name", ["n8", "n64", "n1024", "n64_default_stop"])
+def test_symmetric_restatement_within_1e12_of_reference(oracle, golden, name):
+    """tree = 2 (update with denom * (s[i] s[j]), products summed block-wise as the symmetric
+    kernels stream the upper blocks of H) against the reference's own runs: f within 1e-12; the
+    inverse Hessian it carries is bitwise symmetric at every iteration."""
+    from tests import _oracle as O
+    c = golden("bfgs.json")[name]
+    n = c["n"]
+    x0 = np.full(n, float.fromhex(c["x0"]))
+    kw = dict(max_iter=c["max_iter"], grad_eps=float.fromhex(c["grad_eps"]),
+              alpha=float.fromhex(c["alpha"]))
+    st, x, _ = O.bfgs_quad(oracle, x0, tree=2, **kw)
+    fref = float.fromhex(c["f"])
+    assert abs(st.f_value - fref) <= 1e-12 * abs(fref)
+    if kw["grad_eps"] >= 1e-6:
+        assert (st.iteration, st.function_calls_used, st.gradient_evals_used) == \
+            (c["iters"], c["fcalls"], c["gcalls"])
+    for k in (1, 2, 5, 12):
+        H = np.zeros((n, n))
+        O.bfgs_quad(oracle, x0, tree=2, hessian=H, max_iter=k, grad_eps=0.0, alpha=kw["alpha"])
+        assert np.array_equal(H, H.T) and not np.isnan(H).any()
