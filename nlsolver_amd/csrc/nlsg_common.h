@@ -120,6 +120,14 @@ __host__ __device__ inline uint64_t ctr_key(uint64_t parent, uint64_t index) {
 __host__ __device__ inline double u01(uint64_t bits) {
   return static_cast<double>(bits) * 0x1p-64;
 }
+// The two uniforms of ONE normal variate (rnorm, nlsolver.h:2479-2485: sqrt(-2 ln u1) cos(2 pi u2))
+// from one 64-bit draw: the radius' uniform is the draw as every other uniform takes it (all 64
+// bits into the fp64), the angle's uniform its low 32 bits (an angular resolution of 1.5e-9 rad; the
+// bits it shares with u1 sit below u1's 32 leading bits). Half the mixing work of two draws — the
+// kernels that draw normal variates are bound by exactly this arithmetic.
+__host__ __device__ inline double u01_low32(uint64_t bits) {
+  return static_cast<double>(static_cast<uint32_t>(bits)) * 0x1p-32;
+}
 // generate_index (nlsolver.h:2325-2329) with the u == 1.0 corner clamped (B10).
 __host__ __device__ inline uint64_t clamp_index(double u, uint64_t n) {
   uint64_t p = static_cast<uint64_t>(u * static_cast<double>(n));
@@ -414,6 +422,46 @@ __device__ inline void store_row(double *__restrict__ row, uint64_t D,
     } else {
       if (e0 < D) row[e0] = v[c][0];
       if (e0 + 1 < D) row[e0 + 1] = v[c][1];
+    }
+  }
+}
+
+// The same for rows that are touched once per pass and by their owner only (a particle's
+// position, a trial row nobody reads before the next generation): nontemporal, streamed past the
+// caches' retention so that what IS re-read (donor rows, the swarm best) keeps its place.
+typedef double nlsg_v2d __attribute__((ext_vector_type(2)));
+template <int CHUNKS, bool VEC>
+__device__ inline void load_row_stream(const double *__restrict__ row, uint64_t D,
+                                       const double *__restrict__ zero, double (&v)[CHUNKS][2]) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int c = 0; c < CHUNKS; c++) {
+    const uint64_t e0 = static_cast<uint64_t>(c) * 128 + 2 * static_cast<uint64_t>(lane);
+    if (VEC) {
+      const nlsg_v2d t = __builtin_nontemporal_load(reinterpret_cast<const nlsg_v2d *>((e0 < D) ? row + e0 : zero));
+      v[c][0] = t.x;
+      v[c][1] = t.y;
+    } else {
+      v[c][0] = __builtin_nontemporal_load((e0 < D) ? row + e0 : zero);
+      v[c][1] = __builtin_nontemporal_load((e0 + 1 < D) ? row + e0 + 1 : zero);
+    }
+  }
+}
+template <int CHUNKS, bool VEC>
+__device__ inline void store_row_stream(double *__restrict__ row, uint64_t D,
+                                        const double (&v)[CHUNKS][2]) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int c = 0; c < CHUNKS; c++) {
+    const uint64_t e0 = static_cast<uint64_t>(c) * 128 + 2 * static_cast<uint64_t>(lane);
+    if (VEC) {
+      nlsg_v2d t;
+      t.x = v[c][0];
+      t.y = v[c][1];
+      if (e0 < D) __builtin_nontemporal_store(t, reinterpret_cast<nlsg_v2d *>(row + e0));
+    } else {
+      if (e0 < D) __builtin_nontemporal_store(v[c][0], row + e0);
+      if (e0 + 1 < D) __builtin_nontemporal_store(v[c][1], row + e0 + 1);
     }
   }
 }

@@ -395,6 +395,10 @@ static int de_create(const nlsg_de_config *cfg, const nlsg_custom_objective *cus
   p.seed = cfg->seed;
   p.strategy = cfg->strategy;
   p.vec = (D % 2 == 0) ? 1 : 0;
+  // measured at pop 2^20 (1 GiB per buffer): generation 0.892 -> 0.805 ms; at pop 65 536 (both
+  // buffers inside the Infinity Cache): 47.8 -> 46.6 us — the streamed stores win at both sizes
+  p.stream = 1;
+  if (const char *sv = std::getenv("NLSG_DE_STREAM")) p.stream = sv[0] == '1' ? 1 : 0;  // A/B switch
   if (custom) {
     const int rc2 = rtc_build_de(custom, e->chunks, p.vec != 0, e->group, &e->rtc);
     if (rc2) {

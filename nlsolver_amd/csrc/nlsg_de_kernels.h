@@ -53,7 +53,9 @@ struct DeParams {
   uint32_t *ticket;    // arrival counter of de_scan_head_kernel's blocks (zero between launches)
   const double *zero;  // 16 bytes of zeros: source for lanes past the row end
   uint32_t ntiles;
-  uint32_t pad0;
+  uint32_t stream;     // the new generation's rows are stored nontemporally: they are read again a
+                       // whole generation later, the caches are better spent on the rows being
+                       // gathered (NLSG_DE_STREAM=0 is the A/B switch)
   uint64_t pop, D, shard_lo, shard_n;
   double CR, F, eps, fmul;
   uint64_t max_iter, best_val_no_change, seed;
@@ -194,7 +196,13 @@ __device__ inline void de_process_agent(const DeParams &p, double *__restrict__ 
   const double score = p.fmul * wave_objective<OBJ, CHUNKS>(trial, D);  // :2463
   const bool accept = score < c.old_score;                               // :2466 (NaN -> keep)
   double *out = nxt + c.a * D;
-  if (accept) {
+  if (p.stream) {  // wave-uniform
+    if (accept) {
+      store_row_stream<CHUNKS, VEC>(out, D, trial);
+    } else {
+      store_row_stream<CHUNKS, VEC>(out, D, c.own);
+    }
+  } else if (accept) {
     store_row<CHUNKS, VEC>(out, D, trial);
   } else {
     store_row<CHUNKS, VEC>(out, D, c.own);

@@ -27,6 +27,7 @@
 namespace nlsg {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d_nt __attribute__((ext_vector_type(2)));
 
 constexpr int kLmN = 64;        // parameters are padded to 64 columns
 constexpr int kLmJStride = 80;  // LDS row stride of the Jacobian block (doubles)
@@ -445,8 +446,11 @@ __device__ inline void lm_eval_wave(const LmParams &p, int first, uint64_t pid, 
   double ysel;
   auto fetch = [&](uint64_t s) {
 #pragma unroll
-    for (int k = 0; k < 8; k++)
-      a[k] = *reinterpret_cast<const double2 *>(Ap + s * stride + (2 * k + half) * kLmN);
+    for (int k = 0; k < 8; k++) {  // the design matrix is read once per evaluation: streamed (nt)
+      const v2d_nt v = __builtin_nontemporal_load(
+          reinterpret_cast<const v2d_nt *>(Ap + s * stride + (2 * k + half) * kLmN));
+      a[k] = make_double2(v.x, v.y);
+    }
     ysel = yp[s * ystride];
   };
   auto step = [&](uint64_t s, double &fw) {

@@ -119,14 +119,14 @@ __global__ __launch_bounds__(256) void pso_move_kernel(PsoParams p, int timing, 
   double xv[CHUNKS][2], gb[CHUNKS][2], lo[CHUNKS][2], hi[CHUNKS][2];
   double vv[CHUNKS][2], pb[CHUNKS][2];
   double *row = p.pos + i * D;
-  load_row<CHUNKS, VEC>(row, D, p.zero, xv);
+  load_row_stream<CHUNKS, VEC>(row, D, p.zero, xv);
   load_row<CHUNKS, VEC>(p.gbest_x, D, p.zero, gb);
   // bounds are only needed when thresholding; unbounded runs read the zero pad
   load_row<CHUNKS, VEC>(p.lower, p.bounded ? D : 0, p.zero, lo);
   load_row<CHUNKS, VEC>(p.upper, p.bounded ? D : 0, p.zero, hi);
   if (TYPE == NLSG_PSO_VANILLA) {
-    load_row<CHUNKS, VEC>(p.vel + i * D, D, p.zero, vv);
-    load_row<CHUNKS, VEC>(p.pbest_pos + i * D, D, p.zero, pb);
+    load_row_stream<CHUNKS, VEC>(p.vel + i * D, D, p.zero, vv);
+    load_row_stream<CHUNKS, VEC>(p.pbest_pos + i * D, D, p.zero, pb);
   }
   const double old_pbest = p.pbest_val[i];
   double inertia = p.inertia;
@@ -142,8 +142,13 @@ __global__ __launch_bounds__(256) void pso_move_kernel(PsoParams p, int timing, 
 #pragma unroll
     for (int k = 0; k < 2; k++) {
       const uint64_t e = static_cast<uint64_t>(c) * 128 + 2 * static_cast<uint64_t>(lane) + k;
-      const double u1 = u01(mix64(kp_lane + kGolden * static_cast<uint64_t>(256 * c + 2 * k)));
-      const double u2 = u01(mix64(kp_lane + kGolden * static_cast<uint64_t>(256 * c + 2 * k + 1)));
+      // Accelerated: one draw (slot 2e) feeds both uniforms of the element's normal variate;
+      // Vanilla: r_p and r_g are draws 2e and 2e + 1
+      const uint64_t z1 = mix64(kp_lane + kGolden * static_cast<uint64_t>(256 * c + 2 * k));
+      const double u1 = u01(z1);
+      const double u2 = TYPE == NLSG_PSO_ACCELERATED
+                            ? u01_low32(z1)
+                            : u01(mix64(kp_lane + kGolden * static_cast<uint64_t>(256 * c + 2 * k + 1)));
       double pnew;
       if (TYPE == NLSG_PSO_ACCELERATED) {
         // rnorm (2479-2485): sqrt(-2 log u1) * cos(2 pi_ u2), pi_ = 3.141593
@@ -163,10 +168,10 @@ __global__ __launch_bounds__(256) void pso_move_kernel(PsoParams p, int timing, 
     }
   }
   const double f = p.fmul * wave_objective<OBJ, CHUNKS>(xv, D);
-  store_row<CHUNKS, VEC>(row, D, xv);
-  if (TYPE == NLSG_PSO_VANILLA) store_row<CHUNKS, VEC>(p.vel + i * D, D, vv);
+  store_row_stream<CHUNKS, VEC>(row, D, xv);
+  if (TYPE == NLSG_PSO_VANILLA) store_row_stream<CHUNKS, VEC>(p.vel + i * D, D, vv);
   const bool better = f < old_pbest;  // :2733-2735
-  if (TYPE == NLSG_PSO_VANILLA && better) store_row<CHUNKS, VEC>(p.pbest_pos + i * D, D, xv);
+  if (TYPE == NLSG_PSO_VANILLA && better) store_row_stream<CHUNKS, VEC>(p.pbest_pos + i * D, D, xv);
   if (lane == 0) {
     p.cur_val[i] = f;
     if (better) p.pbest_val[i] = f;
@@ -218,8 +223,11 @@ __global__ __launch_bounds__(256) void pso_move_groups_kernel(PsoParams p, int t
   const uint64_t kp_lane = kp + kGolden * (4 * static_cast<uint64_t>(g) + 1);
 #pragma unroll
   for (int k = 0; k < 2; k++) {
-    const double u1 = u01(mix64(kp_lane + kGolden * static_cast<uint64_t>(2 * k)));
-    const double u2 = u01(mix64(kp_lane + kGolden * static_cast<uint64_t>(2 * k + 1)));
+    const uint64_t z1 = mix64(kp_lane + kGolden * static_cast<uint64_t>(2 * k));
+    const double u1 = u01(z1);
+    const double u2 = TYPE == NLSG_PSO_ACCELERATED
+                          ? u01_low32(z1)
+                          : u01(mix64(kp_lane + kGolden * static_cast<uint64_t>(2 * k + 1)));
     double pnew;
     if (TYPE == NLSG_PSO_ACCELERATED) {
       const double rn = sqrt(-2 * det_log(u1)) * det_cos(2 * 3.141593 * u2);  // rnorm, :2479-2485

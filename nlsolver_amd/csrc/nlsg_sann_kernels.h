@@ -76,8 +76,8 @@ __global__ __launch_bounds__(256) void sann_anneal_kernel(SannParams p, uint64_t
 #pragma unroll
         for (int k = 0; k < 2; k++) {
           const uint64_t e = static_cast<uint64_t>(c) * 128 + 2 * static_cast<uint64_t>(lane) + k;
-          const double u1 = u01(mix64(ks_lane + kGolden * static_cast<uint64_t>(256 * c + 2 * k)));
-          const double u2 = u01(mix64(ks_lane + kGolden * static_cast<uint64_t>(256 * c + 2 * k + 1)));
+          const uint64_t z1 = mix64(ks_lane + kGolden * static_cast<uint64_t>(256 * c + 2 * k));  // one draw (slot 2e) per normal variate
+          const double u1 = u01(z1), u2 = u01_low32(z1);
           // rnorm (:2479-2485): sqrt(-2 log u1) * cos(2 pi_ u2), pi_ = 3.141593
           const double rn = sqrt(-2 * det_log(u1)) * det_cos(2 * 3.141593 * u2);
           pt[c][k] = (e < D) ? pc[c][k] + current_scale * rn : 0.0;  // :2800
@@ -157,8 +157,8 @@ __global__ __launch_bounds__(256) void sann_anneal_groups_kernel(SannParams p, u
       double pt[2];
 #pragma unroll
       for (int k = 0; k < 2; k++) {
-        const double u1 = u01(mix64(ks_lane + kGolden * static_cast<uint64_t>(2 * k)));
-        const double u2 = u01(mix64(ks_lane + kGolden * static_cast<uint64_t>(2 * k + 1)));
+        const uint64_t z1 = mix64(ks_lane + kGolden * static_cast<uint64_t>(2 * k));  // one draw (slot 2e) per normal variate
+        const double u1 = u01(z1), u2 = u01_low32(z1);
         const double rn = sqrt(-2 * det_log(u1)) * det_cos(2 * 3.141593 * u2);
         pt[k] = ((k ? in1 : in0)) ? pc[k] + current_scale * rn : 0.0;
       }

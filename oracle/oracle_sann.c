@@ -63,7 +63,7 @@ orc_status orc_sann_serial(int obj, int minimize, double *x, size_t D, orc_xorsh
 }
 
 /* Draws of chain `chain`: kc = key(seed, chain); inner step s = iter * (temp_iter - 1) + (j - 1)
- * has ks = key(kc, s); coordinate e uses draws 2e (log) and 2e + 1 (cos) of ks, the acceptance
+ * has ks = key(kc, s); coordinate e uses draw 2e of ks for both uniforms of its normal variate, the acceptance
  * test draw 2 D. */
 orc_status orc_sann_sync(int obj, int minimize, double *x, size_t D, uint64_t seed, uint64_t chain,
                          size_t max_iter, size_t temp_iter, double temp_max, double *f_log,
@@ -86,8 +86,8 @@ orc_status orc_sann_sync(int obj, int minimize, double *x, size_t D, uint64_t se
       const uint64_t ks = orc_ctr_key(kc, iter * (temp_iter - 1) + (j - 1));
       const double current_scale = t * scale;
       for (size_t i = 0; i < D; i++) {
-        const double u1 = orc_u01(orc_ctr_key(ks, 2 * i));
-        const double u2 = orc_u01(orc_ctr_key(ks, 2 * i + 1));
+        const uint64_t z1 = orc_ctr_key(ks, 2 * i); /* one draw per normal variate (u01_low32) */
+        const double u1 = orc_u01(z1), u2 = (double)(uint32_t)z1 * 0x1p-32;
         ptry[i] = p[i] + current_scale * (sqrt(-2 * orc_log(u1)) * orc_cos(2 * pi_ * u2));
       }
       fv = orc_objective_tree(obj, ptry, D);
