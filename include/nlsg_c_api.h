@@ -294,7 +294,7 @@ typedef struct {
   int32_t objective;   /* nlsg_grad_objective (analytic gradient functor), or one of */
                        /* NLSG_OBJ_ROSENBROCK / SPHERE / STYBLINSKI_TANG / RASTRIGIN:  */
                        /* reference's default gradient fin_diff (nlsolver.h:         */
-                       /* 1385-1413, 2849-2855), evaluated on the device; dim <= 256 */
+                       /* 1385-1413, 2849-2855), evaluated on the device              */
   int32_t flags;       /* 0, or NLSG_BFGS_SYMMETRIC                               */
   uint64_t batch;      /* independent problems                                    */
   uint64_t dim;        /* x.size() of each problem (<= 1024)                      */

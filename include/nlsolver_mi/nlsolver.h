@@ -936,7 +936,7 @@ class BFGS {
                 const scalar_t grad_eps = 5e-3, const scalar_t alpha = 1)
       : f(f), g(g), max_iter(max_iter), grad_eps(grad_eps), alpha(alpha) {}
   // Device coverage of the default-gradient path (fin_diff on a built-in objective): the
-  // objectives whose arithmetic is deterministic on the device, up to 256 dimensions.
+  // objectives whose arithmetic is deterministic on the device (up to the engine's 1024 dimensions).
   static constexpr bool device_fd() {
     if constexpr (device::is_device_objective<Callable>::value &&
                   std::is_same_v<Grad, fin_diff<Callable, scalar_t>>)
@@ -956,7 +956,7 @@ class BFGS {
       return st[0];
     } else if constexpr (device_fd()) {
       if constexpr (Callable::nlsg_objective != NLSG_OBJ_CUSTOM)  // (Custom has no host evaluation)
-        if (x.size() > 256) return solve_host(x);  // beyond the device coverage: host functor path
+        if (x.size() > 1024) return solve_host(x);  // beyond the device coverage: host functor path
       std::vector<std::vector<scalar_t>> one{x};
       auto st = minimize_batch(one);
       x = one[0];

@@ -4,7 +4,7 @@ Reference interface (nlsolver.h:3169-3196):
     BFGS<Callable, scalar_t, Grad>(f, g = fin_diff, max_iter = 100, grad_eps = 5e-3, alpha = 1)
     solver_status minimize(std::vector<T>& x)          (one start per call)
 Here `f` is a device objective: QuadDiagRank1 with its analytic gradient, or the name of a
-built-in objective ("rosenbrock", "sphere", "styblinski_tang"; dim <= 256), for which the
+built-in objective ("rosenbrock", "sphere", "styblinski_tang", "rastrigin"), for which the
 reference's DEFAULT gradient runs on the device (fin_diff = finite_difference_gradient<.,.,1>,
 nlsolver.h:1385-1413: four probes per coordinate, each counted as a function call). minimize()
 accepts one start (n,) or a batch of independent starts (batch, n) — BASELINE config 3 — solved

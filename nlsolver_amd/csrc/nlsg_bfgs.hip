@@ -41,30 +41,25 @@ namespace {
     }                                                                                            \
   } while (0)
 
-// search / init kernels also depend on what is minimised: the quadratic for every dim, the
-// finite-difference models for dim <= 256
+// search / init kernels also depend on what is minimised
 #define BFGS_MODEL_CASE(KERNEL, C, V, grid, ...)                                                    \
   switch (e->p.model) {                                                                             \
     case kBfgsQuad:                                                                                 \
       hipLaunchKernelGGL((KERNEL<C, V, kBfgsQuad>), dim3(grid), dim3(256), 0, e->stream, __VA_ARGS__); \
       break;                                                                                        \
     case NLSG_OBJ_ROSENBROCK:                                                                       \
-      if constexpr (C <= 2)                                                                         \
         hipLaunchKernelGGL((KERNEL<C, V, NLSG_OBJ_ROSENBROCK>), dim3(grid), dim3(256), 0, e->stream, \
                            __VA_ARGS__);                                                            \
       break;                                                                                        \
     case NLSG_OBJ_SPHERE:                                                                           \
-      if constexpr (C <= 2)                                                                         \
         hipLaunchKernelGGL((KERNEL<C, V, NLSG_OBJ_SPHERE>), dim3(grid), dim3(256), 0, e->stream,    \
                            __VA_ARGS__);                                                            \
       break;                                                                                        \
     case NLSG_OBJ_STYBLINSKI_TANG:                                                                  \
-      if constexpr (C <= 2)                                                                         \
         hipLaunchKernelGGL((KERNEL<C, V, NLSG_OBJ_STYBLINSKI_TANG>), dim3(grid), dim3(256), 0,      \
                            e->stream, __VA_ARGS__);                                                 \
       break;                                                                                        \
     case NLSG_OBJ_RASTRIGIN:                                                                        \
-      if constexpr (C <= 2)                                                                         \
         hipLaunchKernelGGL((KERNEL<C, V, NLSG_OBJ_RASTRIGIN>), dim3(grid), dim3(256), 0, e->stream, \
                            __VA_ARGS__);                                                            \
       break;                                                                                        \
@@ -144,10 +139,6 @@ static int bfgs_create(const nlsg_bfgs_config *cfg, const double *diag_host, con
   if (!quad && !fd) return fail(NLSG_ERR_INVALID_ARG, "unknown objective %d", cfg->objective);
   if (quad && (!diag_host || !lin_host))
     return fail(NLSG_ERR_INVALID_ARG, "the quadratic needs its d and b vectors");
-  if (fd && cfg->dim > 256)
-    return fail(NLSG_ERR_UNSUPPORTED,
-                "dim %llu > 256: finite-difference objectives are covered up to 256 dimensions",
-                (unsigned long long)cfg->dim);
   if (cfg->dim < 1 || cfg->batch < 1) return fail(NLSG_ERR_INVALID_ARG, "dim and batch must be >= 1");
   if (cfg->dim > 1024)
     return fail(NLSG_ERR_UNSUPPORTED, "dim %llu > 1024 is not covered by the device path",

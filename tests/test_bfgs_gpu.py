@@ -176,9 +176,27 @@ def test_bfgs_finite_difference_close_to_reference(mod, oracle, golden):
     assert np.max(np.abs(x[0] - xr)) <= 1e-5
 
 
-def test_bfgs_finite_difference_rejects_large_dim(mod):
-    with pytest.raises(RuntimeError, match="256"):
-        mod.BFGSEngine("rosenbrock", 2, dim=300)
+@pytest.mark.parametrize("obj,n,batch", [("rosenbrock", 257, 2), ("rosenbrock", 300, 2),
+                                         ("sphere", 600, 2), ("rosenbrock", 1024, 2)])
+def test_bfgs_finite_difference_gradient_past_256_dimensions(mod, oracle, obj, n, batch):
+    """The default-gradient model past the old 256-dimension limit (the reference has none,
+    nlsolver.h:1385-1413): first size past it, ragged chunk counts, the largest vector the
+    wave holds. 4 n probes per gradient, each a full evaluation; bit-exact vs the tree oracle."""
+    kw = dict(max_iter=3, grad_eps=0.0, alpha=1.0)
+    rng = np.random.default_rng(2000 + n)
+    x0 = 0.8 + 0.4 * (rng.random((batch, n)) - 0.5)
+    with mod.BFGSEngine(obj, batch, dim=n, **kw) as eng:
+        x, st = eng.minimize(x0.copy())
+    for p in range(batch):
+        ref, xr, _, _ = O.bfgs_fd(oracle, obj, x0[p], tree=1, **kw)
+        assert (st[p].iteration, st[p].function_calls_used, st[p].gradient_evals_used) == \
+            (ref.iteration, ref.function_calls_used, ref.gradient_evals_used), f"problem {p}"
+        assert st[p].f_value == ref.f_value and np.array_equal(x[p], xr), f"problem {p}"
+
+
+def test_bfgs_rejects_more_than_1024_dimensions(mod):
+    with pytest.raises(RuntimeError, match="1024"):
+        mod.BFGSEngine("rosenbrock", 2, dim=1100)
 
 
 # ---- NLSG_BFGS_SYMMETRIC: the rank-2 update restated so that H stays bitwise symmetric, upper
