@@ -518,7 +518,11 @@ def main_lm(args):
     batch = 8192 if args.pop_per_gpu == POP_PER_GPU else args.pop_per_gpu
     ranks = Ranks(args)
     rng = np.random.default_rng(ranks.slice_seed(12374563468 % 2**32))
-    A = (2 * rng.random((batch, m, n)) - 1) / np.sqrt(n)
+    # the design matrices are built in page-locked memory (nlsolver_amd.pinned_empty): the upload
+    # at engine creation is then DMA at the link's rate (--lm-pageable: ordinary memory)
+    A = np.empty((batch, m, n)) if args.lm_pageable else nlsolver_amd.pinned_empty((batch, m, n))
+    for b0 in range(0, batch, 512):
+        A[b0:b0 + 512] = (2 * rng.random((min(512, batch - b0), m, n)) - 1) / np.sqrt(n)
     star = 2 * rng.random((batch, n)) - 1
     y = np.tanh(np.einsum("bmn,bn->bm", A, star))
     theta0 = 0.5 * star + 0.1 * (2 * rng.random((batch, n)) - 1)
@@ -572,6 +576,8 @@ def main_lm(args):
                                                               (1e-300 + np.abs(th))))},
                        # host buffers in, host buffers out: data upload + one whole solve
                        "upload_s": upload_s, "upload_GBps": (A.nbytes + y.nbytes) / upload_s / 1e9,
+                       "upload_from": "pageable host memory" if args.lm_pageable
+                                      else "page-locked host memory (nlsg_host_alloc)",
                        "pcie_inclusive_value": batch * iters / (upload_s + ms * 1e-3),
                        "parallelism": ranks.replicas()},
             "roofline": {"bound": "mfma", "achieved": tflops, "peak": 78.6, "unit": "TFLOP/s",
@@ -766,6 +772,9 @@ def main():
                     help="lm workload: damped-system solver whose rate is the line's value (cholesky "
                          "= the reference class's get_update_with_hessian; qr = tinyqr::lm, as "
                          "BASELINE configs[3] words it); the other one is reported beside it")
+    ap.add_argument("--lm-pageable", action="store_true",
+                    help="lm workload: hand the design matrices over from ordinary (pageable) host "
+                         "memory instead of page-locked memory")
     ap.add_argument("--bfgs-symmetric", action="store_true",
                     help="bfgs workload: the symmetric restatement of the rank-2 update (streams "
                          "the upper blocks of H only) instead of the reference's literal one")

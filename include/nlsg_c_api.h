@@ -64,11 +64,26 @@ typedef enum {
  * the HIP device math library. Sums run over i < D - 1 when chain != 0, else i < D, in the
  * kernels' fixed lane-tree order; arithmetic is compiled without fp contraction.
  *   term_body   e.g. "double t1 = 1 - xi; double t2 = xn - xi * xi; return t1 * t1 + 100 * t2 * t2;"
- *   finish_body e.g. "return s;"  (NULL = that) */
+ *   finish_body e.g. "return s;"  (NULL = that)
+ *
+ * chain == NLSG_CUSTOM_VECTOR: the WHOLE-VECTOR form for objectives that are not sums of
+ * per-coordinate / neighbour terms (most of the reference's test set, test_functions.h:52-330:
+ * Ackley, Beale, Himmelblau, Goldstein-Price, Shekel ...). term_body is then the body of
+ *     double f(const X &x, uint64_t D)
+ * with  x(i)      coordinate i, for an index that is the same in every lane (a literal, a loop
+ *                 counter),
+ *       x.size()  D,
+ *       x.sum(g)  the sum over all coordinates of g(x_i, i) in the kernels' lane-tree order, g any
+ *                 callable double(double xi, uint64_t i);
+ * every lane runs the body and must return the same value. finish_body is ignored.
+ *   e.g. Himmelblau: "double a = x(0) * x(0) + x(1) - 11, b = x(0) + x(1) * x(1) - 7; return a * a + b * b;" */
+#define NLSG_CUSTOM_TERMS 0   /* f = finish(sum_i term(x_i))            */
+#define NLSG_CUSTOM_CHAIN 1   /* f = finish(sum_{i<D-1} term(x_i, x_{i+1})) */
+#define NLSG_CUSTOM_VECTOR 2  /* f = body(x, D)                          */
 typedef struct {
   const char *term_body;
   const char *finish_body;
-  int32_t chain;
+  int32_t chain;         /* NLSG_CUSTOM_TERMS / _CHAIN / _VECTOR */
   int32_t reserved;
 } nlsg_custom_objective;
 
@@ -368,8 +383,13 @@ int nlsg_lm_create(const nlsg_lm_config *cfg, nlsg_lm **out);
  * default functors on a user objective compiled at run time */
 int nlsg_lm_create_custom(const nlsg_lm_config *cfg, const nlsg_custom_objective *obj, nlsg_lm **out);
 int nlsg_lm_destroy(nlsg_lm *e);
-/* design matrices A [batch][m][n] row-major and targets y [batch][m] (copied to HBM) */
+/* design matrices A [batch][m][n] row-major and targets y [batch][m] (copied to HBM, in chunks
+ * that overlap their repacking on the device). From page-locked memory (nlsg_host_alloc) the
+ * copy runs at the PCIe link's rate; from pageable memory the runtime stages it (~10-15 GB/s). */
 int nlsg_lm_set_data(nlsg_lm *e, const double *a_host, const double *y_host);
+/* Page-locked host memory for buffers handed to the library (any engine); free with nlsg_host_free. */
+int nlsg_host_alloc(void **out, uint64_t bytes);
+int nlsg_host_free(void *ptr);
 /* Switch the damped-system solver of an existing engine (the model data stays resident): the
  * next nlsg_lm_minimize uses it. */
 int nlsg_lm_set_solver(nlsg_lm *e, int32_t solver);

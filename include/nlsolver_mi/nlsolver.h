@@ -214,9 +214,18 @@ template <typename T = double>
 struct Custom {
   static constexpr int nlsg_objective = NLSG_OBJ_CUSTOM;
   std::string term_body, finish_body;
-  bool chain;
+  int chain;  // NLSG_CUSTOM_TERMS / NLSG_CUSTOM_CHAIN / NLSG_CUSTOM_VECTOR
   explicit Custom(std::string term_body, bool chain = false, std::string finish_body = "return s;")
-      : term_body(std::move(term_body)), finish_body(std::move(finish_body)), chain(chain) {}
+      : term_body(std::move(term_body)), finish_body(std::move(finish_body)), chain(chain ? 1 : 0) {}
+  // the whole-vector form: `body` is the body of  double f(const X &x, uint64_t D)  with x(i),
+  // x.size(), x.sum(g) (include/nlsg_c_api.h), for objectives that are not sums of terms:
+  //   auto f = Custom<double>::vector("double a = x(0) * x(0) + x(1) - 11, b = x(0) + x(1) * x(1) - 7;"
+  //                                   " return a * a + b * b;");
+  static Custom vector(std::string body) {
+    Custom c(std::move(body));
+    c.chain = NLSG_CUSTOM_VECTOR;
+    return c;
+  }
 };
 
 // Objectives with an analytic gradient on the device (batched BFGS):
@@ -452,7 +461,7 @@ class DE {
     if constexpr (Callable::nlsg_objective == NLSG_OBJ_CUSTOM) {
       // $NLSG_HIPRTC names the hiprtc of the HIP runtime in use (default: libhiprtc.so)
       api.check(api.rtc_load(std::getenv("NLSG_HIPRTC")));
-      nlsg_custom_objective obj{f.term_body.c_str(), f.finish_body.c_str(), f.chain ? 1 : 0, 0};
+      nlsg_custom_objective obj{f.term_body.c_str(), f.finish_body.c_str(), f.chain, 0};
       api.check(api.de_create_custom(&cfg, &obj, &eng));
     } else {
       api.check(api.de_create(&cfg, &eng));
@@ -621,7 +630,7 @@ class PSO {
       nlsg_pso *eng = nullptr;
       if constexpr (Callable::nlsg_objective == NLSG_OBJ_CUSTOM) {
         api.check(api.rtc_load(std::getenv("NLSG_HIPRTC")));
-        nlsg_custom_objective obj{f.term_body.c_str(), f.finish_body.c_str(), f.chain ? 1 : 0, 0};
+        nlsg_custom_objective obj{f.term_body.c_str(), f.finish_body.c_str(), f.chain, 0};
         api.check(api.pso_create_custom(&cfg, &obj, &eng));
       } else {
         api.check(api.pso_create(&cfg, &eng));
@@ -995,7 +1004,7 @@ class BFGS {
       cfg.objective = Callable::nlsg_objective;
       if constexpr (Callable::nlsg_objective == NLSG_OBJ_CUSTOM) {
         api.check(api.rtc_load(std::getenv("NLSG_HIPRTC")));
-        nlsg_custom_objective obj{f.term_body.c_str(), f.finish_body.c_str(), f.chain ? 1 : 0, 0};
+        nlsg_custom_objective obj{f.term_body.c_str(), f.finish_body.c_str(), f.chain, 0};
         api.check(api.bfgs_create_custom(&cfg, &obj, &eng));
       } else {
         api.check(api.bfgs_create(&cfg, nullptr, nullptr, &eng));
@@ -1139,7 +1148,7 @@ class SANN {
     nlsg_sann *eng = nullptr;
     if constexpr (Callable::nlsg_objective == NLSG_OBJ_CUSTOM) {
       api.check(api.rtc_load(std::getenv("NLSG_HIPRTC")));
-      nlsg_custom_objective obj{f.term_body.c_str(), f.finish_body.c_str(), f.chain ? 1 : 0, 0};
+      nlsg_custom_objective obj{f.term_body.c_str(), f.finish_body.c_str(), f.chain, 0};
       api.check(api.sann_create_custom(&cfg, &obj, &eng));
     } else {
       api.check(api.sann_create(&cfg, &eng));
@@ -1292,7 +1301,7 @@ class NelderMeadPSO {
     nlsg_nmpso *eng = nullptr;
     if constexpr (Callable::nlsg_objective == NLSG_OBJ_CUSTOM) {
       api.check(api.rtc_load(std::getenv("NLSG_HIPRTC")));
-      nlsg_custom_objective obj{f.term_body.c_str(), f.finish_body.c_str(), f.chain ? 1 : 0, 0};
+      nlsg_custom_objective obj{f.term_body.c_str(), f.finish_body.c_str(), f.chain, 0};
       api.check(api.nmpso_create_custom(&cfg, &obj, &eng));
     } else {
       api.check(api.nmpso_create(&cfg, &eng));
@@ -1500,7 +1509,7 @@ class NelderMead {
       nlsg_nm *eng = nullptr;
       if constexpr (Callable::nlsg_objective == NLSG_OBJ_CUSTOM) {
         api.check(api.rtc_load(std::getenv("NLSG_HIPRTC")));
-        nlsg_custom_objective obj{f.term_body.c_str(), f.finish_body.c_str(), f.chain ? 1 : 0, 0};
+        nlsg_custom_objective obj{f.term_body.c_str(), f.finish_body.c_str(), f.chain, 0};
         api.check(api.nm_create_custom(&cfg, &obj, &eng));
       } else {
         api.check(api.nm_create(&cfg, &eng));
@@ -1799,7 +1808,7 @@ class LevenbergMarquardt {
     if constexpr (device::is_device_objective<Callable>::value) {
       if constexpr (Callable::nlsg_objective == NLSG_OBJ_CUSTOM) {
         api.check(api.rtc_load(std::getenv("NLSG_HIPRTC")));
-        nlsg_custom_objective obj{f.term_body.c_str(), f.finish_body.c_str(), f.chain ? 1 : 0, 0};
+        nlsg_custom_objective obj{f.term_body.c_str(), f.finish_body.c_str(), f.chain, 0};
         api.check(api.lm_create_custom(&cfg, &obj, &eng));
         made = true;
       }

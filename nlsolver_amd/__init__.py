@@ -13,7 +13,7 @@ Layout:
     nmpso.py              NelderMeadPSO (batched instances): mirror of nlsolver.h:3546-3920
     dist.py               population sharding across ranks (torch.distributed / RCCL)
 """
-from ._capi import DE_BEST, DE_RANDOM, PSO_ACCELERATED, PSO_VANILLA, NlsgError  # noqa: F401
+from ._capi import DE_BEST, DE_RANDOM, PSO_ACCELERATED, PSO_VANILLA, NlsgError, pinned_empty  # noqa: F401
 from .de import DE, CustomObjective, DEEngine, DESolver  # noqa: F401
 from .pso import PSO, PSOEngine, PSOSolver  # noqa: F401
 from .bfgs import BFGS, BFGSEngine, QuadDiagRank1  # noqa: F401

@@ -176,6 +176,8 @@ SYMBOLS = {
     "nlsg_lm_destroy": (C.c_int, [_H]),
     "nlsg_lm_set_data": (C.c_int, [_H, pd, pd]),
     "nlsg_lm_set_solver": (C.c_int, [_H, i32]),
+    "nlsg_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), u64]),
+    "nlsg_host_free": (C.c_int, [C.c_void_p]),
     "nlsg_lm_minimize": (C.c_int, [_H, pd, C.POINTER(Status), pd]),
     "nlsg_lm_time_solve": (C.c_int, [_H, pd, C.c_uint32, C.POINTER(C.c_float)]),
     "nlsg_lm_time_eval_kernel": (C.c_int, [_H, pd, C.c_uint32, C.POINTER(C.c_float)]),
@@ -219,3 +221,30 @@ def lib():
 def check(rc):
     if rc != 0:
         raise NlsgError(rc, lib().nlsg_last_error().decode(errors="replace"))
+
+
+class _PinnedBlock:
+    """Owner of one nlsg_host_alloc block; numpy arrays made by pinned_empty keep it alive."""
+
+    def __init__(self, nbytes):
+        self.ptr = C.c_void_p()
+        check(lib().nlsg_host_alloc(C.byref(self.ptr), nbytes))
+
+    def __del__(self):
+        if getattr(self, "ptr", None) and self.ptr.value:
+            lib().nlsg_host_free(self.ptr)
+            self.ptr = C.c_void_p()
+
+
+def pinned_empty(shape, dtype="float64"):
+    """numpy array in page-locked host memory (nlsg_host_alloc): what is handed to the engines from
+    there crosses PCIe by DMA at the link's rate (e.g. the design matrices of an LM model). The
+    memory is released when the array (and every view of it) is gone."""
+    import numpy as np
+    dt = np.dtype(dtype)
+    count = int(np.prod(shape))
+    nbytes = max(count * dt.itemsize, 8)
+    block = _PinnedBlock(nbytes)
+    buf = (C.c_char * nbytes).from_address(block.ptr.value)
+    buf._nlsg_owner = block  # the array's base is `buf`; `buf` keeps the block alive
+    return np.frombuffer(buf, dtype=dt, count=count).reshape(shape)

@@ -267,6 +267,7 @@ struct Objective;
 template <>
 struct Objective<NLSG_OBJ_ROSENBROCK> {
   static constexpr bool kChain = true;
+  static constexpr bool kWhole = false;
   __device__ static inline double term(double xi, double xn) {
     const double t1 = 1 - xi;
     const double t2 = (xn - xi * xi);
@@ -278,6 +279,7 @@ struct Objective<NLSG_OBJ_ROSENBROCK> {
 template <>
 struct Objective<NLSG_OBJ_SPHERE> {
   static constexpr bool kChain = false;
+  static constexpr bool kWhole = false;
   __device__ static inline double term(double xi, double) { return xi * xi; }
   __device__ static inline uint64_t n_terms(uint64_t D) { return D; }
   __device__ static inline double finish(double s, uint64_t) { return s; }
@@ -285,6 +287,7 @@ struct Objective<NLSG_OBJ_SPHERE> {
 template <>
 struct Objective<NLSG_OBJ_STYBLINSKI_TANG> {
   static constexpr bool kChain = false;
+  static constexpr bool kWhole = false;
   __device__ static inline double term(double xi, double) {
     const double x2 = xi * xi;
     return x2 * x2 - 16 * x2 + 5 * xi;  // test_functions.h:255-257
@@ -295,6 +298,7 @@ struct Objective<NLSG_OBJ_STYBLINSKI_TANG> {
 template <>
 struct Objective<NLSG_OBJ_RASTRIGIN> {
   static constexpr bool kChain = false;
+  static constexpr bool kWhole = false;
   __device__ static inline double term(double xi, double) {
     return xi * xi - 10 * det_cos_2pi(xi);  // test_functions.h:74-76, deterministic cosine
   }
@@ -304,10 +308,71 @@ struct Objective<NLSG_OBJ_RASTRIGIN> {
   }
 };
 
+// What a whole-vector user objective (nlsg_custom_objective.chain == NLSG_CUSTOM_VECTOR) sees of
+// the point its wave — or its group of G lanes — holds:
+//   x(i)      coordinate i, for an index that is the same in every lane (literals, loop counters)
+//   x.size()  D
+//   x.sum(g)  sum over all coordinates of g(x_i, i), in the kernels' lane-tree order (the order
+//             of the built-in objectives): per lane its coordinates in ascending order, then the
+//             xor butterfly; g is any callable double(double, uint64_t)
+// Every lane evaluates the body and must return the same value.
+template <int CHUNKS>
+struct WavePoint {
+  const double (&v)[CHUNKS][2];
+  uint64_t D;
+  __device__ inline uint64_t size() const { return D; }
+  __device__ inline double operator()(uint64_t i) const {  // i wave-uniform
+    double own = 0.0;
+#pragma unroll
+    for (int c = 0; c < CHUNKS; c++)
+#pragma unroll
+      for (int k = 0; k < 2; k++) own = (static_cast<uint64_t>(c) == (i >> 7) && static_cast<uint64_t>(k) == (i & 1)) ? v[c][k] : own;
+    return lane_broadcast(own, static_cast<int>((i & 127) >> 1));
+  }
+  template <typename F>
+  __device__ inline double sum(F g) const {
+    const uint64_t l2 = 2 * static_cast<uint64_t>(lane_id());
+    double acc = 0.0;
+#pragma unroll
+    for (int c = 0; c < CHUNKS; c++)
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const uint64_t e = static_cast<uint64_t>(c) * 128 + l2 + k;
+        if (e < D) acc = acc + g(v[c][k], e);
+      }
+    return wave_sum(acc);
+  }
+};
+template <int G>
+struct GroupPoint {  // a point of at most 2 G coordinates in a group of G lanes
+  double x0, x1;
+  uint64_t D;
+  __device__ inline uint64_t size() const { return D; }
+  __device__ inline double operator()(uint64_t i) const {  // i the same in every lane
+    const int src = (lane_id() & ~(G - 1)) + static_cast<int>(i >> 1);
+    const double own = (i & 1) ? x1 : x0;
+    const uint64_t b = static_cast<uint64_t>(__double_as_longlong(own));
+    const uint32_t lo = static_cast<uint32_t>(__shfl(static_cast<int>(b & 0xffffffffu), src, 64));
+    const uint32_t hi = static_cast<uint32_t>(__shfl(static_cast<int>(b >> 32), src, 64));
+    return __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(hi) << 32) | lo));
+  }
+  template <typename F>
+  __device__ inline double sum(F g) const {
+    const uint64_t e0 = 2 * static_cast<uint64_t>(lane_id() & (G - 1));
+    double acc = 0.0;
+    if (e0 < D) acc = acc + g(x0, e0);
+    if (e0 + 1 < D) acc = acc + g(x1, e0 + 1);
+    if constexpr (G > 1)
+      butterfly_levels<G / 2>([&](auto off) { acc = acc + lane_xor<decltype(off)::value>(acc); });
+    return acc;
+  }
+};
+
 // f(x) for the point held by the wave; all lanes return the same bits.
 template <int OBJ, int CHUNKS>
 __device__ inline double wave_objective(const double (&xv)[CHUNKS][2], uint64_t D) {
   using O = Objective<OBJ>;
+  if constexpr (O::kWhole) return O::whole(WavePoint<CHUNKS>{xv, D}, D);
   const int lane = lane_id();
   const uint64_t nt = O::n_terms(D);
   double acc = 0.0;
@@ -337,6 +402,7 @@ __device__ inline double wave_objective(const double (&xv)[CHUNKS][2], uint64_t 
 template <int OBJ, int G>
 __device__ inline double group_objective(double x0, double x1, uint64_t D) {
   using O = Objective<OBJ>;
+  if constexpr (O::kWhole) return O::whole(GroupPoint<G>{x0, x1, D}, D);
   const uint64_t e0 = 2 * static_cast<uint64_t>(lane_id() & (G - 1));
   const uint64_t nt = O::n_terms(D);
   double xn = 0.0;

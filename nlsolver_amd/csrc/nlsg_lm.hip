@@ -1,4 +1,5 @@
 // nlsolver_amd/csrc/nlsg_lm.hip — host side of the batched LM engine + C-ABI.
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>
@@ -239,21 +240,65 @@ int nlsg_lm_set_data(nlsg_lm *e, const double *a_host, const double *y_host) {
   const uint64_t B = e->p.batch, m = e->p.m, n = e->p.n;
   // host layout [problem][m][n] -> device layout [row group][problem][16][64] (zero padded):
   // problems that run side by side read one contiguous stretch of HBM per row group instead
-  // of addresses a whole problem (m * 512 bytes) apart, which camp on a few channels
-  double *raw = nullptr;
-  NLSG_HIP(hipMalloc(reinterpret_cast<void **>(&raw), B * m * (n + 1) * 8));
-  hipError_t he = hipMemcpy(raw, a_host, B * m * n * 8, hipMemcpyHostToDevice);
-  if (he == hipSuccess) he = hipMemcpy(raw + B * m * n, y_host, B * m * 8, hipMemcpyHostToDevice);
-  if (he == hipSuccess) {
-    const uint64_t total = e->p.nstep * B * 16 * kLmN;
-    hipLaunchKernelGGL(lm_repack_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256),
-                       0, e->stream, e->p, raw, raw + B * m * n, e->A_dev, e->y_dev);
-    he = hipGetLastError();
+  // of addresses a whole problem (m * 512 bytes) apart, which camp on a few channels.
+  // The matrices cross PCIe in chunks of problems through two staging buffers on a copy stream
+  // of their own while the previous chunk is repacked: from pinned host memory (nlsg_host_alloc)
+  // the copies are plain DMA at the link's rate; from pageable memory the runtime stages them.
+  const uint64_t per = m * n * 8;
+  uint64_t chunk = std::max<uint64_t>(1, (64ull << 20) / per);  // ~64 MiB per staging buffer
+  if (chunk > B) chunk = B;
+  double *raw[2] = {nullptr, nullptr}, *y_raw = nullptr;
+  hipStream_t copy = nullptr;
+  hipEvent_t landed[2] = {nullptr, nullptr}, packed[2] = {nullptr, nullptr};
+  hipError_t he = hipStreamCreateWithFlags(&copy, hipStreamNonBlocking);
+  for (int k = 0; k < 2 && he == hipSuccess; k++) {
+    he = hipMalloc(reinterpret_cast<void **>(&raw[k]), chunk * per);
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&landed[k], hipEventDisableTiming);
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&packed[k], hipEventDisableTiming);
   }
-  if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
-  hipFree(raw);
+  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&y_raw), B * m * 8);
+  if (he == hipSuccess) he = hipMemcpyAsync(y_raw, y_host, B * m * 8, hipMemcpyHostToDevice, copy);
+  uint64_t k = 0;
+  for (uint64_t b0 = 0; b0 < B && he == hipSuccess; b0 += chunk, k++) {
+    const uint64_t nbp = std::min(chunk, B - b0);
+    const int slot = static_cast<int>(k & 1);
+    if (k >= 2) he = hipStreamWaitEvent(copy, packed[slot], 0);  // the buffer's previous chunk is repacked
+    if (he == hipSuccess)
+      he = hipMemcpyAsync(raw[slot], a_host + b0 * m * n, nbp * per, hipMemcpyHostToDevice, copy);
+    if (he == hipSuccess) he = hipEventRecord(landed[slot], copy);
+    if (he == hipSuccess) he = hipStreamWaitEvent(e->stream, landed[slot], 0);
+    if (he == hipSuccess) {
+      const uint64_t total = e->p.nstep * nbp * 16 * kLmN;
+      hipLaunchKernelGGL(lm_repack_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256),
+                         0, e->stream, e->p, raw[slot], y_raw, e->A_dev, e->y_dev, b0, nbp);
+      he = hipGetLastError();
+    }
+    if (he == hipSuccess) he = hipEventRecord(packed[slot], e->stream);
+  }
+  if (he == hipSuccess) he = hipStreamSynchronize(e->stream);  // the host buffers are borrowed for this call only
+  if (copy) hipStreamSynchronize(copy);
+  for (int q = 0; q < 2; q++) {
+    hipFree(raw[q]);
+    if (landed[q]) hipEventDestroy(landed[q]);
+    if (packed[q]) hipEventDestroy(packed[q]);
+  }
+  hipFree(y_raw);
+  if (copy) hipStreamDestroy(copy);
   NLSG_HIP(he);
   e->has_data = true;
+  return NLSG_OK;
+}
+
+// Page-locked host memory for buffers that cross PCIe at the boundary (design matrices, start
+// points): what lives there is copied by DMA at the link's rate instead of being staged.
+int nlsg_host_alloc(void **out, uint64_t bytes) {
+  if (!out) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  *out = nullptr;
+  NLSG_HIP(hipHostMalloc(out, bytes ? bytes : 8, hipHostMallocDefault));
+  return NLSG_OK;
+}
+int nlsg_host_free(void *ptr) {
+  if (ptr) NLSG_HIP(hipHostFree(ptr));
   return NLSG_OK;
 }
 

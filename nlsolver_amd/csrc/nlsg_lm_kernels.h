@@ -819,14 +819,15 @@ __global__ __launch_bounds__(THREADS) void lm_qr_step_kernel(LmParams p) {
   if (t < n) p.theta[pid * kLmN + t] = p.theta[pid * kLmN + t] - qs.upd[t];  // :3534
 }
 
-// host layout -> device layout of A and y (see nlsg_lm_set_data)
+// host layout -> device layout of A and y (see nlsg_lm_set_data), for the problems [b0, b0 + nb):
+// a_raw holds those problems' matrices only ([nb][m][n]), y_raw all of y ([batch][m])
 __global__ void lm_repack_kernel(LmParams p, const double *a_raw, const double *y_raw, double *A,
-                                 double *y) {
-  const uint64_t e = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (e >= p.nstep * p.batch * 16 * kLmN) return;
-  const uint64_t c = e % kLmN, r = (e / kLmN) % 16, b = (e / (16 * kLmN)) % p.batch;
-  const uint64_t s = e / (16 * kLmN * p.batch), i = 16 * s + r;
-  A[e] = (i < p.m && c < p.n) ? a_raw[(b * p.m + i) * p.n + c] : 0.0;
+                                 double *y, uint64_t b0, uint64_t nb) {
+  const uint64_t q = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (q >= p.nstep * nb * 16 * kLmN) return;
+  const uint64_t c = q % kLmN, r = (q / kLmN) % 16, bl = (q / (16 * kLmN)) % nb;
+  const uint64_t s = q / (16 * kLmN * nb), i = 16 * s + r, b = b0 + bl;
+  A[((s * p.batch + b) * 16 + r) * kLmN + c] = (i < p.m && c < p.n) ? a_raw[(bl * p.m + i) * p.n + c] : 0.0;
   if (c == 0) y[(s * p.batch + b) * 16 + r] = i < p.m ? y_raw[b * p.m + i] : 0.0;
 }
 

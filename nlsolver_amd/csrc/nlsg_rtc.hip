@@ -82,18 +82,36 @@ static int rtc_compile(const nlsg_custom_objective *obj, const char *kernel_head
   std::string src = std::string("#include \"") + kernel_header + "\"\n"
                     "namespace nlsg {\n"
                     "template <>\n"
-                    "struct Objective<NLSG_OBJ_CUSTOM> {\n"
-                    "  static constexpr bool kChain = ";
-  src += obj->chain ? "true" : "false";
-  src += ";\n  __device__ static inline double term(double xi, double xn) {\n    (void)xn;\n#line 1 "
-         "\"term_body\"\n";
-  src += obj->term_body;
-  src += "\n  }\n"
-         "  __device__ static inline uint64_t n_terms(uint64_t D) { return kChain ? (D ? D - 1 : 0) : D; }\n"
-         "  __device__ static inline double finish(double s, uint64_t D) {\n    (void)D;\n#line 1 "
-         "\"finish_body\"\n";
-  src += (obj->finish_body && obj->finish_body[0]) ? obj->finish_body : "return s;";
-  src += "\n  }\n};\n}  // namespace nlsg\n";
+                    "struct Objective<NLSG_OBJ_CUSTOM> {\n";
+  if (obj->chain == NLSG_CUSTOM_VECTOR) {
+    // whole-vector form: term_body is the body of  double f(const X &x, uint64_t D)
+    src += "  static constexpr bool kChain = false;\n"
+           "  static constexpr bool kWhole = true;\n"
+           "  __device__ static inline double term(double, double) { return 0.0; }\n"
+           "  __device__ static inline uint64_t n_terms(uint64_t) { return 0; }\n"
+           "  __device__ static inline double finish(double s, uint64_t) { return s; }\n"
+           "  template <typename X>\n"
+           "  __device__ static inline double whole(const X &x, uint64_t D) {\n    (void)D;\n#line 1 "
+           "\"vector_body\"\n";
+    src += obj->term_body;
+    src += "\n  }\n};\n}  // namespace nlsg\n";
+  } else {
+    src += "  static constexpr bool kWhole = false;\n"
+           "  static constexpr bool kChain = ";
+    src += obj->chain ? "true" : "false";
+    src += ";\n  __device__ static inline double term(double xi, double xn) {\n    (void)xn;\n#line 1 "
+           "\"term_body\"\n";
+    src += obj->term_body;
+    src += "\n  }\n"
+           "  __device__ static inline uint64_t n_terms(uint64_t D) { return kChain ? (D ? D - 1 : 0) : D; }\n"
+           "  __device__ static inline double finish(double s, uint64_t D) {\n    (void)D;\n#line 1 "
+           "\"finish_body\"\n";
+    src += (obj->finish_body && obj->finish_body[0]) ? obj->finish_body : "return s;";
+    src += "\n  }\n"
+           "  template <typename X>\n"
+           "  __device__ static inline double whole(const X &, uint64_t) { return 0.0; }\n"
+           "};\n}  // namespace nlsg\n";
+  }
 
   const int nh = static_cast<int>(sizeof(kEmbedded) / sizeof(kEmbedded[0]));
   std::vector<const char *> names(nh), texts(nh);

@@ -39,10 +39,19 @@ class CustomObjective:
         CustomObjective("return fabs(xi) * xi * xi;")     # sum |x_i|^3
 
     In the bodies: `xi`, `xn` (= x_{i+1}; chain objectives sum over i < D - 1) for `term`; `s`, `D`
-    for `finish` (default "return s;")."""
+    for `finish` (default "return s;").
 
-    def __init__(self, term_body, *, chain=False, finish_body="return s;"):
-        self.term_body, self.finish_body, self.chain = term_body, finish_body, bool(chain)
+    vector=True: the whole-vector form (NLSG_CUSTOM_VECTOR) for objectives that are not sums of
+    such terms — `term_body` is the body of `double f(const X &x, uint64_t D)` with `x(i)`
+    (coordinate i, same index in every lane), `x.size()` and `x.sum(g)` (lane-tree sum of
+    g(x_i, i) over the coordinates):
+
+        CustomObjective("double a = x(0) * x(0) + x(1) - 11, b = x(0) + x(1) * x(1) - 7;"
+                        " return a * a + b * b;", vector=True)    # Himmelblau"""
+
+    def __init__(self, term_body, *, chain=False, finish_body="return s;", vector=False):
+        self.term_body, self.finish_body = term_body, finish_body
+        self.chain = 2 if vector else int(bool(chain))  # nlsg_custom_objective.chain
 
 
 def rtc_library_path():

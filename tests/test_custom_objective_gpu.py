@@ -174,3 +174,110 @@ def test_lm_custom_objective_quartic(mod):
     # stationary points of t^2 + 0.1 x: 4 x (x^2 - 1) + 0.1 = 0
     r = 4 * x0 * (x0 * x0 - 1) + 0.1
     assert np.max(np.abs(r)) < 1e-4, (x0, st[0].f_value)
+
+
+# ---- whole-vector objectives (NLSG_CUSTOM_VECTOR): the reference's test set is mostly made of
+# ---- functions that are not sums of per-coordinate terms (test_functions.h:52-330)
+HIMMELBLAU = ("double a = x(0) * x(0) + x(1) - 11, b = x(0) + x(1) * x(1) - 7;"
+              " return a * a + b * b;")  # test_functions.h:131-135
+BOOTH = "double a = x(0) + 2 * x(1) - 7, b = 2 * x(0) + x(1) - 5; return a * a + b * b;"  # :291-294
+MATYAS = "return 0.26 * (x(0) * x(0) + x(1) * x(1)) - 0.48 * x(0) * x(1);"  # :311-313
+# the Rosenbrock chain spelled with the accessor and a loop over a wave-uniform index (slow but
+# legal): the terms are added sequentially — the reference's own order
+ROSENBROCK_LOOP = ("double s = 0; for (uint64_t i = 0; i + 1 < D; i++) { double t1 = 1 - x(i);"
+                   " double t2 = x(i + 1) - x(i) * x(i); s += t1 * t1 + 100 * t2 * t2; } return s;")
+# sum |x_i| * (i + 1) through x.sum: the index is available to the term
+WEIGHTED = "return x.sum([](double xi, uint64_t i) { return fabs(xi) * (double)(i + 1); });"
+
+
+def himmelblau(p):
+    a = p[:, 0] * p[:, 0] + p[:, 1] - 11
+    b = p[:, 0] + p[:, 1] * p[:, 1] - 7
+    return a * a + b * b
+
+
+@pytest.mark.parametrize("strategy", [0, 1])
+def test_whole_vector_objective_scores_are_exact(mod, strategy):
+    """A polynomial whole-vector objective has no summation tree at all: the device's scores equal
+    the same expression evaluated by numpy bit for bit, at the initial population and after turns."""
+    pop, D = 256, 2
+    kw = dict(strategy=strategy, CR=0.7, F=0.6, eps=0.0, max_iter=1000, best_val_no_change=1000,
+              seed=77)
+    x0 = np.array([5.0, 7.0])
+    P, S, st, bx, bf, bi = run(mod, mod.CustomObjective(HIMMELBLAU, vector=True), pop, D, x0, 0, **kw)
+    assert np.array_equal(S, himmelblau(P))
+    P, S, st, bx, bf, bi = run(mod, mod.CustomObjective(HIMMELBLAU, vector=True), pop, D, x0, 25, **kw)
+    assert np.array_equal(S, himmelblau(P))
+    assert bf == S.min() and np.array_equal(bx, P[bi]) and bf < 1.0  # and it does minimise
+
+
+def test_whole_vector_loop_over_coordinates_matches_sequential_reference_arithmetic(mod, oracle):
+    """x(i) with a loop counter, D = 130 (two chunks): the body adds the Rosenbrock terms
+    sequentially — exactly the reference functor's arithmetic (orc_objective_seq), not the
+    kernels' tree."""
+    pop, D = 64, 130
+    x0 = np.full(D, 0.9)
+    P, S, *_ = run(mod, mod.CustomObjective(ROSENBROCK_LOOP, vector=True), pop, D, x0, 0, eps=0.0)
+    seq = np.array([oracle.orc_objective_seq(0, np.ascontiguousarray(r).ctypes.data_as(O.pd), D)
+                    for r in P])
+    assert np.array_equal(S, seq)
+
+
+@pytest.mark.parametrize("D", [3, 16, 64, 128, 200])
+def test_whole_vector_sum_uses_the_lane_tree(mod, D):
+    """x.sum(g) is the built-in objectives' reduction (per lane ascending, then the butterfly) and
+    hands g the coordinate's index — packed agents (D <= 64: several per wave) and whole waves."""
+    pop = 128
+    x0 = np.full(D, 2.0)
+    P, S, *_ = run(mod, mod.CustomObjective(WEIGHTED, vector=True), pop, D, x0, 0, eps=0.0)
+    w = np.arange(1, D + 1, dtype=np.float64)
+    ref = np.empty(pop)
+    for a in range(pop):
+        lanes = np.zeros(64)
+        for e in range(D):
+            lanes[(e % 128) // 2] += abs(P[a, e]) * w[e]
+        off = 32
+        while off >= 1:
+            lanes = lanes + lanes[np.arange(64) ^ off]
+            off //= 2
+        ref[a] = lanes[0]
+    assert np.array_equal(S, ref)
+
+
+def test_whole_vector_objective_in_every_engine(mod):
+    """The same body through PSO, Nelder-Mead, SANN, the hybrid, finite-difference BFGS and LM:
+    each engine lands on a minimum of Himmelblau / Booth / Matyas (the reference's tolerance: 0.05)."""
+    obj = mod.CustomObjective(HIMMELBLAU, vector=True)
+    minima = np.array([[3.0, 2.0], [-2.805118, 3.131312], [-3.779310, -3.283186], [3.584428, -1.848126]])
+
+    def near_a_minimum(x):
+        return np.min(np.max(np.abs(minima - x), axis=1)) < 0.05
+
+    x = np.array([-0.5, -0.5])
+    st = mod.NelderMead(obj).minimize(x)
+    assert near_a_minimum(x) and st.f_value < 1e-3
+    x = np.array([[-0.5, -0.5]])
+    st = mod.BFGS(obj).minimize(x)
+    assert near_a_minimum(x[0])
+    x = np.array([-0.5, -0.5])
+    st = mod.lm.LevenbergMarquardt(obj).minimize(x)
+    # the class is a damped Newton iteration with an always-accepted step (nlsolver.h:3465-3544):
+    # from this start it lands on Himmelblau's local maximum, a stationary point all the same
+    grad = np.array([4 * x[0] * (x[0] ** 2 + x[1] - 11) + 2 * (x[0] + x[1] ** 2 - 7),
+                     2 * (x[0] ** 2 + x[1] - 11) + 4 * x[1] * (x[0] + x[1] ** 2 - 7)])
+    assert np.max(np.abs(grad)) < 1e-4 and np.allclose(x, [-0.270845, -0.923039], atol=1e-5)
+    x = np.array([4.0, 4.0])
+    st = mod.PSO(obj, 7, n_particles=64, max_iter=500).minimize(x)
+    assert near_a_minimum(x)
+    x = np.array([1.0, 3.0])
+    booth = mod.CustomObjective(BOOTH, vector=True)
+    st = mod.NelderMeadPSO(booth, 11).minimize(x)
+    assert np.max(np.abs(x - [1.0, 3.0])) < 0.05
+    x = np.array([0.5, -0.5])
+    st = mod.SANN(mod.CustomObjective(MATYAS, vector=True), 5).minimize(x)
+    assert st.f_value <= 0.26 * 0.5 + 0.48 * 0.25  # never worse than the start
+
+
+def test_whole_vector_compile_error_is_reported(mod):
+    with pytest.raises(mod.NlsgError, match="does not compile"):
+        mod.DEEngine(mod.CustomObjective("return x(0) +;", vector=True), 64, 2)

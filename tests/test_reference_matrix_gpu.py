@@ -94,6 +94,66 @@ def test_nelder_mead_pso_row(mod, golden, problem):
     assert np.all(np.isfinite(x))
 
 
+# ---- the other eleven problems of the reference's program are not sums of per-coordinate terms:
+# ---- they run on the device as whole-vector user objectives (NLSG_CUSTOM_VECTOR), spelled as in
+# ---- test_functions.h:80-330
+PI = "3.14159265358979323846"
+VECTOR_PROBLEMS = {
+    "Ackley": (f"double a = -20 * exp(-0.2 * sqrt(0.5 * (x(0) * x(0) + x(1) * x(1))));"
+               f" double b = -exp(0.5 * (cos(2 * {PI} * x(0)) + cos(2 * {PI} * x(1))));"
+               " return a + b + exp(1.0) + 20;", [0.0, 0.0]),
+    "Beale": ("double a = 1.5 - x(0) + x(0) * x(1), b = 2.25 - x(0) + x(0) * x(1) * x(1),"
+              " c = 2.625 - x(0) + x(0) * x(1) * x(1) * x(1); return a * a + b * b + c * c;", [3.0, 0.5]),
+    "Goldstein_Price": ("double s1 = x(0) + x(1) + 1, s2 = 2 * x(0) - 3 * x(1);"
+                        " double a = 1 + s1 * s1 * (19 - 14 * x(0) + 3 * x(0) * x(0) - 14 * x(1)"
+                        " + 6 * x(0) * x(1) + 3 * x(1) * x(1));"
+                        " double b = 30 + s2 * s2 * (18 - 32 * x(0) + 12 * x(0) * x(0) + 48 * x(1)"
+                        " - 36 * x(0) * x(1) + 27 * x(1) * x(1)); return a * b;", [0.0, -1.0]),
+    "ThreeHumpCamel": ("return 2 * x(0) * x(0) - 1.05 * pow(x(0), 4.0) + pow(x(0), 6.0) / 6"
+                       " + x(0) * x(1) + x(1) * x(1);", [0.0, 0.0]),
+    "McCormick": ("double d = x(0) - x(1); return sin(x(0) + x(1)) + d * d - 1.5 * x(0)"
+                  " + 2.5 * x(1) + 1;", [-0.54719, -1.54719]),
+    "SchafferN2": ("double sn = sin(x(0) * x(0) - x(1) * x(1)), dn = 1 + 0.001 * (x(0) * x(0) + x(1) * x(1));"
+                   " return 0.5 + (sn * sn - 0.5) / (dn * dn);", [0.0, 0.0]),
+    "Shekel": ("const double a[40] = {4, 4, 4, 4, 1, 1, 1, 1, 8, 8, 8, 8, 6, 6, 6, 6, 3, 7, 3, 7,"
+               " 2, 9, 2, 9, 5, 5, 3, 3, 8, 1, 8, 1, 6, 2, 6, 2, 7, 3.6, 7, 3.2};"
+               " const double c[10] = {0.1, 0.2, 0.2, 0.4, 0.4, 0.6, 0.3, 0.7, 0.5, 0.5};"
+               " double sum = 0.0; for (int i = 0; i < 10; i++) { double inner = 0.0;"
+               " for (int j = 0; j < 4; j++) { double d = x(j) - a[i * 4 + j]; inner += d * d; }"
+               " sum += 1.0 / (inner + c[i]); } return -sum;", [4.0, 4.0, 4.0, 4.0]),
+    "Booth": ("double a = x(0) + 2 * x(1) - 7, b = 2 * x(0) + x(1) - 5; return a * a + b * b;",
+              [1.0, 3.0]),
+    "BukinN6": ("return 100 * sqrt(fabs(x(1) - 0.01 * x(0) * x(0))) + 0.01 * fabs(x(0) + 10);",
+                [-10.0, 1.0]),
+    "Matyas": ("return 0.26 * (x(0) * x(0) + x(1) * x(1)) - 0.48 * x(0) * x(1);", [0.0, 0.0]),
+    "LeviN13": (f"double s3 = sin(3 * {PI} * x(0)), t3 = sin(3 * {PI} * x(1)), t2 = sin(2 * {PI} * x(1));"
+                " double u = x(0) - 1, v = x(1) - 1;"
+                " return s3 * s3 + u * u * (1 + t3 * t3) + v * v * (1 + t2 * t2);", [1.0, 1.0]),
+}
+
+
+@pytest.mark.parametrize("problem", list(VECTOR_PROBLEMS))
+@pytest.mark.parametrize("solver", ["Nelder-Mead", "BFGS"])
+def test_deterministic_rows_on_whole_vector_objectives(mod, golden, problem, solver):
+    """Nelder-Mead and default-gradient BFGS with their default arguments from (-0.5, ...) on the
+    reference's non-separable problems: the device run reproduces the reference's verdict on every
+    one of them — and, where the reference failed, ends where it printed (to the print precision;
+    libm's sin / cos / exp differ from the device library's in the last bits)."""
+    body, minimum = VECTOR_PROBLEMS[problem]
+    ref = golden("reference_matrix.json")[problem][solver]
+    x = np.full(len(minimum), -0.5)
+    obj = mod.CustomObjective(body, vector=True)
+    if solver == "Nelder-Mead":
+        mod.NelderMead(obj).minimize(x)
+    else:
+        xb = x[None].copy()
+        mod.BFGS(obj).minimize(xb)
+        x = xb[0]
+    assert passed(x, minimum) == ref["passed"], (x, ref)
+    if not ref["passed"]:
+        assert np.allclose(x, ref["result"], rtol=1e-3, atol=1e-4), (x, ref["result"])
+
+
 def test_matrix_fixture_is_the_recorded_one(golden):
     m = golden("reference_matrix.json")
     assert len(m) == 15 and sum(len(v) for v in m.values()) == 330
