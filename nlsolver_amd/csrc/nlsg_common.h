@@ -394,6 +394,36 @@ __device__ inline double wave_objective(const double (&xv)[CHUNKS][2], uint64_t 
 }
 
 
+// The chunk loop of wave_objective, resumable: a row longer than the registers hold (D > 1024) is
+// taken in segments of CHUNKS chunks; `acc` carries the lane's partial from segment to segment
+// (ascending — the order of the whole-row loop), `e_base` is the segment's first element and
+// `next_first` the element after its last one (x[e_base + 128 CHUNKS]; chain objectives only).
+// objective_finish() closes the sum. Same bits as wave_objective on a hypothetical longer row.
+template <int OBJ, int CHUNKS>
+__device__ inline void objective_accumulate(double &acc, const double (&xv)[CHUNKS][2], uint64_t e_base,
+                                            uint64_t D, double next_first) {
+  using O = Objective<OBJ>;
+  const int lane = lane_id();
+  const uint64_t nt = O::n_terms(D);
+#pragma unroll
+  for (int c = 0; c < CHUNKS; c++) {
+    const uint64_t e0 = e_base + static_cast<uint64_t>(c) * 128 + 2 * static_cast<uint64_t>(lane);
+    double xn = 0.0;
+    if (O::kChain) {
+      const double same = lane_down1(xv[c][0]);
+      double next = next_first;
+      if (c + 1 < CHUNKS) next = lane_first(xv[c + 1][0]);
+      xn = (lane == 63) ? next : same;
+    }
+    if (e0 < nt) acc = acc + O::term(xv[c][0], xv[c][1]);
+    if (e0 + 1 < nt) acc = acc + O::term(xv[c][1], xn);
+  }
+}
+template <int OBJ>
+__device__ inline double objective_finish(double acc, uint64_t D) {
+  return Objective<OBJ>::finish(wave_sum(acc), D);
+}
+
 // The same for a point of at most 2 G coordinates held by a GROUP of G lanes (G a power of two;
 // lane g of the group holds x[2g], x[2g+1]): a wave then evaluates 64 / G points at once. It is
 // wave_objective restricted to the group — the same per-lane partial and the levels G/2 .. 1 of
@@ -530,6 +560,27 @@ __device__ inline void store_row_stream(double *__restrict__ row, uint64_t D,
       if (e0 + 1 < D) __builtin_nontemporal_store(v[c][1], row + e0 + 1);
     }
   }
+}
+
+// a segment of kSeg chunks of a long row (D > 1024): elements e_base + 128 c + 2 lane + k
+constexpr int kSeg = 8;
+template <bool VEC, bool STREAM = false>
+__device__ inline void load_segment(const double *__restrict__ row, uint64_t e_base, uint64_t D,
+                                    const double *__restrict__ zero, double (&v)[kSeg][2]) {
+  const uint64_t left = e_base < D ? D - e_base : 0;
+  if (STREAM)
+    load_row_stream<kSeg, VEC>(row + e_base, left, zero, v);
+  else
+    load_row<kSeg, VEC>(row + e_base, left, zero, v);
+}
+template <bool VEC, bool STREAM = false>
+__device__ inline void store_segment(double *__restrict__ row, uint64_t e_base, uint64_t D,
+                                     const double (&v)[kSeg][2]) {
+  const uint64_t left = e_base < D ? D - e_base : 0;
+  if (STREAM)
+    store_row_stream<kSeg, VEC>(row + e_base, left, v);
+  else
+    store_row<kSeg, VEC>(row + e_base, left, v);
 }
 
 // lower value wins; equal values keep the lower index; NaN never wins

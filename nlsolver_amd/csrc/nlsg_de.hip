@@ -23,6 +23,7 @@ struct nlsg_de {
   double *rec = nullptr;  // local record (single-GPU finaliser input)
   int chunks = 0;
   int group = 0;  // lanes per agent when several agents share a wave (D <= 64), else 0
+  bool long_rows = false;  // D > 1024: rows streamed in segments (de_*_long_kernel)
   bool initialised = false;
   uint64_t k = 0;            // generations launched so far (= index of the next head)
   // strategy random: the head of turn k (scan, stop tests) does not feed generation k+1
@@ -67,11 +68,31 @@ void launch_module(nlsg_de *e, hipFunction_t fn, unsigned grid, void **args) {
   launch_module_kernel(fn, grid, 256, 0, e->stream, args);
 }
 
+// D > 1024: the segment-streaming kernels, per objective and row alignment only
+#define NLSG_FOR_OBJ_LONG(obj, CALL)                                  \
+  switch (obj) {                                                      \
+    case NLSG_OBJ_ROSENBROCK: CALL(NLSG_OBJ_ROSENBROCK); break;       \
+    case NLSG_OBJ_SPHERE: CALL(NLSG_OBJ_SPHERE); break;               \
+    case NLSG_OBJ_STYBLINSKI_TANG: CALL(NLSG_OBJ_STYBLINSKI_TANG); break; \
+    case NLSG_OBJ_RASTRIGIN: CALL(NLSG_OBJ_RASTRIGIN); break;         \
+    default: break;                                                   \
+  }
+
 void launch_init(nlsg_de *e) {
   const dim3 grid(static_cast<unsigned>((e->p.shard_n + 3) / 4)), block(256);
   if (e->cfg.objective == NLSG_OBJ_CUSTOM) {
     void *args[] = {&e->p, &e->x0_dev};
     launch_module(e, e->rtc.init, grid.x, args);
+    return;
+  }
+  if (e->long_rows) {
+#define CALL(OBJ)                                                                              \
+  if (e->p.vec)                                                                                \
+    hipLaunchKernelGGL((de_init_long_kernel<OBJ, true>), grid, block, 0, e->stream, e->p, e->x0_dev); \
+  else                                                                                         \
+    hipLaunchKernelGGL((de_init_long_kernel<OBJ, false>), grid, block, 0, e->stream, e->p, e->x0_dev)
+    NLSG_FOR_OBJ_LONG(e->cfg.objective, CALL)
+#undef CALL
     return;
   }
 #define CALL(OBJ, C)                                                                          \
@@ -116,6 +137,18 @@ void launch_generation(nlsg_de *e, int par, uint64_t generation, int ignore_done
   if (e->cfg.objective == NLSG_OBJ_CUSTOM) {
     void *args[] = {&e->p, &par, &generation, &ignore_done};
     launch_module(e, e->rtc.generation, grid.x, args);
+    return;
+  }
+  if (e->long_rows) {
+#define CALL(OBJ)                                                                               \
+  if (e->p.vec)                                                                                 \
+    hipLaunchKernelGGL((de_generation_long_kernel<OBJ, true>), grid, block, 0, e->stream, e->p, \
+                       par, generation, ignore_done);                                           \
+  else                                                                                          \
+    hipLaunchKernelGGL((de_generation_long_kernel<OBJ, false>), grid, block, 0, e->stream, e->p, \
+                       par, generation, ignore_done)
+    NLSG_FOR_OBJ_LONG(e->cfg.objective, CALL)
+#undef CALL
     return;
   }
   if (e->group) {
@@ -299,9 +332,11 @@ static int de_create(const nlsg_de_config *cfg, const nlsg_custom_objective *cus
     return fail(NLSG_ERR_INVALID_ARG, "nlsg_de_config size mismatch (%u vs %zu)",
                 cfg->struct_size, sizeof(nlsg_de_config));
   if (cfg->dim < 1) return fail(NLSG_ERR_INVALID_ARG, "dim must be >= 1");
-  if (cfg->dim > 1024)
-    return fail(NLSG_ERR_UNSUPPORTED, "dim %llu > 1024 is not covered by the device path",
+  if (cfg->dim > 1024 && custom && custom->chain == NLSG_CUSTOM_VECTOR)
+    return fail(NLSG_ERR_UNSUPPORTED,
+                "dim %llu > 1024: a whole-vector objective needs the point in the wave's registers",
                 (unsigned long long)cfg->dim);
+  if (cfg->dim > 0xffffffffull) return fail(NLSG_ERR_UNSUPPORTED, "dim beyond 2^32");
   if (!custom && (cfg->objective < 0 || cfg->objective > NLSG_OBJ_RASTRIGIN))
     return fail(NLSG_ERR_INVALID_ARG, "unknown objective %d", cfg->objective);
   if (cfg->strategy != NLSG_DE_BEST && cfg->strategy != NLSG_DE_RANDOM)
@@ -323,6 +358,7 @@ static int de_create(const nlsg_de_config *cfg, const nlsg_custom_objective *cus
   e->cfg = *cfg;
   const uint64_t D = cfg->dim, n = cfg->shard_n;
   e->chunks = D <= 128 ? 1 : D <= 256 ? 2 : D <= 512 ? 4 : 8;
+  e->long_rows = D > 1024;  // the reference has no limit (nlsolver.h:2302-2477)
   e->group = D <= 8 ? 4 : D <= 16 ? 8 : D <= 32 ? 16 : D <= 64 ? 32 : 0;
   if (const char *g = std::getenv("NLSG_DE_GROUPS"))  // A/B switch: 0 = one agent per wave at any D
     if (g[0] == '0') e->group = 0;
@@ -368,7 +404,7 @@ static int de_create(const nlsg_de_config *cfg, const nlsg_custom_objective *cus
   const char *ov = std::getenv("NLSG_DE_OVERLAP");
   e->overlap = cfg->strategy == NLSG_DE_RANDOM && cfg->shard_n == cfg->pop && ov && ov[0] == '1';
   const char *fu = std::getenv("NLSG_DE_FUSED_TURN");
-  e->fused = cfg->strategy == NLSG_DE_RANDOM && cfg->shard_n == cfg->pop &&
+  e->fused = cfg->strategy == NLSG_DE_RANDOM && cfg->shard_n == cfg->pop && !e->long_rows &&
              !e->overlap && !cfg->trace && !(fu && fu[0] == '0');  // the trace buffer is not double-buffered
   if (e->overlap) {
     if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking);
@@ -400,7 +436,7 @@ static int de_create(const nlsg_de_config *cfg, const nlsg_custom_objective *cus
   p.stream = 1;
   if (const char *sv = std::getenv("NLSG_DE_STREAM")) p.stream = sv[0] == '1' ? 1 : 0;  // A/B switch
   if (custom) {
-    const int rc2 = rtc_build_de(custom, e->chunks, p.vec != 0, e->group, &e->rtc);
+    const int rc2 = rtc_build_de(custom, e->long_rows ? 0 : e->chunks, p.vec != 0, e->group, &e->rtc);
     if (rc2) {
       nlsg_de_destroy(e);
       return rc2;

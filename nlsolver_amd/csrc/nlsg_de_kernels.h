@@ -603,6 +603,133 @@ __global__ __launch_bounds__(256) void de_finalize_kernel(DeParams p, const doub
   for (uint64_t d = threadIdx.x; d < p.D; d += 256) p.best_x[d] = src[d];
 }
 
+// ---- rows longer than a wave's registers hold (D > 1024; the reference has no limit) -----------
+// One wave per agent, the rows taken in segments of 1024 coordinates. A generation makes two
+// passes: the first builds the trial segment by segment, scores it (objective_accumulate: the
+// whole-row summation order) and stores it; the second, only for a rejected trial, copies the
+// survivor's row over it. Same draws (the element's index keys them), same arithmetic, same bits
+// as the register-resident kernels would give — the oracle restates neither layout.
+template <int OBJ, bool VEC>
+__global__ __launch_bounds__(256) void de_init_long_kernel(DeParams p, const double *__restrict__ x0) {
+  const uint64_t a = static_cast<uint64_t>(blockIdx.x) * 4 +
+                     __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+  if (a >= p.shard_n) return;
+  const int lane = lane_id();
+  const uint64_t D = p.D;
+  const uint64_t ka = ctr_key(ctr_key(p.seed, 0), p.shard_lo + a);
+  auto element = [&](uint64_t e) {  // generate_sequence, nlsolver.h:2309
+    return (e < D) ? (u01(ctr_key(ka, e)) - 0.5) * x0[e] : 0.0;
+  };
+  double acc = 0.0;
+  for (uint64_t e_base = 0; e_base < D; e_base += 128 * kSeg) {
+    double xv[kSeg][2];
+#pragma unroll
+    for (int c = 0; c < kSeg; c++)
+#pragma unroll
+      for (int k = 0; k < 2; k++)
+        xv[c][k] = element(e_base + static_cast<uint64_t>(c) * 128 + 2 * static_cast<uint64_t>(lane) + k);
+    store_segment<VEC>(p.buf[0] + a * D, e_base, D, xv);
+    objective_accumulate<OBJ, kSeg>(acc, xv, e_base, D, element(e_base + 128 * kSeg));
+  }
+  const double f = p.fmul * objective_finish<OBJ>(acc, D);  // :2423-2425
+  if (lane == 0) p.scores[0][a] = f;
+}
+
+template <int OBJ, bool VEC>
+__global__ __launch_bounds__(256) void de_generation_long_kernel(DeParams p, int par, uint64_t generation,
+                                                               int ignore_done) {
+  const DeState *__restrict__ st = p.state;
+  if (!ignore_done && st->done) return;
+  const uint64_t a = static_cast<uint64_t>(blockIdx.x) * 4 +
+                     __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+  if (a >= p.shard_n) return;
+  const int lane = lane_id();
+  const uint64_t D = p.D;
+  const double *__restrict__ cur = p.buf[par];
+  double *__restrict__ nxt = p.buf[par ^ 1];
+  const uint64_t kg = first64(ctr_key(on_valu(p.seed), generation));
+  // donors and the forced dimension exactly as de_fetch_agent draws them
+  const uint64_t ga = p.shard_lo + a;
+  const uint64_t ka = first64(ctr_key(kg, on_valu(ga)));
+  const uint64_t drawn = clamp_index(u01(ctr_key(ka, D + static_cast<uint64_t>(lane))),
+                                     lane == 0 ? D : p.shard_n);
+  const uint64_t best_id = st->best_id;
+  const bool rnd = p.strategy == NLSG_DE_RANDOM;
+  const uint64_t fixed = rnd ? ga : best_id;
+  uint64_t r0 = ~0ull, r1 = ~0ull, r2 = ~0ull;
+  int have = 0;
+  for (int k = 0; k < kDeMaxTries && have < 3; k++) {
+    const uint64_t cand = p.shard_lo + (k < 63 ? readlane64(drawn, k + 1)
+                                               : clamp_index(u01(ctr_key(ka, D + 1 + k)), p.shard_n));
+    const bool used = (cand == fixed) || (have > 0 && cand == r0) || (have > 1 && cand == r1);
+    if (!used) {
+      if (have == 0) r0 = cand;
+      else if (have == 1) r1 = cand;
+      else r2 = cand;
+      have++;
+    }
+  }
+  for (uint64_t cand = p.shard_lo; have < 3; cand++) {
+    const bool used = (cand == fixed) || (have > 0 && cand == r0) || (have > 1 && cand == r1);
+    if (!used) {
+      if (have == 0) r0 = cand;
+      else if (have == 1) r1 = cand;
+      else r2 = cand;
+      have++;
+    }
+  }
+  const uint64_t jrand = readlane64(drawn, 0);
+  const double *own = cur + a * D, *d1 = cur + (r0 - p.shard_lo) * D, *d2 = cur + (r1 - p.shard_lo) * D,
+               *d3 = cur + (r2 - p.shard_lo) * D;
+  const double *keep = rnd ? own : p.best_x;  // non-crossed coordinates (:2369-2372)
+  auto trial_at = [&](uint64_t e) {  // one coordinate of the trial, the same in every lane
+    if (e >= D) return 0.0;
+    const double u = u01(ctr_key(ka, e));
+    const double mut = d1[e] + p.F * (d2[e] - d3[e]);
+    return (u < p.CR || e == jrand) ? mut : keep[e];
+  };
+  double *out = nxt + a * D;
+  double acc = 0.0;
+  const uint64_t ka_lane = ka + kGolden * (2 * static_cast<uint64_t>(lane) + 1);
+  for (uint64_t e_base = 0; e_base < D; e_base += 128 * kSeg) {
+    double v1[kSeg][2], v2[kSeg][2], v3[kSeg][2], vk[kSeg][2], trial[kSeg][2];
+    load_segment<VEC>(d1, e_base, D, p.zero, v1);
+    load_segment<VEC>(d2, e_base, D, p.zero, v2);
+    load_segment<VEC>(d3, e_base, D, p.zero, v3);
+    load_segment<VEC>(keep, e_base, D, p.zero, vk);
+    const uint64_t kseg = ka_lane + kGolden * e_base;
+#pragma unroll
+    for (int ch = 0; ch < kSeg; ch++)
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const uint64_t e = e_base + static_cast<uint64_t>(ch) * 128 + 2 * static_cast<uint64_t>(lane) + k;
+        const double u = u01(mix64(kseg + kGolden * static_cast<uint64_t>(128 * ch + k)));
+        const double mut = v1[ch][k] + p.F * (v2[ch][k] - v3[ch][k]);
+        trial[ch][k] = (u < p.CR || e == jrand) ? mut : vk[ch][k];
+      }
+    store_segment<VEC, true>(out, e_base, D, trial);
+    objective_accumulate<OBJ, kSeg>(acc, trial, e_base, D, trial_at(e_base + 128 * kSeg));
+  }
+  const double score = p.fmul * objective_finish<OBJ>(acc, D);  // :2463
+  const double old_score = p.scores[par][a];
+  const bool accept = score < old_score;  // :2466 (NaN -> keep)
+  if (!accept)
+    for (uint64_t e_base = 0; e_base < D; e_base += 128 * kSeg) {
+      double vo[kSeg][2];
+      load_segment<VEC>(own, e_base, D, p.zero, vo);
+      store_segment<VEC, true>(out, e_base, D, vo);
+    }
+  if (lane == 0) p.scores[par ^ 1][a] = accept ? score : old_score;
+  if (p.trace != nullptr && lane == 0) {
+    uint64_t *t = p.trace + a * kTraceWords;
+    t[0] = r0;
+    t[1] = r1;
+    t[2] = r2;
+    t[3] = jrand;
+    t[4] = accept ? 1u : 0u;
+  }
+}
+
 // Before the host reads the state: unless a stop test fired, the engine stands after the
 // k generations it has launched (the last head only saw k-1 of them).
 __global__ void de_settle_kernel(DeParams p, uint64_t k) {

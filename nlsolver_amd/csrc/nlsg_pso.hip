@@ -23,6 +23,7 @@ struct nlsg_pso {
   double *rec = nullptr;
   int chunks = 0;
   int group = 0;  // lanes per particle when several particles share a wave (D <= 64), else 0
+  bool long_rows = false;  // D > 1024: rows streamed in segments (pso_*_long_kernel)
   bool initialised = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -48,12 +49,32 @@ namespace {
     default: break;                                                                     \
   }
 
+// D > 1024: the segment-streaming kernels, per objective, row alignment and PSO type only
+#define PSO_FOR_OBJ_LONG(obj, CALL)                                   \
+  switch (obj) {                                                      \
+    case NLSG_OBJ_ROSENBROCK: CALL(NLSG_OBJ_ROSENBROCK); break;       \
+    case NLSG_OBJ_SPHERE: CALL(NLSG_OBJ_SPHERE); break;               \
+    case NLSG_OBJ_STYBLINSKI_TANG: CALL(NLSG_OBJ_STYBLINSKI_TANG); break; \
+    case NLSG_OBJ_RASTRIGIN: CALL(NLSG_OBJ_RASTRIGIN); break;         \
+    default: break;                                                   \
+  }
+
 void launch_init(nlsg_pso *e) {
   const dim3 grid(static_cast<unsigned>((e->p.shard_n + 3) / 4)), block(256);
   const bool vec = e->p.D % 2 == 0;
   if (e->cfg.objective == NLSG_OBJ_CUSTOM) {
     void *args[] = {&e->p};
     launch_module_kernel(e->rtc.init, grid.x, 256, 0, e->stream, args);
+    return;
+  }
+  if (e->long_rows) {
+#define CALL(OBJ)                                                                            \
+  if (vec)                                                                                   \
+    hipLaunchKernelGGL((pso_init_long_kernel<OBJ, true>), grid, block, 0, e->stream, e->p);  \
+  else                                                                                       \
+    hipLaunchKernelGGL((pso_init_long_kernel<OBJ, false>), grid, block, 0, e->stream, e->p)
+    PSO_FOR_OBJ_LONG(e->cfg.objective, CALL)
+#undef CALL
     return;
   }
 #define CALL(OBJ, C)                                                                        \
@@ -105,6 +126,24 @@ void launch_move(nlsg_pso *e, int timing, uint64_t iter_ovr) {
   if (e->cfg.objective == NLSG_OBJ_CUSTOM) {
     void *args[] = {&e->p, &timing, &iter_ovr};
     launch_module_kernel(e->rtc.move, grid.x, 256, 0, e->stream, args);
+    return;
+  }
+  if (e->long_rows) {
+#define CALL(OBJ)                                                                                \
+  if (vec && accel)                                                                              \
+    hipLaunchKernelGGL((pso_move_long_kernel<OBJ, true, NLSG_PSO_ACCELERATED>), grid, block, 0,  \
+                       e->stream, e->p, timing, iter_ovr);                                       \
+  else if (vec)                                                                                  \
+    hipLaunchKernelGGL((pso_move_long_kernel<OBJ, true, NLSG_PSO_VANILLA>), grid, block, 0,      \
+                       e->stream, e->p, timing, iter_ovr);                                       \
+  else if (accel)                                                                                \
+    hipLaunchKernelGGL((pso_move_long_kernel<OBJ, false, NLSG_PSO_ACCELERATED>), grid, block, 0, \
+                       e->stream, e->p, timing, iter_ovr);                                       \
+  else                                                                                           \
+    hipLaunchKernelGGL((pso_move_long_kernel<OBJ, false, NLSG_PSO_VANILLA>), grid, block, 0,     \
+                       e->stream, e->p, timing, iter_ovr)
+    PSO_FOR_OBJ_LONG(e->cfg.objective, CALL)
+#undef CALL
     return;
   }
   if (e->group) {
@@ -209,9 +248,11 @@ static int pso_create(const nlsg_pso_config *cfg, const nlsg_custom_objective *c
     return fail(NLSG_ERR_INVALID_ARG, "nlsg_pso_config size mismatch (%u vs %zu)",
                 cfg->struct_size, sizeof(nlsg_pso_config));
   if (cfg->dim < 1) return fail(NLSG_ERR_INVALID_ARG, "dim must be >= 1");
-  if (cfg->dim > 1024)
-    return fail(NLSG_ERR_UNSUPPORTED, "dim %llu > 1024 is not covered by the device path",
+  if (cfg->dim > 1024 && custom && custom->chain == NLSG_CUSTOM_VECTOR)
+    return fail(NLSG_ERR_UNSUPPORTED,
+                "dim %llu > 1024: a whole-vector objective needs the point in the wave's registers",
                 (unsigned long long)cfg->dim);
+  if (cfg->dim > 0xffffffffull) return fail(NLSG_ERR_UNSUPPORTED, "dim beyond 2^32");
   if (!custom && (cfg->objective < 0 || cfg->objective > NLSG_OBJ_RASTRIGIN))
     return fail(NLSG_ERR_INVALID_ARG, "unknown objective %d", cfg->objective);
   if (cfg->type != NLSG_PSO_VANILLA && cfg->type != NLSG_PSO_ACCELERATED)
@@ -231,6 +272,7 @@ static int pso_create(const nlsg_pso_config *cfg, const nlsg_custom_objective *c
   e->cfg = *cfg;
   const uint64_t D = cfg->dim, n = cfg->shard_n;
   e->chunks = D <= 128 ? 1 : D <= 256 ? 2 : D <= 512 ? 4 : 8;
+  e->long_rows = D > 1024;  // the reference has no limit (nlsolver.h:2498-2742)
   e->group = D <= 8 ? 4 : D <= 16 ? 8 : D <= 32 ? 16 : D <= 64 ? 32 : 0;
   if (const char *g = std::getenv("NLSG_PSO_GROUPS"))  // A/B switch: 0 = one particle per wave at any D
     if (g[0] == '0') e->group = 0;
@@ -317,7 +359,7 @@ static int pso_create(const nlsg_pso_config *cfg, const nlsg_custom_objective *c
   p.type = cfg->type;
   p.bounded = cfg->bounded ? 1 : 0;
   if (custom) {
-    const int rc2 = rtc_build_pso(custom, e->chunks, p.D % 2 == 0, cfg->type, e->group, &e->rtc);
+    const int rc2 = rtc_build_pso(custom, e->long_rows ? 0 : e->chunks, p.D % 2 == 0, cfg->type, e->group, &e->rtc);
     if (rc2) {
       nlsg_pso_destroy(e);
       return rc2;

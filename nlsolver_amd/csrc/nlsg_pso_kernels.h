@@ -263,6 +263,143 @@ __global__ __launch_bounds__(256) void pso_move_groups_kernel(PsoParams p, int t
   }
 }
 
+// ---- particles longer than a wave's registers hold (D > 1024; the reference has no limit) --------
+// One wave per particle, rows taken in segments of 1024 coordinates, updated in place; the
+// objective accumulates from segment to segment in the whole-row order. Vanilla: the personal-best
+// row is copied in a second pass once the new value is known to be better.
+template <int OBJ, bool VEC>
+__global__ __launch_bounds__(256) void pso_init_long_kernel(PsoParams p) {
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * 4 +
+                     __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+  if (i >= p.shard_n) return;
+  const int lane = lane_id();
+  const uint64_t D = p.D;
+  const uint64_t kp = ctr_key(ctr_key(p.seed, 0), p.shard_lo + i);
+  auto pos_at = [&](uint64_t e) {  // :2645-2648
+    return e < D ? p.lower[e] + ((p.upper[e] - p.lower[e]) * u01(ctr_key(kp, 2 * e))) : 0.0;
+  };
+  double acc = 0.0;
+  for (uint64_t e_base = 0; e_base < D; e_base += 128 * kSeg) {
+    double lo[kSeg][2], hi[kSeg][2], xv[kSeg][2], vv[kSeg][2];
+    load_segment<VEC>(p.lower, e_base, D, p.zero, lo);
+    load_segment<VEC>(p.upper, e_base, D, p.zero, hi);
+#pragma unroll
+    for (int c = 0; c < kSeg; c++)
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const uint64_t e = e_base + static_cast<uint64_t>(c) * 128 + 2 * static_cast<uint64_t>(lane) + k;
+        const double temp = fabs(hi[c][k] - lo[c][k]);
+        xv[c][k] = lo[c][k] + ((hi[c][k] - lo[c][k]) * u01(ctr_key(kp, 2 * e)));
+        vv[c][k] = -temp + (u01(ctr_key(kp, 2 * e + 1)) * temp);
+        if (e >= D) xv[c][k] = 0.0;
+      }
+    store_segment<VEC>(p.pos + i * D, e_base, D, xv);
+    if (p.type == NLSG_PSO_VANILLA) {
+      store_segment<VEC>(p.vel + i * D, e_base, D, vv);
+      store_segment<VEC>(p.pbest_pos + i * D, e_base, D, xv);
+    }
+    objective_accumulate<OBJ, kSeg>(acc, xv, e_base, D, pos_at(e_base + 128 * kSeg));
+  }
+  const double f = p.fmul * objective_finish<OBJ>(acc, D);
+  if (lane == 0) {
+    p.cur_val[i] = f;
+    p.pbest_val[i] = f;
+  }
+}
+
+template <int OBJ, bool VEC, int TYPE>
+__global__ __launch_bounds__(256) void pso_move_long_kernel(PsoParams p, int timing, uint64_t iter_ovr) {
+  const PsoState *__restrict__ st = p.state;
+  if (!timing && st->done) return;
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * 4 +
+                     __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+  if (i >= p.shard_n) return;
+  const int lane = lane_id();
+  const uint64_t D = p.D;
+  const uint64_t iter = timing ? iter_ovr : st->iter;
+  const uint64_t kp = ctr_key(ctr_key(p.seed, iter + 1), p.shard_lo + i);
+  double *row = p.pos + i * D, *vrow = p.vel + i * D, *brow = p.pbest_pos + i * D;
+  const double old_pbest = p.pbest_val[i];
+  double inertia = p.inertia;
+  if (TYPE == NLSG_PSO_ACCELERATED) inertia = pso_inertia_at(p, iter);
+  // one coordinate of the new position, the same arithmetic as the lane code below (wave-uniform)
+  auto new_at = [&](uint64_t e) {
+    if (e >= D) return 0.0;
+    const uint64_t z1 = ctr_key(kp, 2 * e);
+    const double u1 = u01(z1);
+    double pnew;
+    if (TYPE == NLSG_PSO_ACCELERATED) {
+      const double rn = sqrt(-2 * det_log(u1)) * det_cos(2 * 3.141593 * u01_low32(z1));
+      pnew = inertia * rn + (1 - p.cog) * row[e] + p.soc * p.gbest_x[e];
+    } else {
+      const double u2 = u01(ctr_key(kp, 2 * e + 1));
+      const double v = (inertia * vrow[e]) + p.cog * u1 * (brow[e] - row[e]) + p.soc * u2 * (p.gbest_x[e] - row[e]);
+      pnew = row[e] + v;
+    }
+    if (p.bounded) {
+      pnew = pnew < p.lower[e] ? p.lower[e] : pnew;
+      pnew = pnew > p.upper[e] ? p.upper[e] : pnew;
+    }
+    return pnew;
+  };
+  const uint64_t kp_lane = kp + kGolden * (4 * static_cast<uint64_t>(lane) + 1);
+  double acc = 0.0;
+  for (uint64_t e_base = 0; e_base < D; e_base += 128 * kSeg) {
+    // the first coordinate of the NEXT segment, from its old position: before this segment's store
+    const double next_first = new_at(e_base + 128 * kSeg);
+    double xv[kSeg][2], gb[kSeg][2], lo[kSeg][2], hi[kSeg][2], vv[kSeg][2], pb[kSeg][2];
+    load_segment<VEC, true>(row, e_base, D, p.zero, xv);
+    load_segment<VEC>(p.gbest_x, e_base, D, p.zero, gb);
+    load_segment<VEC>(p.lower, e_base, p.bounded ? D : 0, p.zero, lo);
+    load_segment<VEC>(p.upper, e_base, p.bounded ? D : 0, p.zero, hi);
+    if (TYPE == NLSG_PSO_VANILLA) {
+      load_segment<VEC, true>(vrow, e_base, D, p.zero, vv);
+      load_segment<VEC, true>(brow, e_base, D, p.zero, pb);
+    }
+    const uint64_t kseg = kp_lane + kGolden * (2 * e_base);  // draws 2e, 2e + 1 of element e
+#pragma unroll
+    for (int c = 0; c < kSeg; c++)
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const uint64_t e = e_base + static_cast<uint64_t>(c) * 128 + 2 * static_cast<uint64_t>(lane) + k;
+        const uint64_t z1 = mix64(kseg + kGolden * static_cast<uint64_t>(256 * c + 2 * k));
+        const double u1 = u01(z1);
+        const double u2 = TYPE == NLSG_PSO_ACCELERATED
+                              ? u01_low32(z1)
+                              : u01(mix64(kseg + kGolden * static_cast<uint64_t>(256 * c + 2 * k + 1)));
+        double pnew;
+        if (TYPE == NLSG_PSO_ACCELERATED) {
+          const double rn = sqrt(-2 * det_log(u1)) * det_cos(2 * 3.141593 * u2);
+          pnew = inertia * rn + (1 - p.cog) * xv[c][k] + p.soc * gb[c][k];
+        } else {
+          vv[c][k] = (inertia * vv[c][k]) + p.cog * u1 * (pb[c][k] - xv[c][k]) +
+                     p.soc * u2 * (gb[c][k] - xv[c][k]);
+          pnew = xv[c][k] + vv[c][k];
+        }
+        if (p.bounded) {
+          pnew = pnew < lo[c][k] ? lo[c][k] : pnew;
+          pnew = pnew > hi[c][k] ? hi[c][k] : pnew;
+        }
+        xv[c][k] = (e < D) ? pnew : 0.0;
+      }
+    store_segment<VEC, true>(row, e_base, D, xv);
+    if (TYPE == NLSG_PSO_VANILLA) store_segment<VEC, true>(vrow, e_base, D, vv);
+    objective_accumulate<OBJ, kSeg>(acc, xv, e_base, D, next_first);
+  }
+  const double f = p.fmul * objective_finish<OBJ>(acc, D);
+  const bool better = f < old_pbest;  // :2733-2735
+  if (TYPE == NLSG_PSO_VANILLA && better)
+    for (uint64_t e_base = 0; e_base < D; e_base += 128 * kSeg) {
+      double xv[kSeg][2];
+      load_segment<VEC>(row, e_base, D, p.zero, xv);
+      store_segment<VEC, true>(brow, e_base, D, xv);
+    }
+  if (lane == 0) {
+    p.cur_val[i] = f;
+    if (better) p.pbest_val[i] = f;
+  }
+}
+
 // First level of update_best_positions' scan (min / first argmin of the last
 // evaluation) and of std_err(particle_best_values)'s first pass.
 __global__ __launch_bounds__(256) void pso_scan_partial_kernel(PsoParams p) {

@@ -179,6 +179,20 @@ static std::string targs(int chunks, bool vec) {
 
 int rtc_build_de(const nlsg_custom_objective *obj, int chunks, bool vec, int group,
                  DeRtcKernels *out) {
+  if (chunks == 0) {  // D > 1024: the segment-streaming kernels (no fused turn)
+    const std::string t = std::to_string(static_cast<int>(NLSG_OBJ_CUSTOM)) + ", " + (vec ? "true" : "false");
+    std::vector<hipFunction_t> f;
+    DeRtcKernels k;
+    const int rc = rtc_compile(obj, "nlsg_de_kernels.h",
+                               {"nlsg::de_init_long_kernel<" + t + ">", "nlsg::de_generation_long_kernel<" + t + ">"},
+                               &k.mod, &f);
+    if (rc) return rc;
+    k.init = f[0];
+    k.generation = f[1];
+    k.turn = nullptr;
+    *out = k;
+    return NLSG_OK;
+  }
   const std::string t = targs(chunks, vec);
   const std::string gen =
       group ? "nlsg::de_generation_groups_kernel<" + std::to_string(static_cast<int>(NLSG_OBJ_CUSTOM)) +
@@ -202,6 +216,20 @@ int rtc_build_de(const nlsg_custom_objective *obj, int chunks, bool vec, int gro
 
 int rtc_build_pso(const nlsg_custom_objective *obj, int chunks, bool vec, int type, int group,
                   PsoRtcKernels *out) {
+  if (chunks == 0) {  // D > 1024: the segment-streaming kernels
+    const std::string t = std::to_string(static_cast<int>(NLSG_OBJ_CUSTOM)) + ", " + (vec ? "true" : "false");
+    std::vector<hipFunction_t> f;
+    PsoRtcKernels k;
+    const int rc = rtc_compile(obj, "nlsg_pso_kernels.h",
+                               {"nlsg::pso_init_long_kernel<" + t + ">",
+                                "nlsg::pso_move_long_kernel<" + t + ", " + std::to_string(type) + ">"},
+                               &k.mod, &f);
+    if (rc) return rc;
+    k.init = f[0];
+    k.move = f[1];
+    *out = k;
+    return NLSG_OK;
+  }
   const std::string t = targs(chunks, vec);
   const std::string move =
       group ? "nlsg::pso_move_groups_kernel<" + std::to_string(static_cast<int>(NLSG_OBJ_CUSTOM)) +

@@ -51,6 +51,16 @@ def test_custom_rosenbrock_equals_builtin_bit_for_bit(mod, oracle, D, pop, strat
     assert np.array_equal(b[0], ref.population) and np.array_equal(b[1], ref.scores)
 
 
+def test_custom_objective_on_long_rows(mod):
+    """D = 1500 (> 1024: segment-streaming kernels, compiled at run time as well)."""
+    kw = dict(strategy=1, CR=0.2, F=0.5, eps=0.0, max_iter=1000, best_val_no_change=1000, seed=5)
+    D, pop = 1500, 48
+    x0 = np.full(D, 0.6)
+    a = run(mod, "rosenbrock", pop, D, x0, 5, **kw)
+    b = run(mod, mod.CustomObjective(ROSENBROCK, chain=True), pop, D, x0, 5, **kw)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[4] == b[4]
+
+
 def test_custom_finish_and_maximize(mod):
     """Styblinski-Tang spells its halving in `finish`; maximize flips the sign like the built-in."""
     kw = dict(minimize=False, CR=0.5, F=0.7, eps=0.0, max_iter=1000, best_val_no_change=1000, seed=9)

@@ -63,6 +63,35 @@ def test_generations_bit_exact(eng_mod, oracle, pop, D, strategy):
         assert bi == ref.s.best_id and bf == ref.scores[bi]
 
 
+@pytest.mark.parametrize("pop,D", [(64, 1025), (48, 1026), (32, 2048), (24, 3001)])
+@pytest.mark.parametrize("strategy", [0, 1])
+def test_rows_longer_than_1024_coordinates_bit_exact(eng_mod, oracle, pop, D, strategy):
+    """D > 1024 (the reference has no limit, nlsolver.h:2302-2477): rows are streamed in segments
+    of 1024 coordinates, the trial scored with the whole-row summation order; first size past the
+    old cap, an odd one, whole segments, a ragged last segment. Accepting regime, so both the
+    store of a trial and the copy-back of a survivor run."""
+    x0 = x0_for(D, 0.6)
+    kw = dict(strategy=strategy, CR=0.2, F=0.5, eps=0.0, max_iter=1000, best_val_no_change=1000)
+    ref = O.DESyncRun(oracle, "rosenbrock", pop, D, x0, trace=True, **kw)
+    with eng_mod.DEEngine("rosenbrock", pop, D, trace=True, **kw) as eng:
+        eng.init(x0)
+        P, S = eng.download()
+        assert np.array_equal(P, ref.population) and np.array_equal(S, ref.scores), "init"
+        accepted = 0
+        for g in range(4):
+            eng.step(1)
+            ref.step(1)
+            P, S, T = eng.download(trace=True)
+            assert np.array_equal(T, ref.trace), f"donors / jrand / accept mask gen {g}"
+            assert np.array_equal(P, ref.population) and np.array_equal(S, ref.scores), f"gen {g}"
+            accepted += int(T[:, 4].sum())
+        assert accepted < 4 * pop and (accepted > 0 or strategy == 1 or D > 3000)  # both paths ran (best)
+        eng.step(1)
+        ref.step(1)
+        bx, bf, bi = eng.best()
+        assert bi == ref.s.best_id and bf == ref.scores[bi] and np.array_equal(bx, ref.population[bi])
+
+
 @pytest.mark.parametrize("obj", ["sphere", "styblinski_tang"])
 @pytest.mark.parametrize("minimize", [True, False])
 def test_other_objectives_and_maximize_bit_exact(eng_mod, oracle, obj, minimize):

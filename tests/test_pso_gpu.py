@@ -49,6 +49,28 @@ def test_pso_turns_bit_exact(mod, oracle, n, D, type_, bounded):
         assert np.array_equal(bx, ref.gbest_x) and bf == ref.s.gbest_val and bi == ref.s.gbest_idx
 
 
+@pytest.mark.parametrize("n,D", [(24, 1025), (20, 1026), (16, 2048), (12, 3001)])
+@pytest.mark.parametrize("type_", [O.PSO_ACCELERATED, O.PSO_VANILLA])
+@pytest.mark.parametrize("bounded", [False, True])
+def test_pso_particles_longer_than_1024_coordinates_bit_exact(mod, oracle, n, D, type_, bounded):
+    """D > 1024 (the reference has no limit, nlsolver.h:2498-2742): particles streamed in segments
+    of 1024 coordinates, in place; first size past the old cap, an odd one, whole segments, a ragged
+    last segment."""
+    lo = -2.048 * (1 + 0.0001 * np.arange(D))
+    hi = 2.048 * (1 + 0.0002 * np.arange(D))
+    kw = dict(type=type_, bounded=bounded, eps=0.0, max_iter=1000, best_val_no_change=1000)
+    ref = O.PSOSyncRun(oracle, "rosenbrock", n, D, lo, hi, **kw)
+    with mod.PSOEngine("rosenbrock", n, D, **kw) as eng:
+        eng.init(lo, hi)
+        check_state(eng, ref, "init")
+        for t in range(4):
+            eng.step(1)
+            ref.step(1)
+            check_state(eng, ref, f"turn {t}")
+        bx, bf, bi = eng.best()
+        assert np.array_equal(bx, ref.gbest_x) and bf == ref.s.gbest_val and bi == ref.s.gbest_idx
+
+
 @pytest.mark.parametrize("kw", [dict(eps=10e-4), dict(eps=0.0, max_iter=9),
                                 dict(eps=0.0, best_val_no_change=3), dict(eps=50.0)])
 @pytest.mark.parametrize("type_", [O.PSO_ACCELERATED, O.PSO_VANILLA])
