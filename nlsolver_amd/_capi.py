@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libnlsolver_hip.so")
+# $NLSG_LIBRARY names another build of the library (as for the C++ header): A/B runs of variants
+LIB_PATH = os.environ.get("NLSG_LIBRARY") or os.path.join(HERE, "libnlsolver_hip.so")
 
 u64, i32, f64 = C.c_uint64, C.c_int32, C.c_double
 pd = C.POINTER(C.c_double)
