@@ -456,7 +456,7 @@ typedef struct {
   int32_t objective;         /* nlsg_objective                                       */
   int32_t minimize;          /* 1: minimize(), 0: maximize() (f_multiplier, :2779)   */
   uint64_t batch;            /* independent chains                                   */
-  uint64_t dim;              /* <= 1024                                              */
+  uint64_t dim;              /* any (past 1024 the chain is streamed from memory)    */
   uint64_t chain_lo;         /* global id of chain 0 (keys the draws; batch sharding)*/
   uint64_t max_iter;         /* ctor arg max_iter = 5000 (:2760)                     */
   uint64_t temperature_iter; /* ctor arg temperature_iter = 10 (:2761)               */

@@ -304,7 +304,9 @@ int rtc_build_sann(const nlsg_custom_objective *obj, int chunks, bool vec, int g
   std::vector<hipFunction_t> f;
   SannRtcKernels k;
   const std::string name =
-      group ? "nlsg::sann_anneal_groups_kernel<" + std::to_string(static_cast<int>(NLSG_OBJ_CUSTOM)) +
+      chunks == 0 ? "nlsg::sann_anneal_long_kernel<" + std::to_string(static_cast<int>(NLSG_OBJ_CUSTOM)) +
+                        ", " + (vec ? "true" : "false") + ">"
+      : group ? "nlsg::sann_anneal_groups_kernel<" + std::to_string(static_cast<int>(NLSG_OBJ_CUSTOM)) +
                   ", " + std::to_string(group) + ">"
             : "nlsg::sann_anneal_kernel<" + targs(chunks, vec) + ">";
   const int rc = rtc_compile(obj, "nlsg_sann_kernels.h", {name}, &k.mod, &f);

@@ -75,6 +75,23 @@ void launch_anneal(nlsg_sann *e, uint64_t iter_begin, uint64_t iter_end) {
     launch_module_kernel(e->rtc.anneal, grid.x, 256, 0, e->stream, args);
     return;
   }
+  if (e->p.D > 1024) {  // chains streamed in segments
+#define CALL(OBJ)                                                                                  \
+  if (vec)                                                                                         \
+    hipLaunchKernelGGL((sann_anneal_long_kernel<OBJ, true>), grid, block, 0, e->stream, e->p,      \
+                       iter_begin, iter_end);                                                      \
+  else                                                                                             \
+    hipLaunchKernelGGL((sann_anneal_long_kernel<OBJ, false>), grid, block, 0, e->stream, e->p,     \
+                       iter_begin, iter_end)
+    switch (e->cfg.objective) {
+      case NLSG_OBJ_ROSENBROCK: CALL(NLSG_OBJ_ROSENBROCK); break;
+      case NLSG_OBJ_SPHERE: CALL(NLSG_OBJ_SPHERE); break;
+      case NLSG_OBJ_STYBLINSKI_TANG: CALL(NLSG_OBJ_STYBLINSKI_TANG); break;
+      default: CALL(NLSG_OBJ_RASTRIGIN); break;
+    }
+#undef CALL
+    return;
+  }
   if (e->group) {
     switch (e->cfg.objective) {
       case NLSG_OBJ_ROSENBROCK: launch_groups<NLSG_OBJ_ROSENBROCK>(e, grid, iter_begin, iter_end); break;
@@ -145,9 +162,11 @@ static int sann_create(const nlsg_sann_config *cfg, const nlsg_custom_objective 
   if (!custom && (cfg->objective < 0 || cfg->objective > NLSG_OBJ_RASTRIGIN))
     return fail(NLSG_ERR_INVALID_ARG, "unknown objective %d", cfg->objective);
   if (cfg->dim < 1 || cfg->batch < 1) return fail(NLSG_ERR_INVALID_ARG, "dim and batch must be >= 1");
-  if (cfg->dim > 1024)
-    return fail(NLSG_ERR_UNSUPPORTED, "dim %llu > 1024 (one wave holds a chain's three points)",
+  if (cfg->dim > 1024 && custom && custom->chain == NLSG_CUSTOM_VECTOR)
+    return fail(NLSG_ERR_UNSUPPORTED,
+                "dim %llu > 1024: a whole-vector objective needs the point in the wave's registers",
                 (unsigned long long)cfg->dim);
+  if (cfg->dim > 0xffffffffull) return fail(NLSG_ERR_UNSUPPORTED, "dim beyond 2^32");
   if (cfg->batch > 0x7fffffffull) return fail(NLSG_ERR_UNSUPPORTED, "batch too large");
   int rc = check_device(cfg->device);
   if (rc) return rc;
@@ -173,6 +192,7 @@ static int sann_create(const nlsg_sann_config *cfg, const nlsg_custom_objective 
   hipError_t he = hipSuccess;
   if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p.x), B * D * 8);
   if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p.p), B * D * 8);
+  if (he == hipSuccess && D > 1024) he = hipMalloc(reinterpret_cast<void **>(&p.trial), B * D * 8);
   if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p.prob), B * sizeof(SannProblem));
   if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&e->zero_dev), 16);
   if (he == hipSuccess) he = hipMemset(e->zero_dev, 0, 16);
@@ -184,7 +204,7 @@ static int sann_create(const nlsg_sann_config *cfg, const nlsg_custom_objective 
                 "device setup failed: %s", hipGetErrorString(he));
   }
   if (custom) {
-    const int rc2 = rtc_build_sann(custom, e->chunks, D % 2 == 0, e->group, &e->rtc);
+    const int rc2 = rtc_build_sann(custom, D > 1024 ? 0 : e->chunks, D % 2 == 0, e->group, &e->rtc);
     if (rc2) {
       nlsg_sann_destroy(e);
       return rc2;
@@ -211,6 +231,7 @@ int nlsg_sann_destroy(nlsg_sann *e) {
   rtc_release(&e->rtc);
   hipFree(e->p.x);
   hipFree(e->p.p);
+  hipFree(e->p.trial);
   hipFree(e->p.prob);
   hipFree(e->zero_dev);
   if (e->ev0) hipEventDestroy(e->ev0);

@@ -28,6 +28,7 @@ struct SannProblem {
 struct SannParams {
   double *x;          // [batch][D] in: start, out: best point (:2808)
   double *p;          // [batch][D] current point of the chain between launches
+  double *trial;      // [batch][D] trial point, D > 1024 only (sann_anneal_long_kernel)
   SannProblem *prob;  // [batch]
   const double *zero;
   uint64_t batch, D, seed, chain_lo;
@@ -103,6 +104,99 @@ __global__ __launch_bounds__(256) void sann_anneal_kernel(SannParams p, uint64_t
   }
   store_row<CHUNKS, VEC>(p.x + chain * D, D, xb);
   store_row<CHUNKS, VEC>(p.p + chain * D, D, pc);
+  if (lane == 0) {
+    p.prob[chain].best = best;
+    p.prob[chain].iter = iter_end;
+    p.prob[chain].fcalls = fcalls;
+  }
+}
+
+// Chains longer than a wave's registers hold (D > 1024; the reference has no limit): the three
+// points live in memory (x: best, p: current, trial), a trial is built and scored segment by
+// segment of 1024 coordinates (objective_accumulate: the whole-row order) and copied over the
+// current / best point when it is accepted. Same draws, same arithmetic as the register-resident
+// kernel.
+template <int OBJ, bool VEC>
+__global__ __launch_bounds__(256) void sann_anneal_long_kernel(SannParams p, uint64_t iter_begin,
+                                                               uint64_t iter_end) {
+  const uint64_t chain = static_cast<uint64_t>(blockIdx.x) * 4 +
+                         __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+  if (chain >= p.batch) return;
+  const int lane = lane_id();
+  const uint64_t D = p.D;
+  constexpr double e_minus_1 = 1.7182818;  // :2780
+  double *xb = p.x + chain * D, *pc = p.p + chain * D, *pt = p.trial + chain * D;
+  auto copy_row = [&](double *dst, const double *src) {
+    for (uint64_t e_base = 0; e_base < D; e_base += 128 * kSeg) {
+      double v[kSeg][2];
+      load_segment<VEC>(src, e_base, D, p.zero, v);
+      store_segment<VEC>(dst, e_base, D, v);
+    }
+  };
+  double best;
+  uint64_t fcalls;
+  if (iter_begin == 0) {  // :2781-2785
+    double acc = 0.0;
+    for (uint64_t e_base = 0; e_base < D; e_base += 128 * kSeg) {
+      double v[kSeg][2];
+      load_segment<VEC>(xb, e_base, D, p.zero, v);
+      store_segment<VEC>(pc, e_base, D, v);
+      const uint64_t en = e_base + 128 * kSeg;
+      objective_accumulate<OBJ, kSeg>(acc, v, e_base, D, en < D ? xb[en] : 0.0);
+    }
+    best = p.fmul * objective_finish<OBJ>(acc, D);
+    fcalls = 1;
+  } else {
+    best = p.prob[chain].best;
+    fcalls = p.prob[chain].fcalls;
+  }
+  const double scale = 1.0 / p.temp_max;
+  const uint64_t kc = ctr_key(p.seed, p.chain_lo + chain);
+  const uint64_t inner = p.inner;
+  for (uint64_t iter = iter_begin; iter < iter_end; iter++) {
+    const double t = p.temp_max / det_log(static_cast<double>(iter) + e_minus_1);  // :2793-2794
+    const double current_scale = t * scale;
+    for (uint64_t j = 0; j < inner; j++) {
+      const uint64_t ks = ctr_key(kc, iter * inner + j);
+      const uint64_t ks_lane = ks + kGolden * (4 * static_cast<uint64_t>(lane) + 1);
+      auto trial_at = [&](uint64_t e) {  // one coordinate of the trial point, the same in every lane
+        if (e >= D) return 0.0;
+        const uint64_t z1 = ctr_key(ks, 2 * e);
+        const double rn = sqrt(-2 * det_log(u01(z1))) * det_cos(2 * 3.141593 * u01_low32(z1));
+        return pc[e] + current_scale * rn;
+      };
+      double acc = 0.0;
+      for (uint64_t e_base = 0; e_base < D; e_base += 128 * kSeg) {
+        double vc[kSeg][2], vt[kSeg][2];
+        load_segment<VEC>(pc, e_base, D, p.zero, vc);
+        const uint64_t kseg = ks_lane + kGolden * (2 * e_base);
+#pragma unroll
+        for (int c = 0; c < kSeg; c++)
+#pragma unroll
+          for (int k = 0; k < 2; k++) {
+            const uint64_t e = e_base + static_cast<uint64_t>(c) * 128 + 2 * static_cast<uint64_t>(lane) + k;
+            const uint64_t z1 = mix64(kseg + kGolden * static_cast<uint64_t>(256 * c + 2 * k));
+            const double u1 = u01(z1), u2 = u01_low32(z1);
+            const double rn = sqrt(-2 * det_log(u1)) * det_cos(2 * 3.141593 * u2);  // rnorm, :2479-2485
+            vt[c][k] = (e < D) ? vc[c][k] + current_scale * rn : 0.0;  // :2800
+          }
+        store_segment<VEC>(pt, e_base, D, vt);
+        objective_accumulate<OBJ, kSeg>(acc, vt, e_base, D, trial_at(e_base + 128 * kSeg));
+      }
+      const double current_val = p.fmul * objective_finish<OBJ>(acc, D);
+      fcalls++;
+      const double difference = current_val - best;  // against the best so far (:2804)
+      const bool accept = (difference <= 0.0) ||
+                          (u01(ctr_key(ks, 2 * D)) < det_exp(-difference / t));  // :2805
+      if (accept) {  // wave-uniform
+        copy_row(pc, pt);
+        if (current_val <= best) {
+          copy_row(xb, pt);
+          best = current_val;
+        }
+      }
+    }
+  }
   if (lane == 0) {
     p.prob[chain].best = best;
     p.prob[chain].iter = iter_end;

@@ -125,9 +125,51 @@ def test_sann_custom_objective_equals_builtin(mod):
 def test_sann_rejects_bad_configs(mod):
     from nlsolver_amd._capi import NlsgError
     with pytest.raises(NlsgError):
-        mod.SANNEngine("rosenbrock", 1, 2000)
+        mod.SANNEngine("rosenbrock", 0, 4)
     with pytest.raises(NlsgError):
         mod.SANNEngine(17, 1, 4)
+    with pytest.raises(NlsgError):  # a whole-vector body needs the point in registers
+        mod.SANNEngine(mod.CustomObjective("return x(0) * x(0);", vector=True), 1, 2000)
+
+
+@pytest.mark.parametrize("objective,n,kw", [
+    ("rosenbrock", 1025, dict(max_iter=6, temperature_iter=5, temperature_max=10.0)),
+    ("rosenbrock", 1026, dict(max_iter=6, temperature_iter=5, temperature_max=1e5)),
+    ("sphere", 2048, dict(max_iter=5, temperature_iter=4, temperature_max=1e3)),
+    ("styblinski_tang", 3001, dict(max_iter=4, temperature_iter=4, temperature_max=1e5)),
+    ("rastrigin", 2049, dict(max_iter=4, temperature_iter=4, temperature_max=1e3)),
+])
+@pytest.mark.parametrize("minimize", [True, False])
+def test_sann_long_chains_bit_exact(mod, oracle, objective, n, kw, minimize):
+    """Chains past the register-resident layout (n > 1024; the reference has no limit,
+    nlsolver.h:2777-2814): points streamed from memory in segments, same draws and same
+    whole-row summation order. At the high temperatures worse trials are accepted too, so the
+    current point leaves the best one (the histories differ from the temperature_max = 10 ones
+    in every maximize case: checked against the oracle)."""
+    batch = 5
+    x0 = starts(batch, n, 0.5, 1.0)
+    with mod.SANNEngine(objective, batch, n, minimize=minimize, seed=SEED, chain_lo=1, **kw) as eng:
+        x, st = eng.minimize(x0)
+    for b in range(batch):
+        ref, xr, _ = O.sann_sync(oracle, objective, x0[b], SEED, 1 + b, minimize=minimize,
+                                 max_iter=kw["max_iter"], temp_iter=kw["temperature_iter"],
+                                 temp_max=kw["temperature_max"])
+        assert np.array_equal(x[b], xr), (b, np.flatnonzero(x[b] != xr)[:8])
+        assert st[b].f_value == ref.f_value
+        assert (st[b].iteration, st[b].function_calls_used) == (ref.iteration, ref.function_calls_used)
+
+
+def test_sann_long_chain_custom_objective_equals_builtin(mod):
+    rosen = "double t1 = 1 - xi; double t2 = (xn - xi * xi); return t1 * t1 + 100 * t2 * t2;"
+    n = 1500
+    x0 = starts(3, n, 0.5, 1.0)
+    out = []
+    for obj in ("rosenbrock", mod.CustomObjective(rosen, chain=True)):
+        with mod.SANNEngine(obj, 3, n, max_iter=5, temperature_iter=4, temperature_max=1e5,
+                            seed=5) as eng:
+            x, st = eng.minimize(x0)
+        out.append((x, [(s.f_value, s.function_calls_used) for s in st]))
+    assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
 
 
 def test_sann_bench_size_properties(mod, oracle):
