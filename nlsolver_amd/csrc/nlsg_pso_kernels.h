@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void pso_move_kernel(PsoParams p, int timing, 
       double pnew;
       if (TYPE == NLSG_PSO_ACCELERATED) {
         // rnorm (2479-2485): sqrt(-2 log u1) * cos(2 pi_ u2), pi_ = 3.141593
-        const double rn = sqrt(-2 * det_log(u1)) * det_cos(2 * 3.141593 * u2);
+        const double rn = det_rnorm(z1);
         pnew = inertia * rn + (1 - p.cog) * xv[c][k] + p.soc * gb[c][k];  // :2693-2697
       } else {
         // intended Vanilla update (B7 repaired): pbest[j] - pos, gbest[j] - pos
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void pso_move_groups_kernel(PsoParams p, int t
                           : u01(mix64(kp_lane + kGolden * static_cast<uint64_t>(2 * k + 1)));
     double pnew;
     if (TYPE == NLSG_PSO_ACCELERATED) {
-      const double rn = sqrt(-2 * det_log(u1)) * det_cos(2 * 3.141593 * u2);  // rnorm, :2479-2485
+      const double rn = det_rnorm(z1);  // rnorm, :2479-2485
       pnew = inertia * rn + (1 - p.cog) * xv[k] + p.soc * gb[k];  // :2693-2697
     } else {
       vv[k] = (inertia * vv[k]) + p.cog * u1 * (pb[k] - xv[k]) + p.soc * u2 * (gb[k] - xv[k]);
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void pso_move_long_kernel(PsoParams p, int tim
     const double u1 = u01(z1);
     double pnew;
     if (TYPE == NLSG_PSO_ACCELERATED) {
-      const double rn = sqrt(-2 * det_log(u1)) * det_cos(2 * 3.141593 * u01_low32(z1));
+      const double rn = det_rnorm(z1);
       pnew = inertia * rn + (1 - p.cog) * row[e] + p.soc * p.gbest_x[e];
     } else {
       const double u2 = u01(ctr_key(kp, 2 * e + 1));
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) void pso_move_long_kernel(PsoParams p, int tim
                               : u01(mix64(kseg + kGolden * static_cast<uint64_t>(256 * c + 2 * k + 1)));
         double pnew;
         if (TYPE == NLSG_PSO_ACCELERATED) {
-          const double rn = sqrt(-2 * det_log(u1)) * det_cos(2 * 3.141593 * u2);
+          const double rn = det_rnorm(z1);
           pnew = inertia * rn + (1 - p.cog) * xv[c][k] + p.soc * gb[c][k];
         } else {
           vv[c][k] = (inertia * vv[c][k]) + p.cog * u1 * (pb[c][k] - xv[c][k]) +

@@ -78,9 +78,8 @@ __global__ __launch_bounds__(256) void sann_anneal_kernel(SannParams p, uint64_t
         for (int k = 0; k < 2; k++) {
           const uint64_t e = static_cast<uint64_t>(c) * 128 + 2 * static_cast<uint64_t>(lane) + k;
           const uint64_t z1 = mix64(ks_lane + kGolden * static_cast<uint64_t>(256 * c + 2 * k));  // one draw (slot 2e) per normal variate
-          const double u1 = u01(z1), u2 = u01_low32(z1);
           // rnorm (:2479-2485): sqrt(-2 log u1) * cos(2 pi_ u2), pi_ = 3.141593
-          const double rn = sqrt(-2 * det_log(u1)) * det_cos(2 * 3.141593 * u2);
+          const double rn = det_rnorm(z1);
           pt[c][k] = (e < D) ? pc[c][k] + current_scale * rn : 0.0;  // :2800
         }
       }
@@ -162,7 +161,7 @@ __global__ __launch_bounds__(256) void sann_anneal_long_kernel(SannParams p, uin
       auto trial_at = [&](uint64_t e) {  // one coordinate of the trial point, the same in every lane
         if (e >= D) return 0.0;
         const uint64_t z1 = ctr_key(ks, 2 * e);
-        const double rn = sqrt(-2 * det_log(u01(z1))) * det_cos(2 * 3.141593 * u01_low32(z1));
+        const double rn = det_rnorm(z1);
         return pc[e] + current_scale * rn;
       };
       double acc = 0.0;
@@ -176,8 +175,7 @@ __global__ __launch_bounds__(256) void sann_anneal_long_kernel(SannParams p, uin
           for (int k = 0; k < 2; k++) {
             const uint64_t e = e_base + static_cast<uint64_t>(c) * 128 + 2 * static_cast<uint64_t>(lane) + k;
             const uint64_t z1 = mix64(kseg + kGolden * static_cast<uint64_t>(256 * c + 2 * k));
-            const double u1 = u01(z1), u2 = u01_low32(z1);
-            const double rn = sqrt(-2 * det_log(u1)) * det_cos(2 * 3.141593 * u2);  // rnorm, :2479-2485
+            const double rn = det_rnorm(z1);  // rnorm, :2479-2485
             vt[c][k] = (e < D) ? vc[c][k] + current_scale * rn : 0.0;  // :2800
           }
         store_segment<VEC>(pt, e_base, D, vt);
@@ -252,8 +250,7 @@ __global__ __launch_bounds__(256) void sann_anneal_groups_kernel(SannParams p, u
 #pragma unroll
       for (int k = 0; k < 2; k++) {
         const uint64_t z1 = mix64(ks_lane + kGolden * static_cast<uint64_t>(2 * k));  // one draw (slot 2e) per normal variate
-        const double u1 = u01(z1), u2 = u01_low32(z1);
-        const double rn = sqrt(-2 * det_log(u1)) * det_cos(2 * 3.141593 * u2);
+        const double rn = det_rnorm(z1);
         pt[k] = ((k ? in1 : in0)) ? pc[k] + current_scale * rn : 0.0;
       }
       const double current_val = p.fmul * group_objective<OBJ, G>(pt[0], pt[1], D);
