@@ -95,6 +95,23 @@ int nlsg_abi_version(void);
 /* Number of visible HIP devices whose arch is gfx950 (0 if none / no runtime). */
 int nlsg_device_count(void);
 
+/* The device's deterministic math primitives (the log / cos of rnorm nlsolver.h:2479-2485, the
+ * exp / tanh of the NLLS model, the cosine of Rastrigin test_functions.h:74-76) evaluated on n
+ * caller-chosen arguments: in / out are the IEEE-754 bit patterns of the doubles (for
+ * NLSG_PROBE_U01 and NLSG_PROBE_RNORM the input is the 64-bit draw itself). Exists so that the
+ * bit-for-bit agreement with the CPU restatement can be tested on the primitives directly. */
+typedef enum {
+  NLSG_PROBE_LOG = 0,
+  NLSG_PROBE_COS = 1,
+  NLSG_PROBE_EXP = 2,
+  NLSG_PROBE_TANH = 3,
+  NLSG_PROBE_COS_2PI = 4,
+  NLSG_PROBE_U01 = 5,   /* draw -> uniform in [0, 1] (xorshift::yield's conversion, :1358) */
+  NLSG_PROBE_RNORM = 6  /* draw -> normal variate (both uniforms from the one draw)       */
+} nlsg_probe_fn;
+int nlsg_probe_math(int32_t fn, const uint64_t *in_host, uint64_t *out_host, uint64_t n,
+                    int32_t device);
+
 /* solver_status<T> (nlsolver.h:2054-2097) plus engine bookkeeping. */
 typedef struct {
   double f_value;               /* best objective (sign as the solver minimises) */
@@ -372,7 +389,7 @@ typedef struct {
   int32_t solver;         /* nlsg_lm_solver                                          */
   uint64_t batch;         /* independent problems                                    */
   uint64_t m;             /* residuals per problem                                   */
-  uint64_t n;             /* parameters per problem (<= 64)                          */
+  uint64_t n;             /* parameters per problem (<= 1024; NLSG_LM_QR: <= 64)     */
   double lambda, up, down; /* ctor args lambda, upward_mult, downward_mult (:3443-45) */
   uint64_t max_iter;      /* :3446                                                   */
   double f_delta;         /* :3447                                                   */

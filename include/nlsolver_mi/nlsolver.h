@@ -1739,7 +1739,7 @@ class LevenbergMarquardt {
         max_iter(max_iter), f_delta(f_delta) {}
   // Device coverage of the default functors (fin_diff + fin_diff_h on a built-in objective,
   // nlsolver.h:3494-3511): the objectives whose arithmetic is deterministic on the device, up
-  // to 64 parameters.
+  // to the engine's 1024 parameters (past 64: a workgroup per problem instead of a wave).
   static constexpr bool device_fd() {
     if constexpr (device::is_device_objective<Callable>::value &&
                   std::is_same_v<Grad, fin_diff<Callable, scalar_t>> &&
@@ -1760,7 +1760,7 @@ class LevenbergMarquardt {
       return st[0];
     } else if constexpr (device_fd()) {
       if constexpr (Callable::nlsg_objective != NLSG_OBJ_CUSTOM)  // (Custom has no host evaluation)
-        if (x.size() > 64) return solve_host(x);  // beyond the device coverage: host functor path
+        if (x.size() > 1024) return solve_host(x);  // beyond the device coverage: host functor path
       std::vector<std::vector<scalar_t>> one{x};
       auto st = minimize_batch(one);
       x = one[0];

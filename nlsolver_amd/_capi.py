@@ -116,6 +116,7 @@ SYMBOLS = {
     "nlsg_last_error": (C.c_char_p, []),
     "nlsg_abi_version": (C.c_int, []),
     "nlsg_device_count": (C.c_int, []),
+    "nlsg_probe_math": (C.c_int, [C.c_int32, pu, pu, u64, C.c_int32]),
     "nlsg_de_create": (C.c_int, [C.POINTER(DEConfig), C.POINTER(_H)]),
     "nlsg_de_destroy": (C.c_int, [_H]),
     "nlsg_de_init": (C.c_int, [_H, pd]),
@@ -249,3 +250,18 @@ def pinned_empty(shape, dtype="float64"):
     buf = (C.c_char * nbytes).from_address(block.ptr.value)
     buf._nlsg_owner = block  # the array's base is `buf`; `buf` keeps the block alive
     return np.frombuffer(buf, dtype=dt, count=count).reshape(shape)
+
+
+PROBE_FUNCTIONS = {"log": 0, "cos": 1, "exp": 2, "tanh": 3, "cos_2pi": 4, "u01": 5, "rnorm": 6}
+
+
+def probe_math(fn, bits, device=0):
+    """nlsg_probe_math: the device's deterministic primitive `fn` ("log", "cos", "exp", "tanh",
+    "cos_2pi": argument = a double's bit pattern; "u01", "rnorm": argument = a 64-bit draw) on
+    a uint64 array; returns the results' bit patterns."""
+    import numpy as np
+    bits = np.ascontiguousarray(bits, dtype=np.uint64)
+    out = np.empty_like(bits)
+    check(lib().nlsg_probe_math(PROBE_FUNCTIONS[fn], bits.ctypes.data_as(pu), out.ctypes.data_as(pu),
+                                bits.size, device))
+    return out

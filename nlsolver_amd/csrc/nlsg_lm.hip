@@ -19,6 +19,8 @@ struct nlsg_lm {
   double *A_dev = nullptr, *y_dev = nullptr, *zero_dev = nullptr;
   unsigned long long *count_dev = nullptr;
   bool has_data = false;
+  bool wide = false;   // n > 64: the workgroup-per-problem kernels (lm_wide_*)
+  uint64_t ldt = kLmN; // row stride of theta / gg on the device: 64, or n when wide
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   LmRtcKernels rtc;  // objective == NLSG_OBJ_CUSTOM: the kernel hiprtc built for it
 };
@@ -26,6 +28,10 @@ struct nlsg_lm {
 namespace {
 int upload_theta(nlsg_lm *e, const double *theta_host) {
   const uint64_t B = e->p.batch, n = e->p.n;
+  if (e->wide) {
+    NLSG_HIP(hipMemcpy(e->p.theta, theta_host, B * n * sizeof(double), hipMemcpyHostToDevice));
+    return NLSG_OK;
+  }
   std::vector<double> padded(B * kLmN, 0.0);
   for (uint64_t b = 0; b < B; b++)
     for (uint64_t j = 0; j < n; j++) padded[b * kLmN + j] = theta_host[b * n + j];
@@ -69,10 +75,45 @@ void launch_fd_iter(nlsg_lm *e, int first) {
   }
 }
 
+// n > 64: evaluation (f, g, H at the current point) as one launch, a workgroup per problem
+template <int OBJ>
+void launch_wide_fd(nlsg_lm *e, dim3 grid, int first) {
+  const uint64_t n = e->p.n;
+  if (n <= 128)
+    hipLaunchKernelGGL((lm_wide_fd_eval_kernel<OBJ, 1>), grid, dim3(lm_wide_fd_threads(1)), 0, e->stream, e->p, first);
+  else if (n <= 256)
+    hipLaunchKernelGGL((lm_wide_fd_eval_kernel<OBJ, 2>), grid, dim3(lm_wide_fd_threads(2)), 0, e->stream, e->p, first);
+  else if (n <= 512)
+    hipLaunchKernelGGL((lm_wide_fd_eval_kernel<OBJ, 4>), grid, dim3(lm_wide_fd_threads(4)), 0, e->stream, e->p, first);
+  else
+    hipLaunchKernelGGL((lm_wide_fd_eval_kernel<OBJ, 8>), grid, dim3(lm_wide_fd_threads(8)), 0, e->stream, e->p, first);
+}
+void launch_wide_eval(nlsg_lm *e, int first) {
+  const dim3 grid(static_cast<unsigned>(e->p.batch));
+  if (!e->p.fd) {
+    hipLaunchKernelGGL(lm_wide_tanh_eval_kernel, grid, dim3(kLmWideThreads), 0, e->stream, e->p, first);
+    return;
+  }
+  if (e->cfg.objective == NLSG_OBJ_CUSTOM) {
+    void *args[] = {&e->p, &first};
+    const uint64_t n = e->p.n;
+    launch_module_kernel(e->rtc.iter, grid.x, lm_wide_fd_threads(n <= 512 ? 4 : 8), 0, e->stream, args);
+    return;
+  }
+  switch (e->cfg.objective) {
+    case NLSG_OBJ_ROSENBROCK: launch_wide_fd<NLSG_OBJ_ROSENBROCK>(e, grid, first); break;
+    case NLSG_OBJ_SPHERE: launch_wide_fd<NLSG_OBJ_SPHERE>(e, grid, first); break;
+    case NLSG_OBJ_RASTRIGIN: launch_wide_fd<NLSG_OBJ_RASTRIGIN>(e, grid, first); break;
+    default: launch_wide_fd<NLSG_OBJ_STYBLINSKI_TANG>(e, grid, first); break;
+  }
+}
+
 int launch_solve(nlsg_lm *e) {
   const dim3 grid(static_cast<unsigned>(e->p.batch));
   const bool qr = e->cfg.solver == NLSG_LM_QR, fd = e->p.fd != 0;
-  if (fd)
+  if (e->wide)
+    launch_wide_eval(e, 1);
+  else if (fd)
     launch_fd_iter(e, 1);
   else
     hipLaunchKernelGGL(lm_iter_kernel, grid, dim3(64), 0, e->stream, e->p, 1, 0);
@@ -82,7 +123,10 @@ int launch_solve(nlsg_lm *e) {
     const uint64_t left = e->p.max_iter + 1 - launched;
     const uint64_t chunk = left < 8 ? left : 8;
     for (uint64_t i = 0; i < chunk; i++) {
-      if (fd) {
+      if (e->wide) {
+        hipLaunchKernelGGL(lm_wide_step_kernel, grid, dim3(kLmWideThreads), 0, e->stream, e->p);
+        launch_wide_eval(e, 0);
+      } else if (fd) {
         launch_fd_iter(e, 0);
       } else if (qr) {
         hipLaunchKernelGGL(lm_qr_step_kernel<kLmQrThreads>, grid, dim3(kLmQrThreads), sizeof(LmQrShared), e->stream, e->p);
@@ -139,8 +183,15 @@ static int lm_create(const nlsg_lm_config *cfg, const nlsg_custom_objective *cus
   if (fd && cfg->solver != NLSG_LM_CHOLESKY)
     return fail(NLSG_ERR_UNSUPPORTED,
                 "the finite-difference model runs the reference's own solve (Cholesky) only");
-  if (cfg->n < 1 || cfg->n > kLmN || (!fd && cfg->m < 1) || cfg->batch < 1)
-    return fail(NLSG_ERR_INVALID_ARG, "need 1 <= n <= 64, m >= 1, batch >= 1");
+  if (cfg->n < 1 || (!fd && cfg->m < 1) || cfg->batch < 1)
+    return fail(NLSG_ERR_INVALID_ARG, "need n >= 1, m >= 1, batch >= 1");
+  const bool wide = cfg->n > kLmN;
+  if (cfg->n > kLmWideMaxN)
+    return fail(NLSG_ERR_UNSUPPORTED, "n = %llu > %d (a thread of the step follows at most four rows)",
+                (unsigned long long)cfg->n, kLmWideMaxN);
+  if (wide && cfg->solver != NLSG_LM_CHOLESKY)
+    return fail(NLSG_ERR_UNSUPPORTED, "the tinyqr solve is built for n <= 64; n = %llu runs the "
+                "class's own Cholesky solve", (unsigned long long)cfg->n);
   if (cfg->batch > 0x7fffffffull) return fail(NLSG_ERR_UNSUPPORTED, "batch too large");
   int rc = check_device(cfg->device);
   if (rc) return rc;
@@ -148,6 +199,8 @@ static int lm_create(const nlsg_lm_config *cfg, const nlsg_custom_objective *cus
   nlsg_lm *e = new (std::nothrow) nlsg_lm();
   if (!e) return fail(NLSG_ERR_OOM, "host allocation failed");
   e->cfg = *cfg;
+  e->wide = wide;
+  e->ldt = wide ? cfg->n : kLmN;
   if (cfg->stream) {
     e->stream = borrowed_stream(cfg->stream);
   } else {
@@ -162,17 +215,24 @@ static int lm_create(const nlsg_lm_config *cfg, const nlsg_custom_objective *cus
   std::memset(&p, 0, sizeof p);
   const uint64_t B = cfg->batch, m = fd ? 0 : cfg->m;  // no design matrix behind an objective
   hipError_t he = hipSuccess;
-  const uint64_t nstep = (m + 15) / 16;
+  const uint64_t nstep = wide ? 0 : (m + 15) / 16;
   p.nstep = nstep;
   if (he == hipSuccess && nstep)
     he = hipMalloc(reinterpret_cast<void **>(&e->A_dev), nstep * B * 16 * kLmN * 8);
   if (he == hipSuccess && nstep)
     he = hipMalloc(reinterpret_cast<void **>(&e->y_dev), nstep * B * 16 * 8);
-  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p.theta), B * kLmN * 8);
+  if (he == hipSuccess && wide && m) {  // the caller's layout, [batch][m][n]
+    he = hipMalloc(reinterpret_cast<void **>(&e->A_dev), B * m * cfg->n * 8);
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&e->y_dev), B * m * 8);
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p.rw), B * 2 * m * 8);
+  }
+  if (he == hipSuccess && wide)
+    he = hipMalloc(reinterpret_cast<void **>(&p.Hw), B * cfg->n * cfg->n * 8);
+  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p.theta), B * e->ldt * 8);
   if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p.prob), B * sizeof(LmProblem));
-  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p.Hg), B * kLmTri * 8);
-  if (he == hipSuccess) he = hipMemset(p.Hg, 0, B * kLmTri * 8);  // rows past n are never written
-  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p.gg), B * kLmN * 8);
+  if (he == hipSuccess && !wide) he = hipMalloc(reinterpret_cast<void **>(&p.Hg), B * kLmTri * 8);
+  if (he == hipSuccess && !wide) he = hipMemset(p.Hg, 0, B * kLmTri * 8);  // rows past n are never written
+  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p.gg), B * e->ldt * 8);
   if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&e->count_dev), 8);
   if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&e->zero_dev), 16);
   if (he == hipSuccess) he = hipMemset(e->zero_dev, 0, 16);
@@ -187,7 +247,9 @@ static int lm_create(const nlsg_lm_config *cfg, const nlsg_custom_objective *cus
                 "device setup failed: %s", hipGetErrorString(he));
   }
   if (custom) {
-    const int rc2 = rtc_build_lm(custom, &e->rtc);
+    const uint64_t n = cfg->n;
+    const int rc2 = rtc_build_lm(custom, !wide ? 0 : n <= 128 ? 1 : n <= 256 ? 2 : n <= 512 ? 4 : 8,
+                                 &e->rtc);
     if (rc2) {
       nlsg_lm_destroy(e);
       return rc2;
@@ -195,6 +257,8 @@ static int lm_create(const nlsg_lm_config *cfg, const nlsg_custom_objective *cus
   }
   p.A = e->A_dev;
   p.y = e->y_dev;
+  p.Aw = e->A_dev;
+  p.yw = e->y_dev;
   p.zero = e->zero_dev;
   p.batch = B;
   p.m = m;
@@ -222,6 +286,8 @@ int nlsg_lm_destroy(nlsg_lm *e) {
   hipFree(e->p.theta);
   hipFree(e->p.prob);
   hipFree(e->p.Hg);
+  hipFree(e->p.Hw);
+  hipFree(e->p.rw);
   hipFree(e->p.gg);
   hipFree(e->count_dev);
   hipFree(e->zero_dev);
@@ -238,6 +304,12 @@ int nlsg_lm_set_data(nlsg_lm *e, const double *a_host, const double *y_host) {
   if (e->p.fd) return fail(NLSG_ERR_STATE, "this engine minimises a built-in objective: no data");
   NLSG_HIP(hipSetDevice(e->cfg.device));
   const uint64_t B = e->p.batch, m = e->p.m, n = e->p.n;
+  if (e->wide) {  // kept as handed over
+    NLSG_HIP(hipMemcpy(e->A_dev, a_host, B * m * n * 8, hipMemcpyHostToDevice));
+    NLSG_HIP(hipMemcpy(e->y_dev, y_host, B * m * 8, hipMemcpyHostToDevice));
+    e->has_data = true;
+    return NLSG_OK;
+  }
   // host layout [problem][m][n] -> device layout [row group][problem][16][64] (zero padded):
   // problems that run side by side read one contiguous stretch of HBM per row group instead
   // of addresses a whole problem (m * 512 bytes) apart, which camp on a few channels.
@@ -306,6 +378,8 @@ int nlsg_lm_set_solver(nlsg_lm *e, int32_t solver) {
   if (!e) return fail(NLSG_ERR_INVALID_ARG, "null engine");
   if (solver != NLSG_LM_CHOLESKY && solver != NLSG_LM_QR)
     return fail(NLSG_ERR_INVALID_ARG, "unknown solver %d", solver);
+  if (e->wide && solver != NLSG_LM_CHOLESKY)
+    return fail(NLSG_ERR_UNSUPPORTED, "the tinyqr solve is built for n <= 64");
   if (e->p.fd && solver != NLSG_LM_CHOLESKY)
     return fail(NLSG_ERR_UNSUPPORTED,
                 "the finite-difference model runs the reference's own solve (Cholesky) only");
@@ -325,10 +399,14 @@ int nlsg_lm_minimize(nlsg_lm *e, double *theta_inout_host, nlsg_status *status_h
   NLSG_HIP(launches_status());
   NLSG_HIP(hipStreamSynchronize(e->stream));
   const uint64_t B = e->p.batch, n = e->p.n;
-  std::vector<double> padded(B * kLmN);
-  NLSG_HIP(hipMemcpy(padded.data(), e->p.theta, padded.size() * 8, hipMemcpyDeviceToHost));
-  for (uint64_t b = 0; b < B; b++)
-    for (uint64_t j = 0; j < n; j++) theta_inout_host[b * n + j] = padded[b * kLmN + j];
+  if (e->wide) {
+    NLSG_HIP(hipMemcpy(theta_inout_host, e->p.theta, B * n * 8, hipMemcpyDeviceToHost));
+  } else {
+    std::vector<double> padded(B * kLmN);
+    NLSG_HIP(hipMemcpy(padded.data(), e->p.theta, padded.size() * 8, hipMemcpyDeviceToHost));
+    for (uint64_t b = 0; b < B; b++)
+      for (uint64_t j = 0; j < n; j++) theta_inout_host[b * n + j] = padded[b * kLmN + j];
+  }
   std::vector<LmProblem> pr(B);
   NLSG_HIP(hipMemcpy(pr.data(), e->p.prob, B * sizeof(LmProblem), hipMemcpyDeviceToHost));
   for (uint64_t b = 0; b < B; b++) {
@@ -379,6 +457,7 @@ int nlsg_lm_time_solve(nlsg_lm *e, const double *theta0_host, uint32_t repeats, 
 int nlsg_lm_time_eval_kernel(nlsg_lm *e, const double *theta0_host, uint32_t repeats, float *ms_total) {
   if (!e || !theta0_host || !ms_total) return fail(NLSG_ERR_INVALID_ARG, "null argument");
   if (e->p.fd) return fail(NLSG_ERR_UNSUPPORTED, "Gauss-Newton model only");
+  if (e->wide) return fail(NLSG_ERR_UNSUPPORTED, "the one-wave evaluation kernel: n <= 64 only");
   if (!e->has_data) return fail(NLSG_ERR_STATE, "nlsg_lm_set_data has not been called");
   NLSG_HIP(hipSetDevice(e->cfg.device));
   int rc = upload_theta(e, theta0_host);
@@ -404,6 +483,7 @@ int nlsg_lm_time_eval_kernel(nlsg_lm *e, const double *theta0_host, uint32_t rep
 int nlsg_lm_time_qr_kernel(nlsg_lm *e, const double *theta0_host, uint32_t repeats, float *ms_total) {
   if (!e || !theta0_host || !ms_total) return fail(NLSG_ERR_INVALID_ARG, "null argument");
   if (e->p.fd) return fail(NLSG_ERR_UNSUPPORTED, "Gauss-Newton model only");
+  if (e->wide) return fail(NLSG_ERR_UNSUPPORTED, "the tinyqr step kernel: n <= 64 only");
   if (!e->has_data) return fail(NLSG_ERR_STATE, "nlsg_lm_set_data has not been called");
   NLSG_HIP(hipSetDevice(e->cfg.device));
   int rc = upload_theta(e, theta0_host);

@@ -54,6 +54,11 @@ struct LmParams {
   double *gg;        // [batch][64] 2 J^T r
   double eps_h;      // finite-difference model: step of fin_diff_h, pow(DBL_EPSILON, 1/4)
   int32_t fd, pad;   // 1: the functors are the reference's defaults on a built-in objective
+  // n > 64 (the lm_wide_* kernels below; theta and gg are then [batch][n]):
+  double *Hw;        // [batch][n][n] the Hessian as evaluated, row-major, both triangles
+  const double *Aw;  // [batch][m][n] design matrices in the caller's layout
+  const double *yw;  // [batch][m]
+  double *rw;        // [batch][2][m] residuals r_i and weights 1 - tanh^2 of the current evaluation
 };
 
 // The damped matrix as the Cholesky solve sees it: the packed lower triangle (the solve only
@@ -829,6 +834,320 @@ __global__ void lm_repack_kernel(LmParams p, const double *a_raw, const double *
   const uint64_t s = q / (16 * kLmN * nb), i = 16 * s + r, b = b0 + bl;
   A[((s * p.batch + b) * 16 + r) * kLmN + c] = (i < p.m && c < p.n) ? a_raw[(bl * p.m + i) * p.n + c] : 0.0;
   if (c == 0) y[(s * p.batch + b) * 16 + r] = i < p.m ? y_raw[b * p.m + i] : 0.0;
+}
+
+// ---- n > 64 (the reference has no limit, nlsolver.h:3428-3545): one WORKGROUP per problem, the
+// Hessian as a full n x n matrix in global memory (L2-resident: 128 KiB at n = 128), step and
+// evaluation as launches of their own. Same arithmetic rules as the one-wave kernels above, so
+// oracle_lm.c's order-1 restatement covers both: every element of the Cholesky factor is its
+// k-ordered fma chain (:251-269), the substitutions are column sweeps (forward sums in j order,
+// backward sums from j = n-1 down), the finite-difference probes are full lane-tree evaluations,
+// 2 J^T J is one fma chain over the rows per element. Built for generality, not for a roofline:
+// n <= 1024 (a thread follows at most four matrix rows; a wave holds a probe point).
+constexpr int kLmWideThreads = 256;
+constexpr int kLmWideMaxN = 1024;
+
+__global__ __launch_bounds__(kLmWideThreads) void lm_wide_step_kernel(LmParams p) {
+  __shared__ double piv[kLmWideMaxN];  // the pivot row of a column step / the solution vector
+  __shared__ double diag;
+  const uint64_t pid = blockIdx.x;
+  LmProblem *pr = p.prob + pid;
+  if (pr->done) return;
+  const int t = threadIdx.x, n = static_cast<int>(p.n);
+  constexpr int T = kLmWideThreads, R = kLmWideMaxN / kLmWideThreads;
+  const double prev = pr->prev, cur = pr->f;
+  if (pr->iter >= p.max_iter || fabs(prev - cur) < p.f_delta || isnan(prev)) {  // :3520-3527
+    __syncthreads();  // every thread has read `done` before it flips
+    if (t == 0) pr->done = 1;
+    return;
+  }
+  double *H = p.Hw + pid * p.n * p.n;
+  const double *g = p.gg + pid * p.n;
+  double *th = p.theta + pid * p.n;
+  const double lambda = pr->lambda;
+  for (int i = t; i < n; i += T) H[static_cast<uint64_t>(i) * n + i] += lambda;  // :3529-3531
+  __syncthreads();
+  // is_diagonal (:295-307): any off-diagonal of either triangle above eps * 1e12
+  bool off = false;
+  for (int i = 0; i < n; i++)
+    for (int j = t; j < n; j += T)
+      off |= (i != j) && H[static_cast<uint64_t>(i) * n + j] > 2.220446049250313e-16 * 1e12;
+  if (!__syncthreads_or(off)) {  // :310-318
+    for (int i = t; i < n; i += T) th[i] = th[i] - g[i] / H[static_cast<uint64_t>(i) * n + i];
+    return;
+  }
+  // cholesky (:251-269), column by column: L[i][j] = 1 / L[j][j] * (A[i][j] - sum_k<j L[i][k] L[j][k]),
+  // each sum one fma chain in k order (the diagonal's is the same chain on its own row)
+  double s[R];
+  for (int j = 0; j < n; j++) {
+    for (int k = t; k < j; k += T) piv[k] = H[static_cast<uint64_t>(j) * n + k];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+      const int i = t + T * q;
+      double sum = 0.0;
+      if (i >= j && i < n) {
+        const double *row = H + static_cast<uint64_t>(i) * n;
+        for (int k = 0; k < j; k++) sum = __builtin_fma(row[k], piv[k], sum);
+        if (i == j) diag = sqrt(row[j] - sum);
+      }
+      s[q] = sum;
+    }
+    __syncthreads();
+    const double d = diag;
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+      const int i = t + T * q;
+      if (i >= j && i < n) {
+        double *e = H + static_cast<uint64_t>(i) * n + j;
+        *e = i == j ? d : (1.0 / d * (*e - s[q]));
+      }
+    }
+    __syncthreads();
+  }
+  // forwardsolve_inplace (:282-294): column sweep, each row's sum grows in j order
+#pragma unroll
+  for (int q = 0; q < R; q++) s[q] = 0.0;
+  for (int j = 0; j < n; j++) {
+    if (t == (j & (T - 1))) {
+      double sj = 0.0;
+#pragma unroll
+      for (int q = 0; q < R; q++) sj = (j / T == q) ? s[q] : sj;
+      piv[j] = (g[j] - sj) / H[static_cast<uint64_t>(j) * n + j];
+    }
+    __syncthreads();
+    const double uj = piv[j];
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+      const int i = t + T * q;
+      if (i > j && i < n) s[q] = __builtin_fma(H[static_cast<uint64_t>(i) * n + j], uj, s[q]);
+    }
+  }
+  // backsolve_inplace_t (:270-281), the inner sums taken from j = n-1 down to i+1
+#pragma unroll
+  for (int q = 0; q < R; q++) s[q] = 0.0;
+  for (int j = n - 1; j >= 0; j--) {
+    if (t == (j & (T - 1))) {
+      double sj = 0.0;
+#pragma unroll
+      for (int q = 0; q < R; q++) sj = (j / T == q) ? s[q] : sj;
+      piv[j] = (piv[j] - sj) / H[static_cast<uint64_t>(j) * n + j];
+    }
+    __syncthreads();
+    const double bj = piv[j];
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+      const int i = t + T * q;
+      if (i < j) s[q] = __builtin_fma(H[static_cast<uint64_t>(j) * n + i], bj, s[q]);
+    }
+  }
+  __syncthreads();
+  for (int i = t; i < n; i += T) th[i] = th[i] - piv[i];  // :3534
+}
+
+// The default functors (fin_diff, fin_diff_h; see lm_fd_eval_groups above) for n > 64: sixteen
+// (n > 512: eight) waves per problem, a probe point per wave (CHUNKS x 128 coordinates in registers), gradient
+// coordinates and Hessian entries dealt to the waves round robin. Every probe is a full
+// wave_objective evaluation: the bits of the oracle's tree.
+__host__ __device__ constexpr int lm_wide_fd_threads(int chunks) {
+  return chunks >= 8 ? 512 : 1024;  // the 1024-coordinate point needs more than 128 registers
+}
+template <int OBJ, int CHUNKS>
+__global__ __launch_bounds__(lm_wide_fd_threads(CHUNKS)) void lm_wide_fd_eval_kernel(LmParams p, int first) {
+  const uint64_t pid = blockIdx.x;
+  LmProblem *pr = p.prob + pid;
+  if (!first && pr->done) return;
+  constexpr int W = lm_wide_fd_threads(CHUNKS) / 64;
+  const int lane = lane_id();
+  const int w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+  const uint64_t n = p.n;
+  const double *th = p.theta + pid * n;
+  double xv[CHUNKS][2];
+  load_row<CHUNKS, false>(th, n, p.zero, xv);
+  // the point with coordinate i set to vi and coordinate j set to vj (j wins when i == j: the
+  // reference's x[i] and x[j] are then the same element)
+  auto eval2 = [&](uint64_t i, double vi, uint64_t j, double vj) {
+    double xp[CHUNKS][2];
+#pragma unroll
+    for (int c = 0; c < CHUNKS; c++)
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const uint64_t e = static_cast<uint64_t>(c) * 128 + 2 * static_cast<uint64_t>(lane) + k;
+        xp[c][k] = e == j ? vj : e == i ? vi : xv[c][k];
+      }
+    return wave_objective<OBJ, CHUNKS>(xp, n);
+  };
+  {  // fin_diff<1> (:1385-1413)
+    constexpr double eps = 2.220446049250313e-16 * 10e7;
+    constexpr double dd_val = 12 * eps;
+    for (uint64_t d = w; d < n; d += W) {
+      const double xd = th[d];
+      double acc = 0.0;
+      acc = acc + 1.0 * eval2(d, xd + -2.0 * eps, d, xd + -2.0 * eps);
+      acc = acc + -8.0 * eval2(d, xd + -1.0 * eps, d, xd + -1.0 * eps);
+      acc = acc + 8.0 * eval2(d, xd + 1.0 * eps, d, xd + 1.0 * eps);
+      acc = acc + -1.0 * eval2(d, xd + 2.0 * eps, d, xd + 2.0 * eps);
+      if (lane == 0) p.gg[pid * n + d] = acc / dd_val;
+    }
+  }
+  // fin_diff_h<1> (:1446-1515): the sixteen probes of an entry, x[i] and x[j] walked through the
+  // reference's += / -= steps (one element when i == j)
+  const double e1 = p.eps_h, e2 = 2 * e1, e3 = 3 * e1, e4 = 4 * e1;
+  const double denom = (600.0 * e1 * e1);
+  double *H = p.Hw + pid * n * n;
+  for (uint64_t en = w; en < n * n; en += W) {
+    const uint64_t i = en / n, j = en - i * n;
+    const bool same = i == j;
+    double xi = th[i], xj = th[j];
+    auto add_i = [&](double d) { xi = xi + d; xj = same ? xi : xj; };
+    auto sub_i = [&](double d) { xi = xi - d; xj = same ? xi : xj; };
+    auto add_j = [&](double d) { xj = xj + d; xi = same ? xj : xi; };
+    auto sub_j = [&](double d) { xj = xj - d; xi = same ? xj : xi; };
+    auto f = [&]() { return eval2(i, xi, j, xj); };
+    double result = 0.0, temp = 0.0;
+    add_i(e1); sub_j(e2); temp = temp + f();
+    add_i(e1); add_j(e1); temp = temp + f();
+    sub_i(e4); add_j(e2); temp = temp + f();
+    add_i(e1); add_j(e1); temp = temp + f();
+    result = result - 63 * temp;
+    temp = 0.0;
+    sub_j(e4); temp = temp + f();
+    sub_i(e1); add_j(e1); temp = temp + f();
+    add_i(e3); add_j(e3); temp = temp + f();
+    add_i(e1); sub_j(e1); temp = temp + f();
+    result = result + 63 * temp;
+    temp = 0.0;
+    sub_j(e3); temp = temp + f();
+    sub_i(e4); add_j(e4); temp = temp + f();
+    sub_j(e4); temp = temp - f();
+    add_i(e4); add_j(e4); temp = temp - f();
+    result = result + 44 * temp;
+    temp = 0.0;
+    sub_i(e3); sub_j(e3); temp = temp + f();
+    add_i(e2); add_j(e2); temp = temp + f();
+    sub_j(e2); temp = temp - f();
+    sub_i(e2); add_j(e2); temp = temp - f();
+    result = result + 74 * temp;
+    if (lane == 0) H[en] = result / denom;
+  }
+  if (w == 0) {
+    const double fx = wave_objective<OBJ, CHUNKS>(xv, n);
+    if (lane == 0) lm_publish_state(p, pr, first, fx);
+  }
+}
+
+// Gauss-Newton functors of the tanh regression for n > 64: f = sum r^2, g = 2 J^T r, H = 2 J^T J
+// with J = -diag(1 - tanh^2(A theta)) A, in the order-1 sums of oracle_lm.c: z_i by 32 column
+// pairs per 64 columns (the pairs of later 64-column blocks continue each lane's fma chain), then
+// the xor butterfly 16..1; f in eight fma chains by (row / 16 mod 4, row parity); g_j in four by
+// row mod 4; H_jk one fma chain over the rows. A thread owns an 8 x 8 block of a 128 x 128
+// super-block of H; the scaled Jacobian rows of the two column ranges pass through LDS sixteen
+// rows at a time; the upper triangle is the mirror image (products commute: bitwise symmetric).
+__global__ __launch_bounds__(kLmWideThreads) void lm_wide_tanh_eval_kernel(LmParams p, int first) {
+  __shared__ double Jj[16][128 + 8], Jk[16][128 + 8];
+  __shared__ double part[8];
+  const uint64_t pid = blockIdx.x;
+  LmProblem *pr = p.prob + pid;
+  if (!first && pr->done) return;
+  constexpr int T = kLmWideThreads;
+  const int t = threadIdx.x, lane = lane_id(), w = t >> 6;
+  const uint64_t n = p.n, m = p.m;
+  const double *A = p.Aw + pid * m * n, *y = p.yw + pid * m, *th = p.theta + pid * n;
+  double *r = p.rw + pid * 2 * m, *wt = r + m;
+  // residuals and weights, a wave per row
+  const int lp = lane & 31;
+  for (uint64_t i = w; i < m; i += T / 64) {
+    const double *row = A + i * n;
+    double acc = 0.0;
+    for (uint64_t c0 = 0; c0 < n; c0 += 64) {
+      const uint64_t e0 = c0 + 2 * lp, e1 = e0 + 1;
+      const double a0 = e0 < n ? row[e0] : 0.0, b0 = e0 < n ? th[e0] : 0.0;
+      const double a1 = e1 < n ? row[e1] : 0.0, b1 = e1 < n ? th[e1] : 0.0;
+      acc = c0 == 0 ? __builtin_fma(a1, b1, a0 * b0) : __builtin_fma(a1, b1, __builtin_fma(a0, b0, acc));
+    }
+    acc = acc + lane_xor<16>(acc);
+    acc = acc + lane_xor<8>(acc);
+    acc = acc + lane_xor<4>(acc);
+    acc = acc + lane_xor<2>(acc);
+    acc = acc + lane_xor<1>(acc);
+    const double tz = det_tanh(acc);
+    if (lane == 0) {
+      r[i] = y[i] - tz;
+      wt[i] = 1 - tz * tz;
+    }
+  }
+  __syncthreads();
+  if (t < 8) {  // f: eight chains, idx = 2 * ((i % 64) / 16) + i % 2
+    double acc = 0.0;
+    for (uint64_t i = 0; i < m; i++) {
+      const uint64_t rb = i & 63;
+      if (2 * (rb >> 4) + (rb & 1) == static_cast<uint64_t>(t)) acc = __builtin_fma(r[i], r[i], acc);
+    }
+    part[t] = acc;
+  }
+  for (uint64_t j = t; j < n; j += T) {  // g_j: four chains by i mod 4, then ((a0 + a1) + a2) + a3
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    for (uint64_t i = 0; i < m; i++) {
+      const double Jij = -(wt[i] * A[i * n + j]);
+      const double v = __builtin_fma(Jij, r[i], a[i & 3]);
+      a[0] = (i & 3) == 0 ? v : a[0];
+      a[1] = (i & 3) == 1 ? v : a[1];
+      a[2] = (i & 3) == 2 ? v : a[2];
+      a[3] = (i & 3) == 3 ? v : a[3];
+    }
+    p.gg[pid * n + j] = 2 * (((a[0] + a[1]) + a[2]) + a[3]);
+  }
+  // H by super-blocks of the lower triangle
+  double *H = p.Hw + pid * n * n;
+  const int tj = t >> 4, tk = t & 15;
+  const uint64_t SB = (n + 127) / 128;
+  for (uint64_t bj = 0; bj < SB; bj++)
+    for (uint64_t bk = 0; bk <= bj; bk++) {
+      double acc[8][8];
+#pragma unroll
+      for (int a = 0; a < 8; a++)
+#pragma unroll
+        for (int b = 0; b < 8; b++) acc[a][b] = 0.0;
+      for (uint64_t i0 = 0; i0 < m; i0 += 16) {
+        __syncthreads();  // the previous group's tiles are consumed
+        for (int e = t; e < 16 * 128; e += T) {
+          const int rr = e >> 7, cc = e & 127;
+          const uint64_t i = i0 + rr, cj = bj * 128 + cc, ck = bk * 128 + cc;
+          const double wi = i < m ? wt[i] : 0.0;
+          Jj[rr][cc] = (i < m && cj < n) ? -(wi * A[i * n + cj]) : 0.0;
+          Jk[rr][cc] = (i < m && ck < n) ? -(wi * A[i * n + ck]) : 0.0;
+        }
+        __syncthreads();
+        for (int rr = 0; rr < 16; rr++) {  // rows in order: each element's one fma chain
+          double vj[8], vk[8];
+#pragma unroll
+          for (int a = 0; a < 8; a++) vj[a] = Jj[rr][tj * 8 + a];
+#pragma unroll
+          for (int b = 0; b < 8; b++) vk[b] = Jk[rr][tk * 8 + b];
+#pragma unroll
+          for (int a = 0; a < 8; a++)
+#pragma unroll
+            for (int b = 0; b < 8; b++) acc[a][b] = __builtin_fma(vj[a], vk[b], acc[a][b]);
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < 8; a++)
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+          const uint64_t j = bj * 128 + tj * 8 + a, k = bk * 128 + tk * 8 + b;
+          if (j < n && k < n) {
+            const double v = 2 * acc[a][b];
+            H[j * n + k] = v;
+            H[k * n + j] = v;
+          }
+        }
+    }
+  __syncthreads();
+  if (t == 0) {
+    double f = 0.0;
+    for (int k = 0; k < 8; k++) f = f + part[k];
+    lm_publish_state(p, pr, first, f);
+  }
 }
 
 __global__ void lm_count_unfinished_kernel(LmParams p, unsigned long long *count) {

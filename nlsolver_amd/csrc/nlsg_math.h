@@ -96,6 +96,34 @@ __device__ inline double det_cos(double y) {
   return q == 0 ? c : q == 1 ? -s : q == 2 ? -c : s;
 }
 
+// n / d and sqrt(x) as the compiler expands them for gfx950 (v_rcp_f64 / v_rsq_f64 seed, the same
+// Newton and residual steps, hence the same correctly rounded results — tests/test_math_gpu.py
+// checks them against the CPU's division and sqrt on millions of arguments) minus the operand
+// scaling and the special-case fix-up, for operands that need neither: the division for
+// 1 < d < 4 and |n| < 1 (or n = 0), the root for x = 0, x = +inf or x >= 2^-767.
+__device__ inline double div_midrange(double n, double d) {
+  double y = __builtin_amdgcn_rcp(d);
+  double e = __builtin_fma(-d, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-d, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  const double q = n * y;
+  const double r = __builtin_fma(-d, q, n);
+  return __builtin_fma(r, y, q);
+}
+__device__ inline double sqrt_unscaled(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  return (x == 0.0 || x == __builtin_inf()) ? x : g;
+}
+
 // One normal variate from one 64-bit draw z (rnorm, nlsolver.h:2479-2485):
 // sqrt(-2 log u1) * cos(2 * 3.141593 * u2) with u1 = z 2^-64 and u2 = (z mod 2^32) 2^-32 — the
 // values det_log and det_cos give (the CPU restatement calls exactly those), written for the
@@ -113,8 +141,12 @@ __device__ inline double det_rnorm(uint64_t zbits) {
                    Lg7 = 1.479819860511658591e-01;
   constexpr double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00,
                    pio2_1t = 6.07710050650619224932e-11;
-  const double u1 = static_cast<double>(zbits) * 0x1p-64;
-  const double u2 = static_cast<double>(static_cast<uint32_t>(zbits)) * 0x1p-32;
+  // u1 = (double)z 2^-64 rounded once, as the conversion rounds: hi 2^-32 + lo 2^-64 in one fma
+  // (both terms exact); the angle y = 2 pi_ u2 = lo (2 pi_ 2^-32) — scaling by 2^-32 is exact, so
+  // the one rounding is that of 2 pi_ u2
+  const double hi_d = static_cast<double>(static_cast<uint32_t>(zbits >> 32));
+  const double lo_d = static_cast<double>(static_cast<uint32_t>(zbits));
+  const double u1 = __builtin_fma(hi_d, 0x1p-32, lo_d * 0x1p-64);
   // log u1 (det_log's normal-number path)
   const uint64_t u = static_cast<uint64_t>(__double_as_longlong(u1));
   uint32_t hx = static_cast<uint32_t>(u >> 32);
@@ -125,7 +157,7 @@ __device__ inline double det_rnorm(uint64_t zbits) {
       static_cast<long long>((static_cast<uint64_t>(hx) << 32) | (u & 0xffffffffull)));
   const double f = m - 1.0;
   const double hfsq = 0.5 * f * f;
-  const double s = f / (2.0 + f);
+  const double s = div_midrange(f, 2.0 + f);  // = f / (2.0 + f): 1.7 < 2 + f < 2.42
   const double z = s * s;
   const double w = z * z;
   const double t1 = w * fma_k(w, __builtin_fma(w, Lg6, Lg4), Lg2);
@@ -135,7 +167,7 @@ __device__ inline double det_rnorm(uint64_t zbits) {
   double lg = s * (hfsq + R) + dk * ln2_lo - hfsq + f + dk * ln2_hi;
   lg = u1 == 0.0 ? -__builtin_inf() : lg;
   // cos(2 pi_ u2) (det_cos's path for 0 <= y <= 64)
-  const double y = 2 * 3.141593 * u2;
+  const double y = lo_d * (2 * 3.141593 * 0x1p-32);
   const double fn = floor(__builtin_fma(y, invpio2, 0.5));
   const double r = __builtin_fma(-fn, pio2_1t, __builtin_fma(-fn, pio2_1, y));
   const uint32_t q = static_cast<uint32_t>(static_cast<int>(fn));  // 0 .. 4
@@ -144,7 +176,7 @@ __device__ inline double det_rnorm(uint64_t zbits) {
   const uint64_t mag = static_cast<uint64_t>(__double_as_longlong((q & 1u) ? sn : c));
   const uint64_t flip = static_cast<uint64_t>((q + 1u) & 2u) << 62;
   const double cs = __longlong_as_double(static_cast<long long>(mag ^ flip));
-  return sqrt(-2 * lg) * cs;
+  return sqrt_unscaled(-2 * lg) * cs;  // -2 lg is 0, +inf or at least 2^-53
 }
 
 // cos(2 pi x) the way the reference's Rastrigin writes it (test_functions.h:74-76): the product

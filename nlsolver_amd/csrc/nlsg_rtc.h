@@ -38,7 +38,9 @@ struct LmRtcKernels {  // finite-difference model (default functors) around the 
   hipModule_t mod = nullptr;
   hipFunction_t iter = nullptr;
 };
-int rtc_build_lm(const nlsg_custom_objective *obj, LmRtcKernels *out);
+// wide_chunks != 0: the evaluation kernel of the n > 64 path (a probe point of wide_chunks x 128
+// coordinates per wave) instead of the one-wave iteration kernel
+int rtc_build_lm(const nlsg_custom_objective *obj, int wide_chunks, LmRtcKernels *out);
 void rtc_release(LmRtcKernels *k);
 struct HybRtcKernels {
   hipModule_t mod = nullptr;

@@ -320,12 +320,14 @@ void rtc_release(SannRtcKernels *k) {
   if (k) *k = SannRtcKernels();
 }
 
-int rtc_build_lm(const nlsg_custom_objective *obj, LmRtcKernels *out) {
+int rtc_build_lm(const nlsg_custom_objective *obj, int wide_chunks, LmRtcKernels *out) {
   std::vector<hipFunction_t> f;
   LmRtcKernels k;
-  const int rc = rtc_compile(obj, "nlsg_lm_kernels.h",
-                             {"nlsg::lm_fd_iter_kernel<" + std::to_string(static_cast<int>(NLSG_OBJ_CUSTOM)) + ">"},
-                             &k.mod, &f);
+  const std::string id = std::to_string(static_cast<int>(NLSG_OBJ_CUSTOM));
+  const std::string name = wide_chunks ? "nlsg::lm_wide_fd_eval_kernel<" + id + ", " +
+                                             std::to_string(wide_chunks) + ">"
+                                       : "nlsg::lm_fd_iter_kernel<" + id + ">";
+  const int rc = rtc_compile(obj, "nlsg_lm_kernels.h", {name}, &k.mod, &f);
   if (rc) return rc;
   k.iter = f[0];
   *out = k;

@@ -259,13 +259,16 @@ static void residual_jacobian(const orc_nlls *q, const double *x, double *r, dou
       if (order == 0) {
         for (size_t j = 0; j < n; j++) z += q->A[i * n + j] * x[j];
         th = tanh(z);
-      } else { /* kernel order: 32 column pairs, xor butterfly 16..1 (columns >= n are 0) */
+      } else { /* kernel order: 32 column pairs per block of 64 columns (columns >= n are 0; the
+                * pairs of later blocks continue each lane's fma chain), xor butterfly 16..1 */
         double lane[32], tmp[32];
         for (size_t l = 0; l < 32; l++) {
-          const double a0 = 2 * l < n ? q->A[i * n + 2 * l] : 0.0, b0 = 2 * l < n ? x[2 * l] : 0.0;
-          const double a1 = 2 * l + 1 < n ? q->A[i * n + 2 * l + 1] : 0.0,
-                       b1 = 2 * l + 1 < n ? x[2 * l + 1] : 0.0;
-          lane[l] = fma(a1, b1, a0 * b0);
+          for (size_t c0 = 0; c0 == 0 || c0 < n; c0 += 64) {
+            const size_t e0 = c0 + 2 * l, e1 = e0 + 1;
+            const double a0 = e0 < n ? q->A[i * n + e0] : 0.0, b0 = e0 < n ? x[e0] : 0.0;
+            const double a1 = e1 < n ? q->A[i * n + e1] : 0.0, b1 = e1 < n ? x[e1] : 0.0;
+            lane[l] = c0 == 0 ? fma(a1, b1, a0 * b0) : fma(a1, b1, fma(a0, b0, lane[l]));
+          }
         }
         for (int off = 16; off >= 1; off >>= 1) {
           for (int l = 0; l < 32; l++) tmp[l] = lane[l] + lane[l ^ off];

@@ -104,3 +104,30 @@ double orc_cos(double y) {
     default: return kernel_sin(r);
   }
 }
+
+/* One normal variate from one 64-bit draw (rnorm, nlsolver.h:2479-2485): u1 (the radius) from
+ * all of the draw, u2 (the angle) from its low 32 bits — what nlsg_math.h's det_rnorm computes
+ * on the device. */
+double orc_rnorm(uint64_t z1) {
+  const double pi_ = 3.141593; /* the reference's literal, :2480 */
+  const double u1 = orc_u01(z1), u2 = (double)(uint32_t)z1 * 0x1p-32;
+  return sqrt(-2 * orc_log(u1)) * orc_cos(2 * pi_ * u2);
+}
+
+/* The primitives on arrays of bit patterns (the CPU side of nlsg_probe_math; fn = nlsg_probe_fn) */
+void orc_probe_math(int fn, const uint64_t *in, uint64_t *out, size_t n) {
+  for (size_t i = 0; i < n; i++) {
+    const double x = from_bits(in[i]);
+    double r;
+    switch (fn) {
+      case 0: r = orc_log(x); break;
+      case 1: r = orc_cos(x); break;
+      case 2: r = orc_exp(x); break;
+      case 3: r = orc_tanh(x); break;
+      case 4: r = orc_cos_2pi(x); break;
+      case 5: r = orc_u01(in[i]); break;
+      default: r = orc_rnorm(in[i]); break;
+    }
+    out[i] = bits_of(r);
+  }
+}

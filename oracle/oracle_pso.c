@@ -129,12 +129,8 @@ orc_status orc_pso_serial(int obj, int minimize, int type, int bounded, double *
 /* Synchronous restatement (what the GPU executes)                            */
 /* ------------------------------------------------------------------------- */
 static double rnorm_ctr(uint64_t kp, size_t j) {
-  const double pi_ = 3.141593;
-  /* one draw (slot 2j) per normal variate: u1 from all of it, u2 from its low 32 bits
-   * (nlsg_common.h u01_low32) */
-  const uint64_t z1 = orc_ctr_key(kp, 2 * j);
-  const double u1 = orc_u01(z1), u2 = (double)(uint32_t)z1 * 0x1p-32;
-  return sqrt(-2 * orc_log(u1)) * orc_cos(2 * pi_ * u2);
+  /* one draw (slot 2j) per normal variate: u1 from all of it, u2 from its low 32 bits */
+  return orc_rnorm(orc_ctr_key(kp, 2 * j));
 }
 
 void orc_pso_sync_init(orc_pso_sync *s) {

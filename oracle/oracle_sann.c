@@ -68,7 +68,7 @@ orc_status orc_sann_serial(int obj, int minimize, double *x, size_t D, orc_xorsh
 orc_status orc_sann_sync(int obj, int minimize, double *x, size_t D, uint64_t seed, uint64_t chain,
                          size_t max_iter, size_t temp_iter, double temp_max, double *f_log,
                          size_t f_cap) {
-  const double fm = minimize ? 1.0 : -1.0, e_minus_1 = 1.7182818, pi_ = 3.141593;
+  const double fm = minimize ? 1.0 : -1.0, e_minus_1 = 1.7182818;
   size_t f_evals = 0, logged = 0, iter = 0;
   const uint64_t kc = orc_ctr_key(seed, chain);
   double fv = orc_objective_tree(obj, x, D);
@@ -86,9 +86,8 @@ orc_status orc_sann_sync(int obj, int minimize, double *x, size_t D, uint64_t se
       const uint64_t ks = orc_ctr_key(kc, iter * (temp_iter - 1) + (j - 1));
       const double current_scale = t * scale;
       for (size_t i = 0; i < D; i++) {
-        const uint64_t z1 = orc_ctr_key(ks, 2 * i); /* one draw per normal variate (u01_low32) */
-        const double u1 = orc_u01(z1), u2 = (double)(uint32_t)z1 * 0x1p-32;
-        ptry[i] = p[i] + current_scale * (sqrt(-2 * orc_log(u1)) * orc_cos(2 * pi_ * u2));
+        const uint64_t z1 = orc_ctr_key(ks, 2 * i); /* one draw per normal variate */
+        ptry[i] = p[i] + current_scale * orc_rnorm(z1);
       }
       fv = orc_objective_tree(obj, ptry, D);
       log_value(f_log, f_cap, &logged, fv);

@@ -277,6 +277,9 @@ def load():
         fn = getattr(lib, name)
         fn.restype = f64
         fn.argtypes = [f64]
+    lib.orc_rnorm.restype = f64
+    lib.orc_rnorm.argtypes = [u64]
+    lib.orc_probe_math.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), sz]
     lib.orc_cholesky.argtypes = [pd, sz]
     lib.orc_update_with_hessian.argtypes = [pd, pd, pd, sz]
     lib.orc_qr_decomposition.argtypes = [pd, sz, sz, f64, pd, pd]
@@ -501,3 +504,15 @@ class OraclePSOShardEngine:
             return
         self.lib.orc_pso_shard_move(C.byref(s), self.lo, self.m, 1)
         self.lib.orc_pso_commit(C.byref(s))
+
+
+PROBE = {"log": 0, "cos": 1, "exp": 2, "tanh": 3, "cos_2pi": 4, "u01": 5, "rnorm": 6}
+
+
+def probe_math(lib, fn, bits):
+    """The oracle's math primitive `fn` on an array of uint64 bit patterns (cf. nlsg_probe_math)."""
+    bits = np.ascontiguousarray(bits, dtype=np.uint64)
+    out = np.empty_like(bits)
+    pu = C.POINTER(C.c_uint64)
+    lib.orc_probe_math(PROBE[fn], bits.ctypes.data_as(pu), out.ctypes.data_as(pu), bits.size)
+    return out

@@ -259,9 +259,9 @@ def test_nm_device_objective_through_header_matches_oracle(built, oracle, golden
 
 
 @pytest.mark.gpu
-def test_lm_device_model_through_header_matches_oracle(built, oracle):
+@pytest.mark.parametrize("m,n,B,iters", [(96, 12, 3, 15), (120, 80, 2, 6)])
+def test_lm_device_model_through_header_matches_oracle(built, oracle, m, n, B, iters):
     import math
-    m, n, B, iters = 96, 12, 3, 15
     out = subprocess.check_output([os.path.join(built, "header_nm_lm"), "lm-device", str(m), str(n),
                                    str(B), str(iters)], env=dict(os.environ, NLSG_LIBRARY=LIB),
                                   text=True)
@@ -287,7 +287,7 @@ def test_lm_device_model_through_header_matches_oracle(built, oracle):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["lm-device-fd", "lm-device-fd-custom"])
-@pytest.mark.parametrize("n,iters", [(2, 12), (5, 8), (16, 4)])
+@pytest.mark.parametrize("n,iters", [(2, 12), (5, 8), (16, 4), (70, 2)])
 def test_lm_default_functors_on_device_objective_through_header(built, oracle, n, iters, mode):
     """LevenbergMarquardt<device::Rosenbrock<double>, double>(f).minimize(x): fin_diff and
     fin_diff_h (nlsolver.h:3494-3511) evaluated on the GPU; bit-exact vs the tree oracle."""

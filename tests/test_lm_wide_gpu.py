@@ -1,0 +1,113 @@
+"""Parity tests of the LM engine past 64 parameters (the reference class has no limit,
+nlsolver.h:3428-3545): the workgroup-per-problem kernels (lm_wide_step_kernel: Cholesky in the
+reference's per-element sums; lm_wide_tanh_eval_kernel: Gauss-Newton functors; lm_wide_fd_eval_kernel:
+the default fin_diff / fin_diff_h functors) against oracle_lm.c in the kernels' operation order
+(order = 1) — bit-exact parameters, objective values, damping and counters — and against the
+reference's arithmetic (order = 0) within rounding."""
+import numpy as np
+import pytest
+
+from tests import _oracle as O
+from tests.test_lm_gpu import fd_starts, problems
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mod():
+    import torch
+    assert torch.cuda.is_available()
+    import nlsolver_amd
+    return nlsolver_amd
+
+
+def check(st, ref, th, xr, lam, lam_r, tag):
+    assert (st.iteration, st.function_calls_used, st.gradient_evals_used, st.hessian_evals_used) == \
+           (ref.iteration, ref.function_calls_used, ref.gradient_evals_used, ref.hessian_evals_used), tag
+    assert np.array_equal(st.f_value, ref.f_value, equal_nan=True), (tag, st.f_value, ref.f_value)
+    assert np.array_equal(th, xr, equal_nan=True), (tag, np.flatnonzero(th != xr)[:8])
+    assert np.array_equal(lam, lam_r, equal_nan=True), tag
+
+
+@pytest.mark.parametrize("m,n,batch", [(80, 65, 3), (200, 100, 3), (300, 128, 2), (150, 129, 2),
+                                       (260, 200, 2), (40, 70, 2)])
+@pytest.mark.parametrize("kw", [dict(lam=10.0, max_iter=8, f_delta=0.0),
+                                dict(lam=0.5, up=4.0, down=3.0, max_iter=100, f_delta=1e-12)])
+def test_lm_wide_tanh_bit_exact_vs_kernel_order_oracle(mod, oracle, m, n, batch, kw):
+    A, y, t0 = problems(oracle, 7, batch, m, n)
+    with mod.LMEngine(mod.TanhRegression(A, y), **kw) as eng:
+        th, st, lam = eng.minimize(t0.copy())
+    for b in range(batch):
+        ref, xr, lam_r, _ = O.lm_solve(oracle, A[b], y[b], t0[b], order=1, **kw)
+        check(st[b], ref, th[b], xr, lam[b], lam_r, (m, n, b))
+
+
+def test_lm_wide_tanh_agrees_with_reference_arithmetic(mod, oracle):
+    """Against the serial oracle (the reference's sequential sums and libm tanh): after one
+    iteration the parameters agree to rounding, and the run converges to the planted solution."""
+    m, n = 400, 96
+    A, y, t0 = problems(oracle, 3, 2, m, n)
+    for b in range(2):
+        x = t0[b].copy()
+        st = mod.LevenbergMarquardt(mod.TanhRegression(A[b], y[b]), 10.0, 10.0, 10.0, 1, 0.0).minimize(x)
+        ser, xs, _, _ = O.lm_solve(oracle, A[b], y[b], t0[b], order=0, lam=10.0, max_iter=1, f_delta=0.0)
+        assert st.iteration == ser.iteration == 1
+        assert np.max(np.abs(x - xs)) <= 1e-12 and abs(st.f_value - ser.f_value) <= 1e-12 * ser.f_value
+        x = t0[b].copy()
+        st = mod.LevenbergMarquardt(mod.TanhRegression(A[b], y[b]), 10.0, 10.0, 10.0, 30, 0.0).minimize(x)
+        assert st.f_value < 1e-20
+
+
+@pytest.mark.parametrize("objective,n,scale", [("rosenbrock", 65, 1.0), ("sphere", 100, 3.0),
+                                               ("styblinski_tang", 129, 4.0), ("rastrigin", 70, 4.0),
+                                               ("rosenbrock", 130, 1.0)])
+def test_lm_wide_default_functors_bit_exact_vs_oracle(mod, oracle, objective, n, scale):
+    kw = dict(lam=1.0, up=4.0, down=3.0, max_iter=2, f_delta=0.0)
+    batch = 2
+    x0 = fd_starts(oracle, objective, batch, n, scale)
+    with mod.lm.LMEngine(objective, batch=batch, n=n, **kw) as eng:
+        x, st, lam = eng.minimize(x0.copy())
+    for b in range(batch):
+        ref, xr, lam_r, _ = O.lm_fd(oracle, objective, x0[b], order=1, **kw)
+        check(st[b], ref, x[b], xr, lam[b], lam_r, (objective, n, b))
+        assert st[b].function_calls_used == 3 * (1 + 4 * n + 16 * n * n)
+
+
+def test_lm_wide_default_functors_long_point(mod, oracle):
+    """A probe point past 256 coordinates (more than two 128-coordinate chunks per wave)."""
+    n, kw = 300, dict(lam=1.0, max_iter=1, f_delta=0.0)
+    x0 = fd_starts(oracle, "sphere", 1, n, 2.0)
+    with mod.lm.LMEngine("sphere", batch=1, n=n, **kw) as eng:
+        x, st, lam = eng.minimize(x0.copy())
+    ref, xr, lam_r, _ = O.lm_fd(oracle, "sphere", x0[0], order=1, **kw)
+    check(st[0], ref, x[0], xr, lam[0], lam_r, n)
+
+
+def test_lm_wide_custom_objective_equals_builtin(mod):
+    rosen = "double t1 = 1 - xi; double t2 = (xn - xi * xi); return t1 * t1 + 100 * t2 * t2;"
+    n, kw = 72, dict(lam=1.0, max_iter=1, f_delta=0.0)
+    x0 = np.linspace(-1.0, 1.0, 2 * n).reshape(2, n)
+    out = []
+    for obj in ("rosenbrock", mod.CustomObjective(rosen, chain=True)):
+        with mod.lm.LMEngine(obj, batch=2, n=n, **kw) as eng:
+            x, st, lam = eng.minimize(x0.copy())
+        out.append((x, [(s.f_value, s.function_calls_used) for s in st], lam))
+    assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
+
+
+def test_lm_wide_diagonal_shortcut_and_limits(mod, oracle):
+    """Sphere's finite-difference Hessian at a point where every off-diagonal probe difference
+    vanishes takes is_diagonal's shortcut (:310-318) — same branch in kernel and oracle; QR and
+    n > 1024 are refused."""
+    from nlsolver_amd._capi import LM_QR, NlsgError
+    n, kw = 66, dict(lam=2.0, max_iter=2, f_delta=0.0)
+    x0 = np.zeros((1, n))
+    with mod.lm.LMEngine("sphere", batch=1, n=n, **kw) as eng:
+        x, st, lam = eng.minimize(x0.copy())
+    ref, xr, lam_r, _ = O.lm_fd(oracle, "sphere", x0[0], order=1, **kw)
+    check(st[0], ref, x[0], xr, lam[0], lam_r, "diag")
+    A, y, _ = problems(oracle, 0, 1, 80, 70)
+    with pytest.raises(NlsgError):
+        mod.LMEngine(mod.TanhRegression(A, y), solver=LM_QR)
+    with pytest.raises(NlsgError):
+        mod.lm.LMEngine("sphere", batch=1, n=1025)
