@@ -12,6 +12,8 @@ namespace {
 
 __global__ __launch_bounds__(256) void probe_kernel(int fn, const uint64_t *in, uint64_t *out,
                                                     uint64_t n) {
+  __shared__ double rn_tab[kRnormTabDoubles];
+  rnorm_table_to_lds(rn_tab);
   const uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (i >= n) return;
   const uint64_t b = in[i];
@@ -24,7 +26,7 @@ __global__ __launch_bounds__(256) void probe_kernel(int fn, const uint64_t *in, 
     case NLSG_PROBE_TANH: r = det_tanh(x); break;
     case NLSG_PROBE_COS_2PI: r = det_cos_2pi(x); break;
     case NLSG_PROBE_U01: r = u01(b); break;
-    default: r = det_rnorm(b); break;  // NLSG_PROBE_RNORM: the input is the 64-bit draw
+    default: r = det_rnorm(b, rn_tab); break;  // NLSG_PROBE_RNORM: the input is the 64-bit draw
   }
   out[i] = static_cast<uint64_t>(__double_as_longlong(r));
 }

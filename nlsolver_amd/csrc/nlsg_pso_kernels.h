@@ -108,35 +108,44 @@ template <int OBJ, int CHUNKS, bool VEC, int TYPE>
 __global__ __launch_bounds__(256) void pso_move_kernel(PsoParams p, int timing, uint64_t iter_ovr) {
   const PsoState *__restrict__ st = p.state;
   if (!timing && st->done) return;
-  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * 4 +
-                     __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
-  if (i >= p.shard_n) return;
+  // the logarithm table of det_rnorm (Accelerated only; a workgroup-wide step, so before any
+  // wave leaves)
+  __shared__ double rn_tab[TYPE == NLSG_PSO_ACCELERATED ? kRnormTabDoubles : 1];
+  if (TYPE == NLSG_PSO_ACCELERATED) rnorm_table_to_lds(rn_tab);
+  // A wave takes particles i0, i0 + (waves in the grid), ...: the rows every particle reads
+  // (swarm best, bounds), the iteration's key and inertia, and the table above are fetched once
+  // per wave instead of once per particle (they were 3/5 of the kernel's L2 reads).
+  const uint64_t nwaves = static_cast<uint64_t>(gridDim.x) * 4;
   const int lane = lane_id();
   const uint64_t D = p.D;
   const uint64_t iter = timing ? iter_ovr : st->iter;
-  const uint64_t kp = ctr_key(ctr_key(p.seed, iter + 1), p.shard_lo + i);
-
-  double xv[CHUNKS][2], gb[CHUNKS][2], lo[CHUNKS][2], hi[CHUNKS][2];
-  double vv[CHUNKS][2], pb[CHUNKS][2];
-  double *row = p.pos + i * D;
-  load_row_stream<CHUNKS, VEC>(row, D, p.zero, xv);
+  const uint64_t kit = ctr_key(p.seed, iter + 1);
+  double gb[CHUNKS][2], lo[CHUNKS][2], hi[CHUNKS][2];
   load_row<CHUNKS, VEC>(p.gbest_x, D, p.zero, gb);
   // bounds are only needed when thresholding; unbounded runs read the zero pad
   load_row<CHUNKS, VEC>(p.lower, p.bounded ? D : 0, p.zero, lo);
   load_row<CHUNKS, VEC>(p.upper, p.bounded ? D : 0, p.zero, hi);
+  double inertia = p.inertia;
+  if (TYPE == NLSG_PSO_ACCELERATED)  // :2613 inertia = pow(init_inertia, iter)
+    inertia = pso_inertia_at(p, iter);
+  const uint64_t lane_off = kGolden * (4 * static_cast<uint64_t>(lane) + 1);
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * 4 +
+                    __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+       i < p.shard_n; i += nwaves) {
+  const uint64_t kp = ctr_key(kit, p.shard_lo + i);
+  double xv[CHUNKS][2], vv[CHUNKS][2], pb[CHUNKS][2];
+  double *row = p.pos + i * D;
+  load_row_stream<CHUNKS, VEC>(row, D, p.zero, xv);
   if (TYPE == NLSG_PSO_VANILLA) {
     load_row_stream<CHUNKS, VEC>(p.vel + i * D, D, p.zero, vv);
     load_row_stream<CHUNKS, VEC>(p.pbest_pos + i * D, D, p.zero, pb);
   }
   const double old_pbest = p.pbest_val[i];
-  double inertia = p.inertia;
-  if (TYPE == NLSG_PSO_ACCELERATED)  // :2613 inertia = pow(init_inertia, iter)
-    inertia = pso_inertia_at(p, iter);
 
   // draws 2e and 2e+1 of element e = 128 c + 2 lane + k: ctr_key(kp, j) = mix64(kp + G (j + 1))
   // with j + 1 = (4 lane + 1) + (256 c + 2 k [+ 1]) -- one 64-bit multiply per wave, the rest
-  // are compile-time constants (64-bit multiplies are four quarter-rate 32-bit ones each)
-  const uint64_t kp_lane = kp + kGolden * (4 * static_cast<uint64_t>(lane) + 1);
+  // are compile-time constants
+  const uint64_t kp_lane = kp + lane_off;
 #pragma unroll
   for (int c = 0; c < CHUNKS; c++) {
 #pragma unroll
@@ -152,7 +161,7 @@ __global__ __launch_bounds__(256) void pso_move_kernel(PsoParams p, int timing, 
       double pnew;
       if (TYPE == NLSG_PSO_ACCELERATED) {
         // rnorm (2479-2485): sqrt(-2 log u1) * cos(2 pi_ u2), pi_ = 3.141593
-        const double rn = det_rnorm(z1);
+        const double rn = det_rnorm(z1, rn_tab);
         pnew = inertia * rn + (1 - p.cog) * xv[c][k] + p.soc * gb[c][k];  // :2693-2697
       } else {
         // intended Vanilla update (B7 repaired): pbest[j] - pos, gbest[j] - pos
@@ -176,6 +185,7 @@ __global__ __launch_bounds__(256) void pso_move_kernel(PsoParams p, int timing, 
     p.cur_val[i] = f;
     if (better) p.pbest_val[i] = f;
   }
+  }  // particles of this wave
 }
 
 // The same move for particles of at most 64 coordinates: 64 / G particles per wave, one per group
@@ -189,6 +199,10 @@ __global__ __launch_bounds__(256) void pso_move_groups_kernel(PsoParams p, int t
   constexpr int P = 64 / G;
   const PsoState *__restrict__ st = p.state;
   if (!timing && st->done) return;
+  // the logarithm table of det_rnorm (Accelerated only; a workgroup-wide step, so before any
+  // wave leaves)
+  __shared__ double rn_tab[TYPE == NLSG_PSO_ACCELERATED ? kRnormTabDoubles : 1];
+  if (TYPE == NLSG_PSO_ACCELERATED) rnorm_table_to_lds(rn_tab);
   const uint64_t wave = static_cast<uint64_t>(blockIdx.x) * 4 +
                         __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
   if (wave * P >= p.shard_n) return;
@@ -230,7 +244,7 @@ __global__ __launch_bounds__(256) void pso_move_groups_kernel(PsoParams p, int t
                           : u01(mix64(kp_lane + kGolden * static_cast<uint64_t>(2 * k + 1)));
     double pnew;
     if (TYPE == NLSG_PSO_ACCELERATED) {
-      const double rn = det_rnorm(z1);  // rnorm, :2479-2485
+      const double rn = det_rnorm(z1, rn_tab);  // rnorm, :2479-2485
       pnew = inertia * rn + (1 - p.cog) * xv[k] + p.soc * gb[k];  // :2693-2697
     } else {
       vv[k] = (inertia * vv[k]) + p.cog * u1 * (pb[k] - xv[k]) + p.soc * u2 * (gb[k] - xv[k]);
@@ -311,6 +325,10 @@ template <int OBJ, bool VEC, int TYPE>
 __global__ __launch_bounds__(256) void pso_move_long_kernel(PsoParams p, int timing, uint64_t iter_ovr) {
   const PsoState *__restrict__ st = p.state;
   if (!timing && st->done) return;
+  // the logarithm table of det_rnorm (Accelerated only; a workgroup-wide step, so before any
+  // wave leaves)
+  __shared__ double rn_tab[TYPE == NLSG_PSO_ACCELERATED ? kRnormTabDoubles : 1];
+  if (TYPE == NLSG_PSO_ACCELERATED) rnorm_table_to_lds(rn_tab);
   const uint64_t i = static_cast<uint64_t>(blockIdx.x) * 4 +
                      __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
   if (i >= p.shard_n) return;
@@ -329,7 +347,7 @@ __global__ __launch_bounds__(256) void pso_move_long_kernel(PsoParams p, int tim
     const double u1 = u01(z1);
     double pnew;
     if (TYPE == NLSG_PSO_ACCELERATED) {
-      const double rn = det_rnorm(z1);
+      const double rn = det_rnorm(z1, rn_tab);
       pnew = inertia * rn + (1 - p.cog) * row[e] + p.soc * p.gbest_x[e];
     } else {
       const double u2 = u01(ctr_key(kp, 2 * e + 1));
@@ -369,7 +387,7 @@ __global__ __launch_bounds__(256) void pso_move_long_kernel(PsoParams p, int tim
                               : u01(mix64(kseg + kGolden * static_cast<uint64_t>(256 * c + 2 * k + 1)));
         double pnew;
         if (TYPE == NLSG_PSO_ACCELERATED) {
-          const double rn = det_rnorm(z1);
+          const double rn = det_rnorm(z1, rn_tab);
           pnew = inertia * rn + (1 - p.cog) * xv[c][k] + p.soc * gb[c][k];
         } else {
           vv[c][k] = (inertia * vv[c][k]) + p.cog * u1 * (pb[c][k] - xv[c][k]) +

@@ -40,6 +40,8 @@ struct SannParams {
 template <int OBJ, int CHUNKS, bool VEC>
 __global__ __launch_bounds__(256) void sann_anneal_kernel(SannParams p, uint64_t iter_begin,
                                                           uint64_t iter_end) {
+  __shared__ double rn_tab[kRnormTabDoubles];  // det_rnorm's logarithm table
+  rnorm_table_to_lds(rn_tab);
   const uint64_t chain = static_cast<uint64_t>(blockIdx.x) * 4 +
                          __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
   if (chain >= p.batch) return;
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(256) void sann_anneal_kernel(SannParams p, uint64_t
           const uint64_t e = static_cast<uint64_t>(c) * 128 + 2 * static_cast<uint64_t>(lane) + k;
           const uint64_t z1 = mix64(ks_lane + kGolden * static_cast<uint64_t>(256 * c + 2 * k));  // one draw (slot 2e) per normal variate
           // rnorm (:2479-2485): sqrt(-2 log u1) * cos(2 pi_ u2), pi_ = 3.141593
-          const double rn = det_rnorm(z1);
+          const double rn = det_rnorm(z1, rn_tab);
           pt[c][k] = (e < D) ? pc[c][k] + current_scale * rn : 0.0;  // :2800
         }
       }
@@ -118,6 +120,8 @@ __global__ __launch_bounds__(256) void sann_anneal_kernel(SannParams p, uint64_t
 template <int OBJ, bool VEC>
 __global__ __launch_bounds__(256) void sann_anneal_long_kernel(SannParams p, uint64_t iter_begin,
                                                                uint64_t iter_end) {
+  __shared__ double rn_tab[kRnormTabDoubles];  // det_rnorm's logarithm table
+  rnorm_table_to_lds(rn_tab);
   const uint64_t chain = static_cast<uint64_t>(blockIdx.x) * 4 +
                          __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
   if (chain >= p.batch) return;
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(256) void sann_anneal_long_kernel(SannParams p, uin
       auto trial_at = [&](uint64_t e) {  // one coordinate of the trial point, the same in every lane
         if (e >= D) return 0.0;
         const uint64_t z1 = ctr_key(ks, 2 * e);
-        const double rn = det_rnorm(z1);
+        const double rn = det_rnorm(z1, rn_tab);
         return pc[e] + current_scale * rn;
       };
       double acc = 0.0;
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(256) void sann_anneal_long_kernel(SannParams p, uin
           for (int k = 0; k < 2; k++) {
             const uint64_t e = e_base + static_cast<uint64_t>(c) * 128 + 2 * static_cast<uint64_t>(lane) + k;
             const uint64_t z1 = mix64(kseg + kGolden * static_cast<uint64_t>(256 * c + 2 * k));
-            const double rn = det_rnorm(z1);  // rnorm, :2479-2485
+            const double rn = det_rnorm(z1, rn_tab);  // rnorm, :2479-2485
             vt[c][k] = (e < D) ? vc[c][k] + current_scale * rn : 0.0;  // :2800
           }
         store_segment<VEC>(pt, e_base, D, vt);
@@ -210,6 +214,8 @@ __global__ __launch_bounds__(256) void sann_anneal_long_kernel(SannParams p, uin
 template <int OBJ, int G>
 __global__ __launch_bounds__(256) void sann_anneal_groups_kernel(SannParams p, uint64_t iter_begin,
                                                                  uint64_t iter_end) {
+  __shared__ double rn_tab[kRnormTabDoubles];  // det_rnorm's logarithm table
+  rnorm_table_to_lds(rn_tab);
   constexpr int P = 64 / G;
   const int lane = lane_id(), g = lane & (G - 1), gi = lane / G;
   const uint64_t wave = static_cast<uint64_t>(blockIdx.x) * 4 +
@@ -250,7 +256,7 @@ __global__ __launch_bounds__(256) void sann_anneal_groups_kernel(SannParams p, u
 #pragma unroll
       for (int k = 0; k < 2; k++) {
         const uint64_t z1 = mix64(ks_lane + kGolden * static_cast<uint64_t>(2 * k));  // one draw (slot 2e) per normal variate
-        const double rn = det_rnorm(z1);
+        const double rn = det_rnorm(z1, rn_tab);
         pt[k] = ((k ? in1 : in0)) ? pc[k] + current_scale * rn : 0.0;
       }
       const double current_val = p.fmul * group_objective<OBJ, G>(pt[0], pt[1], D);

@@ -54,6 +54,7 @@ double orc_u01(uint64_t bits); /* (double)bits * 2^-64, cf. nlsolver.h:1358 */
 double orc_log(double x);
 double orc_cos(double y);
 double orc_cos_2pi(double x); /* cos(2 pi x), the device's Rastrigin cosine (nlsg_math.h) */
+double orc_log_unit(double x); /* log for x in [2^-64, 1]: det_rnorm's table-driven logarithm */
 double orc_rnorm(uint64_t z1); /* one normal variate from one 64-bit draw (nlsg_math.h det_rnorm) */
 void orc_probe_math(int fn, const uint64_t *in, uint64_t *out, size_t n); /* cf. nlsg_probe_math */
 

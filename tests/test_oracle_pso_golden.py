@@ -66,6 +66,39 @@ def test_deterministic_log_cos_within_one_ulp_of_libm(oracle):
     assert oracle.orc_cos(0.0) == 1.0
 
 
+def test_rnorm_table_logarithm_accuracy(oracle):
+    """orc_log_unit (the table-driven logarithm of the normal variates, nlsg_math.h det_log_unit):
+    within 0.62 ulp of the exact value on [2^-64, 1] (200-bit arithmetic), hence within 1 ulp of
+    libm's log; exact at the ends; the normal variate itself is what libm's formula gives, to
+    rounding."""
+    import ctypes as C
+    import math
+    import mpmath as mp
+    oracle.orc_log_unit.restype, oracle.orc_log_unit.argtypes = C.c_double, [C.c_double]
+    mp.mp.prec = 200
+    rng = np.random.default_rng(7)
+    xs = np.concatenate([rng.random(6000), 1 - rng.random(6000) * 2.0 ** -rng.integers(1, 52, 6000),
+                         rng.random(6000) * 2.0 ** -rng.integers(0, 63, 6000).astype(float),
+                         [0.5, 2.0 ** -64, 0.70710678118654746, 0.70710678118654757, 1 - 2.0 ** -53]])
+    worst = 0.0
+    for x in xs:
+        x = float(x)
+        if not 2.0 ** -64 <= x < 1.0:
+            continue
+        v, e = oracle.orc_log_unit(x), mp.log(mp.mpf(x))
+        worst = max(worst, float(abs(mp.mpf(v) - e) / mp.mpf(float(np.spacing(abs(float(e)))))))
+    assert worst <= 0.62, worst
+    assert oracle.orc_log_unit(1.0) == 0.0 and oracle.orc_log_unit(2.0 ** -64) == -64 * math.log(2.0)
+    for x in rng.random(100000):
+        ref = math.log(x)
+        assert abs(oracle.orc_log_unit(x) - ref) <= np.spacing(abs(ref))
+    for z in rng.integers(1, 2**64, size=20000, dtype=np.uint64):
+        z = int(z)
+        u1, u2 = z * 2.0 ** -64, (z & 0xFFFFFFFF) * 2.0 ** -32
+        ref = math.sqrt(-2 * math.log(u1)) * math.cos(2 * 3.141593 * u2)
+        assert abs(oracle.orc_rnorm(z) - ref) <= 4e-16 * max(1.0, abs(ref))
+
+
 def test_sync_pso_converges_like_the_reference(oracle, golden):
     """Accelerated PSO, Rosenbrock-2D, 10 particles, 50 iterations from bounds +-3: the
     synchronous counter-RNG algorithm reaches the reference's quality (f ~ 1e-3)."""
