@@ -441,7 +441,7 @@ typedef struct {
   int32_t bounded;     /* 1 = the (x, upper, lower) overloads (2136, 2155)         */
   int32_t reserved;
   uint64_t batch;
-  uint64_t dim;        /* <= 128 (the simplex lives in LDS)                        */
+  uint64_t dim;        /* <= 1024 (past 128 the simplex lives in a global workspace) */
   double step, alpha, gamma, rho, sigma, eps; /* ctor args, nlsolver.h:2110-2113   */
   uint64_t max_iter, no_change_best_tol, restarts; /* :2114-2115                   */
 } nlsg_nm_config;
@@ -514,7 +514,7 @@ typedef struct {
                         * the simplex points and the velocity (by coordinate)          */
   int32_t reserved;
   uint64_t batch;      /* independent instances                                       */
-  uint64_t dim;        /* 2 <= dim <= 128; 3 dim + 1 particles per instance           */
+  uint64_t dim;        /* 2 <= dim <= 1024; 3 dim + 1 particles per instance          */
   uint64_t inst_lo;    /* global id of instance 0 (keys the draws; batch sharding)    */
   double alpha, gamma, rho, sigma;      /* ctor args, defaults 1, 2, 0.5, 0.5 (3564-3566) */
   double inertia, cognitive, social;    /* 0.8, 1.8, 1.8 (3566-3567)                   */

@@ -20,11 +20,44 @@ struct nlsg_nmpso {
 
 namespace {
 
+int wide_chunks(uint64_t n) { return n <= kHybMaxN ? 0 : n <= 256 ? 2 : n <= 512 ? 4 : 8; }
+
+template <int OBJ>
+void launch_wide(nlsg_nmpso *e, dim3 grid) {
+  const dim3 block(hyb_wide_threads(wide_chunks(e->p.n)));
+  const unsigned lds = static_cast<unsigned>(hyb_view_bytes(e->p.n));
+  switch (wide_chunks(e->p.n)) {
+    case 2: hipLaunchKernelGGL((nmpso_solve_wide_kernel<OBJ, 2>), grid, block, lds, e->stream, e->p); break;
+    case 4: hipLaunchKernelGGL((nmpso_solve_wide_kernel<OBJ, 4>), grid, block, lds, e->stream, e->p); break;
+    default: hipLaunchKernelGGL((nmpso_solve_wide_kernel<OBJ, 8>), grid, block, lds, e->stream, e->p); break;
+  }
+}
+template <int OBJ>
+hipError_t allow_wide_lds(uint64_t n) {  // past 64 KiB the dynamic allocation has to be announced
+  const int bytes = static_cast<int>(hyb_view_bytes(n));
+  const void *fn = wide_chunks(n) == 2   ? reinterpret_cast<const void *>(nmpso_solve_wide_kernel<OBJ, 2>)
+                   : wide_chunks(n) == 4 ? reinterpret_cast<const void *>(nmpso_solve_wide_kernel<OBJ, 4>)
+                                         : reinterpret_cast<const void *>(nmpso_solve_wide_kernel<OBJ, 8>);
+  return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
 void launch(nlsg_nmpso *e) {
-  const dim3 grid(static_cast<unsigned>(e->p.batch)), block(hyb_block_threads(e->p.n));
+  const bool wide = e->p.n > kHybMaxN;
+  const dim3 grid(static_cast<unsigned>(e->p.batch)),
+      block(wide ? hyb_wide_threads(wide_chunks(e->p.n)) : hyb_block_threads(e->p.n));
   if (e->cfg.objective == NLSG_OBJ_CUSTOM) {
     void *args[] = {&e->p};
-    launch_module_kernel(e->rtc.solve, grid.x, block.x, 0, e->stream, args);
+    launch_module_kernel(e->rtc.solve, grid.x, block.x,
+                         wide ? static_cast<unsigned>(hyb_view_bytes(e->p.n)) : 0, e->stream, args);
+    return;
+  }
+  if (wide) {
+    switch (e->cfg.objective) {
+      case NLSG_OBJ_ROSENBROCK: launch_wide<NLSG_OBJ_ROSENBROCK>(e, grid); break;
+      case NLSG_OBJ_SPHERE: launch_wide<NLSG_OBJ_SPHERE>(e, grid); break;
+      case NLSG_OBJ_STYBLINSKI_TANG: launch_wide<NLSG_OBJ_STYBLINSKI_TANG>(e, grid); break;
+      default: launch_wide<NLSG_OBJ_RASTRIGIN>(e, grid); break;
+    }
     return;
   }
   switch (e->cfg.objective) {
@@ -87,8 +120,10 @@ static int hyb_create(const nlsg_nmpso_config *cfg, const nlsg_custom_objective 
   if (cfg->batch < 1) return fail(NLSG_ERR_INVALID_ARG, "batch must be >= 1");
   if (cfg->dim < 2)  // the reference refuses it too (3627-3637)
     return fail(NLSG_ERR_INVALID_ARG, "dim must be >= 2: the hybrid does not support one dimension");
-  if (cfg->dim > kHybMaxN)
-    return fail(NLSG_ERR_UNSUPPORTED, "dim %llu > %d", (unsigned long long)cfg->dim, kHybMaxN);
+  if (cfg->dim > kHybWideMaxN)
+    return fail(NLSG_ERR_UNSUPPORTED, "dim %llu > %d (an instance's sort keys, orders and trial "
+                "points live in one workgroup's shared memory)", (unsigned long long)cfg->dim,
+                kHybWideMaxN);
   if (cfg->batch > 0x7fffffffull) return fail(NLSG_ERR_UNSUPPORTED, "batch too large");
   int rc = check_device(cfg->device);
   if (rc) return rc;
@@ -120,13 +155,21 @@ static int hyb_create(const nlsg_nmpso_config *cfg, const nlsg_custom_objective 
   if (he == hipSuccess) he = hipMemset(e->zero_dev, 0, 16);
   if (he == hipSuccess) he = hipEventCreate(&e->ev0);
   if (he == hipSuccess) he = hipEventCreate(&e->ev1);
+  if (he == hipSuccess && n > kHybMaxN && !custom) {
+    switch (cfg->objective) {
+      case NLSG_OBJ_ROSENBROCK: he = allow_wide_lds<NLSG_OBJ_ROSENBROCK>(n); break;
+      case NLSG_OBJ_SPHERE: he = allow_wide_lds<NLSG_OBJ_SPHERE>(n); break;
+      case NLSG_OBJ_STYBLINSKI_TANG: he = allow_wide_lds<NLSG_OBJ_STYBLINSKI_TANG>(n); break;
+      default: he = allow_wide_lds<NLSG_OBJ_RASTRIGIN>(n); break;
+    }
+  }
   if (he != hipSuccess) {
     nlsg_nmpso_destroy(e);
     return fail(he == hipErrorOutOfMemory ? NLSG_ERR_OOM : NLSG_ERR_HIP,
                 "device setup failed: %s", hipGetErrorString(he));
   }
   if (custom) {
-    const int rc2 = rtc_build_nmpso(custom, &e->rtc);
+    const int rc2 = rtc_build_nmpso(custom, wide_chunks(n), &e->rtc);
     if (rc2) {
       nlsg_nmpso_destroy(e);
       return rc2;

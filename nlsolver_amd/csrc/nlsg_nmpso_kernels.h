@@ -86,7 +86,8 @@ __device__ inline uint64_t hyb_key(double v) {
 // stable rank sort of the particles by value: order[cur] -> order[cur ^ 1]. The values are first
 // laid out in their current order as ordered integers, so the counting loop reads one LDS word
 // per step that every lane shares (a broadcast) and compares integers, four steps per trip.
-__device__ inline void hyb_sort(HybShared &sh, uint32_t total) {
+template <typename SH>
+__device__ inline void hyb_sort(SH &sh, uint32_t total) {
   const uint32_t *src = sh.order[sh.cur];
   uint32_t *dst = sh.order[sh.cur ^ 1];
   for (uint32_t q = threadIdx.x; q < total + 3; q += blockDim.x)
@@ -111,7 +112,8 @@ __device__ inline void hyb_sort(HybShared &sh, uint32_t total) {
 
 // simplex_std_err (3903-3918) over the best `count` particles, by one wave (lane l adds the
 // elements l, l + 64, ... in order, then the xor butterfly; two passes)
-__device__ inline double hyb_std_err_wave(const HybShared &sh, uint32_t count) {
+template <typename SH>
+__device__ inline double hyb_std_err_wave(const SH &sh, uint32_t count) {
   const uint32_t *ord = sh.order[sh.cur];
   const int lane = lane_id();
   double acc = 0.0;
@@ -130,8 +132,8 @@ __device__ inline double hyb_std_err_wave(const HybShared &sh, uint32_t count) {
 // group holds coordinates 2g, 2g + 1). group_objective gives each the bits of the full-wave tree.
 
 // values of `count` particles (row_of(i) = particle id of the i-th), 64 / G per wave pass
-template <int OBJ, int G, typename RowOf>
-__device__ inline void hyb_eval_rows(const HybParams &p, HybShared &sh, const double *pos,
+template <int OBJ, int G, typename SH, typename RowOf>
+__device__ inline void hyb_eval_rows(const HybParams &p, SH &sh, const double *pos,
                                      uint32_t n, uint32_t count, RowOf row_of) {
   constexpr int P = 64 / G;
   const int lane = lane_id(), g = lane & (G - 1), gi = lane / G;
@@ -149,8 +151,8 @@ __device__ inline void hyb_eval_rows(const HybParams &p, HybShared &sh, const do
 }
 
 // apply_pso (3823-3866): the 2n particles behind the simplex, one PAIR per group and pass
-template <int OBJ, int G>
-__device__ inline void hyb_pso_move(const HybParams &p, HybShared &sh, double *pos,
+template <int OBJ, int G, typename SH>
+__device__ inline void hyb_pso_move(const HybParams &p, SH &sh, double *pos,
                                     const double *vel, uint32_t n, uint32_t ns, uint64_t kc) {
   constexpr int P = 64 / G;
   const int lane = lane_id(), g = lane & (G - 1), gi = lane / G;
@@ -216,6 +218,132 @@ __device__ inline void hyb_pso_move(const HybParams &p, HybShared &sh, double *p
   }
 }
 
+
+// ---- more than 128 coordinates (the reference has no limit): the same kernel body over a view of
+// DYNAMIC shared memory sized by n (values, sort keys, two orders: 3n + 1 entries each; six
+// n-vectors) — 121 KiB at n = 1024 — a 1024-thread workgroup, and one particle (or one pair)
+// per wave pass with the point in CHUNKS x 128 registers per lane. wave_objective gives the same
+// bits for every CHUNKS that covers n, so the oracle is the one of the packed kernels.
+constexpr int kHybWideMaxN = 1024;
+struct HybScalars {
+  double ref_score, trial_score, best_val0;
+  uint64_t iter, fcalls, no_change;
+  int stop, cur;
+};
+struct HybView {
+  double *val;
+  uint64_t *key;
+  uint32_t *order[2];
+  double *centroid, *tr, *te, *tc, *up, *lo;
+  double &ref_score, &trial_score, &best_val0;
+  uint64_t &iter, &fcalls, &no_change;
+  int &stop, &cur;
+};
+__host__ __device__ inline size_t hyb_view_bytes(uint64_t n) {
+  const uint64_t total = 3 * n + 1;
+  return sizeof(HybScalars) + (total + 1) * 8 + (total + 3) * 8 + 2 * (total + 2) * 4 + 6 * n * 8;
+}
+__device__ inline HybView hyb_make_view(unsigned char *base, uint32_t n) {
+  const uint32_t total = 3 * n + 1;
+  HybScalars *sc = reinterpret_cast<HybScalars *>(base);
+  double *val = reinterpret_cast<double *>(base + sizeof(HybScalars));
+  uint64_t *key = reinterpret_cast<uint64_t *>(val + total + 1);
+  double *vec = reinterpret_cast<double *>(key + total + 3);
+  uint32_t *ord = reinterpret_cast<uint32_t *>(vec + 6 * n);
+  return HybView{val, key, {ord, ord + total + 2}, vec, vec + n, vec + 2 * n, vec + 3 * n,
+                 vec + 4 * n, vec + 5 * n, sc->ref_score, sc->trial_score, sc->best_val0,
+                 sc->iter, sc->fcalls, sc->no_change, sc->stop, sc->cur};
+}
+
+template <int OBJ, int CHUNKS>
+__device__ inline double hyb_wave_f_wide(const double *pt, uint64_t n, double fmul) {
+  const int lane = lane_id();
+  double xv[CHUNKS][2];
+#pragma unroll
+  for (int c = 0; c < CHUNKS; c++) {
+    const uint32_t j0 = 128 * c + 2 * lane;
+    xv[c][0] = j0 < n ? pt[j0] : 0.0;
+    xv[c][1] = j0 + 1 < n ? pt[j0 + 1] : 0.0;
+  }
+  return fmul * wave_objective<OBJ, CHUNKS>(xv, n);
+}
+
+template <int OBJ, int CHUNKS, typename SH, typename RowOf>
+__device__ inline void hyb_eval_rows_wide(const HybParams &p, SH &sh, const double *pos,
+                                          uint32_t n, uint32_t count, RowOf row_of) {
+  const int lane = lane_id();
+  const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+  for (uint32_t i = wid; i < count; i += (blockDim.x >> 6)) {
+    const uint32_t id = row_of(i);
+    const double f = hyb_wave_f_wide<OBJ, CHUNKS>(pos + static_cast<uint64_t>(id) * n, n, p.fmul);
+    if (lane == 0) sh.val[id] = f;
+  }
+}
+
+// apply_pso (3823-3866), one pair per wave pass; the two new points stay in registers for their
+// evaluation, everything else streams through per 128-coordinate chunk
+template <int OBJ, int CHUNKS, typename SH>
+__device__ inline void hyb_pso_move_wide(const HybParams &p, SH &sh, double *pos,
+                                         const double *vel, uint32_t n, uint32_t ns, uint64_t kc) {
+  const int lane = lane_id();
+  const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+  const uint32_t *ord = sh.order[sh.cur];
+  const double *best = pos + static_cast<uint64_t>(ord[0]) * n;
+  const uint64_t kit = ctr_key(kc, sh.iter + 1);
+  for (uint32_t m = wid; m < n; m += (blockDim.x >> 6)) {
+    const uint32_t id_a = ord[ns + 2 * m], id_b = ord[ns + 2 * m + 1];
+    double *ra = pos + static_cast<uint64_t>(id_a) * n, *rb = pos + static_cast<uint64_t>(id_b) * n;
+    const double *va = vel + static_cast<uint64_t>(id_a) * n, *vb = vel + static_cast<uint64_t>(id_b) * n;
+    const uint64_t ka = ctr_key(kit, 2 * m), kb = ctr_key(kit, 2 * m + 1);
+    double a[CHUNKS][2], b[CHUNKS][2];
+#pragma unroll
+    for (int c = 0; c < CHUNKS; c++) {
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const uint32_t j = 128 * c + 2 * lane + k;
+        const bool in = j < n;
+        const uint32_t jj = in ? j : 0;
+        const double bbj = best[jj], loj = sh.lo[jj], upj = sh.up[jj];
+        double av = ra[jj], bv = rb[jj];
+        const double wa = va[jj], wb = vb[jj];
+        // draws 2j, 2j + 1 of the particle's key: mix64(key + G64 (2j + 1 [+ 1]))
+        const uint64_t off = kGolden * (2 * static_cast<uint64_t>(j) + 1);
+        {  // first of the pair: its "pairwise best" is itself (pair 0) or its partner (H4)
+          const double r_p = u01(mix64(ka + off)), r_g = u01(mix64(ka + off + kGolden));
+          const double pair = m == 0 ? av : bv;
+          double temp = (p.inertia * wa) + p.cog * r_p * (pair - av) + p.soc * r_g * (bbj - av);
+          if (p.bounded) temp = temp < loj ? loj : (upj < temp ? upj : temp);
+          av = av + temp;
+        }
+        {  // second of the pair: the first one's NEW position (pair 0) or itself
+          const double r_p = u01(mix64(kb + off)), r_g = u01(mix64(kb + off + kGolden));
+          const double pair = m == 0 ? av : bv;
+          double temp = (p.inertia * wb) + p.cog * r_p * (pair - bv) + p.soc * r_g * (bbj - bv);
+          if (p.bounded) temp = temp < loj ? loj : (upj < temp ? upj : temp);
+          bv = bv + temp;
+        }
+        a[c][k] = in ? av : 0.0;
+        b[c][k] = in ? bv : 0.0;
+        if (in) ra[j] = av, rb[j] = bv;
+      }
+    }
+    const double fa = p.fmul * wave_objective<OBJ, CHUNKS>(a, n);
+    const double fb = p.fmul * wave_objective<OBJ, CHUNKS>(b, n);
+    if (lane == 0) {
+      sh.val[id_a] = fa;
+      sh.val[id_b] = fb;
+    }
+  }
+}
+
+template <int OBJ, int WIDE>
+__device__ inline double hyb_trial_f(const double *pt, uint64_t n, double fmul) {
+  if constexpr (WIDE == 0)
+    return hyb_wave_f<OBJ>(pt, n, fmul);
+  else
+    return hyb_wave_f_wide<OBJ, WIDE>(pt, n, fmul);
+}
+
 // lanes per particle: the smallest power of two >= n / 2, at least 4
 #define NLSG_HYB_GROUPS(n, CALL) \
   do {                           \
@@ -232,14 +360,14 @@ __device__ inline void hyb_pso_move(const HybParams &p, HybShared &sh, double *p
     }                            \
   } while (0)
 
-template <int OBJ>
-__global__ __launch_bounds__(kHybThreads) void nmpso_solve_kernel(HybParams p) {
-  __shared__ HybShared sh;
+// WIDE = 0: the packed kernels above (n <= 128); else the point's chunks per lane (n <= 128 WIDE)
+template <int OBJ, int WIDE, typename SH>
+__device__ inline void nmpso_run(const HybParams &p, SH &sh) {
   const uint64_t inst = blockIdx.x;
   const uint32_t n = static_cast<uint32_t>(p.n), ns = n + 1, total = 3 * n + 1;
   const int t = threadIdx.x, lane = lane_id();
   const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
-  double *pos = p.pos + inst * total * n, *vel = p.vel + inst * total * n;
+  double *pos = p.pos + inst * total * static_cast<uint64_t>(n), *vel = p.vel + inst * total * static_cast<uint64_t>(n);
   const double *x0 = p.x + inst * n;
   const uint64_t kc = ctr_key(p.seed, p.inst_lo + inst);
 
@@ -283,23 +411,30 @@ __global__ __launch_bounds__(kHybThreads) void nmpso_solve_kernel(HybParams p) {
     for (uint32_t r = wid; r < 2 * n; r += (blockDim.x >> 6)) {  // PSO particles, one per wave pass
       const uint64_t kp_lane = ctr_key(kinit, r) + kGolden * (4 * static_cast<uint64_t>(lane) + 1);
 #pragma unroll
-      for (int k = 0; k < 2; k++) {
-        const uint32_t j = 2 * lane + k;
-        if (j < n) {
-          const double lo = sh.lo[j], up = sh.up[j];
-          const double temp = fabs(up - lo);
-          const double u1 = u01(mix64(kp_lane + kGolden * static_cast<uint64_t>(2 * k)));
-          const double u2 = u01(mix64(kp_lane + kGolden * static_cast<uint64_t>(2 * k + 1)));
-          pos[(ns + r) * n + j] = lo + ((up - lo) * u1);
-          vel[(ns + r) * n + j] = -temp + (u2 * temp);
+      for (int c = 0; c < (WIDE ? WIDE : 1); c++) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+          const uint32_t j = 128 * c + 2 * lane + k;  // draws 2j, 2j + 1 of the particle's key
+          if (j < n) {
+            const double lo = sh.lo[j], up = sh.up[j];
+            const double temp = fabs(up - lo);
+            const double u1 = u01(mix64(kp_lane + kGolden * static_cast<uint64_t>(256 * c + 2 * k)));
+            const double u2 = u01(mix64(kp_lane + kGolden * static_cast<uint64_t>(256 * c + 2 * k + 1)));
+            pos[static_cast<uint64_t>(ns + r) * n + j] = lo + ((up - lo) * u1);
+            vel[static_cast<uint64_t>(ns + r) * n + j] = -temp + (u2 * temp);
+          }
         }
       }
     }
   }
   __syncthreads();  // block-scope visibility of the rows written above
+  if constexpr (WIDE != 0) {
+    hyb_eval_rows_wide<OBJ, WIDE>(p, sh, pos, n, total, [](uint32_t i) { return i; });
+  } else {
 #define HYB_EVAL_ALL(G) hyb_eval_rows<OBJ, G>(p, sh, pos, n, total, [](uint32_t i) { return i; })
-  NLSG_HYB_GROUPS(n, HYB_EVAL_ALL);
+    NLSG_HYB_GROUPS(n, HYB_EVAL_ALL);
 #undef HYB_EVAL_ALL
+  }
   for (uint32_t i = t; i < total; i += blockDim.x) sh.order[0][i] = i;
   __syncthreads();
   if (t == 0) {
@@ -353,7 +488,7 @@ __global__ __launch_bounds__(kHybThreads) void nmpso_solve_kernel(HybParams p) {
       }
       __syncthreads();
       if (wid == 0) {
-        const double f = hyb_wave_f<OBJ>(sh.tr, n, p.fmul);
+        const double f = hyb_trial_f<OBJ, WIDE>(sh.tr, n, p.fmul);
         if (lane == 0) sh.ref_score = f;
       }
       __syncthreads();
@@ -371,7 +506,7 @@ __global__ __launch_bounds__(kHybThreads) void nmpso_solve_kernel(HybParams p) {
         }
         __syncthreads();
         if (wid == 0) {
-          const double f = hyb_wave_f<OBJ>(sh.te, n, p.fmul);
+          const double f = hyb_trial_f<OBJ, WIDE>(sh.te, n, p.fmul);
           if (lane == 0) sh.trial_score = f;
         }
         __syncthreads();
@@ -390,7 +525,7 @@ __global__ __launch_bounds__(kHybThreads) void nmpso_solve_kernel(HybParams p) {
         }
         __syncthreads();
         if (wid == 0) {
-          const double f = hyb_wave_f<OBJ>(sh.tc, n, p.fmul);
+          const double f = hyb_trial_f<OBJ, WIDE>(sh.tc, n, p.fmul);
           if (lane == 0) sh.trial_score = f;
         }
         __syncthreads();
@@ -407,10 +542,15 @@ __global__ __launch_bounds__(kHybThreads) void nmpso_solve_kernel(HybParams p) {
             cur[j] = best[j] + p.sigma * (cur[j] - best[j]);
           }
           __syncthreads();
+          if constexpr (WIDE != 0) {
+            hyb_eval_rows_wide<OBJ, WIDE>(p, sh, pos, n, ns - 1,
+                                          [ord](uint32_t i) { return ord[1 + i]; });
+          } else {
 #define HYB_EVAL_SHRUNK(G) \
   hyb_eval_rows<OBJ, G>(p, sh, pos, n, ns - 1, [ord](uint32_t i) { return ord[1 + i]; })
-          NLSG_HYB_GROUPS(n, HYB_EVAL_SHRUNK);
+            NLSG_HYB_GROUPS(n, HYB_EVAL_SHRUNK);
 #undef HYB_EVAL_SHRUNK
+          }
           calls += ns - 1;
           __syncthreads();
           hyb_sort(sh, total);
@@ -420,9 +560,13 @@ __global__ __launch_bounds__(kHybThreads) void nmpso_solve_kernel(HybParams p) {
       __syncthreads();
     }
     // ---- apply_pso (3823-3866)
+    if constexpr (WIDE != 0) {
+      hyb_pso_move_wide<OBJ, WIDE>(p, sh, pos, vel, n, ns, kc);
+    } else {
 #define HYB_MOVE(G) hyb_pso_move<OBJ, G>(p, sh, pos, vel, n, ns, kc)
-    NLSG_HYB_GROUPS(n, HYB_MOVE);
+      NLSG_HYB_GROUPS(n, HYB_MOVE);
 #undef HYB_MOVE
+    }
     __syncthreads();  // every wave has read sh.iter (the iteration's key) before it moves on
     if (t == 0) {
       sh.fcalls += 2 * n;
@@ -439,6 +583,23 @@ __global__ __launch_bounds__(kHybThreads) void nmpso_solve_kernel(HybParams p) {
       p.prob[inst].fcalls = sh.fcalls;
     }
   }
+}
+
+template <int OBJ>
+__global__ __launch_bounds__(kHybThreads) void nmpso_solve_kernel(HybParams p) {
+  __shared__ HybShared sh;
+  nmpso_run<OBJ, 0>(p, sh);
+}
+
+// 128 < n <= 128 CHUNKS: dynamic shared memory of hyb_view_bytes(n); a thread per coordinate, so
+// 512 threads up to n = 512 (256 registers each: the pair of a wave's move stays in registers)
+// and 1024 beyond
+__host__ __device__ constexpr int hyb_wide_threads(int chunks) { return chunks <= 4 ? 512 : 1024; }
+template <int OBJ, int CHUNKS>
+__global__ __launch_bounds__(hyb_wide_threads(CHUNKS)) void nmpso_solve_wide_kernel(HybParams p) {
+  extern __shared__ __align__(16) unsigned char hyb_smem[];
+  HybView sh = hyb_make_view(hyb_smem, static_cast<uint32_t>(p.n));
+  nmpso_run<OBJ, CHUNKS>(p, sh);
 }
 
 }  // namespace nlsg

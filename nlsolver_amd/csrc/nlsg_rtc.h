@@ -46,7 +46,8 @@ struct HybRtcKernels {
   hipModule_t mod = nullptr;
   hipFunction_t solve = nullptr;
 };
-int rtc_build_nmpso(const nlsg_custom_objective *obj, HybRtcKernels *out);
+// wide_chunks != 0: the n > 128 kernel with that many 128-coordinate chunks per lane
+int rtc_build_nmpso(const nlsg_custom_objective *obj, int wide_chunks, HybRtcKernels *out);
 void rtc_release(HybRtcKernels *k);
 struct SannRtcKernels {
   hipModule_t mod = nullptr;

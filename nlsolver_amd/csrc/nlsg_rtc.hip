@@ -283,12 +283,14 @@ void rtc_release(NmRtcKernels *k) {
   if (k) *k = NmRtcKernels();
 }
 
-int rtc_build_nmpso(const nlsg_custom_objective *obj, HybRtcKernels *out) {
+int rtc_build_nmpso(const nlsg_custom_objective *obj, int wide_chunks, HybRtcKernels *out) {
   std::vector<hipFunction_t> f;
   HybRtcKernels k;
-  const int rc = rtc_compile(obj, "nlsg_nmpso_kernels.h",
-                             {"nlsg::nmpso_solve_kernel<" + std::to_string(static_cast<int>(NLSG_OBJ_CUSTOM)) + ">"},
-                             &k.mod, &f);
+  const std::string id = std::to_string(static_cast<int>(NLSG_OBJ_CUSTOM));
+  const std::string name = wide_chunks ? "nlsg::nmpso_solve_wide_kernel<" + id + ", " +
+                                             std::to_string(wide_chunks) + ">"
+                                       : "nlsg::nmpso_solve_kernel<" + id + ">";
+  const int rc = rtc_compile(obj, "nlsg_nmpso_kernels.h", {name}, &k.mod, &f);
   if (rc) return rc;
   k.solve = f[0];
   *out = k;

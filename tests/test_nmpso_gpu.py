@@ -63,6 +63,42 @@ def test_hybrid_instances_bit_exact_vs_sync_oracle(mod, oracle, objective, n, kw
     check(mod, oracle, objective, n, 5, starts(5, n, 0.5, 1.0), **kw)
 
 
+@pytest.mark.parametrize("objective,n,kw,bounded", [
+    ("rosenbrock", 129, dict(max_iter=10, eps=0.0, no_change_best_iter=1000), False),
+    ("sphere", 200, dict(max_iter=8, eps=0.0, no_change_best_iter=1000), True),
+    ("styblinski_tang", 257, dict(max_iter=6, eps=0.0, no_change_best_iter=1000), False),
+    ("rastrigin", 300, dict(max_iter=5, eps=1e-9, no_change_best_iter=3), False),
+    ("rosenbrock", 513, dict(max_iter=4, eps=0.0, no_change_best_iter=1000), False),
+    ("sphere", 1024, dict(max_iter=3, eps=0.0, no_change_best_iter=1000), True),
+])
+def test_hybrid_past_128_coordinates_bit_exact(mod, oracle, objective, n, kw, bounded):
+    """n > 128 (the reference has no limit, nlsolver.h:3546-3920): the same kernel body over
+    dynamic shared memory, one particle / pair per wave pass with the point in registers."""
+    batch = 2
+    x0 = starts(batch, n, 0.5, 1.0)
+    bounds = (np.full(n, -1.5), np.full(n, 2.5)) if bounded else None
+    check(mod, oracle, objective, n, batch, x0, bounds=bounds, **kw)
+
+
+def test_hybrid_past_128_maximize_shrinks_and_custom(mod, oracle):
+    """The shrink branch (sigma path, rescoring of n particles) and a run-time compiled objective
+    at n = 200."""
+    n = 200
+    x0 = starts(2, n, 0.5, 1.0)
+    check(mod, oracle, "sphere", n, 2, x0, minimize=False, max_iter=6, eps=0.0,
+          no_change_best_iter=1000, alpha=0.4, gamma=1.1, rho=0.9, sigma=0.3)
+    rosen = "double t1 = 1 - xi; double t2 = (xn - xi * xi); return t1 * t1 + 100 * t2 * t2;"
+    out = []
+    for obj in ("rosenbrock", mod.CustomObjective(rosen, chain=True)):
+        with mod.NMPSOEngine(obj, 2, n, max_iter=5, eps=0.0, seed=5) as eng:
+            x, st = eng.minimize(x0)
+        out.append((x, [(s.f_value, s.function_calls_used) for s in st]))
+    assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
+    from nlsolver_amd._capi import NlsgError
+    with pytest.raises(NlsgError):
+        mod.NMPSOEngine("sphere", 1, 1025)
+
+
 def test_hybrid_maximize_and_other_coefficients(mod, oracle):
     x0 = starts(4, 6, 0.5, 1.0)
     check(mod, oracle, "styblinski_tang", 6, 4, x0, minimize=False, max_iter=50, eps=0.0,
@@ -113,7 +149,7 @@ def test_hybrid_one_dimension_is_refused_like_the_reference(mod):
     with pytest.raises(NlsgError):
         mod.NMPSOEngine("sphere", 1, 1)
     with pytest.raises(NlsgError):
-        mod.NMPSOEngine("sphere", 1, 129)
+        mod.NMPSOEngine("sphere", 1, 1025)
 
 
 def test_hybrid_custom_objective_equals_builtin(mod):
