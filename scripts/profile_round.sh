@@ -4,13 +4,16 @@
 # passes, FETCH_SIZE and WRITE_SIZE apart (they do not fit one pass, MI355X_MICROARCH.md), under
 # gpurun_out/prof_ROUND/. Summarised afterwards, off the box, by profiles/summarize_pmc.py into
 # profiles/ROUND/{pmc_summary,de_pmc_summary}.json; the csv / json files are copied there as they are.
+# scripts/profile_round.sh ROUND "tag tag ..." limits the run to those workloads.
 round=${1:-r02}
+only=" ${2:-} "
 root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 out=$root/gpurun_out/prof_$round
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 run() {  # tag, bench args...
   local tag=$1; shift
+  if [ "$only" != "  " ] && [[ "$only" != *" $tag "* ]]; then return 0; fi
   echo "== $tag: $*"
   rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats" -o "$tag" -- \
     python3 "$root/bench.py" "$@" > "$out/${tag}_bench.json" 2> "$out/${tag}_bench.err" || return 1
