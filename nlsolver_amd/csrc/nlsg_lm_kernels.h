@@ -289,7 +289,10 @@ __device__ inline void lm_solve_qr(LmQrShared &qs, int n) {
         // one division, one square root, one reciprocal — selected, not branched
         const bool swap = fabs(b) > fabs(a);
         const double r = (swap ? a : b) / (swap ? b : a);
-        const double tt = 1.0 / sqrt(r * r + 1.0);
+        // r^2 + 1 lies in [1, 2] (or is NaN): the square root and the reciprocal without the
+        // compiler's operand scaling and fix-up steps — nine instructions off the chain that is
+        // the workgroup's critical path, same correctly rounded values
+        const double tt = div_unscaled(1.0, sqrt_unscaled(r * r + 1.0));
         const double tr = tt * r;
         cp = swap ? tr : tt;
         sp = swap ? tt : tr;

@@ -100,6 +100,20 @@ __device__ inline double det_cos(double y) {
 // steps, hence the same correctly rounded result — tests/test_math_gpu.py checks det_rnorm against
 // the CPU's sqrt on millions of arguments) minus the operand scaling, for x = 0, x = +inf or
 // x >= 2^-767.
+// n / d as the compiler expands it (v_rcp_f64 seed, two Newton steps, quotient, residual, final
+// fma: the correctly rounded quotient) minus v_div_scale / v_div_fixup, for operands that need
+// neither: d and the quotient well inside the normal range (say 2^-500 < |d|, |n / d| < 2^500), or
+// n = 0; NaN operands give NaN.
+__device__ inline double div_unscaled(double n, double d) {
+  double y = __builtin_amdgcn_rcp(d);
+  double e = __builtin_fma(-d, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-d, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  const double q = n * y;
+  const double r = __builtin_fma(-d, q, n);
+  return __builtin_fma(r, y, q);
+}
 __device__ inline double sqrt_unscaled(double x) {
   const double y = __builtin_amdgcn_rsq(x);
   double g = x * y, h = 0.5 * y;
