@@ -759,6 +759,44 @@ def north_star_pass(steps):
                          "algorithmic_bytes_per_launch": BYTES_PER_CANDIDATE * pop}}
 
 
+def other_configs_pass():
+    """BASELINE configs[2], [3] and [4] (their one-GPU shard) measured in the same run as the
+    headline: each is this script's own --workload line, produced by a CHILD process (a fresh
+    HIP context; the parent's engines are closed by now) without the CPU legs, and cut down to
+    what the line is read for. A failing child costs its own entry, never the headline."""
+    import subprocess
+    runs = [("configs[2] BFGS dim=1024 batch=4096", ["--workload", "bfgs"]),
+            ("configs[3] Levenberg-Marquardt m=512 n=64 batch=8192", ["--workload", "lm"]),
+            ("configs[4] PSO Accelerated, one GPU's shard 131072 x 256",
+             ["--workload", "pso-accel", "--steps", "100", "--warmup", "10"]),
+            ("configs[4] PSO Vanilla, one GPU's shard 131072 x 256",
+             ["--workload", "pso-vanilla", "--steps", "100", "--warmup", "10"])]
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = []
+    for name, extra in runs:
+        entry = {"config": name}
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-cpu-baseline"] + extra,
+                               capture_output=True, text=True, timeout=300, env=env)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not line:
+                raise RuntimeError(f"rc={r.returncode}: {r.stderr.strip()[-200:]}")
+            d = json.loads(line[-1])
+            roof = d.get("roofline", {})
+            entry.update({k: d[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "dtype")})
+            entry["workload"] = d["config"]["workload"]
+            entry["roofline"] = {k: roof.get(k) for k in ("bound", "achieved", "peak", "unit", "frac",
+                                                          "kernel", "kernel_ms")}
+            other = d["config"].get("other_solver")
+            if other:
+                entry["other_solver"] = {k: other[k] for k in ("solver", "value", "ms_per_step")}
+        except Exception as exc:
+            entry["error"] = str(exc)[:300]
+        out.append(entry)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -768,6 +806,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-north-star", action="store_true",
                     help="de workload: skip the pop = 2^20 pass after the configs[1] pass")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="de workload: skip the configs[2..4] passes (child processes) whose "
+                         "summaries ride in the headline line as `other_configs`")
     ap.add_argument("--lm-solver", choices=["cholesky", "qr"], default="cholesky",
                     help="lm workload: damped-system solver whose rate is the line's value (cholesky "
                          "= the reference class's get_update_with_hessian; qr = tinyqr::lm, as "
@@ -916,6 +957,8 @@ def main():
                 out["cpu_baseline_all_cores"] = cpu_baseline_all_cores()
             except Exception as exc:  # the checker library is optional here; never lose the line
                 out["cpu_baseline_all_cores"] = {"error": str(exc)[:200]}
+        if world == 1 and not args.no_other_configs and pop_local == POP_PER_GPU:
+            out["other_configs"] = other_configs_pass()
     ranks.close()
     if rank == 0:
         print(json.dumps(out))

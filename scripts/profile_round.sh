@@ -20,13 +20,13 @@ run() {  # tag, bench args...
   cp "$(find "$out/${tag}_stats" -name '*kernel_stats.csv' | head -1)" "$out/${tag}_kernel_stats.csv"
   for ctr in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$out/${tag}_$ctr" -o "$tag" -- \
-      python3 "$root/bench.py" "$@" --steps 20 --warmup 2 --no-cpu-baseline --no-north-star \
+      python3 "$root/bench.py" "$@" --steps 20 --warmup 2 --no-cpu-baseline --no-north-star --no-other-configs \
       > /dev/null 2> "$out/${tag}_$ctr.err" || return 1
     # keep only the counter csv (the traces are large)
     find "$out/${tag}_$ctr" -type f ! -name '*counter_collection.csv' -delete
   done
 }
-run de_c2 --steps 1000 --warmup 50 &&
+run de_c2 --steps 1000 --warmup 50 --no-other-configs &&
 run de_ns --pop-per-gpu 1048576 --steps 100 --warmup 5 --no-cpu-baseline &&
 run pso_accel --workload pso-accel --steps 100 --warmup 10 &&
 run pso_vanilla --workload pso-vanilla --steps 100 --warmup 10 --no-cpu-baseline &&
