@@ -32,10 +32,12 @@ BYTES_PER_CANDIDATE = 5 * D * 8 + 16  # 4 row reads + 1 row write + score r/w (S
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def launch_ranks(args):
-    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes
-    of this one (which has not imported torch, let alone touched a GPU — never an exec), wait for
-    them, forward rank 0's JSON line, exit non-zero if any rank failed."""
+def spawn_ranks(n, argv, timeout=None):
+    """Start n ranks of this script (fresh child processes, RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set) with the arguments argv and wait for them; returns (exit codes, the non-empty
+    lines rank 0 wrote to stdout). A rank that died leaves its peers inside a collective: they
+    get a grace period, then exactly the processes started here are ended; the same after
+    `timeout` seconds."""
     import socket
     with socket.socket() as sk:  # a free rendezvous port
         sk.bind(("127.0.0.1", 0))
@@ -43,19 +45,19 @@ def launch_ranks(args):
     import tempfile
     procs = []
     with tempfile.TemporaryFile(mode="w+") as out0:
-        for r in range(args.gpus):
-            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
                        MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
             env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]],
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv],
                                           env=env, stdout=out0 if r == 0 else sys.stderr,
                                           stderr=sys.stderr))
-        # a rank that died leaves its peers inside a collective: give them a grace period, then
-        # end exactly the processes started here
-        failed_at = None
+        started, failed_at = time.monotonic(), None
         while any(p.poll() is None for p in procs):
             if failed_at is None and any(p.poll() not in (None, 0) for p in procs):
                 failed_at = time.monotonic()
+            if timeout is not None and failed_at is None and time.monotonic() - started > timeout:
+                failed_at = time.monotonic() - 31.0
             if failed_at is not None and time.monotonic() - failed_at > 30.0:
                 for p in procs:
                     if p.poll() is None:
@@ -64,11 +66,50 @@ def launch_ranks(args):
         rcs = [p.returncode for p in procs]
         out0.seek(0)
         lines = [l for l in out0.read().splitlines() if l.strip()]
+    return rcs, lines
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes
+    of this one (which has not imported torch, let alone touched a GPU — never an exec), wait for
+    them, forward rank 0's JSON line, exit non-zero if any rank failed.
+
+    The headline (DE) job at its default size is followed by a second N-rank job of the same
+    script, BASELINE configs[4] as it is worded — the PSO swarm sharded over the N GPUs, 131 072
+    particles x 256 each, one all-gather of the best record per iteration — whose summary rides in
+    the headline line as `other_configs`; it can only add to the line, never cost it."""
+    rcs, lines = spawn_ranks(args.gpus, sys.argv[1:])
     for l in lines[:-1]:
         print(l, file=sys.stderr)
     if any(rcs) or not lines:
         raise SystemExit(f"bench.py --gpus {args.gpus}: rank exit codes {rcs}")
-    print(lines[-1])
+    line = lines[-1]
+    if (args.workload == "de" and args.pop_per_gpu == POP_PER_GPU and not args.no_other_configs
+            and line.startswith("{")):
+        entry = {"config": f"configs[4] PSO Accelerated, swarm sharded over {args.gpus} GPUs, "
+                           "131072 x 256 per GPU"}
+        try:
+            prc, plines = spawn_ranks(args.gpus, ["--gpus", str(args.gpus), "--workload", "pso-accel",
+                                                  "--steps", "100", "--warmup", "10",
+                                                  "--no-cpu-baseline"], timeout=240.0)
+            pj = [l for l in plines if l.startswith("{")]
+            if any(prc) or not pj:
+                raise RuntimeError(f"rank exit codes {prc}")
+            d = json.loads(pj[-1])
+            entry.update({k: d[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step",
+                                            "scaling", "dtype")})
+            entry["workload"] = d["config"]["workload"]
+            entry["turn_driver"] = d["config"].get("turn_driver")
+            entry["rccl_ranks"] = d["config"].get("rccl_ranks")
+        except Exception as exc:
+            entry["error"] = str(exc)[:300]
+        try:
+            out = json.loads(line)
+            out["other_configs"] = [entry]
+            line = json.dumps(out)
+        except ValueError:
+            pass
+    print(line)
 
 
 class Ranks:

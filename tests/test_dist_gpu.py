@@ -139,6 +139,26 @@ def test_bench_two_rank_flow_rehearsal(workload, extra):
         assert out["config"]["parallelism"].startswith("replicas x2")
 
 
+def test_bench_two_rank_default_line_carries_the_sharded_pso_run():
+    """`python3 bench.py --gpus 2 --steps K --warmup W` at the default size, as the driver runs the
+    scaling series: after the DE job a second two-rank job runs BASELINE configs[4] (the PSO swarm
+    sharded over the ranks) and its summary rides in the one JSON line as `other_configs`."""
+    env = dict(os.environ, NLSG_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "5"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["metric"].startswith("candidate-evals/sec")
+    (pso,) = out["other_configs"]
+    assert "error" not in pso, pso
+    assert pso["n_gpus"] == 2 and pso["value"] > 0 and pso["unit"] == "particle-evals/s"
+    assert pso["turn_driver"].startswith("host")
+
+
 def test_bench_forced_dist_reports_rccl_ranks():
     """One rank, but through the sharded path and the library's own RCCL communicator
     (NLSG_BENCH_FORCE_DIST=1): the line carries the communicator size RCCL reports."""
