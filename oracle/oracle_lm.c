@@ -41,13 +41,31 @@ double orc_exp(double x) {
   const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
   return y * bits2d((uint64_t)(1023 + k) << 52); /* y * 2^k, k in [-1021, 1023] */
 }
+/* tanh from the rational form of the exponential: with 2|x| = k ln2 + r and fdlibm's
+ * c = r - r^2 P(r^2), exp(r) = (2 + 2r - c) / (2 - c), so with s = 2^k and B = 2 - c
+ *   tanh|x| = (e - 1) / (e + 1) = ((s - 1) B + 2 s r) / ((s + 1) B + 2 s r)
+ * — ONE division (1 - 2 / (exp(2|x|) + 1) takes two), no cancellation for small |x| (k = 0:
+ * r / (B + r)), and 1 exactly from |x| = 22 on. Same arithmetic as nlsg_math.h det_tanh. */
 double orc_tanh(double x) {
+  static const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
+                      invln2 = 1.44269504088896338700e+00, P1 = 1.66666666666666019037e-01,
+                      P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+                      P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
   if (x != x) return x;
-  const double ax = fabs(x);
-  if (ax > 22.0) return x < 0 ? -1.0 : 1.0;
-  const double e = orc_exp(2.0 * ax);
-  const double t = 1.0 - 2.0 / (e + 1.0);
-  return x < 0 ? -t : t;
+  double ax = fabs(x);
+  if (ax > 22.0) ax = 22.0;
+  const double X = 2.0 * ax;
+  const int k = (int)fma(invln2, X, 0.5);
+  const double dk = (double)k;
+  const double hi = fma(-dk, ln2HI, X), lo = dk * ln2LO;
+  const double r = hi - lo;
+  const double t = r * r;
+  const double c = fma(-t, fma(t, fma(t, fma(t, fma(t, P5, P4), P3), P2), P1), r);
+  const double B = 2.0 - c;
+  const double s = ldexp(1.0, k), sr2 = ldexp(r, k + 1); /* 2^k and 2 s r, both exact */
+  const double num = fma(s - 1.0, B, sr2), den = fma(s + 1.0, B, sr2);
+  const double tt = num / den;
+  return x < 0 ? -tt : tt;
 }
 
 /* ---- linear algebra of the reference LM ------------------------------------- */
