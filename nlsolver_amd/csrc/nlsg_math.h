@@ -304,14 +304,12 @@ __device__ inline double det_log_unit(double x, const double *tab) {  // x in [2
 // sqrt(-2 log u1) * cos(2 * 3.141593 * u2) with u1 = z 2^-64 and u2 = (z mod 2^32) 2^-32, written
 // for the arguments that occur here: u1 is 0 or a normal number in [2^-64, 1] — the table-driven
 // logarithm above, u1 = 0 -> -inf as a final select; the cosine's argument lies in [0, 6.3] —
-// det_cos's arithmetic without its range test, the quadrant from a 32-bit conversion, the sign of
-// the result set by integer arithmetic instead of nested selects (the bits det_cos gives).
+// one sine polynomial on [-pi/2, pi/2] (below).
 // oracle_math.c's orc_rnorm is the CPU mirror. The kernels that draw normal variates are bound
 // by the vector unit's instruction count: 265 -> ~120 vector instructions per variate since
 // round 1.
 __device__ inline double det_rnorm(uint64_t zbits, const double *tab) {  // tab: the LDS table
-  constexpr double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00,
-                   pio2_1t = 6.07710050650619224932e-11;
+  constexpr double pio2_1 = 1.57079632673412561417e+00, pio2_1t = 6.07710050650619224932e-11;
   // u1 = (double)z 2^-64 rounded once, as the conversion rounds: hi 2^-32 + lo 2^-64 in one fma
   // (both terms exact); the angle y = 2 pi_ u2 = lo (2 pi_ 2^-32) — scaling by 2^-32 is exact, so
   // the one rounding is that of 2 pi_ u2
@@ -320,16 +318,29 @@ __device__ inline double det_rnorm(uint64_t zbits, const double *tab) {  // tab:
   const double u1 = __builtin_fma(hi_d, 0x1p-32, lo_d * 0x1p-64);
   double lg = det_log_unit(u1, tab);  // (u1 = 0: garbage, replaced below)
   lg = u1 == 0.0 ? -__builtin_inf() : lg;
-  // cos(2 pi_ u2) (det_cos's path for 0 <= y <= 64)
+  // cos(2 pi_ u2), y in [0, 6.3]: cos y = -(-1)^g sin(r) with g = rint(y / pi - 1/2) in {0, 1, 2}
+  // and r = y - (g + 1/2) pi in [-pi/2, pi/2] (two-term Cody-Waite, (2g + 1) pio2_1 exact), and
+  // ONE odd polynomial for the sine there, sin r = r + r^3 Q(r^2) (degree 8: Chebyshev fit of
+  // (sin x - x) / x^3, truncation 5e-22) — fdlibm's pair of kernels on [-pi/4, pi/4] costs a
+  // lane both although it needs one. Within 2.3e-16 (absolute) of libm's cos; oracle_math.c's
+  // orc_cos_unit is the same arithmetic.
+  constexpr double invpi = 3.18309886183790671538e-01,
+                   Q8 = -0x1.275ecac266a3ap-57, Q7 = 0x1.9507fb692a94ap-49,
+                   Q6 = -0x1.ae7ee39a09ceap-41, Q5 = 0x1.612460b690375p-33,
+                   Q4 = -0x1.ae64567e73021p-26, Q3 = 0x1.71de3a556b9b2p-19,
+                   Q2 = -0x1.a01a01a01a00dp-13, Q1 = 0x1.1111111111111p-7,
+                   Q0 = -0x1.5555555555555p-3;
   const double y = lo_d * (2 * 3.141593 * 0x1p-32);
-  const double fn = floor(__builtin_fma(y, invpio2, 0.5));
-  const double r = __builtin_fma(-fn, pio2_1t, __builtin_fma(-fn, pio2_1, y));
-  const uint32_t q = static_cast<uint32_t>(static_cast<int>(fn));  // 0 .. 4
-  const double c = det_kernel_cos(r), sn = det_kernel_sin(r);
-  // q mod 4 = 0: c, 1: -s, 2: -c, 3: s
-  const uint64_t mag = static_cast<uint64_t>(__double_as_longlong((q & 1u) ? sn : c));
-  const uint64_t flip = static_cast<uint64_t>((q + 1u) & 2u) << 62;
-  const double cs = __longlong_as_double(static_cast<long long>(mag ^ flip));
+  const double g = rint(__builtin_fma(y, invpi, -0.5));
+  const double h = 2.0 * g + 1.0;
+  const double r = __builtin_fma(-h, pio2_1t, __builtin_fma(-h, pio2_1, y));
+  const double z = r * r;
+  const double q = fma_k(z, fma_k(z, fma_k(z, fma_k(z, fma_k(z, fma_k(z, fma_k(z, __builtin_fma(z, Q8, Q7), Q6), Q5), Q4), Q3), Q2), Q1), Q0);
+  const double sn = __builtin_fma(z * r, q, r);
+  // g odd: sn, g even: -sn (the sign bit set by integer arithmetic)
+  const uint64_t flip = static_cast<uint64_t>(~static_cast<uint32_t>(static_cast<int>(g)) & 1u) << 63;
+  const double cs = __longlong_as_double(static_cast<long long>(
+      static_cast<uint64_t>(__double_as_longlong(sn)) ^ flip));
   return sqrt_unscaled(-2 * lg) * cs;  // -2 lg is 0, +inf or at least 2^-53
 }
 

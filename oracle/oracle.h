@@ -55,6 +55,7 @@ double orc_log(double x);
 double orc_cos(double y);
 double orc_cos_2pi(double x); /* cos(2 pi x), the device's Rastrigin cosine (nlsg_math.h) */
 double orc_log_unit(double x); /* log for x in [2^-64, 1]: det_rnorm's table-driven logarithm */
+double orc_cos_unit(double y); /* cos for y in [0, 6.3]: det_rnorm's one-polynomial cosine */
 double orc_rnorm(uint64_t z1); /* one normal variate from one 64-bit draw (nlsg_math.h det_rnorm) */
 void orc_probe_math(int fn, const uint64_t *in, uint64_t *out, size_t n); /* cf. nlsg_probe_math */
 
