@@ -130,6 +130,7 @@ void launch_generation_groups(nlsg_de *e, dim3 grid, int par, uint64_t generatio
 }
 
 void launch_generation(nlsg_de *e, int par, uint64_t generation, int ignore_done = 0) {
+  e->p.gen_key = ctr_key(e->p.seed, generation);
   // waves: one per agent, or one per 64 / group agents
   const uint64_t per_wave = e->group ? 64 / e->group : 1;
   const uint64_t waves = (e->p.shard_n + per_wave - 1) / per_wave;
@@ -200,6 +201,7 @@ void launch_fused_turn_groups(nlsg_de *e, dim3 grid, int par, uint64_t generatio
 
 // head k and generation k+1 in one launch (de_turn_kernel)
 void launch_fused_turn(nlsg_de *e, int par, uint64_t generation) {
+  e->p.gen_key = ctr_key(e->p.seed, generation);
   const uint64_t per_wave = e->group ? 64 / e->group : 1;
   const uint64_t waves = (e->p.shard_n + per_wave - 1) / per_wave;
   const dim3 grid(static_cast<unsigned>((waves + 3) / 4 + e->p.ntiles)), block(256);
@@ -423,6 +425,23 @@ static int de_create(const nlsg_de_config *cfg, const nlsg_custom_objective *cus
   p.shard_lo = cfg->shard_lo;
   p.shard_n = n;
   p.CR = cfg->CR;
+  {  // the crossover test u01(z) < CR on the draw itself: u01 is monotone in z, so there is a
+     // smallest z whose uniform reaches CR (none: every draw passes)
+    const double cr = cfg->CR;
+    if (u01(~0ull) < cr) {
+      p.cr_all = 1;
+      p.cr_thresh = ~0ull;
+    } else if (!(u01(0) < cr)) {  // CR <= 0 or NaN: no draw passes
+      p.cr_thresh = 0;
+    } else {
+      uint64_t lo = 0, hi = ~0ull;  // u01(lo) < CR <= u01(hi)
+      while (hi - lo > 1) {
+        const uint64_t mid = lo + (hi - lo) / 2;
+        if (u01(mid) < cr) lo = mid; else hi = mid;
+      }
+      p.cr_thresh = hi;
+    }
+  }
   p.F = cfg->F;
   p.eps = cfg->eps;
   p.fmul = cfg->minimize ? 1.0 : -1.0;  // f_multiplier, nlsolver.h:2418

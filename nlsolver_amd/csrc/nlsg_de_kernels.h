@@ -61,6 +61,11 @@ struct DeParams {
   uint64_t max_iter, best_val_no_change, seed;
   int32_t strategy;
   int32_t vec;         // rows are 16-byte aligned (D even)
+  // set by the host (nlsg_de.hip): wave-uniform values every wave of a launch would recompute
+  uint64_t gen_key;    // ctr_key(seed, generation) of the generation being launched
+  uint64_t cr_thresh;  // u01(z) < CR  <=>  z < cr_thresh (u01 is monotone in z): the crossover
+  int32_t cr_all;      // test on the draw's bits; cr_all: CR > 1, every draw passes
+  int32_t pad2;
 };
 
 // ---- generation 0 ----------------------------------------------------------
@@ -120,35 +125,59 @@ __device__ inline void de_fetch_agent(const DeParams &p, const double *__restric
   // the agent's key and its wave-uniform draws are computed on the vector unit (see on_valu):
   // lane L takes draw D + L of the agent's stream — lane 0 the crossover's jrand (:2364), lane
   // 1 + k donor candidate k — so the donor loop below only picks lanes
-  const uint64_t ka = first64(ctr_key(kg, on_valu(ga)));
+  const uint64_t ka = ctr_key(kg, ga);  // wave-uniform: on the scalar unit (the vector unit is
+                                         // the busier one here: 68 % against 35 % at pop = 65 536)
   const int lane = lane_id();
-  const uint64_t drawn = clamp_index(u01(ctr_key(ka, p.D + static_cast<uint64_t>(lane))),
-                                     lane == 0 ? p.D : p.shard_n);
+  // generate_index (:2325-2329), size_t(u * max): shard sizes and D fit 32 bits, so the
+  // conversion is the one-instruction 32-bit one (same truncation)
+  const uint32_t lim = static_cast<uint32_t>(lane == 0 ? p.D : p.shard_n);
+  const uint32_t idx = static_cast<uint32_t>(u01(ctr_key(ka, p.D + static_cast<uint64_t>(lane))) *
+                                             static_cast<double>(lim));
+  const uint64_t drawn = idx >= lim ? lim - 1 : idx;  // the u == 1.0 corner clamped (B10)
   // generate_indices (nlsolver.h:2331-2355): three distinct donors != fixed,
   // by rejection, drawn inside this engine's shard. Wave-uniform (scalar) code.
   const uint64_t fixed = (p.strategy == NLSG_DE_RANDOM) ? ga : best_id;  // :2451-2457
-  uint64_t r0 = ~0ull, r1 = ~0ull, r2 = ~0ull;
-  int have = 0;
-  for (int k = 0; k < kDeMaxTries && have < 3; k++) {
-    // (candidate 63 has no lane: after 61 rejections it is drawn the slow way)
-    const uint64_t cand =
-        p.shard_lo + (k < 63 ? readlane64(drawn, k + 1)
-                             : clamp_index(u01(ctr_key(ka, p.D + 1 + k)), p.shard_n));
-    const bool used = (cand == fixed) || (have > 0 && cand == r0) || (have > 1 && cand == r1);
-    if (!used) {
-      if (have == 0) r0 = cand;
-      else if (have == 1) r1 = cand;
-      else r2 = cand;
-      have++;
+  // Candidate k is the draw of lane k + 1: the first three lanes (in order) whose candidate
+  // differs from `fixed` and from the picks before it are found with three wave-wide compares
+  // and find-first-set — the rejection loop as a handful of instructions instead of a scalar
+  // loop of branches (this kernel was bound by the CU's scalar issue at pop = 65 536: ~400 scalar
+  // instructions per wave against ~320 vector ones). Same candidates in the same order.
+  const uint64_t cand_v = p.shard_lo + drawn;
+  constexpr uint64_t top = 1ull << 63;
+  const uint64_t m0 = __ballot(cand_v != fixed) & ~1ull;  // lane 0 holds jrand
+  const int i0 = __builtin_ctzll(m0 | top);
+  uint64_t r0 = readlane64(cand_v, i0);
+  const uint64_t m1 = m0 & __ballot(cand_v != r0) & ((~0ull << i0) << 1);
+  const int i1 = __builtin_ctzll(m1 | top);
+  uint64_t r1 = readlane64(cand_v, i1);
+  const uint64_t m2 = m1 & __ballot(cand_v != r1) & ((~0ull << i1) << 1);
+  const int i2 = __builtin_ctzll(m2 | top);
+  uint64_t r2 = readlane64(cand_v, i2);
+  if (m0 == 0 || m1 == 0 || m2 == 0) {  // fewer than three among 63 candidates (tiny shards):
+                                         // the literal loop, from the start
+    r0 = r1 = r2 = ~0ull;
+    int have = 0;
+    for (int k = 0; k < kDeMaxTries && have < 3; k++) {
+      // (candidate 63 has no lane: after 61 rejections it is drawn the slow way)
+      const uint64_t cand =
+          p.shard_lo + (k < 63 ? readlane64(drawn, k + 1)
+                               : clamp_index(u01(ctr_key(ka, p.D + 1 + k)), p.shard_n));
+      const bool used = (cand == fixed) || (have > 0 && cand == r0) || (have > 1 && cand == r1);
+      if (!used) {
+        if (have == 0) r0 = cand;
+        else if (have == 1) r1 = cand;
+        else r2 = cand;
+        have++;
+      }
     }
-  }
-  for (uint64_t cand = p.shard_lo; have < 3; cand++) {  // fallback: lowest unused
-    const bool used = (cand == fixed) || (have > 0 && cand == r0) || (have > 1 && cand == r1);
-    if (!used) {
-      if (have == 0) r0 = cand;
-      else if (have == 1) r1 = cand;
-      else r2 = cand;
-      have++;
+    for (uint64_t cand = p.shard_lo; have < 3; cand++) {  // fallback: lowest unused
+      const bool used = (cand == fixed) || (have > 0 && cand == r0) || (have > 1 && cand == r1);
+      if (!used) {
+        if (have == 0) r0 = cand;
+        else if (have == 1) r1 = cand;
+        else r2 = cand;
+        have++;
+      }
     }
   }
   c.a = a;
@@ -187,9 +216,11 @@ __device__ inline void de_process_agent(const DeParams &p, double *__restrict__ 
 #pragma unroll
     for (int k = 0; k < 2; k++) {
       const uint64_t e = static_cast<uint64_t>(ch) * 128 + 2 * static_cast<uint64_t>(lane) + k;
-      const double u = u01(mix64(ka_lane + kGolden * static_cast<uint64_t>(128 * ch + k)));
+      // u01(z) < CR decided on the draw's bits (cr_thresh: the smallest z whose uniform is >= CR)
+      const uint64_t z = mix64(ka_lane + kGolden * static_cast<uint64_t>(128 * ch + k));
+      const bool cross = z < p.cr_thresh || p.cr_all;
       const double mut = c.d1[ch][k] + p.F * (c.d2[ch][k] - c.d3[ch][k]);
-      trial[ch][k] = (u < p.CR || e == c.jrand) ? mut : (rnd ? c.own[ch][k] : c.keep[ch][k]);
+      trial[ch][k] = (cross || e == c.jrand) ? mut : (rnd ? c.own[ch][k] : c.keep[ch][k]);
     }
   }
   // (elements >= D are 0 in every loaded row, hence 0 in the trial as well)
@@ -343,7 +374,7 @@ __device__ inline void de_generation_block(const DeParams &p, int par, uint64_t 
   if (a0 >= p.shard_n) return;
   const double *__restrict__ cur = p.buf[par];
   double *__restrict__ nxt = p.buf[par ^ 1];
-  const uint64_t kg = first64(ctr_key(on_valu(p.seed), generation));
+  const uint64_t kg = p.gen_key;  // = ctr_key(p.seed, generation), from the host
   const uint64_t best_id = st->best_id;
   DeAgent<CHUNKS> A;
   de_fetch_agent<CHUNKS, VEC>(p, cur, par, kg, best_id, a0, true, A);
