@@ -90,7 +90,7 @@ def launch_ranks(args):
                            "131072 x 256 per GPU"}
         try:
             prc, plines = spawn_ranks(args.gpus, ["--gpus", str(args.gpus), "--workload", "pso-accel",
-                                                  "--steps", "100", "--warmup", "10",
+                                                  "--steps", "100", "--warmup", "300",
                                                   "--no-cpu-baseline"], timeout=240.0)
             pj = [l for l in plines if l.startswith("{")]
             if any(prc) or not pj:
@@ -576,7 +576,7 @@ def main_lm(args):
     # the boundary hands over HOST buffers (A: 2 GiB at batch 8192): engine creation = allocation
     # + upload + device repack; reported beside `value`, never inside it
     upload_s = time.perf_counter() - t_up
-    eng.time_solve(theta0, 1)  # warm-up
+    eng.time_solve(theta0, 3)  # warm-up (three solves, ~45 ms: a fresh process starts at idle clocks)
     ms = timed_solves(ranks, eng, theta0, 3)
     th, st, lam = eng.minimize(theta0.copy())
     # the other solver on the same resident data
@@ -809,9 +809,9 @@ def other_configs_pass():
     runs = [("configs[2] BFGS dim=1024 batch=4096", ["--workload", "bfgs"]),
             ("configs[3] Levenberg-Marquardt m=512 n=64 batch=8192", ["--workload", "lm"]),
             ("configs[4] PSO Accelerated, one GPU's shard 131072 x 256",
-             ["--workload", "pso-accel", "--steps", "100", "--warmup", "10"]),
+             ["--workload", "pso-accel", "--steps", "100", "--warmup", "300"]),
             ("configs[4] PSO Vanilla, one GPU's shard 131072 x 256",
-             ["--workload", "pso-vanilla", "--steps", "100", "--warmup", "10"])]
+             ["--workload", "pso-vanilla", "--steps", "100", "--warmup", "300"])]
     env = {k: v for k, v in os.environ.items()
            if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     out = []
