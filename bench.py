@@ -819,7 +819,7 @@ def other_configs_pass():
         entry = {"config": name}
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-cpu-baseline"] + extra,
-                               capture_output=True, text=True, timeout=300, env=env)
+                               capture_output=True, text=True, timeout=150, env=env)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             if r.returncode != 0 or not line:
                 raise RuntimeError(f"rc={r.returncode}: {r.stderr.strip()[-200:]}")
