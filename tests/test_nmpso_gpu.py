@@ -88,12 +88,14 @@ def test_hybrid_past_128_maximize_shrinks_and_custom(mod, oracle):
     check(mod, oracle, "sphere", n, 2, x0, minimize=False, max_iter=6, eps=0.0,
           no_change_best_iter=1000, alpha=0.4, gamma=1.1, rho=0.9, sigma=0.3)
     rosen = "double t1 = 1 - xi; double t2 = (xn - xi * xi); return t1 * t1 + 100 * t2 * t2;"
-    out = []
-    for obj in ("rosenbrock", mod.CustomObjective(rosen, chain=True)):
-        with mod.NMPSOEngine(obj, 2, n, max_iter=5, eps=0.0, seed=5) as eng:
-            x, st = eng.minimize(x0)
-        out.append((x, [(s.f_value, s.function_calls_used) for s in st]))
-    assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
+    for nn, iters in ((200, 5), (600, 2)):  # 600: 72 KiB of dynamic shared memory in the module kernel
+        xs = starts(2, nn, 0.5, 1.0)
+        out = []
+        for obj in ("rosenbrock", mod.CustomObjective(rosen, chain=True)):
+            with mod.NMPSOEngine(obj, 2, nn, max_iter=iters, eps=0.0, seed=5) as eng:
+                x, st = eng.minimize(xs)
+            out.append((x, [(s.f_value, s.function_calls_used) for s in st]))
+        assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
     from nlsolver_amd._capi import NlsgError
     with pytest.raises(NlsgError):
         mod.NMPSOEngine("sphere", 1, 1025)
