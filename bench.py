@@ -807,6 +807,8 @@ def other_configs_pass():
     what the line is read for. A failing child costs its own entry, never the headline."""
     import subprocess
     runs = [("configs[2] BFGS dim=1024 batch=4096", ["--workload", "bfgs"]),
+            ("configs[2] BFGS dim=1024 batch=4096, symmetric restatement of the rank-2 update "
+             "(upper blocks of H only; values equal to rounding)", ["--workload", "bfgs", "--bfgs-symmetric"]),
             ("configs[3] Levenberg-Marquardt m=512 n=64 batch=8192", ["--workload", "lm"]),
             ("configs[4] PSO Accelerated, one GPU's shard 131072 x 256",
              ["--workload", "pso-accel", "--steps", "100", "--warmup", "300"]),
