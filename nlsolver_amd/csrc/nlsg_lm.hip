@@ -89,7 +89,10 @@ void launch_wide_fd(nlsg_lm *e, dim3 grid, int first) {
     hipLaunchKernelGGL((lm_wide_fd_eval_kernel<OBJ, 8>), grid, dim3(lm_wide_fd_threads(8)), 0, e->stream, e->p, first);
 }
 void launch_wide_eval(nlsg_lm *e, int first) {
-  const dim3 grid(static_cast<unsigned>(e->p.batch));
+  // finite-difference model: enough workgroups per problem to fill the device when the batch is small
+  const unsigned split = e->p.fd ? static_cast<unsigned>(std::min<uint64_t>(
+                                       64, std::max<uint64_t>(1, 2048 / e->p.batch))) : 1u;
+  const dim3 grid(static_cast<unsigned>(e->p.batch), split);
   if (!e->p.fd) {
     hipLaunchKernelGGL(lm_wide_tanh_eval_kernel, grid, dim3(kLmWideThreads), 0, e->stream, e->p, first);
     return;
@@ -97,7 +100,7 @@ void launch_wide_eval(nlsg_lm *e, int first) {
   if (e->cfg.objective == NLSG_OBJ_CUSTOM) {
     void *args[] = {&e->p, &first};
     const uint64_t n = e->p.n;
-    launch_module_kernel(e->rtc.iter, grid.x, lm_wide_fd_threads(n <= 512 ? 4 : 8), 0, e->stream, args);
+    launch_module_kernel(e->rtc.iter, grid.x, lm_wide_fd_threads(n <= 512 ? 4 : 8), 0, e->stream, args);  // (one workgroup per problem)
     return;
   }
   switch (e->cfg.objective) {

@@ -960,9 +960,12 @@ __global__ __launch_bounds__(lm_wide_fd_threads(CHUNKS)) void lm_wide_fd_eval_ke
   const uint64_t pid = blockIdx.x;
   LmProblem *pr = p.prob + pid;
   if (!first && pr->done) return;
-  constexpr int W = lm_wide_fd_threads(CHUNKS) / 64;
+  // gridDim.y workgroups share a problem (a single start would otherwise keep one CU busy): the
+  // gradient coordinates and Hessian entries are dealt over all their waves
+  const int W = (lm_wide_fd_threads(CHUNKS) / 64) * static_cast<int>(gridDim.y);
   const int lane = lane_id();
-  const int w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+  const int w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6) +
+                (lm_wide_fd_threads(CHUNKS) / 64) * static_cast<int>(blockIdx.y);
   const uint64_t n = p.n;
   const double *th = p.theta + pid * n;
   double xv[CHUNKS][2];
