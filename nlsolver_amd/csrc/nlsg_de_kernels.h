@@ -327,9 +327,10 @@ __device__ inline void de_generation_groups_block(const DeParams &p, int par, ui
 #pragma unroll
   for (int k = 0; k < 2; k++) {
     const uint64_t e = 2 * static_cast<uint64_t>(g) + k;
-    const double u = u01(mix64(ka_lane + kGolden * static_cast<uint64_t>(k)));
+    const uint64_t zc = mix64(ka_lane + kGolden * static_cast<uint64_t>(k));
     const double mut = d1[k] + p.F * (d2[k] - d3[k]);
-    const double t = (u < p.CR || e == jrand) ? mut : (rnd ? own[k] : keep[k]);
+    // u01(zc) < CR on the draw's bits (DeParams.cr_thresh)
+    const double t = (zc < p.cr_thresh || p.cr_all || e == jrand) ? mut : (rnd ? own[k] : keep[k]);
     trial[k] = (k ? in1 : in0) ? t : 0.0;
   }
   const double score = p.fmul * group_objective<OBJ, G>(trial[0], trial[1], D);  // :2463
@@ -715,9 +716,9 @@ __global__ __launch_bounds__(256) void de_generation_long_kernel(DeParams p, int
   const double *keep = rnd ? own : p.best_x;  // non-crossed coordinates (:2369-2372)
   auto trial_at = [&](uint64_t e) {  // one coordinate of the trial, the same in every lane
     if (e >= D) return 0.0;
-    const double u = u01(ctr_key(ka, e));
+    const uint64_t zc = ctr_key(ka, e);
     const double mut = d1[e] + p.F * (d2[e] - d3[e]);
-    return (u < p.CR || e == jrand) ? mut : keep[e];
+    return (zc < p.cr_thresh || p.cr_all || e == jrand) ? mut : keep[e];
   };
   double *out = nxt + a * D;
   double acc = 0.0;
@@ -734,9 +735,9 @@ __global__ __launch_bounds__(256) void de_generation_long_kernel(DeParams p, int
 #pragma unroll
       for (int k = 0; k < 2; k++) {
         const uint64_t e = e_base + static_cast<uint64_t>(ch) * 128 + 2 * static_cast<uint64_t>(lane) + k;
-        const double u = u01(mix64(kseg + kGolden * static_cast<uint64_t>(128 * ch + k)));
+        const uint64_t zc = mix64(kseg + kGolden * static_cast<uint64_t>(128 * ch + k));
         const double mut = v1[ch][k] + p.F * (v2[ch][k] - v3[ch][k]);
-        trial[ch][k] = (u < p.CR || e == jrand) ? mut : vk[ch][k];
+        trial[ch][k] = (zc < p.cr_thresh || p.cr_all || e == jrand) ? mut : vk[ch][k];
       }
     store_segment<VEC, true>(out, e_base, D, trial);
     objective_accumulate<OBJ, kSeg>(acc, trial, e_base, D, trial_at(e_base + 128 * kSeg));
