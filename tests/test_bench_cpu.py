@@ -1,0 +1,47 @@
+"""bench.py's host logic that needs no GPU: the `other_configs` pass (BASELINE configs[2..4]
+measured by child processes of the script and embedded in the headline line) keeps what it reads
+to the fields the line is read for and turns a failing child into an `error` entry."""
+import importlib.util
+import json
+import os
+import subprocess
+import types
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def load_bench():
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_other_configs_pass_summarises_children_and_survives_failures(monkeypatch):
+    bench = load_bench()
+    calls = []
+
+    def fake_run(cmd, **kw):
+        calls.append(cmd)
+        assert "--no-cpu-baseline" in cmd and kw.get("timeout", 0) <= 300
+        if "lm" in cmd:
+            return types.SimpleNamespace(returncode=1, stdout="", stderr="boom: no GPU here")
+        line = {"metric": "m", "value": 2.5, "unit": "u/s", "steps": 7, "ms_per_step": 0.4, "dtype": "f64",
+                "config": {"workload": "w", "other_solver": {"solver": "qr", "value": 1.0, "ms_per_step": 2.0,
+                                                            "extra": "dropped"}},
+                "roofline": {"bound": "hbm", "achieved": 1.0, "peak": 2.0, "unit": "GB/s", "frac": 0.5,
+                             "kernel": "k", "kernel_ms": 0.1, "traffic": 123, "noise": "dropped"},
+                "cpu_baseline": {"value": 9}}
+        return types.SimpleNamespace(returncode=0, stdout="banner\n" + json.dumps(line) + "\n", stderr="")
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    out = bench.other_configs_pass()
+    assert len(out) == len(calls) >= 4
+    ok = [e for e in out if "error" not in e]
+    bad = [e for e in out if "error" in e]
+    assert len(bad) == 1 and "rc=1" in bad[0]["error"] and "boom" in bad[0]["error"]
+    for e in ok:
+        assert e["value"] == 2.5 and e["workload"] == "w" and e["roofline"]["frac"] == 0.5
+        assert "noise" not in e["roofline"] and "cpu_baseline" not in e
+        assert e["other_solver"] == {"solver": "qr", "value": 1.0, "ms_per_step": 2.0}
+    assert all(e["config"].startswith("configs[") for e in out)
