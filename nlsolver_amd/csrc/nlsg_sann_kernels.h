@@ -36,6 +36,15 @@ struct SannParams {
   double temp_max, fmul;
 };
 
+// The acceptance test of a worse point (:2805), u < exp(-difference / t). A difference beyond
+// 710 t puts the exponential's argument below -708, where det_exp returns 0 and no uniform is below
+// it: the draw, the division and the exponential are then skipped — the same decision, and the
+// usual case once a chain is cold (draws are keyed, so skipping one changes nothing else).
+// `sure_reject` must be wave-uniform where it is branched on.
+__device__ inline bool sann_sure_reject(double difference, double t) {
+  return t > 0.0 && difference > 710.0 * t;
+}
+
 // outer iterations [iter_begin, iter_end) of every chain; iter_begin == 0 also scores the start
 template <int OBJ, int CHUNKS, bool VEC>
 __global__ __launch_bounds__(256) void sann_anneal_kernel(SannParams p, uint64_t iter_begin,
@@ -88,8 +97,9 @@ __global__ __launch_bounds__(256) void sann_anneal_kernel(SannParams p, uint64_t
       const double current_val = p.fmul * wave_objective<OBJ, CHUNKS>(pt, D);
       fcalls++;
       const double difference = current_val - best;  // against the best so far (:2804)
-      const bool accept = (difference <= 0.0) ||
-                          (u01(ctr_key(ks, 2 * D)) < det_exp(-difference / t));  // :2805
+      bool accept = difference <= 0.0;
+      if (!accept && !sann_sure_reject(difference, t))  // wave-uniform
+        accept = u01(ctr_key(ks, 2 * D)) < det_exp(-difference / t);  // :2805
       if (accept) {  // wave-uniform
         const bool better = current_val <= best;
 #pragma unroll
@@ -188,8 +198,9 @@ __global__ __launch_bounds__(256) void sann_anneal_long_kernel(SannParams p, uin
       const double current_val = p.fmul * objective_finish<OBJ>(acc, D);
       fcalls++;
       const double difference = current_val - best;  // against the best so far (:2804)
-      const bool accept = (difference <= 0.0) ||
-                          (u01(ctr_key(ks, 2 * D)) < det_exp(-difference / t));  // :2805
+      bool accept = difference <= 0.0;
+      if (!accept && !sann_sure_reject(difference, t))  // wave-uniform
+        accept = u01(ctr_key(ks, 2 * D)) < det_exp(-difference / t);  // :2805
       if (accept) {  // wave-uniform
         copy_row(pc, pt);
         if (current_val <= best) {
@@ -262,8 +273,10 @@ __global__ __launch_bounds__(256) void sann_anneal_groups_kernel(SannParams p, u
       const double current_val = p.fmul * group_objective<OBJ, G>(pt[0], pt[1], D);
       fcalls++;
       const double difference = current_val - best;
-      const bool accept = (difference <= 0.0) ||
-                          (u01(ctr_key(ks, 2 * D)) < det_exp(-difference / t));
+      bool accept = difference <= 0.0;
+      // (per group; the exponential is skipped when no group of the wave needs it)
+      if (__ballot(!accept && !sann_sure_reject(difference, t)) != 0ull)
+        accept = accept || (u01(ctr_key(ks, 2 * D)) < det_exp(-difference / t));
       const bool better = accept && current_val <= best;
 #pragma unroll
       for (int k = 0; k < 2; k++) {
