@@ -1,3 +1,8 @@
+#!/bin/bash
+# scripts/pmc_de_issue.sh — on the GPU box: rocprofv3 SQ issue counters of the DE headline run
+# (vector / scalar instructions per wave, how busy each unit is, how long the waves wait), three
+# --pmc passes of `bench.py --steps 20` under gpurun_out/pmc_de/. What DESIGN.md §3 "What bounds
+# the generation at pop = 65 536" quotes.
 cd /tmp && export TMPDIR=/tmp
 root=$GRAFT_REPO_ROOT
 out=$root/gpurun_out/pmc_de
