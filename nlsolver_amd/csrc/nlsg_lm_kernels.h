@@ -32,7 +32,13 @@ typedef double v2d_nt __attribute__((ext_vector_type(2)));
 constexpr int kLmN = 64;        // parameters are padded to 64 columns
 constexpr int kLmJStride = 80;  // LDS row stride of the Jacobian block (doubles)
 constexpr int kLmQrThreads = 512;  // the QR step's workgroup: each wave follows 32 / 8 column chains
-constexpr int kLmTri = 33 * 64;  // packed lower triangle of a 64 x 64 matrix (2080) + pad
+constexpr int kLmTri = 33 * 64;  // packed lower triangle of a 64 x 64 matrix, every row starting at
+                                 // an even offset (lm_tri_row): 2112 doubles exactly
+// offset of row r of the packed triangle: rows are padded to an even length, so that a row's
+// pairs of columns (2m, 2m + 1) are 16-byte aligned and the Cholesky panel reads them as one
+// 128-bit LDS load (half as many LDS instructions in its inner loop)
+__host__ __device__ constexpr int lm_tri_row(int r) { return 2 * ((r + 1) / 2) * ((r + 2) / 2); }
+static_assert(lm_tri_row(64) == kLmTri && lm_tri_row(1) == 2 && lm_tri_row(3) == 8, "row offsets");
 
 struct LmProblem {
   double f, lambda, prev;
@@ -65,7 +71,10 @@ struct LmParams {
 // reads H[i][j] with j <= i: Cholesky, both substitutions, and is_diagonal by symmetry).
 struct LmRowsTri {
   double *base;
-  __device__ double &operator()(int i, int j) const { return base[i * (i + 1) / 2 + j]; }
+  __device__ double &operator()(int i, int j) const { return base[lm_tri_row(i) + j]; }
+  __device__ double2 pair(int i, int j) const {  // columns j (even), j + 1
+    return *reinterpret_cast<const double2 *>(base + lm_tri_row(i) + j);
+  }
 };
 // The same for an LDS image that ends with row n - 1: the solve's masked reads (rows >= n,
 // columns past the diagonal) are folded back inside it.
@@ -73,7 +82,10 @@ struct LmRowsTriShort {
   double *base;
   int last;  // n - 1
   __device__ double &operator()(int i, int j) const {
-    return base[min(i, last) * (min(i, last) + 1) / 2 + min(j, last)];
+    return base[lm_tri_row(min(i, last)) + min(j, last)];
+  }
+  __device__ double2 pair(int i, int j) const {  // columns j (even), j + 1, both <= last
+    return *reinterpret_cast<const double2 *>(base + lm_tri_row(min(i, last)) + j);
   }
 };
 
@@ -110,16 +122,15 @@ __device__ inline void lm_solve_cholesky_wave(Rows H, const double *g, double *u
     double s4[4] = {0.0, 0.0, 0.0, 0.0};
     const bool act = row && t >= j0;
     for (int k = 0; k < j0; k += 4) {  // j0 is a multiple of 4
-      double x[4];
-#pragma unroll
-      for (int q = 0; q < 4; q++) x[q] = H(t, k + q);  // lanes t < j0: in-buffer, unused
+      // (rows start at even offsets: a pair of columns is one 128-bit LDS read)
+      const double2 xa = H.pair(t, k), xb = H.pair(t, k + 2);  // lanes t < j0: in-buffer, unused
+      const double x[4] = {xa.x, xa.y, xb.x, xb.y};
 #pragma unroll
       for (int c = 0; c < 4; c++) {
-        // L[j0+c][k..k+3]: a wave-uniform LDS address (one broadcast read per value on the
-        // otherwise idle LDS port instead of two scalar lane reads on the VALU port)
-        double l[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) l[q] = H(min(j0 + c, 63), k + q);
+        // L[j0+c][k..k+3]: a wave-uniform LDS address (broadcast reads on the otherwise idle LDS
+        // port instead of scalar lane reads on the VALU port)
+        const double2 la = H.pair(min(j0 + c, 63), k), lb = H.pair(min(j0 + c, 63), k + 2);
+        const double l[4] = {la.x, la.y, lb.x, lb.y};
 #pragma unroll
         for (int q = 0; q < 4; q++) s4[c] = __builtin_fma(x[q], l[q], s4[c]);
       }
@@ -539,7 +550,7 @@ __device__ inline void lm_eval_wave(const LmParams &p, int first, uint64_t pid, 
       for (int rg = 0; rg < 4; rg++) {
         const int row = 16 * rb + kk + 4 * rg, col = 16 * cb + cc;
         if (col <= row)
-          p.Hg[pid * kLmTri + row * (row + 1) / 2 + col] = 2 * acc[rb * (rb + 1) / 2 + cb][rg];
+          p.Hg[pid * kLmTri + lm_tri_row(row) + col] = 2 * acc[rb * (rb + 1) / 2 + cb][rg];
       }
 #pragma unroll
   for (int b = 0; b < 4; b++) {
@@ -588,7 +599,7 @@ __device__ inline bool lm_step_wave(const LmParams &p, uint64_t pid, LmStepShare
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  if (t < n) sh.tri[t * (t + 1) / 2 + t] += pr->lambda;  // :3529-3531
+  if (t < n) sh.tri[lm_tri_row(t) + t] += pr->lambda;  // :3529-3531
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   if constexpr (FD)
@@ -760,7 +771,7 @@ __device__ inline void lm_fd_eval_groups(const LmParams &p, int first, uint64_t 
       const double hij = result / denom;
       hrow = lane == j ? hij : hrow;
     }
-    if (lane <= i) p.Hg[pid * kLmTri + i * (i + 1) / 2 + lane] = hrow;
+    if (lane <= i) p.Hg[pid * kLmTri + lm_tri_row(i) + lane] = hrow;
     upper |= lane > i && lane < n && hrow > 2.220446049250313e-16 * 1e12;
   }
   const bool any_upper = __ballot(upper) != 0ull;
@@ -772,7 +783,7 @@ __device__ inline void lm_fd_eval_groups(const LmParams &p, int first, uint64_t 
 
 // LDS of the wave: `chunks` x 64 doubles of the triangle (rows 0 .. n-1) | g | upd
 __host__ __device__ inline int lm_fd_chunks(uint64_t n) {
-  return static_cast<int>((n * (n + 1) / 2 + 63) / 64);
+  return (lm_tri_row(static_cast<int>(n)) + 63) / 64;
 }
 template <int OBJ>
 __global__ __launch_bounds__(64) void lm_fd_iter_kernel(LmParams p, int first) {
@@ -818,7 +829,7 @@ __global__ __launch_bounds__(THREADS) void lm_qr_step_kernel(LmParams p) {
   for (int e = t; e < 64 * 64; e += THREADS) {  // the full symmetric matrix from its lower triangle
     const int i = e >> 6, j = e & 63;
     const int hi = i > j ? i : j, lo = i > j ? j : i;
-    const double v = tri[hi * (hi + 1) / 2 + lo];
+    const double v = tri[lm_tri_row(hi) + lo];
     qs.R[i * kLmQrStride + j] = (i == j && i < n) ? v + lambda : v;  // :3529-3531
   }
   if (t < 64) qs.R[t * kLmQrStride + 64] = p.gg[pid * kLmN + t];
