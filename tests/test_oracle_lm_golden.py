@@ -90,6 +90,22 @@ def test_deterministic_exp_tanh_accuracy(oracle):
     assert oracle.orc_tanh(0.0) == 0.0 and oracle.orc_tanh(40.0) == 1.0 and oracle.orc_exp(0.0) == 1.0
 
 
+def test_deterministic_tanh_rational_form_properties(oracle):
+    """orc_tanh = ((s - 1) B + 2 s r) / ((s + 1) B + 2 s r) (one division, oracle_lm.c): odd,
+    non-decreasing, relatively accurate for small arguments (1 - 2 / (e + 1) is not: it cancels),
+    exactly 1 from 22 on, NaN for NaN."""
+    rng = np.random.default_rng(9)
+    xs = np.sort(np.concatenate([rng.uniform(0, 23, 20000), 10.0 ** rng.uniform(-300, 0, 5000)]))
+    vals = np.array([oracle.orc_tanh(float(x)) for x in xs])
+    assert np.all(np.diff(vals) >= -2.3e-16)           # monotone up to the last bit
+    for x, v in zip(xs[::7], vals[::7]):
+        assert oracle.orc_tanh(-float(x)) == -v
+        ref = math.tanh(float(x))
+        assert abs(v - ref) <= 3 * np.spacing(ref)       # RELATIVE accuracy, small x included
+    assert oracle.orc_tanh(22.0) == 1.0 and oracle.orc_tanh(1e6) == 1.0 and oracle.orc_tanh(18.0) < 1.0
+    assert oracle.orc_tanh(1e-300) == 1e-300 and math.isnan(oracle.orc_tanh(float("nan")))
+
+
 @pytest.mark.parametrize("name", ["tanh_m128_n64", "tanh_m512_n64"])
 @pytest.mark.parametrize("solver", [0, 1])
 def test_kernel_order_and_qr_solver_agree_with_reference_arithmetic(oracle, golden, name, solver):
