@@ -95,6 +95,20 @@ def test_lm_wide_custom_objective_equals_builtin(mod):
     assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
 
 
+def test_lm_wide_whole_vector_objective_equals_builtin(mod):
+    """A whole-vector user objective (x.sum over all coordinates: the lane-tree order of the
+    built-in objectives) behind the default functors at n = 70: the bits of the built-in sphere."""
+    n, kw = 70, dict(lam=1.0, max_iter=2, f_delta=0.0)
+    x0 = np.linspace(-2.0, 2.0, 2 * n).reshape(2, n)
+    out = []
+    for obj in ("sphere", mod.CustomObjective(
+            "return x.sum([](double xi, uint64_t) { return xi * xi; });", vector=True)):
+        with mod.lm.LMEngine(obj, batch=2, n=n, **kw) as eng:
+            x, st, lam = eng.minimize(x0.copy())
+        out.append((x, [(s.f_value, s.function_calls_used) for s in st], lam))
+    assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
+
+
 def test_lm_wide_diagonal_shortcut_and_limits(mod, oracle):
     """Sphere's finite-difference Hessian at a point where every off-diagonal probe difference
     vanishes takes is_diagonal's shortcut (:310-318) — same branch in kernel and oracle; QR and
