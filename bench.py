@@ -32,16 +32,21 @@ BYTES_PER_CANDIDATE = 5 * D * 8 + 16  # 4 row reads + 1 row write + score r/w (S
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def free_port():
+    """A free rendezvous port on the loopback interface."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def spawn_ranks(n, argv, timeout=None):
     """Start n ranks of this script (fresh child processes, RANK / LOCAL_RANK / WORLD_SIZE /
     MASTER_* set) with the arguments argv and wait for them; returns (exit codes, the non-empty
     lines rank 0 wrote to stdout). A rank that died leaves its peers inside a collective: they
     get a grace period, then exactly the processes started here are ended; the same after
     `timeout` seconds."""
-    import socket
-    with socket.socket() as sk:  # a free rendezvous port
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    port = free_port()
     import tempfile
     procs = []
     with tempfile.TemporaryFile(mode="w+") as out0:
@@ -136,7 +141,12 @@ class Ranks:
         if self.distributed:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29511")
+            if "MASTER_PORT" not in os.environ:
+                # ranks cannot agree on a port by themselves: a launcher (or spawn_ranks) names it;
+                # only the single-rank self-test may pick any free one
+                if self.world > 1:
+                    raise SystemExit("WORLD_SIZE > 1 needs MASTER_PORT (set by the launcher)")
+                os.environ["MASTER_PORT"] = str(free_port())
             dist.init_process_group(**pg_args(self.rank, self.world, self.device))
             self.dist = dist
 
@@ -152,6 +162,9 @@ class Ranks:
                               device="cpu" if self.dist.get_backend() == "gloo" else self.device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
+
+    def min_over_ranks(self, value):
+        return -self.max_over_ranks(-value)
 
     def slice_seed(self, base):
         """Replica workloads (independent problems, no collective): rank r solves problems
@@ -227,6 +240,14 @@ def cpu_baseline_all_cores():
             "kind": "port",
             "sample": f"oracle synchronous DE (keyed draws) Rosenbrock-{D}D pop={POP_PER_GPU}, "
                       f"{gens} generations ({dt:.1f} s), OpenMP over agents, {threads} threads"}
+
+
+def check_kernel_within_step(kernel_ms, ms_per_step, what):
+    """A line is self-consistent only if the dominant kernel fits into the step that contains it
+    (3 % for timer noise between the two measurements)."""
+    if kernel_ms > 1.03 * ms_per_step:
+        raise AssertionError(f"{what}: roofline.kernel_ms {kernel_ms:.4f} > ms_per_step "
+                             f"{ms_per_step:.4f}: the two describe different regimes")
 
 
 def ref_baseline(cmd, key, unit, sample):
@@ -308,10 +329,24 @@ def main_bfgs(args):
     b = np.array([math.sin(0.1 * i) for i in range(n)])
     rng = np.random.default_rng(ranks.slice_seed(12374563468 % 2**32))
     x0 = 1.0 + 0.5 * (rng.random((batch, n)) - 0.5)
-    steps, warm = min(args.steps, 40), min(args.warmup, 4)
     eng = nlsolver_amd.BFGSEngine(nlsolver_amd.QuadDiagRank1(d, b, 0.01), batch,
                                   max_iter=10**9, grad_eps=0.0, alpha=1.0, device=local_rank,
                                   **({"symmetric": True} if args.bfgs_symmetric else {}))
+    # The line describes ONE regime: iterations in which every problem streams a dense H. Iteration
+    # 0 runs on H = I (never materialised); towards convergence the reset guard (nlsolver.h:
+    # 3253-3260) re-identities H problem by problem and the passes skip their reads. An untimed
+    # pre-pass (it also wakes the device up) finds the window: `dense_upto` = the number of
+    # leading iterations after which no problem has been reset or has stopped.
+    eng.init(x0)
+    eng.step(2)
+    dense_upto = 2
+    while dense_upto < 64 and eng.identity_count() == 0 and eng.unfinished() == batch:
+        dense_upto += 1
+        eng.step(1)
+    dense_upto -= 1  # the iteration that produced the first reset is outside the window
+    dense_upto = int(ranks.min_over_ranks(dense_upto))
+    warm = max(1, min(args.warmup, 4))
+    steps = max(1, min(args.steps, 40, dense_upto - warm))
     eng.init(x0)
     eng.step(warm)
     ranks.barrier()
@@ -319,17 +354,28 @@ def main_bfgs(args):
     eng.step(steps)
     ranks.barrier()
     dt = ranks.max_over_ranks(time.perf_counter() - t0)
-    open_ = eng.unfinished()
-    # the H-pass figure is taken on iterations 8..11 of a fresh run: dense H for every problem
-    # (towards convergence the reset guard re-identities H and the passes skip their reads)
+    dense_verified = eng.identity_count() == 0 and eng.unfinished() == batch
+    # the two H passes alone (hipEvents inside the iteration), same window: iterations k0 .. k0+3
+    k0 = max(1, min(8, dense_upto - 4))
     eng.init(x0)
-    eng.step(8)
+    eng.step(k0)
     total_ms, hess_ms = eng.time_steps(4)
     hess_ms /= 4
+    # what a whole run to the rounding floor averages (identity-H iterations included): reported
+    # beside `value`, never as it
+    eng.init(x0)
+    eng.step(warm)
+    ranks.barrier()
+    t1 = time.perf_counter()
+    eng.step(44)
+    ranks.barrier()
+    dt_run = ranks.max_over_ranks(time.perf_counter() - t1)
+    open_ = eng.unfinished()
     # literal: read H (t = H y) + read & write H (update); symmetric: the upper blocks only
     bytes_per_iter = (eng.hessian_bytes_per_iteration() if args.bfgs_symmetric
                       else 3 * n * n * 8) * batch
     achieved = bytes_per_iter / (hess_ms * 1e-3) / 1e9
+    check_kernel_within_step(hess_ms, dt / steps * 1e3, "bfgs")
     if ranks.rank == 0:
         print(json.dumps({
             "metric": "BFGS iterations x problems / s (quadratic dim=1024)",
@@ -341,6 +387,14 @@ def main_bfgs(args):
                                    "independent starts per GPU (BASELINE configs[2]), "
                                    f"{'symmetric (upper blocks of H)' if args.bfgs_symmetric else 'literal'}"
                                    " rank-2 update",
+                       "timed_iterations": f"{warm} .. {warm + steps - 1} of a fresh run: every problem "
+                                           "streams a dense inverse Hessian",
+                       "dense_h_iterations_available": dense_upto, "dense_h_verified": dense_verified,
+                       "whole_run": {"value": ranks.world * batch * 44 / dt_run,
+                                     "ms_per_step": dt_run / 44 * 1e3, "iterations": f"{warm} .. {warm + 43}",
+                                     "note": "includes the iterations after the quadratic has converged, "
+                                             "in which the reset guard keeps H = I and the passes "
+                                             "skip their reads"},
                        "unfinished_problems": open_, "parallelism": ranks.replicas()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
@@ -595,6 +649,7 @@ def main_lm(args):
     flops = 2.0 * m * 10 * 256 * batch
     tflops = flops / (kms * 1e-3) / 1e12
     hbm_gbps = hbm_eval / (kms * 1e-3) / 1e9
+    check_kernel_within_step(kms, ms / iters, "lm")
     if ranks.rank == 0:
         print(json.dumps({
             "metric": "LM iterations x problems / s (NLLS m=512 n=64)",
@@ -604,6 +659,7 @@ def main_lm(args):
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"Levenberg-Marquardt tanh-regression NLLS m={m} n={n}, "
                                    f"batch={batch} per GPU (BASELINE configs[3]), {args.lm_solver} solve",
+                       "solver": args.lm_solver,
                        "max_final_f": max(s.f_value for s in st),
                        # what an iteration spends outside the evaluation launch (the damped solve)
                        "solve_ms_per_iteration": ms / iters - kms * evals / iters,
@@ -731,6 +787,7 @@ def main_pso(args):
         kern_ms = eng.time_move_kernel(launches) / launches
         bytes_per = (40 if vanilla else 16) * Dp + 24  # rows r/w + cur/pbest values
         achieved = bytes_per * n_local / (kern_ms * 1e-3) / 1e9
+        check_kernel_within_step(kern_ms, dt / args.steps * 1e3, args.workload)
         print(json.dumps({
             "metric": "particle-evals/sec Rosenbrock-256D PSO", "value": n * args.steps / dt,
             "unit": "particle-evals/s", "n_gpus": world, "steps": args.steps,
@@ -809,7 +866,10 @@ def other_configs_pass():
     runs = [("configs[2] BFGS dim=1024 batch=4096", ["--workload", "bfgs"]),
             ("configs[2] BFGS dim=1024 batch=4096, symmetric restatement of the rank-2 update "
              "(upper blocks of H only; values equal to rounding)", ["--workload", "bfgs", "--bfgs-symmetric"]),
-            ("configs[3] Levenberg-Marquardt m=512 n=64 batch=8192", ["--workload", "lm"]),
+            ("configs[3] Levenberg-Marquardt m=512 n=64 batch=8192, tinyqr damped solve (the solver "
+             "BASELINE words: tinyqr::lm on J^T J + lambda I)", ["--workload", "lm", "--lm-solver", "qr"]),
+            ("configs[3] Levenberg-Marquardt m=512 n=64 batch=8192, Cholesky damped solve (the "
+             "reference class's own get_update_with_hessian)", ["--workload", "lm", "--lm-solver", "cholesky"]),
             ("configs[4] PSO Accelerated, one GPU's shard 131072 x 256",
              ["--workload", "pso-accel", "--steps", "100", "--warmup", "300"]),
             ("configs[4] PSO Vanilla, one GPU's shard 131072 x 256",
@@ -831,6 +891,12 @@ def other_configs_pass():
             entry["workload"] = d["config"]["workload"]
             entry["roofline"] = {k: roof.get(k) for k in ("bound", "achieved", "peak", "unit", "frac",
                                                           "kernel", "kernel_ms")}
+            # a line is self-consistent only if its dominant kernel fits into its step
+            km, sm = entry["roofline"]["kernel_ms"], entry["ms_per_step"]
+            entry["kernel_within_step"] = None if km is None else bool(km <= 1.03 * sm)
+            for k in ("solver", "solve_ms_per_iteration", "whole_run", "timed_iterations"):
+                if k in d["config"]:
+                    entry[k] = d["config"][k]
             other = d["config"].get("other_solver")
             if other:
                 entry["other_solver"] = {k: other[k] for k in ("solver", "value", "ms_per_step")}
@@ -958,6 +1024,7 @@ def main():
         launches = max(args.steps, 20)
         kern_ms = eng.time_generation_kernel(launches) / launches
         achieved = BYTES_PER_CANDIDATE * pop_local / (kern_ms * 1e-3) / 1e9
+        check_kernel_within_step(kern_ms, dt / args.steps * 1e3, "de")
         out = {
             "metric": "candidate-evals/sec (pop x iters/s) Rosenbrock-128D DE",
             "value": pop * args.steps / dt,
@@ -992,6 +1059,15 @@ def main():
         if world == 1 and not args.no_north_star and pop_local == POP_PER_GPU:
             try:
                 out["north_star"] = north_star_pass(args.steps)
+                # the HBM-honest fraction next to the headline one: configs[1]'s 128 MiB working
+                # set lives in the 256 MiB Infinity Cache, the north-star population does not
+                ns = out["north_star"]["roofline"]
+                out["roofline"]["frac_at_north_star_size"] = ns["frac"]
+                out["roofline"]["frac_note"] = (
+                    f"frac = {out['roofline']['frac']:.3f} is configs[1] (pop 65536: both population "
+                    f"buffers sit in the Infinity Cache); the HBM-bound figure is pop = 2^20: "
+                    f"{ns['frac']:.3f} of peak ({ns['achieved']:.0f} GB/s), see north_star")
+                out["config"]["hbm_frac_at_north_star_size"] = ns["frac"]
             except Exception as exc:  # never lose the headline line to the second pass
                 out["north_star"] = {"error": str(exc)[:300]}
         if not args.no_cpu_baseline and world == 1:

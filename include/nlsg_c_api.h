@@ -350,6 +350,10 @@ int nlsg_bfgs_init(nlsg_bfgs *e, const double *x0_host);
 int nlsg_bfgs_step(nlsg_bfgs *e, uint64_t iters);
 /* Number of problems whose stop test has not fired yet. Synchronises. */
 int nlsg_bfgs_unfinished(nlsg_bfgs *e, uint64_t *count);
+/* Number of unfinished problems whose inverse Hessian is the identity right now (the start,
+ * 3212, or the reset guard of 3253-3260 fired in the last turn): the H passes skip their reads
+ * for those, so a throughput figure is a dense-H figure only while this is 0. Synchronises. */
+int nlsg_bfgs_identity_count(nlsg_bfgs *e, uint64_t *count);
 /* x (batch*dim) and per-problem status (batch). Synchronises. NULLs are skipped.
  * status.f_value is f(x) evaluated when the stop test fired (3243). */
 int nlsg_bfgs_download(nlsg_bfgs *e, double *x_host, nlsg_status *status_host);

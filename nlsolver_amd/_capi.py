@@ -4,6 +4,7 @@ The library is the product's only compute path. There is no CPU fallback: if
 the shared object is missing or no gfx950 device is visible, calls raise.
 """
 import ctypes as C
+import sys
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -170,6 +171,7 @@ SYMBOLS = {
     "nlsg_bfgs_init": (C.c_int, [_H, pd]),
     "nlsg_bfgs_step": (C.c_int, [_H, u64]),
     "nlsg_bfgs_unfinished": (C.c_int, [_H, pu]),
+    "nlsg_bfgs_identity_count": (C.c_int, [_H, pu]),
     "nlsg_bfgs_download": (C.c_int, [_H, pd, C.POINTER(Status)]),
     "nlsg_bfgs_download_state": (C.c_int, [_H, pd, pd]),
     "nlsg_bfgs_minimize": (C.c_int, [_H, pd, C.POINTER(Status)]),
@@ -233,9 +235,16 @@ class _PinnedBlock:
         check(lib().nlsg_host_alloc(C.byref(self.ptr), nbytes))
 
     def __del__(self):
-        if getattr(self, "ptr", None) and self.ptr.value:
-            lib().nlsg_host_free(self.ptr)
-            self.ptr = C.c_void_p()
+        # at interpreter shutdown the module globals, the ctypes handle or the HIP runtime may be
+        # gone already: the process is about to release the memory anyway
+        try:
+            if sys.is_finalizing():
+                return
+            if getattr(self, "ptr", None) and self.ptr.value:
+                lib().nlsg_host_free(self.ptr)
+                self.ptr = C.c_void_p()
+        except Exception:
+            pass
 
 
 def pinned_empty(shape, dtype="float64"):

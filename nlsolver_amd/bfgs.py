@@ -102,6 +102,13 @@ class BFGSEngine:
         check(lib().nlsg_bfgs_unfinished(self._h, C.byref(c)))
         return c.value
 
+    def identity_count(self):
+        """Unfinished problems whose inverse Hessian is the identity right now (start / reset guard):
+        the H passes skip their reads for those."""
+        c = C.c_uint64()
+        check(lib().nlsg_bfgs_identity_count(self._h, C.byref(c)))
+        return c.value
+
     def download(self):
         B, n = self.cfg.batch, self.cfg.dim
         x = np.empty((B, n))

@@ -298,6 +298,21 @@ int nlsg_bfgs_unfinished(nlsg_bfgs *e, uint64_t *count) {
   return NLSG_OK;
 }
 
+int nlsg_bfgs_identity_count(nlsg_bfgs *e, uint64_t *count) {
+  if (!e || !count) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  if (!e->initialised) return fail(NLSG_ERR_STATE, "nlsg_bfgs_init has not been called");
+  NLSG_HIP(hipSetDevice(e->cfg.device));
+  NLSG_HIP(hipMemsetAsync(e->count_dev, 0, 8, e->stream));
+  hipLaunchKernelGGL(bfgs_count_identity_kernel,
+                     dim3(static_cast<unsigned>((e->p.batch + 255) / 256)), dim3(256), 0, e->stream,
+                     e->p, e->count_dev);
+  unsigned long long c = 0;
+  NLSG_HIP(hipMemcpyAsync(&c, e->count_dev, 8, hipMemcpyDeviceToHost, e->stream));
+  NLSG_HIP(hipStreamSynchronize(e->stream));
+  *count = c;
+  return NLSG_OK;
+}
+
 int nlsg_bfgs_download(nlsg_bfgs *e, double *x_host, nlsg_status *status_host) {
   if (!e) return fail(NLSG_ERR_INVALID_ARG, "null engine");
   if (!e->initialised) return fail(NLSG_ERR_STATE, "nlsg_bfgs_init has not been called");

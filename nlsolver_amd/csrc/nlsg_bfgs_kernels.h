@@ -834,5 +834,9 @@ __global__ void bfgs_count_unfinished_kernel(BfgsParams p, unsigned long long *c
   const uint64_t pid = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (pid < p.batch && !p.prob[pid].done) atomicAdd(count, 1ull);
 }
+__global__ void bfgs_count_identity_kernel(BfgsParams p, unsigned long long *count) {
+  const uint64_t pid = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (pid < p.batch && !p.prob[pid].done && p.prob[pid].identity) atomicAdd(count, 1ull);
+}
 
 }  // namespace nlsg

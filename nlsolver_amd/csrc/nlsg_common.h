@@ -86,8 +86,8 @@ inline hipError_t &module_launch_error() {
   return err;
 }
 inline void launch_module_kernel(hipFunction_t fn, unsigned grid, unsigned block, unsigned lds_bytes,
-                                 hipStream_t stream, void **args) {
-  const hipError_t r = hipModuleLaunchKernel(fn, grid, 1, 1, block, 1, 1, lds_bytes, stream, args, nullptr);
+                                 hipStream_t stream, void **args, unsigned grid_y = 1) {
+  const hipError_t r = hipModuleLaunchKernel(fn, grid, grid_y, 1, block, 1, 1, lds_bytes, stream, args, nullptr);
   if (r != hipSuccess && module_launch_error() == hipSuccess) module_launch_error() = r;
 }
 inline hipError_t launches_status() {

@@ -349,8 +349,8 @@ static int de_create(const nlsg_de_config *cfg, const nlsg_custom_objective *cus
                 "distinct donors besides the target, nlsolver.h:2331-2355)",
                 (unsigned long long)cfg->shard_lo, (unsigned long long)cfg->shard_n,
                 (unsigned long long)cfg->pop);
-  if (cfg->shard_n > (1ull << 32))
-    return fail(NLSG_ERR_UNSUPPORTED, "shard_n > 2^32 agents per engine");
+  if (cfg->shard_n > 0xffffffffull)  // donor indices are drawn as 32-bit values inside a shard
+    return fail(NLSG_ERR_UNSUPPORTED, "shard_n >= 2^32 agents per engine");
   int rc = check_device(cfg->device);
   if (rc) return rc;
   NLSG_HIP(hipSetDevice(cfg->device));

@@ -78,15 +78,12 @@ void launch_fd_iter(nlsg_lm *e, int first) {
 // n > 64: evaluation (f, g, H at the current point) as one launch, a workgroup per problem
 template <int OBJ>
 void launch_wide_fd(nlsg_lm *e, dim3 grid, int first) {
-  const uint64_t n = e->p.n;
-  if (n <= 128)
-    hipLaunchKernelGGL((lm_wide_fd_eval_kernel<OBJ, 1>), grid, dim3(lm_wide_fd_threads(1)), 0, e->stream, e->p, first);
-  else if (n <= 256)
-    hipLaunchKernelGGL((lm_wide_fd_eval_kernel<OBJ, 2>), grid, dim3(lm_wide_fd_threads(2)), 0, e->stream, e->p, first);
-  else if (n <= 512)
-    hipLaunchKernelGGL((lm_wide_fd_eval_kernel<OBJ, 4>), grid, dim3(lm_wide_fd_threads(4)), 0, e->stream, e->p, first);
-  else
-    hipLaunchKernelGGL((lm_wide_fd_eval_kernel<OBJ, 8>), grid, dim3(lm_wide_fd_threads(8)), 0, e->stream, e->p, first);
+  switch (lm_wide_chunks(e->p.n)) {
+    case 1: hipLaunchKernelGGL((lm_wide_fd_eval_kernel<OBJ, 1>), grid, dim3(lm_wide_fd_threads(1)), 0, e->stream, e->p, first); break;
+    case 2: hipLaunchKernelGGL((lm_wide_fd_eval_kernel<OBJ, 2>), grid, dim3(lm_wide_fd_threads(2)), 0, e->stream, e->p, first); break;
+    case 4: hipLaunchKernelGGL((lm_wide_fd_eval_kernel<OBJ, 4>), grid, dim3(lm_wide_fd_threads(4)), 0, e->stream, e->p, first); break;
+    default: hipLaunchKernelGGL((lm_wide_fd_eval_kernel<OBJ, 8>), grid, dim3(lm_wide_fd_threads(8)), 0, e->stream, e->p, first); break;
+  }
 }
 void launch_wide_eval(nlsg_lm *e, int first) {
   // finite-difference model: enough workgroups per problem to fill the device when the batch is small
@@ -99,8 +96,8 @@ void launch_wide_eval(nlsg_lm *e, int first) {
   }
   if (e->cfg.objective == NLSG_OBJ_CUSTOM) {
     void *args[] = {&e->p, &first};
-    const uint64_t n = e->p.n;
-    launch_module_kernel(e->rtc.iter, grid.x, lm_wide_fd_threads(n <= 512 ? 4 : 8), 0, e->stream, args);  // (one workgroup per problem)
+    launch_module_kernel(e->rtc.iter, grid.x, lm_wide_fd_threads(lm_wide_chunks(e->p.n)), 0, e->stream,
+                         args, grid.y);
     return;
   }
   switch (e->cfg.objective) {
@@ -251,7 +248,7 @@ static int lm_create(const nlsg_lm_config *cfg, const nlsg_custom_objective *cus
   }
   if (custom) {
     const uint64_t n = cfg->n;
-    const int rc2 = rtc_build_lm(custom, !wide ? 0 : n <= 128 ? 1 : n <= 256 ? 2 : n <= 512 ? 4 : 8,
+    const int rc2 = rtc_build_lm(custom, !wide ? 0 : lm_wide_chunks(n),
                                  &e->rtc);
     if (rc2) {
       nlsg_lm_destroy(e);

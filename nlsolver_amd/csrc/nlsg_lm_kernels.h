@@ -963,6 +963,9 @@ __global__ __launch_bounds__(kLmWideThreads) void lm_wide_step_kernel(LmParams p
 // (n > 512: eight) waves per problem, a probe point per wave (CHUNKS x 128 coordinates in registers), gradient
 // coordinates and Hessian entries dealt to the waves round robin. Every probe is a full
 // wave_objective evaluation: the bits of the oracle's tree.
+// the ONE place that maps n to the CHUNKS instantiation (engine creation, the run-time compiler's
+// template arguments and every launch take it from here)
+__host__ __device__ constexpr int lm_wide_chunks(uint64_t n) { return n <= 128 ? 1 : n <= 256 ? 2 : n <= 512 ? 4 : 8; }
 __host__ __device__ constexpr int lm_wide_fd_threads(int chunks) {
   return chunks >= 8 ? 512 : 1024;  // the 1024-coordinate point needs more than 128 registers
 }

@@ -386,7 +386,7 @@ __device__ inline double det_tanh(double x) {
                    P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
                    P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
   double ax = fabs(x);
-  ax = ax > 22.0 ? 22.0 : ax;  // (NaN stays NaN: the comparison is false)
+  ax = ax < 22.0 ? ax : 22.0;  // a NaN takes the cap too: the integer conversion below stays defined
   const double X = 2.0 * ax;
   const int k = static_cast<int>(__builtin_fma(invln2, X, 0.5));
   const double dk = static_cast<double>(k);
@@ -398,7 +398,7 @@ __device__ inline double det_tanh(double x) {
   const double s = __builtin_ldexp(1.0, k), sr2 = __builtin_ldexp(r, k + 1);  // 2^k, 2 s r: exact
   const double num = __builtin_fma(s - 1.0, B, sr2), den = __builtin_fma(s + 1.0, B, sr2);
   const double tt = num / den;
-  return x < 0 ? -tt : tt;
+  return x != x ? x : __builtin_copysign(tt, x);  // tanh(-0) = -0
 }
 
 }  // namespace nlsg

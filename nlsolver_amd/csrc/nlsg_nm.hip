@@ -19,18 +19,22 @@ struct nlsg_nm {
 };
 
 namespace {
+// The opt-in for more than 64 KiB of dynamic LDS belongs to the kernel instantiation <OBJ, CHUNKS>,
+// which every engine of that chunk class shares: it is set to the class maximum (the largest n the
+// instantiation serves), never to one engine's size — a later, smaller engine must not lower it.
 template <int OBJ, int CHUNKS>
-hipError_t prepare1(size_t lds) {
+hipError_t prepare1() {
   return hipFuncSetAttribute(reinterpret_cast<const void *>(nm_solve_kernel<OBJ, CHUNKS>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+                             hipFuncAttributeMaxDynamicSharedMemorySize,
+                             static_cast<int>(nm_lds_bytes(128ull * CHUNKS)));
 }
 template <int OBJ>
-hipError_t prepare(size_t lds, int chunks) {
+hipError_t prepare(int chunks) {
   switch (chunks) {
-    case 1: return prepare1<OBJ, 1>(lds);
-    case 2: return prepare1<OBJ, 2>(lds);
-    case 4: return prepare1<OBJ, 4>(lds);
-    default: return prepare1<OBJ, 8>(lds);
+    case 1: return prepare1<OBJ, 1>();
+    case 2: return prepare1<OBJ, 2>();
+    case 4: return prepare1<OBJ, 4>();
+    default: return prepare1<OBJ, 8>();
   }
 }
 template <int OBJ>
@@ -128,10 +132,10 @@ static int nm_create(const nlsg_nm_config *cfg, const nlsg_custom_objective *cus
   if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&e->lower_dev), n * 8);
   if (he == hipSuccess) he = hipEventCreate(&e->ev0);
   if (he == hipSuccess) he = hipEventCreate(&e->ev1);
-  if (he == hipSuccess) he = prepare<NLSG_OBJ_ROSENBROCK>(e->lds, chunks);
-  if (he == hipSuccess) he = prepare<NLSG_OBJ_SPHERE>(e->lds, chunks);
-  if (he == hipSuccess) he = prepare<NLSG_OBJ_STYBLINSKI_TANG>(e->lds, chunks);
-  if (he == hipSuccess) he = prepare<NLSG_OBJ_RASTRIGIN>(e->lds, chunks);
+  if (he == hipSuccess) he = prepare<NLSG_OBJ_ROSENBROCK>(chunks);
+  if (he == hipSuccess) he = prepare<NLSG_OBJ_SPHERE>(chunks);
+  if (he == hipSuccess) he = prepare<NLSG_OBJ_STYBLINSKI_TANG>(chunks);
+  if (he == hipSuccess) he = prepare<NLSG_OBJ_RASTRIGIN>(chunks);
   if (he == hipSuccess && custom) {
     const int rc2 = rtc_build_nm(custom, chunks, &e->rtc);
     if (rc2) {

@@ -34,7 +34,9 @@ void launch_wide(nlsg_nmpso *e, dim3 grid) {
 }
 template <int OBJ>
 hipError_t allow_wide_lds(uint64_t n) {  // past 64 KiB the dynamic allocation has to be announced
-  const int bytes = static_cast<int>(hyb_view_bytes(n));
+  // the attribute belongs to the instantiation, shared by every engine of the chunk class: the class
+  // maximum, so that an engine created later with a smaller n cannot lower an earlier one's limit
+  const int bytes = static_cast<int>(hyb_view_bytes(128ull * wide_chunks(n)));
   const void *fn = wide_chunks(n) == 2   ? reinterpret_cast<const void *>(nmpso_solve_wide_kernel<OBJ, 2>)
                    : wide_chunks(n) == 4 ? reinterpret_cast<const void *>(nmpso_solve_wide_kernel<OBJ, 4>)
                                          : reinterpret_cast<const void *>(nmpso_solve_wide_kernel<OBJ, 8>);

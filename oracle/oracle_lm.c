@@ -51,9 +51,8 @@ double orc_tanh(double x) {
                       invln2 = 1.44269504088896338700e+00, P1 = 1.66666666666666019037e-01,
                       P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
                       P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
-  if (x != x) return x;
   double ax = fabs(x);
-  if (ax > 22.0) ax = 22.0;
+  ax = ax < 22.0 ? ax : 22.0; /* a NaN takes the cap too: the conversion below stays defined */
   const double X = 2.0 * ax;
   const int k = (int)fma(invln2, X, 0.5);
   const double dk = (double)k;
@@ -65,7 +64,7 @@ double orc_tanh(double x) {
   const double s = ldexp(1.0, k), sr2 = ldexp(r, k + 1); /* 2^k and 2 s r, both exact */
   const double num = fma(s - 1.0, B, sr2), den = fma(s + 1.0, B, sr2);
   const double tt = num / den;
-  return x < 0 ? -tt : tt;
+  return x != x ? x : copysign(tt, x); /* tanh(-0) = -0 */
 }
 
 /* ---- linear algebra of the reference LM ------------------------------------- */

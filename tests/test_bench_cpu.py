@@ -24,10 +24,10 @@ def test_other_configs_pass_summarises_children_and_survives_failures(monkeypatc
     def fake_run(cmd, **kw):
         calls.append(cmd)
         assert "--no-cpu-baseline" in cmd and kw.get("timeout", 0) <= 300
-        if "lm" in cmd:
+        if "lm" in cmd and "cholesky" in cmd:
             return types.SimpleNamespace(returncode=1, stdout="", stderr="boom: no GPU here")
         line = {"metric": "m", "value": 2.5, "unit": "u/s", "steps": 7, "ms_per_step": 0.4, "dtype": "f64",
-                "config": {"workload": "w", "other_solver": {"solver": "qr", "value": 1.0, "ms_per_step": 2.0,
+                "config": {"workload": "w", "solver": "qr", "whole_run": {"value": 3.0}, "other_solver": {"solver": "qr", "value": 1.0, "ms_per_step": 2.0,
                                                             "extra": "dropped"}},
                 "roofline": {"bound": "hbm", "achieved": 1.0, "peak": 2.0, "unit": "GB/s", "frac": 0.5,
                              "kernel": "k", "kernel_ms": 0.1, "traffic": 123, "noise": "dropped"},
@@ -44,4 +44,20 @@ def test_other_configs_pass_summarises_children_and_survives_failures(monkeypatc
         assert e["value"] == 2.5 and e["workload"] == "w" and e["roofline"]["frac"] == 0.5
         assert "noise" not in e["roofline"] and "cpu_baseline" not in e
         assert e["other_solver"] == {"solver": "qr", "value": 1.0, "ms_per_step": 2.0}
+        # every entry states whether its dominant kernel fits into its step (0.1 <= 0.4 here)
+        assert e["kernel_within_step"] is True and e["solver"] == "qr" and e["whole_run"] == {"value": 3.0}
     assert all(e["config"].startswith("configs[") for e in out)
+    # BASELINE words configs[3] with the tinyqr solve: that solver is an entry of its own, and it
+    # comes before the Cholesky one
+    lm = [c for c in calls if "lm" in c]
+    assert len(lm) == 2 and "qr" in lm[0] and "cholesky" in lm[1]
+    assert any("tinyqr" in e["config"] for e in out)
+
+
+def test_kernel_within_step_check():
+    bench = load_bench()
+    bench.check_kernel_within_step(0.50, 0.51, "x")
+    bench.check_kernel_within_step(0.515, 0.51, "x")  # timer noise
+    import pytest
+    with pytest.raises(AssertionError, match="different regimes"):
+        bench.check_kernel_within_step(16.2, 13.4, "bfgs")

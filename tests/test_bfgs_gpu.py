@@ -134,8 +134,13 @@ def test_bfgs_config3_full_batch(mod, oracle):
     assert all(s.done == 1 and 1 <= s.iteration <= 50 for s in st)
     assert np.all(f_end <= f_start) and np.allclose(f_end, quad(x), rtol=1e-12, atol=1e-12)
     assert len({s.iteration for s in st}) > 1
-    # all of them found the one minimiser of the convex quadratic
-    assert np.max(np.abs(x - x[0])) < 1e-2  # stopped by grad_eps = 1e-6 on the gradient norm
+    # all of them are near the one minimiser of the convex quadratic. How near is the reference's
+    # own behaviour, not a device tolerance: its stop test (nlsolver.h:3239-3241) fires
+    # when ||g|| < grad_eps OR when the DIFFERENCE of two successive gradient norms does,
+    # | ||g_k|| - ||g_{k-1}|| | < grad_eps — so a start whose norm stalls between two iterations
+    # stops with ||g|| ~ 1e-3 still on the table (measured spread of the end points: 1.1e-3 with these 4096
+    # starts; the sampled problems above are bit-equal to the oracle's runs, which is the parity)
+    assert np.max(np.abs(x - x[0])) < 1e-2
 
 
 @pytest.mark.parametrize("obj,n,batch", [("rosenbrock", 2, 6), ("rosenbrock", 5, 4),

@@ -285,6 +285,54 @@ def test_sharded_path_on_one_gpu_bit_exact(eng_mod, oracle, kw, pop, D, shards):
         e.close()
 
 
+@pytest.mark.parametrize("strategy", [1, 0])
+def test_global_size_eight_shards_on_one_gpu_bit_exact(eng_mod, oracle, strategy):
+    """The headline configuration as the 8-GPU scaling run shards it: pop = 8 x 65536 agents x
+    128, island donors, one record exchange per generation — all eight shard engines on the one
+    device. Global agent ids up to 2^19 - 1, shard_lo up to 7 x 65536, an 8-record finaliser;
+    bit-compared with the restatement run with n_shards = 8 on the whole population."""
+    import torch
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    shards, n, D, turns = 8, 65536, 128, 3
+    pop = shards * n
+    x0 = x0_for(D, 0.6)
+    kw = dict(strategy=strategy, eps=0.0, best_val_no_change=1000, CR=0.2, F=0.5)  # accepting regime
+    ref = O.DESyncRun(oracle, "rosenbrock", pop, D, x0, n_shards=shards, **kw)
+    ref.step(turns, threads=16)
+    engs = [eng_mod.DEEngine("rosenbrock", pop, D, shard_lo=r * n, shard_n=n, stream=stream, **kw)
+            for r in range(shards)]
+    rec = engs[0].record_doubles()
+    gathered = torch.zeros(shards * rec, dtype=torch.float64, device=dev)
+    for e in engs:
+        e.init(x0)
+    speculate = engs[0].can_speculate()
+    for _ in range(turns):
+        for r, e in enumerate(engs):
+            e.turn_begin(gathered[r * rec:(r + 1) * rec].data_ptr())
+        if speculate:
+            for e in engs:
+                e.turn_generation()
+            for e in engs:
+                e.turn_finalize(gathered.data_ptr(), shards)
+        else:
+            for e in engs:
+                e.turn_end(gathered.data_ptr(), shards)
+    stats = []
+    for r, e in enumerate(engs):
+        P, S = e.download()
+        assert np.array_equal(P, ref.population[r * n:(r + 1) * n]), f"shard {r} population"
+        assert np.array_equal(S, ref.scores[r * n:(r + 1) * n]), f"shard {r} scores"
+        st = e.status()
+        stats.append((st.best_index, st.iteration, st.val_no_change, st.function_calls_used, st.done))
+        bx, bf, bi = e.best()
+        assert bi == ref.s.best_id and bf == ref.scores[bi] and np.array_equal(bx, ref.population[bi])
+        e.close()
+    assert all(s == stats[0] for s in stats)
+    assert stats[0] == (ref.s.best_id, ref.s.iter, ref.s.val_no_change, ref.s.fcalls, ref.s.done)
+    assert np.mean(ref.scores < np.inf) == 1.0 and stats[0][3] == pop * (turns + 1)
+
+
 @pytest.mark.parametrize("mode", ["fused", "serial", "overlap"])
 def test_overlapped_and_serial_turns_are_identical(eng_mod, oracle, mode, monkeypatch):
     """One GPU, strategy random: head k and generation k+1 in one launch (default when eps <= 0),

@@ -1,6 +1,8 @@
-"""N>1 path on CPU: world_size-2 gloo processes drive nlsolver_amd.dist.ShardedDE
-(the product's host-side sharding/exchange logic) over a CPU stand-in engine built on
-the oracle. The result must equal the single-process restatement with n_shards=2."""
+"""N>1 path on CPU: world_size-2 and world_size-8 gloo processes drive nlsolver_amd.dist.ShardedDE /
+ShardedPSO (the product's host-side sharding/exchange logic) over a CPU stand-in engine built on
+the oracle. The result must equal the single-process restatement with n_shards = world. Eight
+ranks — the scaling run's size, an 8-record finaliser on every rank — can only be rehearsed here:
+a GPU box of this pool admits at most six processes on its card."""
 import os
 import socket
 
@@ -49,8 +51,9 @@ def _worker(rank, world, port, cfg, out_dir):
                                 dict(strategy=0, eps=0.0, best_val_no_change=1000),
                                 dict(strategy=1, eps=5000.0, best_val_no_change=1000),
                                 dict(strategy=0, eps=0.0, best_val_no_change=2)])
-def test_world2_gloo_matches_single_process_oracle(tmp_path, oracle, kw):
-    world, pop, D, turns = 2, 64, 16, 12
+@pytest.mark.parametrize("world", [2, 8])
+def test_gloo_ranks_match_single_process_oracle(tmp_path, oracle, kw, world):
+    pop, D, turns = 32 * world, 16, 12
     cfg = dict(pop=pop, D=D, turns=turns, kw=kw)
     mp.start_processes(_worker, args=(world, _free_port(), cfg, str(tmp_path)), nprocs=world,
                        join=True, start_method="fork")
@@ -94,8 +97,9 @@ def _pso_worker(rank, world, port, cfg, out_dir):
 @pytest.mark.parametrize("kw", [dict(type=O.PSO_ACCELERATED, eps=0.0, best_val_no_change=1000),
                                 dict(type=O.PSO_VANILLA, eps=0.0, best_val_no_change=1000),
                                 dict(type=O.PSO_ACCELERATED, eps=2000.0, best_val_no_change=1000)])
-def test_world2_gloo_pso_matches_single_process_oracle(tmp_path, oracle, kw):
-    world, n, D, turns = 2, 64, 16, 10
+@pytest.mark.parametrize("world", [2, 8])
+def test_gloo_ranks_pso_match_single_process_oracle(tmp_path, oracle, kw, world):
+    n, D, turns = 32 * world, 16, 10
     cfg = dict(n=n, D=D, turns=turns, kw=kw)
     mp.start_processes(_pso_worker, args=(world, _free_port(), cfg, str(tmp_path)), nprocs=world,
                        join=True, start_method="fork")

@@ -139,6 +139,28 @@ def test_bench_two_rank_flow_rehearsal(workload, extra):
         assert out["config"]["parallelism"].startswith("replicas x2")
 
 
+@pytest.mark.parametrize("workload", ["de", "pso-accel"])
+def test_bench_four_rank_flow_rehearsal(workload):
+    """`python3 bench.py --gpus 4` — the largest self-launched job this pool lets a one-GPU box run
+    (at most six processes may hold the card, and this test process is one of them; the eight-rank
+    exchange is rehearsed over gloo on the CPU, tests/test_dist_gloo.py): four ranks share device
+    0, every collective step is entered by every rank, ONE JSON line with n_gpus = 4 whose global
+    size is four shards."""
+    env = dict(os.environ, NLSG_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "20",
+           "--warmup", "5", "--workload", workload, "--no-cpu-baseline", "--pop-per-gpu", "4096"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 4 and out["value"] > 0 and out["steps"] == 20
+    assert out["config"]["global_pop" if workload == "de" else "global_swarm"] == 4 * 4096
+    assert out["config"]["turn_driver"].startswith("host")
+
+
 def test_bench_two_rank_default_line_carries_the_sharded_pso_run():
     """`python3 bench.py --gpus 2 --steps K --warmup W` at the default size, as the driver runs the
     scaling series: after the DE job a second two-rank job runs BASELINE configs[4] (the PSO swarm

@@ -179,3 +179,22 @@ def test_nm_device_130d_ragged_golden(mod, oracle, golden):
     assert st[0].f_value == ref.f_value and np.array_equal(x[0], xr)
     assert st[0].iteration == g["iters"]
     assert abs(st[0].f_value - hx(g["f"])) <= 1e-12 * hx(g["f"])
+
+
+def test_a_later_smaller_engine_does_not_lower_the_lds_opt_in(mod, oracle):
+    """The > 64 KiB dynamic-LDS opt-in belongs to the kernel instantiation, which every engine of
+    a chunk class shares: an engine of n = 128 (132 KiB), then one of n = 10 in the same class,
+    then the first one's launch — which must still be admitted and give the same bits."""
+    kw = dict(max_iter=60, eps=0.0, no_change_best_tol=100000)
+    x_big, x_small = starts(2, 128, seed=1), starts(3, 10, seed=2)
+    big = mod.NMEngine("rosenbrock", 2, 128, **kw)
+    small = mod.NMEngine("rosenbrock", 3, 10, **kw)
+    xs, sts, _ = small.minimize(x_small.copy())
+    xb, stb, _ = big.minimize(x_big.copy())
+    small.close()
+    big.close()
+    okw = dict(max_iter=60, eps=0.0, no_change=100000)
+    for x0, x, st in ((x_big, xb, stb), (x_small, xs, sts)):
+        for b in range(x0.shape[0]):
+            ref, xr, _, _ = O.nm_run(oracle, x0[b], order=1, **okw)
+            assert st[b].f_value == ref.f_value and np.array_equal(x[b], xr)

@@ -185,3 +185,20 @@ def test_hybrid_bench_size_properties(mod, oracle):
         assert np.array_equal(xa[b], xr) and sa[b].f_value == ref.f_value
         assert sa[b].function_calls_used == ref.function_calls_used
         assert sa[b].f_value == oracle.orc_objective_tree(0, xa[b].ctypes.data_as(O.pd), n)
+
+
+def test_a_later_smaller_engine_does_not_lower_the_lds_opt_in(mod, oracle):
+    """n = 600, then n = 520 — the same kernel instantiation (eight chunks), whose dynamic-LDS
+    opt-in is per instantiation, not per engine — then the first engine's launch."""
+    kw = dict(max_iter=3, eps=0.0, no_change_best_iter=1000)
+    x_big, x_small = starts(1, 600, 0.5, 1.0), starts(1, 520, 0.5, 1.0)
+    big = mod.NMPSOEngine("rosenbrock", 1, 600, seed=SEED, inst_lo=2, **kw)
+    small = mod.NMPSOEngine("rosenbrock", 1, 520, seed=SEED, inst_lo=2, **kw)
+    xs, sts = small.minimize(x_small, None, None)
+    xb, stb = big.minimize(x_big, None, None)
+    small.close()
+    big.close()
+    for x0, x, st in ((x_big, xb, stb), (x_small, xs, sts)):
+        ref, xr, _ = O.nmpso_sync(oracle, "rosenbrock", x0[0], SEED, 2, eps=0.0, max_iter=3,
+                                  no_change=1000)
+        assert np.array_equal(x[0], xr) and st[0].f_value == ref.f_value

@@ -104,6 +104,10 @@ def test_deterministic_tanh_rational_form_properties(oracle):
         assert abs(v - ref) <= 3 * np.spacing(ref)       # RELATIVE accuracy, small x included
     assert oracle.orc_tanh(22.0) == 1.0 and oracle.orc_tanh(1e6) == 1.0 and oracle.orc_tanh(18.0) < 1.0
     assert oracle.orc_tanh(1e-300) == 1e-300 and math.isnan(oracle.orc_tanh(float("nan")))
+    # the sign comes from the argument's sign bit, zero included (libm: tanh(-0.0) = -0.0)
+    assert math.copysign(1.0, oracle.orc_tanh(-0.0)) == -1.0 and oracle.orc_tanh(-0.0) == 0.0
+    assert math.copysign(1.0, oracle.orc_tanh(0.0)) == 1.0
+    assert oracle.orc_tanh(float("-inf")) == -1.0 and oracle.orc_tanh(float("inf")) == 1.0
 
 
 @pytest.mark.parametrize("name", ["tanh_m128_n64", "tanh_m512_n64"])

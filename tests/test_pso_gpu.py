@@ -163,6 +163,58 @@ def test_pso_config5_shard_size_properties(mod, oracle):
         check_state(eng, ref, "config5 shard")
 
 
+@pytest.mark.parametrize("type_", [O.PSO_ACCELERATED])
+def test_pso_config5_global_size_eight_shards_on_one_gpu(mod, oracle, type_):
+    """BASELINE configs[4] AS WORDED: swarm = 2^20 particles x D = 256 sharded 8 x 131072, the best
+    record exchanged every iteration — all eight shard engines on the one device (2 GiB of
+    positions), the records concatenated where RCCL's all-gather would put them. Exercises what no
+    smaller rehearsal does: global particle ids >= 2^17 (the counter RNG is keyed by them),
+    shard_lo >= 2^17 and the finaliser over eight records. Bit-compared with the restatement run
+    with n_shards = 8 on the whole swarm (nlsolver.h:2593-2741 through SURVEY §8e's partitioning)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    n, D, shards, turns = 1 << 20, 256, 8, 2
+    m = n // shards
+    kw = dict(type=type_, eps=0.0, max_iter=1000, best_val_no_change=1000)
+    ref = O.PSOSyncRun(oracle, "rosenbrock", n, D, -2.048, 2.048, n_shards=shards, **kw)
+    ref.step(turns, threads=16)
+    engs = [mod.PSOEngine("rosenbrock", n, D, shard_lo=r * m, shard_n=m, stream=stream, **kw)
+            for r in range(shards)]
+    rec = engs[0].record_doubles()
+    gathered = torch.zeros(shards * rec, dtype=torch.float64, device=dev)
+    for e in engs:
+        e.init(-2.048, 2.048)
+    for _ in range(turns):
+        for r, e in enumerate(engs):
+            e.turn_begin(gathered[r * rec:(r + 1) * rec].data_ptr())
+        for e in engs:
+            e.turn_end(gathered.data_ptr(), shards)
+    records = gathered.cpu().numpy().reshape(shards, rec)
+    # every rank sees the same eight records and draws the same conclusion from them
+    stats, mins = [], []
+    for r, e in enumerate(engs):
+        pos, vel, pbest, cur = e.download()
+        sl = slice(r * m, (r + 1) * m)
+        assert np.array_equal(pos, ref.pos[sl]), f"shard {r}: positions"
+        assert np.array_equal(pbest, ref.pbest_val[sl]), f"shard {r}: personal bests"
+        mins.append((pbest.min(), r * m + int(pbest.argmin())))
+        st = e.status()
+        stats.append((st.iteration, st.function_calls_used, st.val_no_change, st.done, st.best_index,
+                      st.f_value))
+        bx, _, _ = e.best()
+        assert np.array_equal(bx, ref.gbest_x), f"shard {r}: swarm best"
+        e.close()
+    assert all(s == stats[0] for s in stats)
+    assert stats[0] == (ref.s.iter, ref.s.fevals, ref.s.val_no_change, ref.s.done, ref.s.gbest_idx,
+                        ref.s.gbest_val)
+    assert stats[0][1] == n * (turns + 1) and 0 <= stats[0][4] < n
+    # independent of the oracle: the swarm best every shard reports is the minimum over all
+    # downloaded personal bests (a particle's personal best is the least value it ever had)
+    assert np.isfinite(records).all()
+    assert stats[0][5] == min(v for v, _ in mins)
+
+
 def _sweep_cases(n=24, seed=20261004):
     rng = np.random.default_rng(seed)
     out = []
