@@ -539,6 +539,26 @@ int nlsg_nmpso_minimize(nlsg_nmpso *e, double *x_inout_host, const double *lower
                         const double *upper_host, nlsg_status *status_host);
 int nlsg_nmpso_time_solve(nlsg_nmpso *e, const double *x0_host, uint32_t repeats, float *ms_total);
 
+/* ========================================================================== */
+/* Batched linear least squares by Givens QR — replaces tinyqr::lm             */
+/* (tinyqr.h:461-470: qr_decomposition :291-310 -> qr_impl :253-283 with        */
+/* givens_rotation :86-97 and rotate_matrix :126-139, then back_solve :437-459) */
+/* for `batch` independent n x p systems, n >= p, 1 <= p <= 64 (the reference   */
+/* solves one system per call). Same rotations in the same per-element order;   */
+/* Q is never formed (y is rotated along with R); values agree with the          */
+/* reference's to rounding, bit for bit with oracle_lm.c order 1.               */
+/* ========================================================================== */
+/* X_host: [batch][p][n] — every system column-major n x p exactly as tinyqr::lm takes it
+ * (X[j * n + i] = element (i, j)); y_host: [batch][n]; beta_host out: [batch][p]; tol: lm()'s
+ * third argument (default 1e-12 there), entries of R below it are read as 0. ms_kernel (may be
+ * NULL): the kernel's duration by HIP events, transfers excluded. */
+int nlsg_tinyqr_lm(const double *X_host, const double *y_host, uint64_t batch, uint64_t n, uint64_t p,
+                   double tol, int32_t device, double *beta_host, float *ms_kernel);
+/* The same on systems that already live in HBM (device pointers, same layouts); enqueued on
+ * `stream` (NULL: the null stream), asynchronous. */
+int nlsg_tinyqr_lm_device(const double *X_dev, const double *y_dev, uint64_t batch, uint64_t n,
+                          uint64_t p, double tol, int32_t device, void *stream, double *beta_dev);
+
 #ifdef __cplusplus
 }
 #endif

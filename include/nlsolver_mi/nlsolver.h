@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "../nlsg_c_api.h"
+#include "./tinyqr.h"  // namespace tinyqr: qr_decomposition / back_solve / lm (reference: nlsolver.h:46)
 
 namespace nlsolver {
 

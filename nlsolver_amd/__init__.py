@@ -11,6 +11,7 @@ Layout:
     nm.py                 NelderMead (batched starts): mirror of nlsolver.h:2099-2300
     sann.py               SANN (batched chains): mirror of nlsolver.h:2744-2815
     nmpso.py              NelderMeadPSO (batched instances): mirror of nlsolver.h:3546-3920
+    tinyqr.py             tinyqr.lm on batches of n x p systems: mirror of tinyqr.h:461-470
     dist.py               population sharding across ranks (torch.distributed / RCCL)
 """
 from ._capi import DE_BEST, DE_RANDOM, PSO_ACCELERATED, PSO_VANILLA, NlsgError, pinned_empty  # noqa: F401
@@ -21,3 +22,4 @@ from .lm import LevenbergMarquardt, LMEngine, TanhRegression  # noqa: F401
 from .nm import NelderMead, NMEngine  # noqa: F401
 from .sann import SANN, SANNEngine  # noqa: F401
 from .nmpso import NelderMeadPSO, NMPSOEngine  # noqa: F401
+from . import tinyqr  # noqa: F401

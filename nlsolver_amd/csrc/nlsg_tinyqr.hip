@@ -1,0 +1,105 @@
+// nlsolver_amd/csrc/nlsg_tinyqr.hip — host side of the batched tinyqr::lm + C-ABI.
+#include "nlsg_tinyqr_kernels.h"
+
+using namespace nlsg;
+
+namespace {
+
+int check_shape(uint64_t batch, uint64_t n, uint64_t p) {
+  if (batch < 1 || n < 1 || p < 1) return fail(NLSG_ERR_INVALID_ARG, "batch, n and p must be >= 1");
+  if (p > kTqrMaxP)
+    return fail(NLSG_ERR_UNSUPPORTED, "p = %llu columns > %d is not covered by the device path",
+                (unsigned long long)p, kTqrMaxP);
+  if (n < p)
+    return fail(NLSG_ERR_INVALID_ARG, "n = %llu rows < p = %llu columns: tinyqr::lm needs n >= p",
+                (unsigned long long)n, (unsigned long long)p);
+  if (batch > 0x7fffffffull) return fail(NLSG_ERR_UNSUPPORTED, "batch too large for one launch grid");
+  return NLSG_OK;
+}
+
+// The opt-in for more than 64 KiB of dynamic LDS belongs to the kernel, not to a call: set once
+// to the largest p the kernel serves.
+int allow_lds() {
+  static const hipError_t he =
+      hipFuncSetAttribute(reinterpret_cast<const void *>(tinyqr_lm_kernel<kTqrThreads>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize,
+                          static_cast<int>(tqr_lds_bytes(kTqrMaxP)));
+  NLSG_HIP(he);
+  return NLSG_OK;
+}
+
+void launch(const double *X, const double *y, double *beta, uint64_t batch, uint64_t n, uint64_t p,
+            double tol, hipStream_t stream) {
+  TqrParams q;
+  q.X = X;
+  q.y = y;
+  q.beta = beta;
+  q.batch = batch;
+  q.n = n;
+  q.p = static_cast<uint32_t>(p);
+  q.ring = tqr_ring_rows(q.p);
+  q.stride = tqr_stride(q.p);
+  q.tol = tol;
+  hipLaunchKernelGGL(tinyqr_lm_kernel<kTqrThreads>, dim3(static_cast<unsigned>(batch)),
+                     dim3(kTqrThreads), tqr_lds_bytes(q.p), stream, q);
+}
+
+}  // namespace
+
+extern "C" {
+
+int nlsg_tinyqr_lm_device(const double *X_dev, const double *y_dev, uint64_t batch, uint64_t n,
+                          uint64_t p, double tol, int32_t device, void *stream, double *beta_dev) {
+  if (!X_dev || !y_dev || !beta_dev) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  int rc = check_shape(batch, n, p);
+  if (rc) return rc;
+  rc = check_device(device);
+  if (rc) return rc;
+  NLSG_HIP(hipSetDevice(device));
+  rc = allow_lds();
+  if (rc) return rc;
+  launch(X_dev, y_dev, beta_dev, batch, n, p, tol, stream ? borrowed_stream(stream) : nullptr);
+  NLSG_HIP(launches_status());
+  return NLSG_OK;
+}
+
+int nlsg_tinyqr_lm(const double *X_host, const double *y_host, uint64_t batch, uint64_t n, uint64_t p,
+                   double tol, int32_t device, double *beta_host, float *ms_kernel) {
+  if (!X_host || !y_host || !beta_host) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  int rc = check_shape(batch, n, p);
+  if (rc) return rc;
+  rc = check_device(device);
+  if (rc) return rc;
+  NLSG_HIP(hipSetDevice(device));
+  rc = allow_lds();
+  if (rc) return rc;
+  double *X = nullptr, *y = nullptr, *beta = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipError_t he = hipMalloc(reinterpret_cast<void **>(&X), batch * n * p * sizeof(double));
+  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&y), batch * n * sizeof(double));
+  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&beta), batch * p * sizeof(double));
+  if (he == hipSuccess) he = hipEventCreate(&e0);
+  if (he == hipSuccess) he = hipEventCreate(&e1);
+  if (he == hipSuccess) he = hipMemcpy(X, X_host, batch * n * p * sizeof(double), hipMemcpyHostToDevice);
+  if (he == hipSuccess) he = hipMemcpy(y, y_host, batch * n * sizeof(double), hipMemcpyHostToDevice);
+  if (he == hipSuccess) he = hipEventRecord(e0, nullptr);
+  if (he == hipSuccess) {
+    launch(X, y, beta, batch, n, p, tol, nullptr);
+    he = launches_status();
+  }
+  if (he == hipSuccess) he = hipEventRecord(e1, nullptr);
+  if (he == hipSuccess) he = hipEventSynchronize(e1);
+  if (he == hipSuccess && ms_kernel) he = hipEventElapsedTime(ms_kernel, e0, e1);
+  if (he == hipSuccess) he = hipMemcpy(beta_host, beta, batch * p * sizeof(double), hipMemcpyDeviceToHost);
+  hipFree(X);
+  hipFree(y);
+  hipFree(beta);
+  if (e0) hipEventDestroy(e0);
+  if (e1) hipEventDestroy(e1);
+  if (he != hipSuccess)
+    return fail(he == hipErrorOutOfMemory ? NLSG_ERR_OOM : NLSG_ERR_HIP, "nlsg_tinyqr_lm failed: %s",
+                hipGetErrorString(he));
+  return NLSG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,181 @@
+// nlsolver_amd/csrc/nlsg_tinyqr_kernels.h — batched linear least squares by Givens QR:
+// tinyqr::lm (tinyqr.h:461-470) = back_solve(qr_decomposition(X)) on `batch` independent n x p
+// systems, n >= p, p <= 64 (the square damped system of the LM engine is the
+// special case n = p that nlsg_lm_kernels.h solves inside its iteration).
+//
+// The reference eliminates column by column, rows bottom-up (qr_impl, tinyqr.h:253-283): rotation
+// (j, i) mixes rows i-1 and i to annihilate R[i][j], j = 0 .. p-1, i = n-1 .. j+1. Rotations of
+// different columns commute as soon as they touch different row pairs, and (j, i) depends only
+// on (j, i+1) and (j-1, i-1), so rotation (j, i) can run at STEP (n-1-i) + 2j: the eliminations
+// of column j form a chain that climbs one row per step, two rows behind chain j-1. Every element
+// sees exactly the sequence of updates of the serial loop — same (a, b) -> (c, s), same element
+// updates, hence the same bits — while up to p rotations run side by side.
+//
+// At step k the chains occupy rows n-2-k .. n-1-k+2(p-1): a WINDOW of 2p+1 rows that slides up by
+// one row per step. Rows below it are finished (annihilated in all p columns — lm() never reads
+// them), rows above it have not been touched. So a system of ANY height needs 2p+4 rows of LDS:
+// a ring indexed by row mod RING, fed one row per step from global memory (two steps ahead, the
+// value waiting in a register in between).
+//
+// Arithmetic = oracle_lm.c order 1 (tinyqr_lm_corotated), as in the LM engine's solver:
+//  * no Q: lm() uses Q only through Q^T y (back_solve, :437-459), so y is rotated along with R
+//    as column p;
+//  * an element update is one rounded product and one fused multiply-add,
+//    lower' = fma(c, lower, s * upper), upper' = fma(c, upper, (-s) * lower);
+//  * Givens pair as givens_rotation (:86-97) with r * r for pow(r, 2);
+//  * back-substitution sums from j = p-1 down to i+1, lm()'s cleanup (|v| < tol -> 0, :278-282)
+//    applied to the entries that are read.
+// One workgroup per system. Wave 0 computes the step's Givens pairs (one chain per lane) while
+// waves 1 and 2 move the entering row; then all waves apply the rotations (chain j on wave
+// j mod W, one column per lane). Two barriers per step; latency-bound (the Givens pair is ~45
+// dependent fp64 instructions), not roofline-graded.
+#pragma once
+#include "nlsg_common.h"
+#include "nlsg_math.h"
+
+namespace nlsg {
+
+constexpr int kTqrThreads = 512;
+constexpr int kTqrMaxP = 64;
+
+struct TqrParams {
+  const double *X;  // [batch][p][n]: each system column-major n x p, as tinyqr takes it
+  const double *y;  // [batch][n]
+  double *beta;     // [batch][p]
+  uint64_t batch, n;
+  uint32_t p, ring, stride;  // ring rows (2p + 4), doubles per ring row ((p + 1) | 1: odd)
+  double tol;
+};
+
+__host__ __device__ inline uint32_t tqr_ring_rows(uint32_t p) { return 2 * p + 4; }
+__host__ __device__ inline uint32_t tqr_stride(uint32_t p) { return (p + 1) | 1u; }
+__host__ __device__ inline size_t tqr_lds_bytes(uint32_t p) {
+  return (static_cast<size_t>(tqr_ring_rows(p)) * tqr_stride(p) + 2 * kTqrMaxP) * sizeof(double);
+}
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void tinyqr_lm_kernel(TqrParams q) {
+  constexpr int W = THREADS / 64;
+  extern __shared__ __align__(16) double tqr_smem[];
+  const int t = threadIdx.x, lane = lane_id();
+  const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int p = static_cast<int>(q.p), S = static_cast<int>(q.stride), RING = static_cast<int>(q.ring);
+  const long long n = static_cast<long long>(q.n);
+  double *ring = tqr_smem;                                              // [RING][S]
+  double2 *cs = reinterpret_cast<double2 *>(tqr_smem + RING * S);       // [64]
+  const uint64_t sys = blockIdx.x;
+  const double *X = q.X + sys * q.n * q.p, *y = q.y + sys * q.n;
+  const int nch = static_cast<int>(n - 1 < p ? n - 1 : p);  // chains: columns that have a row below the diagonal
+  const long long last = nch > 0 ? static_cast<long long>(nch - 1) + n - 2 : -1;  // last step
+
+  // element `c` of row r (c < p: X, c == p: y) — what the loader lanes fetch
+  auto fetch = [&](long long r, int c) -> double {
+    if (r < 0) return 0.0;
+    return c < p ? X[static_cast<uint64_t>(c) * q.n + r] : y[r];
+  };
+  auto slot_of = [&](long long r) -> int { return static_cast<int>(r % RING); };
+
+  // prologue: rows n-1 and n-2 (step 0), row n-3 waits in a register for step 1
+  const bool loader = (wid == 1 && lane <= p) || (wid == 2 && lane == 0 && p == 64);
+  const int lcol = wid == 1 ? lane : 64;  // wave 1: columns 0 .. min(p, 63); wave 2 lane 0: column 64
+  double pending = 0.0;
+  if (loader) {
+    ring[slot_of(n - 1) * S + lcol] = fetch(n - 1, lcol);
+    if (n >= 2) ring[slot_of(n - 2) * S + lcol] = fetch(n - 2, lcol);
+    pending = fetch(n - 3, lcol);
+  }
+  __syncthreads();
+
+  int s0 = slot_of(n - 1);  // slot of row i0 = n-1-k, chain 0's lower row at step k
+  int sin = slot_of(n >= 3 ? n - 3 : 0);  // slot of the row entering for step k+1: n-3-k
+  for (long long k = 0; k <= last; k++) {
+    // ---- phase A: Givens pairs of this step (wave 0), the entering row (waves 1, 2)
+    if (wid == 0) {
+      const int j = lane;
+      const bool act = j < nch && k >= 2 * j && k <= j + n - 2;
+      if (act) {
+        int si = s0 + 2 * j;  // row i = i0 + 2j
+        si -= si >= RING ? RING : 0;
+        const int sm = si == 0 ? RING - 1 : si - 1;  // row i-1
+        const double a = ring[sm * S + j], b = ring[si * S + j];
+        // givens_rotation (tinyqr.h:86-97): both branches are r = small / large,
+        // t = 1 / sqrt(r^2 + 1), {t, t r} — selected, not branched
+        const bool swap = fabs(b) > fabs(a);
+        const double r = (swap ? a : b) / (swap ? b : a);
+        const double tt = div_unscaled(1.0, sqrt_unscaled(r * r + 1.0));  // r^2 + 1 in [1, 2] or NaN
+        const double tr = tt * r;
+        const double c = swap ? tr : tt, s = swap ? tt : tr;
+        cs[j] = make_double2(c, s);
+        ring[sm * S + j] = __builtin_fma(c, a, s * b);  // the pivot column's lower' (upper' is annihilated)
+      }
+    } else if (loader && k + 1 <= last) {
+      // row n-3-k enters for step k+1; the one after it is requested now and waits in `pending`
+      if (n - 3 - k >= 0) ring[sin * S + lcol] = pending;
+      pending = fetch(n - 4 - k, lcol);
+    }
+    __syncthreads();
+    // ---- phase B: rotate_matrix (tinyqr.h:126-139) on the columns right of each chain's pivot
+    double t1[(kTqrMaxP + W - 1) / W], t2[(kTqrMaxP + W - 1) / W];
+    double2 g[(kTqrMaxP + W - 1) / W];
+    int om[(kTqrMaxP + W - 1) / W], oi[(kTqrMaxP + W - 1) / W];
+#pragma unroll
+    for (int u = 0; u < (kTqrMaxP + W - 1) / W; u++) {
+      const int j = wid + u * W;  // wave-uniform
+      const bool act = j < nch && k >= 2 * j && k <= j + n - 2;
+      const int col = j + 1 + lane;
+      if (act && col <= p) {
+        int si = s0 + 2 * j;
+        si -= si >= RING ? RING : 0;
+        const int sm = si == 0 ? RING - 1 : si - 1;
+        om[u] = sm * S + col;
+        oi[u] = si * S + col;
+        g[u] = cs[j];
+        t1[u] = ring[om[u]];
+        t2[u] = ring[oi[u]];
+      } else {
+        om[u] = -1;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < (kTqrMaxP + W - 1) / W; u++) {
+      if (om[u] >= 0) {
+        const double c = g[u].x, s = g[u].y;
+        ring[om[u]] = __builtin_fma(c, t1[u], s * t2[u]);
+        ring[oi[u]] = __builtin_fma(c, t2[u], (-s) * t1[u]);
+      }
+    }
+    s0 = s0 == 0 ? RING - 1 : s0 - 1;
+    sin = sin == 0 ? RING - 1 : sin - 1;
+    __syncthreads();
+  }
+
+  // back_solve (tinyqr.h:437-459) on R beta = w; rows 0 .. p-1 sit in ring slots 0 .. p-1
+  if (t < 64) {
+    const double tol = q.tol;
+    const double w = t < p ? ring[t * S + p] : 0.0;
+    double temp = 0.0, u = 0.0;
+    for (int j0 = ((p - 1) | 3); j0 >= 0; j0 -= 4) {
+      double h[4], d[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int j = min(j0 - e, p - 1);
+        h[e] = ring[min(t, j) * S + j];
+        d[e] = ring[j * S + j];
+        h[e] = fabs(h[e]) < tol ? 0.0 : h[e];
+        d[e] = fabs(d[e]) < tol ? 0.0 : d[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int j = j0 - e;
+        if (j < p) {  // wave-uniform
+          if (t == j) u = (w - temp) / d[e];
+          const double uj = lane_broadcast(u, j);
+          if (t < j) temp += h[e] * uj;
+        }
+      }
+    }
+    if (t < p) q.beta[sys * q.p + t] = u;
+  }
+}
+
+}  // namespace nlsg

@@ -209,6 +209,8 @@ void orc_cholesky(double *A, size_t n);                        /* nlsolver.h:251
 void orc_update_with_hessian(double *update, double *hess, const double *grad, size_t n); /* :310-330 */
 void orc_qr_decomposition(const double *X, size_t n, size_t p, double tol, double *Q, double *R);
 void orc_tinyqr_lm(const double *X, const double *y, size_t n, size_t p, double *beta);
+void orc_tinyqr_lm_tol(const double *X, const double *y, size_t n, size_t p, double *beta, int order,
+                       double tol);
 void orc_tinyqr_lm_order(const double *X, const double *y, size_t n, size_t p, double *beta,
                          int order);
 void orc_lm_make_tanh_problem(uint64_t seed, uint64_t problem, size_t m, size_t n, double *A,

@@ -193,7 +193,8 @@ void orc_tinyqr_lm(const double *X, const double *y, size_t n, size_t p, double 
  * lower' = fma(c, lower, s * upper), upper' = fma(c, upper, (-s) * lower); the back-substitution
  * sums are taken from j = p-1 down to i+1 (the order in which the kernel's column sweep produces
  * them). Same rotations in the same per-element order as qr_impl. */
-static void tinyqr_lm_corotated(const double *X, const double *y, size_t n, size_t p, double *beta) {
+static void tinyqr_lm_corotated(const double *X, const double *y, size_t n, size_t p, double *beta,
+                                double tol) {
   double *Rw = (double *)calloc(n * p, sizeof(double));
   double *w = (double *)malloc(n * sizeof(double));
   for (size_t i = 0; i < n; i++) {
@@ -214,7 +215,7 @@ static void tinyqr_lm_corotated(const double *X, const double *y, size_t n, size
       w[i - 1] = fma(c, t1, s * t2);
       w[i] = fma(c, t2, (-s) * t1);
     }
-  for (size_t e = 0; e < n * p; e++) Rw[e] = fabs(Rw[e]) < 1e-12 ? 0.0 : Rw[e]; /* cleanup */
+  for (size_t e = 0; e < n * p; e++) Rw[e] = fabs(Rw[e]) < tol ? 0.0 : Rw[e]; /* cleanup */
   for (size_t i = 0; i < p; i++) beta[i] = 0.0;
   for (size_t i = p; i-- > 0;) {
     double temp = 0.0;
@@ -226,12 +227,17 @@ static void tinyqr_lm_corotated(const double *X, const double *y, size_t n, size
 }
 void orc_tinyqr_lm_order(const double *X, const double *y, size_t n, size_t p, double *beta,
                          int order) {
+  orc_tinyqr_lm_tol(X, y, n, p, beta, order, 1e-12); /* lm()'s default third argument, :464 */
+}
+/* tol: lm()'s third argument, handed to qr_decomposition's cleanup (tinyqr.h:278-282, 467) */
+void orc_tinyqr_lm_tol(const double *X, const double *y, size_t n, size_t p, double *beta, int order,
+                       double tol) {
   if (order) {
-    tinyqr_lm_corotated(X, y, n, p, beta);
+    tinyqr_lm_corotated(X, y, n, p, beta, tol);
     return;
   }
   double *Q = (double *)malloc(n * p * sizeof(double)), *R = (double *)malloc(p * p * sizeof(double));
-  qr_decomposition_order(X, n, p, 1e-12, Q, R, order);
+  qr_decomposition_order(X, n, p, tol, Q, R, order);
   for (size_t i = 0; i < p; i++) beta[i] = 0.0;
   for (size_t i = p; i-- > 0;) {
     double temp = 0.0;

@@ -284,6 +284,8 @@ def load():
     lib.orc_update_with_hessian.argtypes = [pd, pd, pd, sz]
     lib.orc_qr_decomposition.argtypes = [pd, sz, sz, f64, pd, pd]
     lib.orc_tinyqr_lm.argtypes = [pd, pd, sz, sz, pd]
+    lib.orc_tinyqr_lm_order.argtypes = [pd, pd, sz, sz, pd, C.c_int]
+    lib.orc_tinyqr_lm_tol.argtypes = [pd, pd, sz, sz, pd, C.c_int, f64]
     lib.orc_lm_make_tanh_problem.argtypes = [u64, u64, sz, sz, pd, pd, pd]
     lib.orc_nm_run.restype = Status
     lib.orc_nm_run.argtypes = [C.c_int, C.c_int, C.c_int, pd, sz, pd, pd, f64, f64, f64, f64, f64,

@@ -107,6 +107,12 @@ def main():
     }
     write("lm.json", g8)
 
+    # G9b — tinyqr on rectangular systems (n >= p; a25): qr_decomposition + lm on pseudo-random
+    # X, y: tinyqr-rect n p seed
+    write("tinyqr.json", {f"rect_{n}x{p}": run("tinyqr-rect", n, p, sd) for n, p, sd in
+                          [(1, 1, 1), (3, 1, 2), (5, 3, 3), (12, 5, 4), (8, 8, 5), (65, 64, 6),
+                           (200, 17, 7), (576, 64, 8)]})
+
     # G5 — NelderMead (nlsolver.h:2099-2300) on Rosenbrock-ND. Even D only: the reference's
     # simplex ctor writes one element past an n-vector, which for odd n lands on
     # the allocator's chunk header and aborts the process (observed for D = 3).

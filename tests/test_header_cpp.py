@@ -408,3 +408,83 @@ def test_hybrid_device_objective_without_library_fails_loudly(built):
                         "0.4", "0.01"], env=dict(os.environ, NLSG_LIBRARY="/nonexistent/lib.so"),
                        capture_output=True, text=True)
     assert r.returncode == 3 and "device_error" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
+def _tinyqr_prog(built, mode, header, arrays):
+    text = header + "\n" + "\n".join(" ".join(float(v).hex() for v in np.ravel(a)) for a in arrays) + "\n"
+    r = subprocess.run([os.path.join(built, "header_tinyqr"), mode], input=text, capture_output=True,
+                       text=True, env=dict(os.environ, NLSG_LIBRARY=LIB))
+    out = {}
+    for line in r.stdout.splitlines():
+        name, *vals = line.split()
+        out[name] = np.array([float.fromhex(v) for v in vals])
+    return r, out
+
+
+def _fnv(a):
+    h = 1469598103934665603
+    for b in np.ascontiguousarray(a, dtype=np.float64).view(np.uint8).tobytes():
+        h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def test_tinyqr_namespace_host_path_matches_reference_bit_exact(built, oracle, golden):
+    """namespace tinyqr of the drop-in header (qr_decomposition, back_solve, lm with the reference's
+    signatures and defaults, tinyqr.h:291-310, 437-470) on the reference's own outputs: the 4 x 2
+    example of SURVEY §3.5, the rectangular systems of tests/golden/tinyqr.json, the 64 x 64 damped
+    system of lm.json — Q, R and beta bit for bit."""
+    from tests.test_oracle_lm_golden import RECT, rect_system
+    g = golden("lm.json")["tinyqr_example"]
+    r, out = _tinyqr_prog(built, "host", "4 2", [[1, 1, 1, 1, 0, 1, 2, 3], [1, 3, 5, 7.5]])
+    assert r.returncode == 0, r.stderr
+    assert out["Q"].tolist() == [hx(v) for v in g["Q"]] and out["R"].tolist() == [hx(v) for v in g["R"]]
+    assert out["beta"].tolist() == [hx(v) for v in g["beta"]]
+    for n, p, seed in RECT:
+        gg = golden("tinyqr.json")[f"rect_{n}x{p}"]
+        X, y = rect_system(oracle, n, p, seed)
+        r, out = _tinyqr_prog(built, "host", f"{n} {p}", [X, y])
+        assert r.returncode == 0, r.stderr
+        assert out["beta"].tolist() == [hx(v) for v in gg["beta"]], (n, p)
+        assert out["beta_tol1e-8"].tolist() == [hx(v) for v in gg["beta_tol1e-8"]], (n, p)
+        assert _fnv(out["Q"]) == int(gg["Q_fnv"]) and _fnv(out["R"]) == int(gg["R_fnv"]), (n, p)
+    # the damped square system of the LM path (lm.json linalg_n64: M = B^T B + lambda I)
+    gl, n = golden("lm.json")["linalg_n64"], 64
+    k = oracle.orc_ctr_key(3, 77)
+    B = np.array([2 * oracle.orc_u01(oracle.orc_ctr_key(k, e)) - 1 for e in range(n * n)]).reshape(n, n)
+    b = np.array([2 * oracle.orc_u01(oracle.orc_ctr_key(k, n * n + i)) - 1 for i in range(n)])
+    M = np.zeros((n, n))
+    for i in range(n):
+        for j in range(n):
+            acc = 0.0
+            for l in range(n):
+                acc += B[l, i] * B[l, j]
+            M[i, j] = acc + (10.0 if i == j else 0.0)
+    r, out = _tinyqr_prog(built, "host", f"{n} {n}", [M.T.reshape(-1), b])
+    assert out["beta"].tolist() == [hx(v) for v in gl["qr_solution"]]
+    assert _fnv(out["Q"]) == int(gl["Q_fnv"]) and _fnv(out["R"]) == int(gl["R_fnv"])
+
+
+def test_tinyqr_device_has_no_cpu_fallback(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    r, _ = _tinyqr_prog(built, "device", "1 4 2", [[1, 1, 1, 1, 0, 1, 2, 3], [1, 3, 5, 7.5]])
+    assert r.returncode == 4 and "no HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_tinyqr_device_batch_through_header(built, oracle):
+    """tinyqr::device::lm: a batch of systems through the header -> dlopen -> C-ABI; every system
+    equals the order-1 oracle bit for bit."""
+    rng = np.random.default_rng(11)
+    batch, n, p = 6, 50, 9
+    X = 2 * rng.random((batch, p, n)) - 1
+    y = 2 * rng.random((batch, n)) - 1
+    r, out = _tinyqr_prog(built, "device", f"{batch} {n} {p}", [X, y])
+    assert r.returncode == 0, r.stderr
+    beta = out["beta"].reshape(batch, p)
+    for b in range(batch):
+        ref = np.zeros(p)
+        oracle.orc_tinyqr_lm_order(O._ptr(np.ascontiguousarray(X[b].reshape(-1))),
+                                   O._ptr(np.ascontiguousarray(y[b])), n, p, O._ptr(ref), 1)
+        assert np.array_equal(beta[b], ref), b

@@ -127,3 +127,37 @@ def test_kernel_order_and_qr_solver_agree_with_reference_arithmetic(oracle, gold
     assert np.allclose(flog[big], ref[big], rtol=1e-9, atol=0)
     assert np.all(flog[~big] < 1e-9)
     assert flog[-1] < 1e-20 or ref[-1] > 1e-20  # both converge to the zero-residual solution
+
+
+RECT = [(1, 1, 1), (3, 1, 2), (5, 3, 3), (12, 5, 4), (8, 8, 5), (65, 64, 6), (200, 17, 7), (576, 64, 8)]
+
+
+def rect_system(oracle, n, p, seed):
+    """The pseudo-random rectangular system of ref_driver's tinyqr-rect: X column-major n x p."""
+    k = oracle.orc_ctr_key(seed, 78)
+    X = np.array([2 * oracle.orc_u01(oracle.orc_ctr_key(k, e)) - 1 for e in range(n * p)])
+    y = np.array([2 * oracle.orc_u01(oracle.orc_ctr_key(k, n * p + i)) - 1 for i in range(n)])
+    return X, y
+
+
+@pytest.mark.parametrize("n,p,seed", RECT)
+def test_tinyqr_rectangular_systems_match_reference(oracle, golden, n, p, seed):
+    """tinyqr::qr_decomposition / lm on n x p systems with n >= p (tinyqr.h:291-310, 437-470; SURVEY
+    row a25): the restatement reproduces the reference's Q, R and beta bit for bit; the kernel
+    arithmetic (order 1: co-rotated right-hand side, fma element updates) agrees to rounding."""
+    g = golden("tinyqr.json")[f"rect_{n}x{p}"]
+    X, y = rect_system(oracle, n, p, seed)
+    beta = np.zeros(p)
+    oracle.orc_tinyqr_lm(O._ptr(X), O._ptr(y), n, p, O._ptr(beta))
+    assert beta.tolist() == [hx(v) for v in g["beta"]]
+    Q, R = np.zeros(n * p), np.zeros(p * p)
+    oracle.orc_qr_decomposition(O._ptr(X), n, p, 1e-8, O._ptr(Q), O._ptr(R))
+    assert _fnv(Q) == int(g["Q_fnv"]) and _fnv(R) == int(g["R_fnv"])
+    if "Q" in g:
+        assert Q.tolist() == [hx(v) for v in g["Q"]] and R.tolist() == [hx(v) for v in g["R"]]
+    b1 = np.zeros(p)
+    oracle.orc_tinyqr_lm_order(O._ptr(X), O._ptr(y), n, p, O._ptr(b1), 1)
+    assert np.allclose(b1, beta, rtol=1e-9, atol=1e-12)
+    # and both are the least-squares solution
+    ls = np.linalg.lstsq(X.reshape(p, n).T, y, rcond=None)[0]
+    assert np.allclose(beta, ls, rtol=1e-8, atol=1e-10)

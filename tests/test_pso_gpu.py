@@ -208,7 +208,7 @@ def test_pso_config5_global_size_eight_shards_on_one_gpu(mod, oracle, type_):
     assert all(s == stats[0] for s in stats)
     assert stats[0] == (ref.s.iter, ref.s.fevals, ref.s.val_no_change, ref.s.done, ref.s.gbest_idx,
                         ref.s.gbest_val)
-    assert stats[0][1] == n * (turns + 1) and 0 <= stats[0][4] < n
+    assert stats[0][1] == n * turns and 0 <= stats[0][4] < n  # one evaluation per particle and turn
     # independent of the oracle: the swarm best every shard reports is the minimum over all
     # downloaded personal bests (a particle's personal best is the least value it ever had)
     assert np.isfinite(records).all()
