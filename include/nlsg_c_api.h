@@ -318,6 +318,14 @@ typedef enum {
  * dim = 1024. Same algorithm, same counts on the reference's runs; values agree with the literal
  * arithmetic to rounding (f within 1e-12), not bit for bit. Default (0): the literal update. */
 #define NLSG_BFGS_SYMMETRIC 1
+/* NLSG_BFGS_REFERENCE_ORDER: every sum of the solve — the objective's terms, math::dot / norm
+ * (nlsolver.h:58-99), the rows of H y and H g (3139-3142, 3248-3251) — is taken in INDEX order,
+ * as the reference's sequential loops take it, instead of the kernels' lane tree. With it the
+ * engine reproduces the reference's own runs bit for bit, the default finite-difference gradient
+ * included (fin_diff divides differences of objective values by 12 eps, which turns the last bit
+ * of a tree sum into 1e-8 .. 1e-6 of the result). A parity mode: a sum costs n dependent
+ * additions; dim <= 256, literal update only, objectives given by their terms. */
+#define NLSG_BFGS_REFERENCE_ORDER 2
 
 typedef struct {
   uint32_t struct_size;
@@ -327,7 +335,7 @@ typedef struct {
                        /* NLSG_OBJ_ROSENBROCK / SPHERE / STYBLINSKI_TANG / RASTRIGIN:  */
                        /* reference's default gradient fin_diff (nlsolver.h:         */
                        /* 1385-1413, 2849-2855), evaluated on the device              */
-  int32_t flags;       /* 0, or NLSG_BFGS_SYMMETRIC                               */
+  int32_t flags;       /* 0, NLSG_BFGS_SYMMETRIC or NLSG_BFGS_REFERENCE_ORDER     */
   uint64_t batch;      /* independent problems                                    */
   uint64_t dim;        /* x.size() of each problem (<= 1024)                      */
   uint64_t max_iter;   /* ctor args of nlsolver.h:3181-3185                       */
@@ -378,7 +386,14 @@ typedef enum {
   /* r_i(theta) = y_i - tanh(sum_j A_ij theta_j)   */
   NLSG_OBJ_TANH_REGRESSION = 32
 } nlsg_nlls_objective;
-typedef enum { NLSG_LM_CHOLESKY = 0, NLSG_LM_QR = 1 } nlsg_lm_solver;
+/* NLSG_LM_CHOLESKY_REFERENCE_ORDER: the class's own solve with the reference's literal arithmetic
+ * — every probe of fin_diff / fin_diff_h sums its objective in INDEX order (the reference's
+ * sequential loops) and math::cholesky / forwardsolve_inplace / backsolve_inplace_t round as the
+ * reference does (separate multiply and add, nlsolver.h:251-294) — so that the default-functor
+ * model reproduces the reference's own runs bit for bit (fin_diff_h divides differences of
+ * objective values by 600 eps^2 = 9e-6: the last bit of a tree sum is worth 1e-9 .. 1e-6 of the
+ * result). A parity mode for the finite-difference model, n <= 64. */
+typedef enum { NLSG_LM_CHOLESKY = 0, NLSG_LM_QR = 1, NLSG_LM_CHOLESKY_REFERENCE_ORDER = 2 } nlsg_lm_solver;
 
 typedef struct {
   uint32_t struct_size;

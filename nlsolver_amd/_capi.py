@@ -75,10 +75,11 @@ class BFGSConfig(C.Structure):
 
 
 BFGS_SYMMETRIC = 1  # NLSG_BFGS_SYMMETRIC
+BFGS_REFERENCE_ORDER = 2  # NLSG_BFGS_REFERENCE_ORDER
 
 
 OBJ_TANH_REGRESSION = 32
-LM_CHOLESKY, LM_QR = 0, 1
+LM_CHOLESKY, LM_QR, LM_CHOLESKY_REFERENCE_ORDER = 0, 1, 2
 
 
 class LMConfig(C.Structure):

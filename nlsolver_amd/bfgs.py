@@ -36,12 +36,16 @@ class QuadDiagRank1:
 class BFGSEngine:
     """symmetric=True: the rank-2 update restated so that H stays bitwise symmetric and only its
     upper 128 x 128 blocks are kept and streamed (NLSG_BFGS_SYMMETRIC, include/nlsg_c_api.h):
-    56 % of the memory and traffic at dim = 1024; results agree with the literal update to rounding."""
+    56 % of the memory and traffic at dim = 1024; results agree with the literal update to rounding.
+    reference_order=True: every sum in index order, as the reference's sequential loops take it
+    (NLSG_BFGS_REFERENCE_ORDER): the reference's own runs bit for bit, default gradient included;
+    a parity mode, dim <= 256."""
 
     def __init__(self, objective, batch, *, dim=None, max_iter=100, grad_eps=5e-3, alpha=1.0,
-                 device=0, stream=None, symmetric=False):
+                 device=0, stream=None, symmetric=False, reference_order=False):
         cfg = BFGSConfig()
-        cfg.flags = _capi.BFGS_SYMMETRIC if symmetric else 0
+        cfg.flags = (_capi.BFGS_SYMMETRIC if symmetric else 0) | \
+            (_capi.BFGS_REFERENCE_ORDER if reference_order else 0)
         self.symmetric = bool(symmetric)
         cfg.struct_size = C.sizeof(BFGSConfig)
         cfg.device = device
@@ -149,13 +153,13 @@ class BFGS:
     """Drop-in for nlsolver::BFGS on a device objective; x may be (n,) or (batch, n)."""
 
     def __init__(self, f, g=None, max_iter=100, grad_eps=5e-3, alpha=1.0, *, device=0,
-                 symmetric=False):
+                 symmetric=False, reference_order=False):
         if g is not None:
             raise TypeError("device objectives carry their analytic gradient or use the default "
                             "finite-difference one; pass g=None")
         self.f = f
         self.args = dict(max_iter=max_iter, grad_eps=grad_eps, alpha=alpha, device=device,
-                         symmetric=symmetric)
+                         symmetric=symmetric, reference_order=reference_order)
 
     def minimize(self, x):
         if not isinstance(x, np.ndarray) or x.dtype != np.float64 or x.ndim not in (1, 2):

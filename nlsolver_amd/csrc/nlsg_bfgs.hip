@@ -41,6 +41,19 @@ namespace {
     }                                                                                            \
   } while (0)
 
+// reference-order mode (n <= 256): the H passes with every row's dot in index order
+#define BFGS_DISPATCH_SEQ(KERNEL, grid, ...)                                                          \
+  do {                                                                                                \
+    const dim3 g_(grid), b_(256);                                                                     \
+    switch (e->chunks * 2 + (e->vec ? 1 : 0)) {                                                       \
+      case 2: hipLaunchKernelGGL((KERNEL<1, false, true>), g_, b_, 0, e->stream, __VA_ARGS__); break; \
+      case 3: hipLaunchKernelGGL((KERNEL<1, true, true>), g_, b_, 0, e->stream, __VA_ARGS__); break;  \
+      case 4: hipLaunchKernelGGL((KERNEL<2, false, true>), g_, b_, 0, e->stream, __VA_ARGS__); break; \
+      case 5: hipLaunchKernelGGL((KERNEL<2, true, true>), g_, b_, 0, e->stream, __VA_ARGS__); break;  \
+      default: break;                                                                                 \
+    }                                                                                                 \
+  } while (0)
+
 // search / init kernels also depend on what is minimised
 #define BFGS_MODEL_CASE(KERNEL, C, V, grid, ...)                                                    \
   switch (e->p.model) {                                                                             \
@@ -96,6 +109,9 @@ void launch_iteration(nlsg_bfgs *e, bool timed) {
     hipLaunchKernelGGL(bfgs_sym_reduce_kernel<false>, probs, dim3(256), 0, e->stream, e->p);
     hipLaunchKernelGGL(bfgs_sym_update_kernel, blocks, dim3(256), 0, e->stream, e->p);
     hipLaunchKernelGGL(bfgs_sym_reduce_kernel<true>, probs, dim3(256), 0, e->stream, e->p);
+  } else if (e->p.seq) {
+    BFGS_DISPATCH_SEQ(bfgs_hy_kernel, row_grid, e->p, e->bpp);
+    BFGS_DISPATCH_SEQ(bfgs_update_kernel, row_grid, e->p, e->bpp);
   } else {
     BFGS_DISPATCH(bfgs_hy_kernel, row_grid, e->p, e->bpp);
     BFGS_DISPATCH(bfgs_update_kernel, row_grid, e->p, e->bpp);
@@ -143,6 +159,23 @@ static int bfgs_create(const nlsg_bfgs_config *cfg, const double *diag_host, con
   if (cfg->dim > 1024)
     return fail(NLSG_ERR_UNSUPPORTED, "dim %llu > 1024 is not covered by the device path",
                 (unsigned long long)cfg->dim);
+  const bool seq = (cfg->flags & NLSG_BFGS_REFERENCE_ORDER) != 0;
+  if (cfg->flags & ~(NLSG_BFGS_SYMMETRIC | NLSG_BFGS_REFERENCE_ORDER))
+    return fail(NLSG_ERR_INVALID_ARG, "unknown flags 0x%x", cfg->flags);
+  if (seq && (cfg->flags & NLSG_BFGS_SYMMETRIC))
+    return fail(NLSG_ERR_INVALID_ARG,
+                "NLSG_BFGS_REFERENCE_ORDER reproduces the reference's literal arithmetic; the symmetric "
+                "restatement is a different one");
+  if (seq && cfg->dim > 256)
+    return fail(NLSG_ERR_UNSUPPORTED, "NLSG_BFGS_REFERENCE_ORDER (a parity mode) covers dim <= 256");
+  if (seq && custom && custom->chain == NLSG_CUSTOM_VECTOR)
+    return fail(NLSG_ERR_UNSUPPORTED,
+                "NLSG_BFGS_REFERENCE_ORDER needs an objective given by its terms (x.sum() of a "
+                "whole-vector body adds in the lane-tree order)");
+  if (seq && cfg->objective == NLSG_OBJ_RASTRIGIN)
+    return fail(NLSG_ERR_UNSUPPORTED,
+                "NLSG_BFGS_REFERENCE_ORDER: Rastrigin's cosine is the device's deterministic one, not "
+                "libm's — there is no reference arithmetic to reproduce");
   int rc = check_device(cfg->device);
   if (rc) return rc;
   NLSG_HIP(hipSetDevice(cfg->device));
@@ -218,6 +251,7 @@ static int bfgs_create(const nlsg_bfgs_config *cfg, const double *diag_host, con
   p.alpha = cfg->alpha;
   p.qc = cfg->quad_c;
   p.model = quad ? kBfgsQuad : cfg->objective;
+  p.seq = seq ? 1 : 0;
   p.nb = nb;
   p.nstored = nstored;
   if (custom) {

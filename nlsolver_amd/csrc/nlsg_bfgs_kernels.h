@@ -36,7 +36,8 @@ struct BfgsParams {
   const double *zero;
   uint64_t batch, n, max_iter;
   double grad_eps, alpha, qc;
-  int32_t model, pad;  // kBfgsQuad, or the nlsg_objective minimised with a finite-difference gradient
+  int32_t model;  // kBfgsQuad, or the nlsg_objective minimised with a finite-difference gradient
+  int32_t seq;    // NLSG_BFGS_REFERENCE_ORDER: every sum in index order (nlsg_common.h wave_sum_seq)
   // symmetric restatement (NLSG_BFGS_SYMMETRIC): the upper 128 x 128 blocks of H, and the block
   // partials of the two products (see "symmetric restatement" below)
   double *Hs;    // [batch][nstored][128][128]
@@ -65,11 +66,39 @@ __device__ inline double wave_total(const double (&a)[CHUNKS][2]) {
   }
   return wave_sum(acc);
 }
+// math::dot (nlsolver.h:58-67) in the engine's summation order: the lane tree, or — reference
+// order (`seq`, wave-uniform) — the products added in index order
+template <int CHUNKS>
+__device__ inline double bfgs_dot(const double (&a)[CHUNKS][2], const double (&b)[CHUNKS][2],
+                                  uint64_t n, int seq) {
+  if (!seq) return wave_dot<CHUNKS>(a, b);
+  double t[CHUNKS][2];
+#pragma unroll
+  for (int c = 0; c < CHUNKS; c++) {
+    t[c][0] = a[c][0] * b[c][0];
+    t[c][1] = a[c][1] * b[c][1];
+  }
+  return wave_sum_seq<CHUNKS>(t, n);
+}
 
 // The G6 quadratic and its gradient (operation order of oracle_bfgs.c quad_f / quad_g).
 template <int CHUNKS>
 __device__ inline double quad_f(const double (&x)[CHUNKS][2], const double (&d)[CHUNKS][2],
-                                const double (&b)[CHUNKS][2], double c) {
+                                const double (&b)[CHUNKS][2], double c, uint64_t n = 0, int seq = 0) {
+  if (seq) {  // reference order: the three sums of oracle_bfgs.c quad_f_raw, each in index order
+    double tq[CHUNKS][2], tl[CHUNKS][2];
+#pragma unroll
+    for (int k = 0; k < CHUNKS; k++)
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        tq[k][h] = d[k][h] * x[k][h] * x[k][h];
+        tl[k][h] = b[k][h] * x[k][h];
+      }
+    const double qq = wave_sum_seq<CHUNKS>(tq, n);
+    const double sx = wave_sum_seq<CHUNKS>(x, n);
+    const double lin = wave_sum_seq<CHUNKS>(tl, n);
+    return 0.5 * qq + 0.5 * c * (sx * sx) - lin;
+  }
   double aq = 0.0, al = 0.0;
 #pragma unroll
   for (int k = 0; k < CHUNKS; k++) {
@@ -86,8 +115,8 @@ __device__ inline double quad_f(const double (&x)[CHUNKS][2], const double (&d)[
 template <int CHUNKS>
 __device__ inline void quad_g(const double (&x)[CHUNKS][2], const double (&d)[CHUNKS][2],
                               const double (&b)[CHUNKS][2], double c, uint64_t n,
-                              double (&g)[CHUNKS][2]) {
-  const double sx = wave_total<CHUNKS>(x);
+                              double (&g)[CHUNKS][2], int seq = 0) {
+  const double sx = seq ? wave_sum_seq<CHUNKS>(x, n) : wave_total<CHUNKS>(x);
   const int lane = lane_id();
 #pragma unroll
   for (int k = 0; k < CHUNKS; k++) {
@@ -113,13 +142,18 @@ constexpr int kBfgsQuad = -1;
 template <int MODEL, int CHUNKS>
 struct BfgsModel {  // finite differences on Objective<MODEL>
   uint64_t n;
+  int seq;
   template <bool VEC>
   __device__ inline void load(const BfgsParams &p) {
     n = p.n;
+    seq = p.seq;
+  }
+  __device__ inline double value(const double (&x)[CHUNKS][2]) const {
+    return seq ? wave_objective_seq<MODEL, CHUNKS>(x, n) : wave_objective<MODEL, CHUNKS>(x, n);
   }
   __device__ inline double f(const double (&x)[CHUNKS][2], uint64_t &fcalls) const {
     fcalls++;
-    return wave_objective<MODEL, CHUNKS>(x, n);
+    return value(x);
   }
   __device__ inline void grad(const double (&x)[CHUNKS][2], double (&g)[CHUNKS][2],
                               uint64_t &fcalls, uint64_t &gcalls) const {
@@ -142,7 +176,7 @@ struct BfgsModel {  // finite differences on Objective<MODEL>
 #pragma unroll
           for (int k = 0; k < 2; k++)
             xp[c][k] = (mine && c == cc && k == kk) ? x[c][k] + coeff2[s] * eps : x[c][k];
-        acc = acc + coeff[s] * wave_objective<MODEL, CHUNKS>(xp, n);
+        acc = acc + coeff[s] * value(xp);
       }
       fcalls += 4;
       const double gd = acc / dd_val;
@@ -160,21 +194,23 @@ struct BfgsModel<kBfgsQuad, CHUNKS> {
   double qd[CHUNKS][2], qb[CHUNKS][2];
   double qc;
   uint64_t n;
+  int seq;
   template <bool VEC>
   __device__ inline void load(const BfgsParams &p) {
     n = p.n;
+    seq = p.seq;
     qc = p.qc;
     load_row<CHUNKS, VEC>(p.qd, n, p.zero, qd);
     load_row<CHUNKS, VEC>(p.qb, n, p.zero, qb);
   }
   __device__ inline double f(const double (&x)[CHUNKS][2], uint64_t &fcalls) const {
     fcalls++;
-    return quad_f<CHUNKS>(x, qd, qb, qc);
+    return quad_f<CHUNKS>(x, qd, qb, qc, n, seq);
   }
   __device__ inline void grad(const double (&x)[CHUNKS][2], double (&g)[CHUNKS][2],
                               uint64_t &, uint64_t &gcalls) const {
     gcalls++;
-    quad_g<CHUNKS>(x, qd, qb, qc, n, g);
+    quad_g<CHUNKS>(x, qd, qb, qc, n, g, seq);
   }
 };
 
@@ -349,7 +385,7 @@ bfgs_search_kernel(BfgsParams p) {
       dir[c][1] = -g[c][1];
     }
   }
-  const double phi = wave_dot<CHUNKS>(g, dir);
+  const double phi = bfgs_dot<CHUNKS>(g, dir, n, p.seq);
   if ((phi > 0) || isnan(phi) || cur_norm > prev_norm) {  // reset guard, :3253-3260
     identity = 1;
 #pragma unroll
@@ -372,7 +408,7 @@ bfgs_search_kernel(BfgsParams p) {
     const double xtol = 1e-15, ftol = 1e-4, gtol = 1e-2, stpmin = 1e-15, stpmax = 1e15, xtrapf = 4;
     const int maxfev = 20;
     int nfev = 0;
-    const double dginit = wave_dot<CHUNKS>(g, dir);
+    const double dginit = bfgs_dot<CHUNKS>(g, dir, n, p.seq);
     if (!(dginit >= 0.0)) {
       int brackt = 0, stage1 = 1;
       const double finit = f0, dgtest = ftol * dginit;
@@ -400,7 +436,7 @@ bfgs_search_kernel(BfgsParams p) {
         const double fcur = model.f(tmp, fcalls);
         model.grad(tmp, g, fcalls, gcalls);
         nfev++;
-        const double dg = wave_dot<CHUNKS>(g, dir);
+        const double dg = bfgs_dot<CHUNKS>(g, dir, n, p.seq);
         const double ftest1 = finit + stp * dgtest;
         if ((brackt & ((stp <= stmin) | (stp >= stmax))) | (infoc == 0)) info = 6;
         if ((stp == stpmax) & (fcur <= ftest1) & (dg <= dgtest)) info = 5;
@@ -443,13 +479,13 @@ bfgs_search_kernel(BfgsParams p) {
   }
   model.grad(x, g, fcalls, gcalls);
   prev_norm = cur_norm;
-  cur_norm = sqrt(wave_dot<CHUNKS>(g, g));
+  cur_norm = sqrt(bfgs_dot<CHUNKS>(g, g, n, p.seq));
 #pragma unroll
   for (int c = 0; c < CHUNKS; c++) {
     y[c][0] = g[c][0] - pg[c][0];
     y[c][1] = g[c][1] - pg[c][1];
   }
-  double rho = wave_dot<CHUNKS>(y, s);
+  double rho = bfgs_dot<CHUNKS>(y, s, n, p.seq);
   rho = 1 / rho;
   store_row<CHUNKS, VEC>(p.x + pid * n, n, x);
   store_row<CHUNKS, VEC>(p.g + pid * n, n, g);
@@ -542,7 +578,8 @@ __device__ inline void bfgs_store_h_row(double *__restrict__ row, uint64_t D, co
 constexpr int kBfgsRowsPerWave = 8;  // rows a wave streams per launch (vector kept in regs)
 
 // t = H y (first loop of update_inverse_hessian, 3139-3142). Block = 4 waves = 32 rows.
-template <int CHUNKS, bool VEC>
+// SEQ: the reference-order mode (every row's dot in index order; parity mode, n <= 256)
+template <int CHUNKS, bool VEC, bool SEQ = false>
 __global__ __launch_bounds__(256) void bfgs_hy_kernel(BfgsParams p, uint32_t blocks_per_problem) {
   const uint64_t pid = blockIdx.x / blocks_per_problem;
   const BfgsProblem *pr = p.prob + pid;
@@ -570,13 +607,13 @@ __global__ __launch_bounds__(256) void bfgs_hy_kernel(BfgsParams p, uint32_t blo
     if (j >= n) break;
     double h[CHUNKS][2];
     bfgs_load_h_row<CHUNKS, VEC>(Hp + j * n, n, p.zero, h);
-    const double v = wave_dot<CHUNKS>(y, h);  // dot(grad_diff, H row), :3140
+    const double v = bfgs_dot<CHUNKS>(y, h, n, SEQ);  // dot(grad_diff, H row), :3140
     if (lane == 0) t[j] = v;
   }
 }
 
 // rank-2 update (3151-3164) fused with the next direction d = -H' g (3248-3251)
-template <int CHUNKS, bool VEC>
+template <int CHUNKS, bool VEC, bool SEQ = false>
 __global__ __launch_bounds__(256) void bfgs_update_kernel(BfgsParams p,
                                                         uint32_t blocks_per_problem) {
   const uint64_t pid = blockIdx.x / blocks_per_problem;
@@ -594,7 +631,7 @@ __global__ __launch_bounds__(256) void bfgs_update_kernel(BfgsParams p,
   load_vec<CHUNKS, VEC>(p.y + pid * n, n, p.zero, y);
   load_vec<CHUNKS, VEC>(p.g + pid * n, n, p.zero, g);
   const double rho = pr->rho;
-  double denom = wave_dot<CHUNKS>(y, t);  // :3143-3145
+  double denom = bfgs_dot<CHUNKS>(y, t, n, SEQ);  // :3143-3145
   denom = (denom * rho) + 1.0;
   const bool identity = pr->identity != 0;
   double *Hp = p.H + pid * n * n;
@@ -619,7 +656,7 @@ __global__ __launch_bounds__(256) void bfgs_update_kernel(BfgsParams p,
       }
     }
     bfgs_store_h_row<CHUNKS, VEC>(Hp + j * n, n, h);
-    const double dj = -wave_dot<CHUNKS>(h, g);  // :3249-3250 with the updated row
+    const double dj = -bfgs_dot<CHUNKS>(h, g, n, SEQ);  // :3249-3250 with the updated row
     if (lane == 0) dir[j] = dj;
   }
 }

@@ -394,6 +394,80 @@ __device__ inline double wave_objective(const double (&xv)[CHUNKS][2], uint64_t 
 }
 
 
+// ---- reference-order ("sequential") sums. The reference adds in index order (its objective
+// functors, math::dot / norm, the matrix-vector loops: plain left-to-right `acc += ...` loops);
+// the kernels' default is the lane tree above, which differs from it in the last bits. Engines
+// that differentiate an objective numerically divide differences of such sums by 12 eps or
+// 600 eps^2, so the last bit of a sum is worth 1e-8 .. 1e-6 of the result after a few iterations.
+// Their reference-order mode (NLSG_BFGS_REFERENCE_ORDER, NLSG_LM_REFERENCE_ORDER) takes every sum
+// in the reference's order instead — the terms are still computed side by side, one per lane
+// slot, only their addition is serial — and reproduces the reference's own runs bit for bit
+// (oracle order 0, pinned to tests/golden). It is a parity mode: a sum costs n dependent additions.
+//
+// sum over e < n of t_e, e ascending; t[c][k] is element 128 c + 2 lane + k. All lanes return it.
+template <int CHUNKS>
+__device__ inline double wave_sum_seq(const double (&t)[CHUNKS][2], uint64_t n) {
+  double acc = 0.0;
+#pragma unroll
+  for (int c = 0; c < CHUNKS; c++) {
+    const uint64_t base = 128ull * static_cast<uint64_t>(c);
+    if (base < n) {  // wave-uniform
+      const int m = n - base >= 128 ? 128 : static_cast<int>(n - base);
+      for (int l = 0; 2 * l < m; l++) {
+        acc = acc + lane_broadcast(t[c][0], l);
+        if (2 * l + 1 < m) acc = acc + lane_broadcast(t[c][1], l);
+      }
+    }
+  }
+  return acc;
+}
+// f(x) with the objective's terms added in index order (oracle_objective.c orc_objective_seq)
+template <int OBJ, int CHUNKS>
+__device__ inline double wave_objective_seq(const double (&xv)[CHUNKS][2], uint64_t D) {
+  using O = Objective<OBJ>;
+  if constexpr (O::kWhole) return O::whole(WavePoint<CHUNKS>{xv, D}, D);  // (rejected at engine creation)
+  const int lane = lane_id();
+  const uint64_t nt = O::n_terms(D);
+  double t[CHUNKS][2];
+#pragma unroll
+  for (int c = 0; c < CHUNKS; c++) {
+    double xn = 0.0;
+    if (O::kChain) {
+      const double same = lane_down1(xv[c][0]);
+      double next = 0.0;
+      if (c + 1 < CHUNKS) next = lane_first(xv[c + 1][0]);
+      xn = (lane == 63) ? next : same;
+    }
+    t[c][0] = O::term(xv[c][0], xv[c][1]);
+    t[c][1] = O::term(xv[c][1], xn);
+  }
+  return O::finish(wave_sum_seq<CHUNKS>(t, nt), D);
+}
+// the same for a point held by a group of G lanes (group_objective below): lane g of the group
+// holds terms 2g and 2g+1; they are added in index order by walking the group's lanes
+template <int OBJ, int G>
+__device__ inline double group_objective_seq(double x0, double x1, uint64_t D) {
+  using O = Objective<OBJ>;
+  if constexpr (O::kWhole) return O::whole(GroupPoint<G>{x0, x1, D}, D);
+  const int base = lane_id() & ~(G - 1);
+  const uint64_t nt = O::n_terms(D);
+  double xn = 0.0;
+  if (O::kChain) xn = lane_down1(x0);
+  const double t0 = O::term(x0, x1), t1 = O::term(x1, xn);
+  auto from = [&](double v, int src) {
+    const uint64_t b = static_cast<uint64_t>(__double_as_longlong(v));
+    const uint32_t lo = static_cast<uint32_t>(__shfl(static_cast<int>(b & 0xffffffffu), src, 64));
+    const uint32_t hi = static_cast<uint32_t>(__shfl(static_cast<int>(b >> 32), src, 64));
+    return __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(hi) << 32) | lo));
+  };
+  double acc = 0.0;
+  for (int l = 0; 2 * static_cast<uint64_t>(l) < nt; l++) {  // nt <= 2 G: the point fits the group
+    acc = acc + from(t0, base + l);
+    if (2 * static_cast<uint64_t>(l) + 1 < nt) acc = acc + from(t1, base + l);
+  }
+  return O::finish(acc, D);
+}
+
 // The chunk loop of wave_objective, resumable: a row longer than the registers hold (D > 1024) is
 // taken in segments of CHUNKS chunks; `acc` carries the lane's partial from segment to segment
 // (ascending — the order of the whole-row loop), `e_base` is the segment's first element and

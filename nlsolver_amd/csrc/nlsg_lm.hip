@@ -59,6 +59,20 @@ void launch_fd_iter(nlsg_lm *e, int first) {
     launch_module_kernel(e->rtc.iter, grid.x, 64, lds, e->stream, args);
     return;
   }
+  if (e->cfg.solver == NLSG_LM_CHOLESKY_REFERENCE_ORDER) {  // (Rastrigin is rejected at creation)
+    switch (e->cfg.objective) {
+      case NLSG_OBJ_ROSENBROCK:
+        hipLaunchKernelGGL((lm_fd_iter_kernel<NLSG_OBJ_ROSENBROCK, true>), grid, dim3(64), lds, e->stream, e->p, first);
+        break;
+      case NLSG_OBJ_SPHERE:
+        hipLaunchKernelGGL((lm_fd_iter_kernel<NLSG_OBJ_SPHERE, true>), grid, dim3(64), lds, e->stream, e->p, first);
+        break;
+      default:
+        hipLaunchKernelGGL((lm_fd_iter_kernel<NLSG_OBJ_STYBLINSKI_TANG, true>), grid, dim3(64), lds, e->stream, e->p, first);
+        break;
+    }
+    return;
+  }
   switch (e->cfg.objective) {
     case NLSG_OBJ_ROSENBROCK:
       hipLaunchKernelGGL(lm_fd_iter_kernel<NLSG_OBJ_ROSENBROCK>, grid, dim3(64), lds, e->stream, e->p, first);
@@ -178,18 +192,24 @@ static int lm_create(const nlsg_lm_config *cfg, const nlsg_custom_objective *cus
   const bool fd = lm_fd_objective(cfg->objective);
   if (cfg->objective != NLSG_OBJ_TANH_REGRESSION && !fd)
     return fail(NLSG_ERR_INVALID_ARG, "unknown objective %d", cfg->objective);
-  if (cfg->solver != NLSG_LM_CHOLESKY && cfg->solver != NLSG_LM_QR)
+  const bool ref_order = cfg->solver == NLSG_LM_CHOLESKY_REFERENCE_ORDER;
+  if (cfg->solver != NLSG_LM_CHOLESKY && cfg->solver != NLSG_LM_QR && !ref_order)
     return fail(NLSG_ERR_INVALID_ARG, "unknown solver %d", cfg->solver);
-  if (fd && cfg->solver != NLSG_LM_CHOLESKY)
+  if (fd && cfg->solver == NLSG_LM_QR)
     return fail(NLSG_ERR_UNSUPPORTED,
                 "the finite-difference model runs the reference's own solve (Cholesky) only");
+  if (ref_order && (!fd || cfg->objective == NLSG_OBJ_RASTRIGIN || cfg->objective == NLSG_OBJ_CUSTOM ||
+                    cfg->n > kLmN))
+    return fail(NLSG_ERR_UNSUPPORTED,
+                "NLSG_LM_CHOLESKY_REFERENCE_ORDER (a parity mode) covers the default functors on "
+                "Rosenbrock / Sphere / Styblinski-Tang with n <= 64");
   if (cfg->n < 1 || (!fd && cfg->m < 1) || cfg->batch < 1)
     return fail(NLSG_ERR_INVALID_ARG, "need n >= 1, m >= 1, batch >= 1");
   const bool wide = cfg->n > kLmN;
   if (cfg->n > kLmWideMaxN)
     return fail(NLSG_ERR_UNSUPPORTED, "n = %llu > %d (a thread of the step follows at most four rows)",
                 (unsigned long long)cfg->n, kLmWideMaxN);
-  if (wide && cfg->solver != NLSG_LM_CHOLESKY)
+  if (wide && cfg->solver == NLSG_LM_QR)
     return fail(NLSG_ERR_UNSUPPORTED, "the tinyqr solve is built for n <= 64; n = %llu runs the "
                 "class's own Cholesky solve", (unsigned long long)cfg->n);
   if (cfg->batch > 0x7fffffffull) return fail(NLSG_ERR_UNSUPPORTED, "batch too large");
@@ -377,7 +397,8 @@ int nlsg_host_free(void *ptr) {
 int nlsg_lm_set_solver(nlsg_lm *e, int32_t solver) {
   if (!e) return fail(NLSG_ERR_INVALID_ARG, "null engine");
   if (solver != NLSG_LM_CHOLESKY && solver != NLSG_LM_QR)
-    return fail(NLSG_ERR_INVALID_ARG, "unknown solver %d", solver);
+    return fail(NLSG_ERR_INVALID_ARG, "unknown solver %d (the reference-order mode is chosen at creation)",
+                solver);
   if (e->wide && solver != NLSG_LM_CHOLESKY)
     return fail(NLSG_ERR_UNSUPPORTED, "the tinyqr solve is built for n <= 64");
   if (e->p.fd && solver != NLSG_LM_CHOLESKY)

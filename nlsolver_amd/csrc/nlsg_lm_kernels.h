@@ -89,7 +89,17 @@ struct LmRowsTriShort {
   }
 };
 
-template <typename Rows>
+// a * b + c: one fused multiply-add (the kernels' arithmetic, oracle order 1), or — REF, the
+// reference's literal arithmetic (oracle order 0) — a rounded product, then the addition
+template <bool REF>
+__device__ inline double lm_mad(double a, double b, double c) {
+  if constexpr (REF) return c + a * b;
+  return __builtin_fma(a, b, c);
+}
+// REF: NLSG_LM_CHOLESKY_REFERENCE_ORDER — math::cholesky / forwardsolve_inplace /
+// backsolve_inplace_t exactly as the reference rounds them (separate multiply and add; the
+// back-substitution's sums from j = i+1 up to n-1, which makes it a serial sweep).
+template <typename Rows, bool REF = false>
 __device__ inline void lm_solve_cholesky_wave(Rows H, const double *g, double *upd, int n,
                                               bool off_upper = false) {
   const int t = lane_id();
@@ -132,7 +142,7 @@ __device__ inline void lm_solve_cholesky_wave(Rows H, const double *g, double *u
         const double2 la = H.pair(min(j0 + c, 63), k), lb = H.pair(min(j0 + c, 63), k + 2);
         const double l[4] = {la.x, la.y, lb.x, lb.y};
 #pragma unroll
-        for (int q = 0; q < 4; q++) s4[c] = __builtin_fma(x[q], l[q], s4[c]);
+        for (int q = 0; q < 4; q++) s4[c] = lm_mad<REF>(x[q], l[q], s4[c]);
       }
     }
     double hd[4];
@@ -151,7 +161,7 @@ __device__ inline void lm_solve_cholesky_wave(Rows H, const double *g, double *u
         // the panel's later columns continue their sums with k = j
 #pragma unroll
         for (int c2 = c + 1; c2 < 4; c2++)
-          s4[c2] = __builtin_fma(v, lane_broadcast(v, min(j0 + c2, 63)), s4[c2]);
+          s4[c2] = lm_mad<REF>(v, lane_broadcast(v, min(j0 + c2, 63)), s4[c2]);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -170,9 +180,22 @@ __device__ inline void lm_solve_cholesky_wave(Rows H, const double *g, double *u
       if (j < n) {
         if (t == j) u = (gt - sum) / dg;
         const double uj = lane_broadcast(u, j);
-        if (row && t > j) sum = __builtin_fma(h[c], uj, sum);
+        if (row && t > j) sum = lm_mad<REF>(h[c], uj, sum);
       }
     }
+  }
+  if constexpr (REF) {
+    // backsolve_inplace_t (:270-281) literally: component i from the sum over j = i+1 .. n-1 in
+    // that order — the terms are ready side by side (lane j holds L[j][i] b[j]), their addition
+    // walks the lanes
+    for (int i = n - 1; i >= 0; i--) {
+      const double term = H(max(t, i), i) * u;
+      double acc = 0.0;
+      for (int j = i + 1; j < n; j++) acc = acc + lane_broadcast(term, j);
+      if (t == i) u = (u - acc) / dg;
+    }
+    if (row) upd[t] = u;
+    return;
   }
   // backsolve_inplace_t (:270-281) with the inner sums taken from j = n-1 down to i+1
   sum = 0.0;
@@ -575,7 +598,7 @@ struct LmStepShared {  // view of the wave's LDS during the step
 // false: a stop test fired (the problem is done). FD = the finite-difference model: the LDS image
 // of the triangle ends with row n - 1 (`chunks` x 64 doubles), and is_diagonal also needs the
 // evaluation's verdict on the upper triangle.
-template <bool FD>
+template <bool FD, bool REF = false>
 __device__ inline bool lm_step_wave(const LmParams &p, uint64_t pid, LmStepShared sh, int chunks = 33) {
   LmProblem *pr = p.prob + pid;
   const int t = threadIdx.x, n = static_cast<int>(p.n);
@@ -603,7 +626,8 @@ __device__ inline bool lm_step_wave(const LmParams &p, uint64_t pid, LmStepShare
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   if constexpr (FD)
-    lm_solve_cholesky_wave(LmRowsTriShort{sh.tri, n - 1}, sh.g, sh.upd, n, pr->upper != 0);
+    lm_solve_cholesky_wave<LmRowsTriShort, REF>(LmRowsTriShort{sh.tri, n - 1}, sh.g, sh.upd, n,
+                                                pr->upper != 0);
   else
     lm_solve_cholesky_wave(LmRowsTri{sh.tri}, sh.g, sh.upd, n);
   const double th = p.theta[pid * kLmN + t];
@@ -657,9 +681,15 @@ __global__ __launch_bounds__(64, 2) void lm_iter_kernel(LmParams p, int first, i
 // from the broadcast values. The result is not symmetric; Cholesky and the substitutions read
 // the lower triangle only (:251-294), is_diagonal reads both (:295-307): the lower triangle goes
 // to Hg, the upper one is reduced to its verdict.
-template <int OBJ, int G>
+// REF (NLSG_LM_CHOLESKY_REFERENCE_ORDER): every probe sums its objective in index order
+// (group_objective_seq), which makes gradient and Hessian the reference's own bit for bit.
+template <int OBJ, int G, bool REF = false>
 __device__ inline void lm_fd_eval_groups(const LmParams &p, int first, uint64_t pid,
                                          const double *theta_lds) {
+  auto objective = [](double a, double b, uint64_t D) {
+    if constexpr (REF) return group_objective_seq<OBJ, G>(a, b, D);
+    else return group_objective<OBJ, G>(a, b, D);
+  };
   constexpr int P = 64 / G;                  // probe points per pass
   constexpr int HP = P >= 16 ? 1 : 16 / P;   // passes per Hessian entry
   LmProblem *pr = p.prob + pid;
@@ -667,7 +697,7 @@ __device__ inline void lm_fd_eval_groups(const LmParams &p, int first, uint64_t 
   const int g = lane & (G - 1), gi = lane / G;
   const double *theta = theta_lds ? theta_lds : p.theta + pid * kLmN;
   const double x0 = theta[2 * g], x1 = theta[2 * g + 1];  // zero past n
-  const double f = lane_broadcast(group_objective<OBJ, G>(x0, x1, n), 0);
+  const double f = lane_broadcast(objective(x0, x1, n), 0);
   {  // fin_diff<1>: coeff {1,-8,8,-1}, coeff2 {-2,-1,1,2}, eps = DBL_EPSILON * 10e7; probe
      // q = 4 d + s of the 4 n probes runs in group q % P of pass q / P
     constexpr double eps = 2.220446049250313e-16 * 10e7;
@@ -678,7 +708,7 @@ __device__ inline void lm_fd_eval_groups(const LmParams &p, int first, uint64_t 
       const double c2 = sq == 0 ? -2.0 : sq == 1 ? -1.0 : sq == 2 ? 1.0 : 2.0;
       const double xp0 = d == 2 * g ? x0 + c2 * eps : x0;
       const double xp1 = d == 2 * g + 1 ? x1 + c2 * eps : x1;
-      const double fv = group_objective<OBJ, G>(xp0, xp1, n);
+      const double fv = objective(xp0, xp1, n);
 #pragma unroll
       for (int u = 0; u < P; u++) {
         const int qu = q0 + u, su = qu & 3;  // wave-uniform
@@ -738,7 +768,7 @@ __device__ inline void lm_fd_eval_groups(const LmParams &p, int first, uint64_t 
       for (int h = 0; h < HP; h++) {
         const double xp0 = mj0 ? cj[h] : mi0 ? ci[h] : x0;
         const double xp1 = mj1 ? cj[h] : mi1 ? ci[h] : x1;
-        fv[h] = group_objective<OBJ, G>(xp0, xp1, n);
+        fv[h] = objective(xp0, xp1, n);
       }
       auto probe = [&](auto k) {
         constexpr int K = decltype(k)::value;
@@ -785,7 +815,7 @@ __device__ inline void lm_fd_eval_groups(const LmParams &p, int first, uint64_t 
 __host__ __device__ inline int lm_fd_chunks(uint64_t n) {
   return (lm_tri_row(static_cast<int>(n)) + 63) / 64;
 }
-template <int OBJ>
+template <int OBJ, bool REF = false>
 __global__ __launch_bounds__(64) void lm_fd_iter_kernel(LmParams p, int first) {
   extern __shared__ __align__(16) double lm_fd_smem[];
   const uint64_t pid = blockIdx.x;
@@ -794,17 +824,17 @@ __global__ __launch_bounds__(64) void lm_fd_iter_kernel(LmParams p, int first) {
     if (p.prob[pid].done) return;
     const int chunks = lm_fd_chunks(p.n);
     double *g = lm_fd_smem + 64 * chunks;
-    if (!lm_step_wave<true>(p, pid, LmStepShared{lm_fd_smem, g, g + 64}, chunks)) return;
+    if (!lm_step_wave<true, REF>(p, pid, LmStepShared{lm_fd_smem, g, g + 64}, chunks)) return;
     theta_lds = g + 64;
   }
   if (p.n <= 8)
-    lm_fd_eval_groups<OBJ, 4>(p, first, pid, theta_lds);
+    lm_fd_eval_groups<OBJ, 4, REF>(p, first, pid, theta_lds);
   else if (p.n <= 16)
-    lm_fd_eval_groups<OBJ, 8>(p, first, pid, theta_lds);
+    lm_fd_eval_groups<OBJ, 8, REF>(p, first, pid, theta_lds);
   else if (p.n <= 32)
-    lm_fd_eval_groups<OBJ, 16>(p, first, pid, theta_lds);
+    lm_fd_eval_groups<OBJ, 16, REF>(p, first, pid, theta_lds);
   else
-    lm_fd_eval_groups<OBJ, 32>(p, first, pid, theta_lds);
+    lm_fd_eval_groups<OBJ, 32, REF>(p, first, pid, theta_lds);
 }
 
 // ---- QR solver (tinyqr::lm on the damped matrix): the step as a kernel of its own, one

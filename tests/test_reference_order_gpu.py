@@ -1,0 +1,132 @@
+"""The reference-order modes (NLSG_BFGS_REFERENCE_ORDER, NLSG_LM_CHOLESKY_REFERENCE_ORDER): every
+sum in index order — the reference's sequential loops — instead of the kernels' lane tree, the
+LM solve with the reference's separate multiply and add. With them the default-functor models
+(fin_diff, fin_diff_h: nlsolver.h:1385-1517) reproduce the reference's OWN runs
+(tests/golden/bfgs_fd.json, lm_fd.json, bfgs.json: outputs of the unmodified reference) BIT FOR
+BIT — counts, iterates and objective values — where the tree order agrees to 1e-8 .. 1e-6 only
+(finite differences divide the last bit of a sum by 12 eps or 600 eps^2)."""
+import numpy as np
+import pytest
+
+from tests import _oracle as O
+from tests.test_oracle_golden import hx
+
+pytestmark = pytest.mark.gpu
+NAMES = {0: "rosenbrock", 1: "sphere", 2: "styblinski_tang"}
+
+
+@pytest.fixture(scope="module")
+def mod():
+    import torch
+    assert torch.cuda.is_available()
+    import nlsolver_amd
+    return nlsolver_amd
+
+
+def start(g):
+    return hx(g["x0"]) + hx(g["x0_step"]) * np.arange(g["n"], dtype=np.float64)
+
+
+@pytest.mark.parametrize("name", ["rosenbrock_n2", "rosenbrock_n4", "rosenbrock_n16_default_stop",
+                                  "rosenbrock_n128_20iters", "sphere_n5", "sphere_n130_alpha_half",
+                                  "styblinski_tang_n8"])
+def test_bfgs_default_gradient_equals_the_reference_run(mod, golden, name):
+    """BFGS with the reference's default gradient on the device, reference order: the reference's
+    run itself — every count, f and x bit for bit (north_star asks for 1e-12; this is 0)."""
+    g = golden("bfgs_fd.json")[name]
+    x = start(g).reshape(1, -1)
+    with mod.BFGSEngine(NAMES[g["objective"]], 1, dim=g["n"], max_iter=g["max_iter"],
+                        grad_eps=hx(g["grad_eps"]), alpha=hx(g["alpha"]), reference_order=True) as eng:
+        x, st = eng.minimize(x)
+    assert (st[0].iteration, st[0].function_calls_used, st[0].gradient_evals_used) == \
+        (g["iters"], g["fcalls"], g["gcalls"])
+    assert st[0].f_value == hx(g["f"])
+    assert x[0].tolist() == [hx(v) for v in g["x"]]
+
+
+@pytest.mark.parametrize("name", ["n8", "n64", "n64_default_stop", "n100_ragged_start",
+                                  "n130_alpha_half", "n256_max_iter_5"])
+def test_bfgs_analytic_gradient_equals_the_reference_run(mod, golden, name):
+    """The G6 quadratic with its analytic gradient functor (tests/golden/bfgs.json), reference
+    order: counts and the final value of the reference's run bit for bit."""
+    g = golden("bfgs.json")[name]
+    n = g["n"]
+    d, b, c = O.quad_problem(n)
+    x = start(g).reshape(1, -1)
+    with mod.BFGSEngine(mod.QuadDiagRank1(d, b, c), 1, max_iter=g["max_iter"],
+                        grad_eps=hx(g["grad_eps"]), alpha=hx(g["alpha"]), reference_order=True) as eng:
+        x, st = eng.minimize(x)
+    assert (st[0].iteration, st[0].function_calls_used, st[0].gradient_evals_used) == \
+        (g["iters"], g["fcalls"], g["gcalls"])
+    assert st[0].f_value == hx(g["f"])
+    assert x[0][:8].tolist() == [hx(v) for v in g["x_head"]]
+
+
+@pytest.mark.parametrize("obj,n,batch", [("rosenbrock", 3, 5), ("rosenbrock", 31, 4), ("sphere", 129, 3),
+                                         ("styblinski_tang", 200, 2), ("rosenbrock", 256, 2)])
+def test_bfgs_reference_order_batches_equal_the_serial_oracle(mod, oracle, obj, n, batch):
+    """Random starts, odd sizes, two chunks: device in reference order == oracle tree 0 (the
+    restatement that is pinned to the reference's runs), bit for bit."""
+    kw = dict(max_iter=6, grad_eps=0.0, alpha=1.0)
+    rng = np.random.default_rng(300 + n)
+    x0 = 0.8 + 0.4 * (rng.random((batch, n)) - 0.5)
+    with mod.BFGSEngine(obj, batch, dim=n, reference_order=True, **kw) as eng:
+        x, st = eng.minimize(x0.copy())
+    for p in range(batch):
+        ref, xr, _, _ = O.bfgs_fd(oracle, obj, x0[p], tree=0, **kw)
+        assert (st[p].iteration, st[p].function_calls_used, st[p].gradient_evals_used) == \
+            (ref.iteration, ref.function_calls_used, ref.gradient_evals_used), p
+        assert st[p].f_value == ref.f_value and np.array_equal(x[p], xr), p
+
+
+def test_bfgs_reference_order_limits(mod):
+    d, b, c = O.quad_problem(300)
+    for args, kw in (((mod.QuadDiagRank1(d, b, c), 1), {}),                    # dim > 256
+                     (("rastrigin", 1), dict(dim=4)),                          # no libm cosine on the device
+                     (("rosenbrock", 1), dict(dim=4, symmetric=True))):        # a different arithmetic
+        with pytest.raises(mod.NlsgError):
+            mod.BFGSEngine(*args, reference_order=True, **kw)
+
+
+def test_lm_default_functors_equal_the_reference_runs(mod, golden):
+    """LevenbergMarquardt with its default functors (fin_diff + fin_diff_h) on the device in
+    reference order: the seven committed runs of the reference bit for bit, the NaN run included."""
+    from nlsolver_amd._capi import LM_CHOLESKY_REFERENCE_ORDER
+    for name, g in golden("lm_fd.json").items():
+        x = start(g)
+        solver = mod.lm.LevenbergMarquardt(NAMES[g["objective"]], hx(g["lambda"]), 10.0, 10.0,
+                                           g["max_iter"], hx(g["f_delta"]),
+                                           solver=LM_CHOLESKY_REFERENCE_ORDER)
+        st = solver.minimize(x)
+        f_ref, x_ref = hx(g["f"]), np.array([hx(v) for v in g["x"]])
+        assert (st.iteration, st.function_calls_used, st.gradient_evals_used, st.hessian_evals_used) == \
+            (g["iters"], g["fcalls"], g["gcalls"], g["hcalls"]), name
+        if np.isnan(f_ref):
+            assert np.isnan(st.f_value) and np.isnan(x).all(), name
+            continue
+        assert st.f_value == f_ref, (name, st.f_value, f_ref)
+        assert np.array_equal(x, x_ref), name
+
+
+@pytest.mark.parametrize("obj,n,batch", [("rosenbrock", 3, 6), ("rosenbrock", 9, 4), ("sphere", 17, 3),
+                                         ("styblinski_tang", 33, 2), ("rosenbrock", 64, 2)])
+def test_lm_reference_order_batches_equal_the_serial_oracle(mod, oracle, obj, n, batch):
+    """Every group width (4, 8, 16, 32 lanes per probe point): device == oracle order 0."""
+    from nlsolver_amd._capi import LM_CHOLESKY_REFERENCE_ORDER
+    kw = dict(lam=10.0, max_iter=3, f_delta=0.0)
+    rng = np.random.default_rng(500 + n)
+    x0 = 0.9 + 0.2 * (rng.random((batch, n)) - 0.5)
+    with mod.lm.LMEngine(obj, batch=batch, n=n, solver=LM_CHOLESKY_REFERENCE_ORDER, **kw) as eng:
+        x, st, lam = eng.minimize(x0.copy())
+    for b in range(batch):
+        ref, xr, lam_r, _ = O.lm_fd(oracle, obj, x0[b], order=0, **kw)
+        assert (st[b].iteration, st[b].function_calls_used) == (ref.iteration, ref.function_calls_used)
+        assert st[b].f_value == ref.f_value and np.array_equal(x[b], xr) and lam[b] == lam_r, b
+
+
+def test_lm_reference_order_limits(mod):
+    from nlsolver_amd._capi import LM_CHOLESKY_REFERENCE_ORDER, NlsgError
+    with pytest.raises(NlsgError):
+        mod.lm.LMEngine("rosenbrock", batch=1, n=70, solver=LM_CHOLESKY_REFERENCE_ORDER)
+    with pytest.raises(NlsgError):
+        mod.lm.LMEngine("rastrigin", batch=1, n=4, solver=LM_CHOLESKY_REFERENCE_ORDER)
