@@ -609,8 +609,11 @@ def main_lm(args):
     solve divided by its iteration count; the roofline object describes the evaluation kernel
     (shared by both solvers) timed on its own."""
     import nlsolver_amd
-    m, n, iters = 512, 64, 20
-    batch = 8192 if args.pop_per_gpu == POP_PER_GPU else args.pop_per_gpu
+    m, n, iters = 512, args.lm_n, 20
+    wide = n > 64  # workgroup-per-problem kernels; the class's own (Cholesky) solve only
+    if wide and args.lm_solver != "cholesky":
+        raise SystemExit("--lm-n > 64: the tinyqr solve is built for n <= 64")
+    batch = (1024 if wide else 8192) if args.pop_per_gpu == POP_PER_GPU else args.pop_per_gpu
     ranks = Ranks(args)
     rng = np.random.default_rng(ranks.slice_seed(12374563468 % 2**32))
     # the design matrices are built in page-locked memory (nlsolver_amd.pinned_empty): the upload
@@ -635,42 +638,50 @@ def main_lm(args):
     th, st, lam = eng.minimize(theta0.copy())
     # the other solver on the same resident data
     other_name = "qr" if args.lm_solver == "cholesky" else "cholesky"
-    eng.set_solver(solvers[other_name])
-    eng.time_solve(theta0, 1)
-    ms_other = timed_solves(ranks, eng, theta0, 3)
-    th_o, st_o, _ = eng.minimize(theta0.copy())
-    eng.set_solver(solvers[args.lm_solver])
+    if not wide:
+        eng.set_solver(solvers[other_name])
+        eng.time_solve(theta0, 1)
+        ms_other = timed_solves(ranks, eng, theta0, 3)
+        th_o, st_o, _ = eng.minimize(theta0.copy())
+        eng.set_solver(solvers[args.lm_solver])
     evals = iters + 1
-    hbm_eval = (m * 64 * 8 + m * 8) * batch  # A and y streamed once per evaluation
+    npad = 64 if not wide else n
+    hbm_eval = (m * npad * 8 + m * 8) * batch  # A and y streamed once per evaluation
     # the evaluation launch (both solvers share it), timed on its own: ten lower 16 x 16 tiles of
     # J^T J per 4-row k-step are what the matrix cores execute (the matrix is symmetric)
     eng.time_eval_kernel(theta0, 60)  # untimed: clocks back up after the host-side pauses
-    kname, kms = "lm_iter_kernel (evaluation-only launches)", eng.time_eval_kernel(theta0, 20) / 20
-    flops = 2.0 * m * 10 * 256 * batch
+    kname = ("lm_wide128_tanh_eval_kernel" if 64 < n <= 128 else "lm_wide_tanh_eval_kernel" if wide
+             else "lm_iter_kernel (evaluation-only launches)")
+    kms = eng.time_eval_kernel(theta0, 20) / 20
+    # executed on the matrix cores: the lower 16 x 16 tiles of J^T J (the matrix is bitwise
+    # symmetric), 2 * 16 * 16 flop per tile and row — 10 tiles at n = 64, 36 at n = 128
+    nb = (n + 15) // 16
+    flops = 2.0 * m * (nb * (nb + 1) // 2) * 256 * batch
     tflops = flops / (kms * 1e-3) / 1e12
     hbm_gbps = hbm_eval / (kms * 1e-3) / 1e9
     check_kernel_within_step(kms, ms / iters, "lm")
     if ranks.rank == 0:
         print(json.dumps({
-            "metric": "LM iterations x problems / s (NLLS m=512 n=64)",
+            "metric": f"LM iterations x problems / s (NLLS m=512 n={n})",
             "value": ranks.world * batch * iters / (ms * 1e-3), "unit": "iteration-problems/s",
             "n_gpus": ranks.world,
             "steps": iters, "warmup": 1, "ms_per_step": ms / iters, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"Levenberg-Marquardt tanh-regression NLLS m={m} n={n}, "
-                                   f"batch={batch} per GPU (BASELINE configs[3]), {args.lm_solver} solve",
+                                   f"batch={batch} per GPU ({'BASELINE configs[3]' if n == 64 else 'past the one-wave size'}), "
+                                   f"{args.lm_solver} solve",
                        "solver": args.lm_solver,
                        "max_final_f": max(s.f_value for s in st),
                        # what an iteration spends outside the evaluation launch (the damped solve)
                        "solve_ms_per_iteration": ms / iters - kms * evals / iters,
-                       "other_solver": {
+                       **({} if wide else {"other_solver": {
                            "solver": other_name,
                            "value": ranks.world * batch * iters / (ms_other * 1e-3),
                            "ms_per_step": ms_other / iters,
                            "solve_ms_per_iteration": ms_other / iters - kms * evals / iters,
                            "max_final_f": max(s.f_value for s in st_o),
                            "max_rel_diff_theta": float(np.max(np.abs(th_o - th) /
-                                                              (1e-300 + np.abs(th))))},
+                                                              (1e-300 + np.abs(th))))}}),
                        # host buffers in, host buffers out: data upload + one whole solve
                        "upload_s": upload_s, "upload_GBps": (A.nbytes + y.nbytes) / upload_s / 1e9,
                        "upload_from": "pageable host memory" if args.lm_pageable
@@ -679,13 +690,16 @@ def main_lm(args):
                        "parallelism": ranks.replicas()},
             "roofline": {"bound": "mfma", "achieved": tflops, "peak": 78.6, "unit": "TFLOP/s",
                          "frac": tflops / 78.6,
-                         **pmc_bytes("lm", ["lm_iter_kernel"], batch == 8192),
+                         **pmc_bytes("lm", ["lm_iter_kernel"], batch == 8192 and not wide),
                          "kernel": kname,
                          "kernel_ms": kms, "algorithmic_flops_per_launch": flops,
+                         # SURVEY §8d's counts: m n (n + 1) exploiting symmetry, 2 m n^2 without
+                         "frac_on_m_n_n1": m * n * (n + 1) * batch / (kms * 1e-3) / 1e12 / 78.6,
+                         "frac_on_2_m_n2": 2.0 * m * n * n * batch / (kms * 1e-3) / 1e12 / 78.6,
                          "hbm_GBps": hbm_gbps, "hbm_frac": hbm_gbps / 8000.0},
             **({} if (args.no_cpu_baseline or ranks.world > 1) else {"cpu_baseline": ref_baseline(
-                ["bench-lm", m, n, 256, iters], "iterations_per_s", "iteration-problems/s",
-                f"reference LevenbergMarquardt + GN functors, m={m} n={n}, 256 problems x {iters} "
+                ["bench-lm", m, n, 256 if n <= 64 else 48, iters], "iterations_per_s", "iteration-problems/s",
+                f"reference LevenbergMarquardt + GN functors, m={m} n={n}, {256 if n <= 64 else 48} problems x {iters} "
                 "iterations")})}))
     eng.close()
     ranks.close()
@@ -922,6 +936,9 @@ def main():
                     help="lm workload: damped-system solver whose rate is the line's value (cholesky "
                          "= the reference class's get_update_with_hessian; qr = tinyqr::lm, as "
                          "BASELINE configs[3] words it); the other one is reported beside it")
+    ap.add_argument("--lm-n", type=int, default=64,
+                    help="lm workload: parameters per problem (64 = BASELINE configs[3]; 65 .. 1024 run "
+                         "the workgroup-per-problem kernels, batch 1024 by default)")
     ap.add_argument("--lm-pageable", action="store_true",
                     help="lm workload: hand the design matrices over from ordinary (pageable) host "
                          "memory instead of page-locked memory")

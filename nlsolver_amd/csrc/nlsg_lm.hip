@@ -20,6 +20,7 @@ struct nlsg_lm {
   unsigned long long *count_dev = nullptr;
   bool has_data = false;
   bool wide = false;   // n > 64: the workgroup-per-problem kernels (lm_wide_*)
+  bool wide_valu = false;  // NLSG_LM_WIDE_MFMA=0: the VALU contraction at every n > 64 (A/B switch)
   uint64_t ldt = kLmN; // row stride of theta / gg on the device: 64, or n when wide
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   LmRtcKernels rtc;  // objective == NLSG_OBJ_CUSTOM: the kernel hiprtc built for it
@@ -105,7 +106,11 @@ void launch_wide_eval(nlsg_lm *e, int first) {
                                        64, std::max<uint64_t>(1, 2048 / e->p.batch))) : 1u;
   const dim3 grid(static_cast<unsigned>(e->p.batch), split);
   if (!e->p.fd) {
-    hipLaunchKernelGGL(lm_wide_tanh_eval_kernel, grid, dim3(kLmWideThreads), 0, e->stream, e->p, first);
+    // up to 128 parameters: one pass over A, J^T J on the matrix cores
+    if (e->p.n <= 128 && !e->wide_valu)
+      hipLaunchKernelGGL(lm_wide128_tanh_eval_kernel, grid, dim3(256), 0, e->stream, e->p, first);
+    else
+      hipLaunchKernelGGL(lm_wide_tanh_eval_kernel, grid, dim3(kLmWideThreads), 0, e->stream, e->p, first);
     return;
   }
   if (e->cfg.objective == NLSG_OBJ_CUSTOM) {
@@ -220,6 +225,10 @@ static int lm_create(const nlsg_lm_config *cfg, const nlsg_custom_objective *cus
   if (!e) return fail(NLSG_ERR_OOM, "host allocation failed");
   e->cfg = *cfg;
   e->wide = wide;
+  {
+    const char *sw = std::getenv("NLSG_LM_WIDE_MFMA");
+    e->wide_valu = sw && sw[0] == '0';
+  }
   e->ldt = wide ? cfg->n : kLmN;
   if (cfg->stream) {
     e->stream = borrowed_stream(cfg->stream);
@@ -478,7 +487,6 @@ int nlsg_lm_time_solve(nlsg_lm *e, const double *theta0_host, uint32_t repeats, 
 int nlsg_lm_time_eval_kernel(nlsg_lm *e, const double *theta0_host, uint32_t repeats, float *ms_total) {
   if (!e || !theta0_host || !ms_total) return fail(NLSG_ERR_INVALID_ARG, "null argument");
   if (e->p.fd) return fail(NLSG_ERR_UNSUPPORTED, "Gauss-Newton model only");
-  if (e->wide) return fail(NLSG_ERR_UNSUPPORTED, "the one-wave evaluation kernel: n <= 64 only");
   if (!e->has_data) return fail(NLSG_ERR_STATE, "nlsg_lm_set_data has not been called");
   NLSG_HIP(hipSetDevice(e->cfg.device));
   int rc = upload_theta(e, theta0_host);
@@ -486,8 +494,11 @@ int nlsg_lm_time_eval_kernel(nlsg_lm *e, const double *theta0_host, uint32_t rep
   float total = 0.f;
   for (uint32_t r = 0; r < repeats; r++) {
     NLSG_HIP(hipEventRecord(e->ev0, e->stream));
-    hipLaunchKernelGGL(lm_iter_kernel, dim3(static_cast<unsigned>(e->p.batch)), dim3(64), 0,
-                       e->stream, e->p, 1, 0);
+    if (e->wide)
+      launch_wide_eval(e, 1);
+    else
+      hipLaunchKernelGGL(lm_iter_kernel, dim3(static_cast<unsigned>(e->p.batch)), dim3(64), 0,
+                         e->stream, e->p, 1, 0);
     NLSG_HIP(hipEventRecord(e->ev1, e->stream));
     NLSG_HIP(hipEventSynchronize(e->ev1));
     NLSG_HIP(launches_status());

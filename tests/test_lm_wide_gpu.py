@@ -125,3 +125,25 @@ def test_lm_wide_diagonal_shortcut_and_limits(mod, oracle):
         mod.LMEngine(mod.TanhRegression(A, y), solver=LM_QR)
     with pytest.raises(NlsgError):
         mod.lm.LMEngine("sphere", batch=1, n=1025)
+
+
+@pytest.mark.parametrize("m,n,batch", [(512, 128, 4), (33, 127, 2), (16, 65, 2), (100, 101, 3), (257, 112, 2),
+                                       (64, 96, 2), (1, 66, 2)])
+def test_lm_wide_matrix_core_kernel_bit_exact(mod, oracle, monkeypatch, m, n, batch):
+    """64 < n <= 128: the one-pass kernel with J^T J on the matrix cores (lm_wide128_tanh_eval_kernel)
+    against the order-1 oracle AND against the VALU contraction it replaces (NLSG_LM_WIDE_MFMA=0):
+    the benchmark size, odd n (scalar loads), m not a multiple of sixteen, fewer rows than a group,
+    column blocks that are entirely padding. An fp64 MFMA is a k-ordered fma chain: same bits."""
+    kw = dict(lam=10.0, max_iter=5, f_delta=0.0)
+    A, y, t0 = problems(oracle, 11, batch, m, n)
+    out = {}
+    for sw in ("1", "0"):
+        monkeypatch.setenv("NLSG_LM_WIDE_MFMA", sw)
+        with mod.LMEngine(mod.TanhRegression(A, y), **kw) as eng:
+            out[sw] = eng.minimize(t0.copy())
+    th, st, lam = out["1"]
+    for b in range(batch):
+        ref, xr, lam_r, _ = O.lm_solve(oracle, A[b], y[b], t0[b], order=1, **kw)
+        check(st[b], ref, th[b], xr, lam[b], lam_r, (m, n, b))
+    assert np.array_equal(out["0"][0], th, equal_nan=True) and np.array_equal(out["0"][2], lam, equal_nan=True)
+    assert [s.f_value for s in out["0"][1]] == [s.f_value for s in st]
