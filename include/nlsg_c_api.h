@@ -474,6 +474,12 @@ int nlsg_nm_destroy(nlsg_nm *e);
  * solver's mutated tolerance (nlsolver.h:2189). NULLs are skipped. Synchronises. */
 int nlsg_nm_minimize(nlsg_nm *e, double *x_inout_host, const double *upper_host,
                      const double *lower_host, nlsg_status *status_host, double *eps_out_host);
+/* Measurement aid: one solve from x0_host with the kernel's phase counters switched on —
+ * cycles_host[batch][8]: shader-clock cycles the start's decision chain spent in 0 the scan
+ * (std_err, best / worst / second worst, stop tests), 1 the centroid, 2 the reflection (transform,
+ * evaluation, decision), 3 expansion or contraction, 4 shrink + rescoring (with its barriers);
+ * [6] iterations, [7] shrinks. x is not returned. */
+int nlsg_nm_phase_cycles(nlsg_nm *e, const double *x0_host, uint64_t *cycles_host);
 int nlsg_nm_time_solve(nlsg_nm *e, const double *x0_host, uint32_t repeats, float *ms_total);
 
 /* ========================================================================== */

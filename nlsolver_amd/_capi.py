@@ -193,6 +193,7 @@ SYMBOLS = {
     "nlsg_nm_create": (C.c_int, [C.POINTER(NMConfig), C.POINTER(_H)]),
     "nlsg_nm_destroy": (C.c_int, [_H]),
     "nlsg_nm_minimize": (C.c_int, [_H, pd, pd, pd, C.POINTER(Status), pd]),
+    "nlsg_nm_phase_cycles": (C.c_int, [_H, pd, pu]),
     "nlsg_nm_time_solve": (C.c_int, [_H, pd, C.c_uint32, C.POINTER(C.c_float)]),
     "nlsg_nmpso_create": (C.c_int, [C.POINTER(NMPSOConfig), C.POINTER(_H)]),
     "nlsg_nmpso_create_custom": (C.c_int, [C.POINTER(NMPSOConfig), C.POINTER(CustomObjectiveC),

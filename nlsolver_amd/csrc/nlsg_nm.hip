@@ -1,4 +1,5 @@
 // nlsolver_amd/csrc/nlsg_nm.hip — host side of the batched Nelder-Mead engine + C-ABI.
+#include <cstdlib>
 #include <new>
 #include <vector>
 
@@ -15,6 +16,8 @@ struct nlsg_nm {
   bool own_stream = false;
   double *upper_dev = nullptr, *lower_dev = nullptr;
   size_t lds = 0;
+  bool driver = false;  // n <= 128: nm_solve_driver_kernel (NLSG_NM_DRIVER=0: the phase-per-barrier kernel)
+  unsigned long long *phase_dev = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -38,7 +41,17 @@ hipError_t prepare(int chunks) {
   }
 }
 template <int OBJ>
+hipError_t prepare_driver() {
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(nm_solve_driver_kernel<OBJ>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize,
+                             static_cast<int>(nm_lds_bytes(128)));
+}
+template <int OBJ>
 void launch_obj(nlsg_nm *e, dim3 grid, dim3 block) {
+  if (e->driver) {
+    hipLaunchKernelGGL(nm_solve_driver_kernel<OBJ>, grid, block, e->lds, e->stream, e->p);
+    return;
+  }
   switch (nm_chunks(e->p.n)) {
     case 1: hipLaunchKernelGGL((nm_solve_kernel<OBJ, 1>), grid, block, e->lds, e->stream, e->p); break;
     case 2: hipLaunchKernelGGL((nm_solve_kernel<OBJ, 2>), grid, block, e->lds, e->stream, e->p); break;
@@ -132,12 +145,21 @@ static int nm_create(const nlsg_nm_config *cfg, const nlsg_custom_objective *cus
   if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&e->lower_dev), n * 8);
   if (he == hipSuccess) he = hipEventCreate(&e->ev0);
   if (he == hipSuccess) he = hipEventCreate(&e->ev1);
+  {
+    const char *sw = std::getenv("NLSG_NM_DRIVER");
+    e->driver = chunks == 1 && !(sw && sw[0] == '0');
+  }
+  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&e->phase_dev), B * kNmPhases * 8);
+  if (he == hipSuccess) he = prepare_driver<NLSG_OBJ_ROSENBROCK>();
+  if (he == hipSuccess) he = prepare_driver<NLSG_OBJ_SPHERE>();
+  if (he == hipSuccess) he = prepare_driver<NLSG_OBJ_STYBLINSKI_TANG>();
+  if (he == hipSuccess) he = prepare_driver<NLSG_OBJ_RASTRIGIN>();
   if (he == hipSuccess) he = prepare<NLSG_OBJ_ROSENBROCK>(chunks);
   if (he == hipSuccess) he = prepare<NLSG_OBJ_SPHERE>(chunks);
   if (he == hipSuccess) he = prepare<NLSG_OBJ_STYBLINSKI_TANG>(chunks);
   if (he == hipSuccess) he = prepare<NLSG_OBJ_RASTRIGIN>(chunks);
   if (he == hipSuccess && custom) {
-    const int rc2 = rtc_build_nm(custom, chunks, &e->rtc);
+    const int rc2 = rtc_build_nm(custom, e->driver ? 0 : chunks, &e->rtc);
     if (rc2) {
       nlsg_nm_destroy(e);
       return rc2;
@@ -180,6 +202,7 @@ int nlsg_nm_destroy(nlsg_nm *e) {
   hipFree(e->p.prob);
   hipFree(e->upper_dev);
   hipFree(e->lower_dev);
+  hipFree(e->phase_dev);
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
   if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
@@ -217,6 +240,21 @@ int nlsg_nm_minimize(nlsg_nm *e, double *x_inout_host, const double *upper_host,
     }
     if (eps_out_host) eps_out_host[b] = pr[b].eps;
   }
+  return NLSG_OK;
+}
+
+int nlsg_nm_phase_cycles(nlsg_nm *e, const double *x0_host, uint64_t *cycles_host) {
+  if (!e || !x0_host || !cycles_host) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  NLSG_HIP(hipSetDevice(e->cfg.device));
+  const uint64_t B = e->p.batch;
+  NLSG_HIP(hipMemcpy(e->p.x, x0_host, B * e->p.n * 8, hipMemcpyHostToDevice));
+  NLSG_HIP(hipMemset(e->phase_dev, 0, B * kNmPhases * 8));
+  e->p.phase = e->phase_dev;
+  launch(e);
+  e->p.phase = nullptr;
+  NLSG_HIP(launches_status());
+  NLSG_HIP(hipStreamSynchronize(e->stream));
+  NLSG_HIP(hipMemcpy(cycles_host, e->phase_dev, B * kNmPhases * 8, hipMemcpyDeviceToHost));
   return NLSG_OK;
 }
 

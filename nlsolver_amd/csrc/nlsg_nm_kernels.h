@@ -44,12 +44,20 @@ struct NmParams {
   uint64_t batch, n, max_iter, no_change_tol, restarts;
   double step, alpha, gamma, rho, sigma, eps, fmul;
   int32_t bounded, pad;
+  // measurement aid (nlsg_nm_phase_cycles; nullptr otherwise): [batch][kNmPhases] shader-clock
+  // cycles the start's decision chain spent per phase, and two counts
+  unsigned long long *phase;
 };
+// phases: 0 scan (std_err, best / worst / second worst, stop tests), 1 centroid, 2 reflection
+// (transform, evaluation, decision), 3 expansion or contraction (transform, evaluation, accept),
+// 4 shrink + rescoring (all waves, the barriers around it included), 5 -, 6 iterations, 7 shrinks
+constexpr int kNmPhases = 8;
 
 struct NmCtl {  // control block in LDS
   double ref_score, exp_score, cont_score, eps, se;
   uint64_t best, worst, second_worst, prev_worst, last_best, no_change, iter, fcalls;
   int stop, shrunk, action;
+  int cmd;  // nm_solve_driver_kernel: what the driver wave asks of the others at the next barrier
 };
 
 // the point at `pt` in the lane layout of the other engines (element 128 c + 2 lane + k)
@@ -101,6 +109,16 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_kernel(NmParams p) {
   __syncthreads();
   uint64_t total_iter = 0;
   double final_f = 0.0;
+  // measurement aid (p.phase): what one thread sees of the workgroup's phases, barriers included
+  unsigned long long ph[kNmPhases] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tk = p.phase ? __builtin_readcyclecounter() : 0;
+  auto lap = [&](int k) {
+    if (p.phase) {
+      const unsigned long long now = __builtin_readcyclecounter();
+      ph[k] += now - tk;
+      tk = now;
+    }
+  };
 
   for (uint64_t run = 0; run <= p.restarts; run++) {
     // ---- simplex ctor (1910-1950) with the effective vertices of SURVEY B1
@@ -218,6 +236,7 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_kernel(NmParams p) {
         }
       }
       __syncthreads();
+      lap(0);
       if (ctl->stop) break;
       const uint64_t best = ctl->best, worst = ctl->worst, second = ctl->second_worst;
       // ---- centroid of all vertices but the worst (1965-1984), only when it can have changed
@@ -232,6 +251,7 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_kernel(NmParams p) {
         }
       }
       __syncthreads();
+      lap(1);
       // ---- reflect (2245): c + alpha (c - p), clamped when bounded
       for (uint64_t j = t; j < n; j += nthreads) {
         double v = centroid[j] + p.alpha * (centroid[j] - S[worst * n + j]);
@@ -252,6 +272,7 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_kernel(NmParams p) {
       __syncthreads();
       const int action = ctl->action;
       const double ref_score = ctl->ref_score;
+      lap(2);
       if (action == 0) {  // 2251-2253
         for (uint64_t j = t; j < n; j += nthreads) S[worst * n + j] = tr[j];
         if (t == 0) scores[worst] = ref_score;
@@ -342,10 +363,326 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_kernel(NmParams p) {
             ctl->fcalls += nv - 1;
             ctl->shrunk = 1;
           }
+          if (p.phase) __syncthreads();  // (uniform) so that the shrink's time is its own
+          ph[7] += p.phase ? 1 : 0;
+          lap(4);
         }
       }
       __syncthreads();
+      lap(3);
     }
+    // x = current_simplex.vals[best] (2235); restarts continue from it (2129-2132)
+    const uint64_t best = ctl->best;
+    for (uint64_t j = t; j < n; j += nthreads) x0[j] = S[best * n + j];
+    total_iter += ctl->iter;
+    ph[6] += p.phase ? ctl->iter : 0;
+    final_f = scores[best];
+    __syncthreads();
+  }
+  for (uint64_t j = t; j < n; j += nthreads) p.x[pid * n + j] = x0[j];
+  if (t == 0) {
+    NmProblem *pr = p.prob + pid;
+    pr->f = final_f;
+    pr->eps = ctl->eps;
+    pr->iter = total_iter;
+    pr->fcalls = ctl->fcalls;
+    if (p.phase)
+      for (int k = 0; k < kNmPhases; k++) p.phase[pid * kNmPhases + k] = ph[k];
+  }
+}
+
+// ---- n <= 128: the same method with ONE wave driving it. An iteration of Nelder-Mead is a chain
+// of data-dependent decisions, each behind an objective evaluation; in nm_solve_kernel every link
+// of that chain is a workgroup phase (decide on one lane, broadcast through LDS, barrier — eight
+// barriers of up to sixteen waves per iteration, which is where its time goes: profiles/r03).
+// Here wave 0 (the driver) keeps the chain in its registers: the scan's results are wave-uniform
+// by construction (butterflies), the centroid and the trial points live in the lane layout (lane l
+// owns coordinates 2l, 2l+1: the centroid's sums run over the vertices in the reference's order,
+// two chains per lane), trial points are scored from registers, decisions need no broadcast. The
+// other waves sleep at a barrier and are woken only for what is parallel: the shrink with its
+// n rescorings (and the run's start and end). Same arithmetic per coordinate, same lane trees:
+// the bits of nm_solve_kernel and of the oracle.
+constexpr int kNmCmdShrink = 1, kNmCmdEnd = 2;
+
+template <int OBJ>
+__device__ inline void nm_shrink_rows(double *S, double *scores, uint64_t n, uint64_t nv, uint64_t best,
+                                      double sigma, double fmul, int wid, uint64_t nwaves) {
+  constexpr int ROWS = 4;
+  const int lane = lane_id();
+  double bv[1][2];
+  nm_load_point<1>(S + best * n, n, bv);
+  for (uint64_t v0 = wid; v0 < nv; v0 += ROWS * nwaves) {
+    double xv[ROWS][1][2];
+#pragma unroll
+    for (int q = 0; q < ROWS; q++) {
+      const uint64_t v = v0 + nwaves * q;
+      const bool live = v < nv && v != best;
+      double *row = S + (live ? v : best) * n;
+      double ov[1][2];
+      nm_load_point<1>(row, n, ov);
+      const uint64_t e0 = 2 * static_cast<uint64_t>(lane);
+      const bool in0 = e0 < n, in1 = e0 + 1 < n;
+      xv[q][0][0] = bv[0][0] + sigma * (ov[0][0] - bv[0][0]);
+      xv[q][0][1] = bv[0][1] + sigma * (ov[0][1] - bv[0][1]);
+      if (live && in0) row[e0] = xv[q][0][0];
+      if (live && in1) row[e0 + 1] = xv[q][0][1];
+      if (!in0) xv[q][0][0] = 0.0;
+      if (!in1) xv[q][0][1] = 0.0;
+    }
+    double f[ROWS];
+#pragma unroll
+    for (int q = 0; q < ROWS; q++) f[q] = fmul * wave_objective<OBJ, 1>(xv[q], n);
+#pragma unroll
+    for (int q = 0; q < ROWS; q++) {
+      const uint64_t v = v0 + nwaves * q;
+      if (lane == 0 && v < nv && v != best) scores[v] = f[q];
+    }
+  }
+}
+
+template <int OBJ>
+__global__ __launch_bounds__(kNmThreads) void nm_solve_driver_kernel(NmParams p) {
+  const uint64_t nthreads = blockDim.x, nwaves = blockDim.x >> 6;
+  extern __shared__ __align__(16) unsigned char nm_smem[];
+  const uint64_t n = p.n, nv = p.n + 1;
+  const uint64_t pid = blockIdx.x;
+  double *const S = reinterpret_cast<double *>(nm_smem);  // [nv][n]
+  double *scores = S + nv * n;                            // [nv] (padded to even)
+  double *centroid = scores + ((nv + 1) & ~1ull);         // (layout of nm_lds_bytes; unused vectors stay)
+  double *x0 = centroid + 4 * n, *up = x0 + n, *lo = up + n;
+  NmCtl *ctl = reinterpret_cast<NmCtl *>(lo + n);
+  const int t = threadIdx.x;
+  const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int lane = lane_id();
+  const uint64_t e0 = 2 * static_cast<uint64_t>(lane), e1 = e0 + 1;
+  const bool in0 = e0 < n, in1 = e1 < n;
+
+  for (uint64_t j = t; j < n; j += nthreads) {
+    x0[j] = p.x[pid * n + j];
+    up[j] = p.bounded ? p.upper[j] : 0.0;
+    lo[j] = p.bounded ? p.lower[j] : 0.0;
+  }
+  if (t == 0) {
+    ctl->eps = p.eps;
+    ctl->fcalls = 0;
+    ctl->iter = 0;
+  }
+  __syncthreads();
+  uint64_t total_iter = 0;
+  double final_f = 0.0;
+  unsigned long long ph[kNmPhases] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  for (uint64_t run = 0; run <= p.restarts; run++) {
+    // ---- simplex ctor (1910-1950) with the effective vertices of SURVEY B1
+    double scale = p.step;
+    if (p.step < 0) {
+      double inf_norm = fabs(x0[0]);  // max_abs_vec, 1894-1904
+      for (uint64_t i = 1; i < n; i++) {
+        const double a = fabs(x0[i]);
+        if (inf_norm < a) inf_norm = a;
+      }
+      const double a = inf_norm < 1.0 ? 1.0 : inf_norm;
+      scale = a < 10 ? a : 10;
+    }
+    for (uint64_t e = t; e < nv * n; e += nthreads) {
+      const uint64_t v = e / n, j = e % n;
+      double val = x0[j];
+      if (v >= 1 && v < n && j == v) val = val + scale;  // vertex n keeps x (the OOB write)
+      if (v == 0 && p.step < 0) {
+        const double nn = static_cast<double>(n);
+        val = x0[j] + ((1.0 - sqrt(nn + 1.0)) / nn * scale);
+      }
+      S[e] = val;
+    }
+    __syncthreads();
+    for (uint64_t v = wid; v < nv; v += nwaves) {  // 2184-2186
+      const double f = nm_wave_f<OBJ, 1>(S + v * n, n, p.fmul);
+      if (lane == 0) scores[v] = f;
+    }
+    __syncthreads();
+
+    if (wid != 0) {
+      // ---- the other waves: asleep at a barrier until the driver has work for all
+      for (;;) {
+        __syncthreads();  // (A) the driver's request is in ctl
+        if (ctl->cmd == kNmCmdEnd) break;
+        nm_shrink_rows<OBJ>(S, scores, n, nv, ctl->best, p.sigma, p.fmul, wid, nwaves);
+        __syncthreads();  // (B) every row is shrunk and rescored
+      }
+    } else {
+      // ---- the driver wave. Everything below is wave-uniform except the coordinates.
+      double eps = ctl->eps;
+      eps = eps * (scores[0] * eps);  // 2189 (B2)
+      uint64_t fcalls = ctl->fcalls + nv, iter = 0, worst = 0, prev_worst = 0, best = 0, second = 0;
+      uint64_t last_best = 99999999, no_change = 0;
+      int shrunk = 0;
+      double c0 = 0.0, c1 = 0.0;  // the centroid, zeroed at :2195
+      unsigned long long tk = p.phase ? __builtin_readcyclecounter() : 0;
+      auto lap = [&](int k) {
+        if (p.phase) {
+          const unsigned long long now = __builtin_readcyclecounter();
+          ph[k] += now - tk;
+          tk = now;
+        }
+      };
+      auto clamp = [&](double v, double l, double u) { return v < l ? l : (u < v ? u : v); };
+      const double lo0 = p.bounded && in0 ? lo[e0] : 0.0, lo1 = p.bounded && in1 ? lo[e1] : 0.0;
+      const double up0 = p.bounded && in0 ? up[e0] : 0.0, up1 = p.bounded && in1 ? up[e1] : 0.0;
+      auto score = [&](double a, double b) {
+        const double xv[1][2] = {{in0 ? a : 0.0, in1 ? b : 0.0}};
+        return p.fmul * wave_objective<OBJ, 1>(xv, n);
+      };
+      for (;;) {
+        // ---- std_err(scores) and the best / worst / second-worst scan (see nm_solve_kernel)
+        double acc = 0.0;
+        double mnv = __builtin_inf(), mxv = -__builtin_inf();
+        uint64_t mni = ~0ull, mxi = ~0ull;
+        for (uint64_t i = lane; i < nv; i += 64) {
+          const double si = scores[i];
+          acc = acc + si;
+          argmin_combine(mnv, mni, si, i);
+          argmax_combine(mxv, mxi, si, i);
+        }
+        butterfly_levels<32>([&](auto off) {
+          constexpr int o = decltype(off)::value;
+          const double oa = lane_xor<o>(acc);
+          const double omn = lane_xor<o>(mnv), omx = lane_xor<o>(mxv);
+          const uint64_t omni = lane_xor<o>(mni), omxi = lane_xor<o>(mxi);
+          acc = acc + oa;
+          argmin_combine(mnv, mni, omn, omni);
+          argmax_combine(mxv, mxi, omx, omxi);
+        });
+        const double mean = acc / static_cast<double>(nv);
+        const bool frozen = isnan(scores[0]);
+        const uint64_t worst_i = (frozen || mxi == ~0ull) ? 0 : mxi;
+        acc = 0.0;
+        double sv = -__builtin_inf();
+        uint64_t svi = ~0ull;
+        for (uint64_t i = lane; i < nv; i += 64) {
+          const double si = scores[i];
+          const double d = si - mean;
+          acc = acc + d * d;
+          if (i < worst_i) argmax_combine(sv, svi, si, i);
+        }
+        butterfly_levels<32>([&](auto off) {
+          constexpr int o = decltype(off)::value;
+          const double oa = lane_xor<o>(acc);
+          const double osv = lane_xor<o>(sv);
+          const uint64_t osvi = lane_xor<o>(svi);
+          acc = acc + oa;
+          argmax_combine(sv, svi, osv, osvi);
+        });
+        const double se = sqrt(acc / static_cast<double>(nv - 1));
+        prev_worst = worst;
+        best = (frozen || mni == ~0ull) ? 0 : mni;
+        worst = worst_i;
+        second = (svi == ~0ull) ? 0 : svi;
+        // the butterflies leave the same bits in every lane: make that visible to the compiler
+        best = static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(best)));
+        worst = static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(worst)));
+        second = static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(second)));
+        if (last_best == best) {  // 2223-2230
+          no_change++;
+        } else {
+          no_change = 0;
+          last_best = best;
+        }
+        const bool stop = iter >= p.max_iter || se < eps || no_change >= p.no_change_tol;  // 2233-2234
+        lap(0);
+        if (__builtin_amdgcn_readfirstlane(stop ? 1 : 0)) break;
+        iter++;
+        // ---- centroid of all vertices but the worst (1965-1984), only when it can have changed:
+        // per coordinate the vertices in order, two branch-free runs around the worst one
+        if (prev_worst != worst || shrunk) {
+          const double *col0 = S + (in0 ? e0 : 0), *col1 = S + (in1 ? e1 : 0);
+          double a0 = 0.0, a1 = 0.0;
+#pragma unroll 8
+          for (uint64_t v = 0; v < worst; v++) {
+            a0 += col0[v * n];
+            a1 += col1[v * n];
+          }
+#pragma unroll 8
+          for (uint64_t v = worst + 1; v < nv; v++) {
+            a0 += col0[v * n];
+            a1 += col1[v * n];
+          }
+          c0 = a0 / static_cast<double>(nv - 1);
+          c1 = a1 / static_cast<double>(nv - 1);
+        }
+        lap(1);
+        // ---- reflect (2245): c + alpha (c - p), clamped when bounded
+        double *wrow = S + worst * n;
+        const double w0 = in0 ? wrow[e0] : 0.0, w1 = in1 ? wrow[e1] : 0.0;
+        double r0 = c0 + p.alpha * (c0 - w0), r1 = c1 + p.alpha * (c1 - w1);
+        if (p.bounded) {
+          r0 = clamp(r0, lo0, up0);
+          r1 = clamp(r1, lo1, up1);
+        }
+        const double rs = score(r0, r1);
+        fcalls++;
+        shrunk = 0;
+        const double sb = scores[best], ss = scores[second], sw = scores[worst];
+        // 0 accept reflection, 1 expand, 2 contract
+        const int action = (rs >= sb && rs < ss) ? 0 : (rs < sb ? 1 : 2);
+        lap(2);
+        if (action == 0) {  // 2251-2253
+          if (in0) wrow[e0] = r0;
+          if (in1) wrow[e1] = r1;
+          if (lane == 0) scores[worst] = rs;
+        } else if (action == 1) {  // expand, 2255-2265: c + gamma (reflected - c)
+          double x0e = c0 + p.gamma * (r0 - c0), x1e = c1 + p.gamma * (r1 - c1);
+          if (p.bounded) {
+            x0e = clamp(x0e, lo0, up0);
+            x1e = clamp(x1e, lo1, up1);
+          }
+          const double es = score(x0e, x1e);
+          fcalls++;
+          const bool take_exp = es < rs;
+          if (in0) wrow[e0] = take_exp ? x0e : r0;
+          if (in1) wrow[e1] = take_exp ? x1e : r1;
+          if (lane == 0) scores[worst] = take_exp ? es : rs;
+          lap(3);
+        } else {  // contraction, 2266-2297 (B4: the reflect transform for both kinds)
+          const bool outside = rs < sw;
+          double x0c = c0 + p.rho * (c0 - (outside ? r0 : w0)), x1c = c1 + p.rho * (c1 - (outside ? r1 : w1));
+          if (p.bounded) {
+            x0c = clamp(x0c, lo0, up0);
+            x1c = clamp(x1c, lo1, up1);
+          }
+          const double cs = score(x0c, x1c);
+          fcalls++;
+          if (cs < (outside ? rs : sw)) {
+            if (in0) wrow[e0] = x0c;
+            if (in1) wrow[e1] = x1c;
+            if (lane == 0) scores[worst] = cs;
+            lap(3);
+          } else {  // shrink (2009-2035) and rescoring (2288-2294): every wave takes its rows
+            lap(3);
+            if (lane == 0) {
+              ctl->best = best;
+              ctl->cmd = kNmCmdShrink;
+            }
+            __syncthreads();  // (A)
+            nm_shrink_rows<OBJ>(S, scores, n, nv, best, p.sigma, p.fmul, 0, nwaves);
+            __syncthreads();  // (B)
+            fcalls += nv - 1;
+            shrunk = 1;
+            ph[7] += p.phase ? 1 : 0;
+            lap(4);
+          }
+        }
+      }
+      if (lane == 0) {
+        ctl->best = best;
+        ctl->iter = iter;
+        ctl->fcalls = fcalls;
+        ctl->eps = eps;
+        ctl->cmd = kNmCmdEnd;
+      }
+      ph[6] += p.phase ? iter : 0;
+      __syncthreads();  // (A) with the end request
+    }
+    __syncthreads();  // ctl as the driver left it, for every wave
     // x = current_simplex.vals[best] (2235); restarts continue from it (2129-2132)
     const uint64_t best = ctl->best;
     for (uint64_t j = t; j < n; j += nthreads) x0[j] = S[best * n + j];
@@ -360,6 +697,8 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_kernel(NmParams p) {
     pr->eps = ctl->eps;
     pr->iter = total_iter;
     pr->fcalls = ctl->fcalls;
+    if (p.phase)
+      for (int k = 0; k < kNmPhases; k++) p.phase[pid * kNmPhases + k] = ph[k];
   }
 }
 

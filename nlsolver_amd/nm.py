@@ -70,6 +70,15 @@ class NMEngine:
                                      st, eps.ctypes.data_as(_capi.pd)))
         return x, list(st), eps
 
+    def phase_cycles(self, x0):
+        """One solve with the kernel's phase counters on: (batch, 8) shader-clock cycles per phase
+        (scan, centroid, reflection, expansion / contraction, shrink, -, iterations, shrinks)."""
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        out = np.zeros((self.cfg.batch, 8), dtype=np.uint64)
+        check(lib().nlsg_nm_phase_cycles(self._h, x0.ctypes.data_as(_capi.pd),
+                                         out.ctypes.data_as(_capi.pu)))
+        return out
+
     def time_solve(self, x0, repeats=1):
         x0 = np.ascontiguousarray(x0, dtype=np.float64)
         ms = C.c_float()
