@@ -705,6 +705,56 @@ def main_lm(args):
     ranks.close()
 
 
+def main_tinyqr(args):
+    """Batched tinyqr::lm (SURVEY row a25; tinyqr.h:461-470): 8192 independent least-squares systems
+    of 576 x 64 — the augmented damped system of configs[3], [J; sqrt(lambda) I] — solved side by
+    side by Givens QR (`nlsg_tinyqr_lm`). One step = one batch solved; the systems are resident in
+    HBM inside the timed region (the kernel's HIP events), the PCIe legs are reported beside it."""
+    import nlsolver_amd
+    n, p = 576, 64
+    batch = 8192 if args.pop_per_gpu == POP_PER_GPU else args.pop_per_gpu
+    ranks = Ranks(args)
+    rng = np.random.default_rng(ranks.slice_seed(12374563468 % 2**32))
+    X = 2 * rng.random((batch, p, n)) - 1
+    y = 2 * rng.random((batch, n)) - 1
+    steps = max(2, min(args.steps, 5))
+    nlsolver_amd.tinyqr.lm(X, y, device=ranks.local_rank)  # warm-up
+    ranks.barrier()
+    t0 = time.perf_counter()
+    ms = []
+    for _ in range(steps):
+        beta, k_ms = nlsolver_amd.tinyqr.lm(X, y, device=ranks.local_rank, return_ms=True)
+        ms.append(k_ms)
+    ranks.barrier()
+    wall = ranks.max_over_ranks(time.perf_counter() - t0)
+    kms = ranks.max_over_ranks(sum(ms) / len(ms))
+    resid = y[:64] - np.einsum("bpn,bp->bn", X[:64], beta[:64])
+    ortho = float(np.max(np.abs(np.einsum("bpn,bn->bp", X[:64], resid))))
+    rotations = batch * sum(n - 1 - j for j in range(p))
+    if ranks.rank == 0:
+        print(json.dumps({
+            "metric": f"tinyqr::lm systems / s ({n} x {p} least squares)",
+            "value": ranks.world * batch / (kms * 1e-3), "unit": "systems/s",
+            "n_gpus": ranks.world, "steps": steps, "warmup": 1, "ms_per_step": kms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"tinyqr::lm, batch={batch} systems of {n} x {p} per GPU",
+                       "givens_rotations_per_s": ranks.world * rotations / (kms * 1e-3),
+                       "max_abs_Xt_residual_first_64_systems": ortho,
+                       "pcie_inclusive_value": ranks.world * batch * steps / wall,
+                       "parallelism": ranks.replicas()},
+            "roofline": {"bound": "latency", "achieved": None, "peak": None, "unit": None,
+                         "frac": None, "traffic": None, "kernel": "tinyqr_lm_kernel", "kernel_ms": kms,
+                         "hbm_GBps": batch * (n * p + n + p) * 8 / (kms * 1e-3) / 1e9,
+                         "note": "wavefront Givens QR: n + p - 2 dependent steps of a Givens pair (~45 "
+                                 "dependent fp64 instructions) and two barriers; not roofline-graded "
+                                 "(SURVEY §8d)"},
+            **({} if (args.no_cpu_baseline or ranks.world > 1) else {"cpu_baseline": ref_baseline(
+                ["bench-tinyqr", n, p, 24], "systems_per_s", "systems/s",
+                f"reference tinyqr::lm on 24 systems of {n} x {p}")})}))
+    ranks.close()
+
+
 def main_nm(args):
     """Batched Nelder-Mead (no BASELINE config names it): Rosenbrock-128D,
     2000 iterations per start, eps = 0, batch = 4096 independent simplexes, one per workgroup, the
@@ -945,7 +995,7 @@ def main():
     ap.add_argument("--bfgs-symmetric", action="store_true",
                     help="bfgs workload: the symmetric restatement of the rank-2 update (streams "
                          "the upper blocks of H only) instead of the reference's literal one")
-    ap.add_argument("--workload", choices=["de", "pso-accel", "pso-vanilla", "bfgs", "bfgs-fd", "lm", "lm-fd", "nm", "sann", "nmpso"],
+    ap.add_argument("--workload", choices=["de", "pso-accel", "pso-vanilla", "bfgs", "bfgs-fd", "lm", "lm-fd", "nm", "sann", "nmpso", "tinyqr"],
                     default="de",
                     help="de = the headline benchmark (BASELINE metric); pso-* = config 5's "
                          "per-GPU shard (secondary, same JSON shape)")
@@ -966,6 +1016,8 @@ def main():
         return main_lm(args)
     if args.workload == "nm":
         return main_nm(args)
+    if args.workload == "tinyqr":
+        return main_tinyqr(args)
     if args.workload != "de":
         return main_pso(args)
 

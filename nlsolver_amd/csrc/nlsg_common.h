@@ -394,6 +394,41 @@ __device__ inline double wave_objective(const double (&xv)[CHUNKS][2], uint64_t 
 }
 
 
+// The lane's share of wave_objective (its terms, added in order) before the butterfly, for callers
+// that reduce several points at once (wave_sum4); term objectives only.
+template <int OBJ>
+__device__ inline double wave_objective_partial(double x0, double x1, uint64_t D) {
+  using O = Objective<OBJ>;
+  const int lane = lane_id();
+  const uint64_t nt = O::n_terms(D), e0 = 2 * static_cast<uint64_t>(lane);
+  double xn = 0.0;
+  if (O::kChain) {
+    const double same = lane_down1(x0);
+    xn = (lane == 63) ? 0.0 : same;
+  }
+  double acc = 0.0;
+  if (e0 < nt) acc = acc + O::term(x0, x1);
+  if (e0 + 1 < nt) acc = acc + O::term(x1, xn);
+  return acc;
+}
+// Four wave_sum butterflies at once. The levels 32 and 16 halve the set of values a lane carries
+// (it keeps the values its lane bits select and hands the others to its partner), the levels 8 .. 1
+// run on the one that is left: 7 exchanges and additions instead of 24, every addition the same
+// own + partner pair as in wave_sum — lanes 16 g .. 16 g + 15 end with the total of value g, the
+// bits wave_sum(value g) leaves in every lane.
+__device__ inline double wave_sum4(double a, double b, double c, double d) {
+  const int lane = lane_id();
+  const bool b5 = (lane & 32) != 0, b4 = (lane & 16) != 0;
+  const double y0 = (b5 ? c : a) + lane_xor<32>(b5 ? a : c);
+  const double y1 = (b5 ? d : b) + lane_xor<32>(b5 ? b : d);
+  double v = (b4 ? y1 : y0) + lane_xor<16>(b4 ? y0 : y1);
+  v = v + lane_xor<8>(v);
+  v = v + lane_xor<4>(v);
+  v = v + lane_xor<2>(v);
+  v = v + lane_xor<1>(v);
+  return v;
+}
+
 // ---- reference-order ("sequential") sums. The reference adds in index order (its objective
 // functors, math::dot / norm, the matrix-vector loops: plain left-to-right `acc += ...` loops);
 // the kernels' default is the lane tree above, which differs from it in the last bits. Engines

@@ -107,10 +107,12 @@ void launch_wide_eval(nlsg_lm *e, int first) {
   const dim3 grid(static_cast<unsigned>(e->p.batch), split);
   if (!e->p.fd) {
     // up to 128 parameters: one pass over A, J^T J on the matrix cores
-    if (e->p.n <= 128 && !e->wide_valu)
-      hipLaunchKernelGGL(lm_wide128_tanh_eval_kernel, grid, dim3(256), 0, e->stream, e->p, first);
-    else
+    if (e->wide_valu)
       hipLaunchKernelGGL(lm_wide_tanh_eval_kernel, grid, dim3(kLmWideThreads), 0, e->stream, e->p, first);
+    else if (e->p.n <= 128)
+      hipLaunchKernelGGL(lm_wide128_tanh_eval_kernel, grid, dim3(256), 0, e->stream, e->p, first);
+    else  // super-blocks of 128 x 128, each on the matrix cores
+      hipLaunchKernelGGL(lm_wide_mfma_tanh_eval_kernel, grid, dim3(256), 0, e->stream, e->p, first);
     return;
   }
   if (e->cfg.objective == NLSG_OBJ_CUSTOM) {
@@ -143,7 +145,11 @@ int launch_solve(nlsg_lm *e) {
     const uint64_t chunk = left < 8 ? left : 8;
     for (uint64_t i = 0; i < chunk; i++) {
       if (e->wide) {
-        hipLaunchKernelGGL(lm_wide_step_kernel, grid, dim3(kLmWideThreads), 0, e->stream, e->p);
+        if (e->p.n <= 128 && !e->wide_valu)  // the damped matrix fits LDS: one thread per row
+          hipLaunchKernelGGL(lm_wide128_step_kernel, grid, dim3(128), sizeof(LmWide128StepShared),
+                             e->stream, e->p);
+        else
+          hipLaunchKernelGGL(lm_wide_step_kernel, grid, dim3(kLmWideThreads), 0, e->stream, e->p);
         launch_wide_eval(e, 0);
       } else if (fd) {
         launch_fd_iter(e, 0);
@@ -270,6 +276,9 @@ static int lm_create(const nlsg_lm_config *cfg, const nlsg_custom_objective *cus
   if (he == hipSuccess)
     he = hipFuncSetAttribute(reinterpret_cast<const void *>(lm_qr_step_kernel<kLmQrThreads>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, sizeof(LmQrShared));
+  if (he == hipSuccess)
+    he = hipFuncSetAttribute(reinterpret_cast<const void *>(lm_wide128_step_kernel),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, sizeof(LmWide128StepShared));
   if (he != hipSuccess) {
     nlsg_lm_destroy(e);
     return fail(he == hipErrorOutOfMemory ? NLSG_ERR_OOM : NLSG_ERR_HIP,

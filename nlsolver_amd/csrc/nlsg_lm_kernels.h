@@ -1200,6 +1200,189 @@ __global__ __launch_bounds__(kLmWideThreads) void lm_wide_tanh_eval_kernel(LmPar
   }
 }
 
+// ---- The step for 64 < n <= 128 with the damped matrix in LDS. lm_wide_step_kernel keeps H in
+// global memory and walks it row-wise from every thread (uncoalesced, three barriers per column):
+// at n = 128 it took 0.72 ms for 1024 problems, 2.4 x the evaluation beside it. Here the packed
+// lower triangle (66.5 KB: two workgroups per CU) is loaded once, column-coalesced, and thread t
+// owns row t, as lane t does in lm_solve_cholesky_wave — the same left-looking four-column
+// panels (one read of the own row feeds four sums, the other factor is a broadcast read). What a
+// wave does with lane broadcasts is done here by REPLICATION: the panel's four rows publish their
+// running sums, and every thread factors the 4 x 4 diagonal block (and, in the substitutions,
+// solves the four unknowns) itself — the same arithmetic on the same inputs, hence the same bits
+// — so a panel costs two barriers (one in the substitutions), not two per column. Every sum is
+// the k-ordered fma chain of the order-1 oracle; back-substitution sums run from j = n-1 down.
+constexpr int kLmW128Tri = lm_tri_row(128);
+struct LmWide128StepShared {
+  double tri[kLmW128Tri];
+  double g[128], u[128];
+  double pubs[2][4][4], pubh[4][4];
+};
+
+__global__ __launch_bounds__(128) void lm_wide128_step_kernel(LmParams p) {
+  extern __shared__ __align__(16) unsigned char lm_w128_smem[];  // 69 KB: past the static limit
+  LmWide128StepShared &sh = *reinterpret_cast<LmWide128StepShared *>(lm_w128_smem);
+  const uint64_t pid = blockIdx.x;
+  LmProblem *pr = p.prob + pid;
+  if (pr->done) return;
+  const int t = threadIdx.x, n = static_cast<int>(p.n);
+  const double prev = pr->prev, cur = pr->f;
+  if (pr->iter >= p.max_iter || fabs(prev - cur) < p.f_delta || isnan(prev)) {  // :3520-3527
+    __syncthreads();  // every thread has read `done` before it flips
+    if (t == 0) pr->done = 1;
+    return;
+  }
+  const double *Hg = p.Hw + pid * p.n * p.n;
+  double *th = p.theta + pid * p.n;
+  const double lambda = pr->lambda;
+  const bool row = t < n;
+  const int tt = row ? t : n - 1;  // threads past n alias the last row for their (unused) reads
+  // column t of every row: coalesced; the lower triangle goes to LDS with the damping on its
+  // diagonal (:3529-3531), both triangles decide is_diagonal (:295-307)
+  bool off = false;
+  for (int i0 = 0; i0 < n; i0 += 8) {
+    double v[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) v[q] = (i0 + q < n) ? Hg[static_cast<uint64_t>(i0 + q) * n + tt] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const int i = i0 + q;
+      if (i < n && row) {
+        off |= (i != t) && v[q] > 2.220446049250313e-16 * 1e12;
+        if (t <= i) sh.tri[lm_tri_row(i) + t] = i == t ? v[q] + lambda : v[q];
+      }
+    }
+  }
+  const double gt = p.gg[pid * p.n + tt];
+  sh.g[t] = gt;
+  if (!__syncthreads_or(off)) {  // :310-318
+    if (row) th[t] = th[t] - gt / sh.tri[lm_tri_row(t) + t];
+    return;
+  }
+  auto L = [&](int i, int j) -> double & { return sh.tri[lm_tri_row(i) + j]; };
+  auto pair = [&](int i, int j) { return *reinterpret_cast<const double2 *>(&sh.tri[lm_tri_row(i) + j]); };
+  // ---- cholesky (:251-269)
+  for (int j0 = 0; j0 < n; j0 += 4) {
+    const int nc = n - j0 < 4 ? n - j0 : 4;
+    double s4[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int k = 0; k < j0; k += 4) {  // (rows start at even offsets: a column pair is one 128-bit read)
+      const double2 xa = pair(tt, k), xb = pair(tt, k + 2);  // rows above the panel: in-buffer, unused
+      const double x[4] = {xa.x, xa.y, xb.x, xb.y};
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const int jc = j0 + c < n ? j0 + c : n - 1;
+        const double2 la = pair(jc, k), lb = pair(jc, k + 2);  // wave-uniform address: broadcast
+        const double l[4] = {la.x, la.y, lb.x, lb.y};
+#pragma unroll
+        for (int q = 0; q < 4; q++) s4[c] = __builtin_fma(x[q], l[q], s4[c]);
+      }
+    }
+    double hd[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) hd[c] = L(tt, min(j0 + c, tt));
+    if (row && t >= j0 && t < j0 + 4) {
+#pragma unroll
+      for (int c = 0; c < 4; c++)
+        if (c <= t - j0) {
+          sh.pubs[0][t - j0][c] = s4[c];
+          sh.pubh[t - j0][c] = hd[c];
+        }
+    }
+    __syncthreads();
+    // the panel's 4 x 4 diagonal block, factored by every thread from the published sums
+    double l[4][4], d[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      if (c < nc) {  // uniform
+        double sd = sh.pubs[0][c][c];
+#pragma unroll
+        for (int e = 0; e < c; e++) sd = __builtin_fma(l[c][e], l[c][e], sd);
+        d[c] = sqrt(sh.pubh[c][c] - sd);
+        l[c][c] = d[c];
+#pragma unroll
+        for (int a = c + 1; a < 4; a++) {
+          if (a < nc) {
+            double sa = sh.pubs[0][a][c];
+#pragma unroll
+            for (int e = 0; e < c; e++) sa = __builtin_fma(l[a][e], l[c][e], sa);
+            l[a][c] = (1.0 / d[c] * (sh.pubh[a][c] - sa));
+          }
+        }
+      }
+    }
+    // the thread's own row below the block: column c continues its sum with k = j0 .. j0 + c - 1
+    if (row && t >= j0) {
+      double mine[4];
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        if (c < nc && t >= j0 + c) {
+          double sv = s4[c];
+#pragma unroll
+          for (int e = 0; e < c; e++) sv = __builtin_fma(mine[e], l[c][e], sv);
+          mine[c] = t == j0 + c ? sqrt(hd[c] - sv) : (1.0 / d[c] * (hd[c] - sv));
+          L(t, j0 + c) = mine[c];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- forwardsolve_inplace (:282-294): each row's sum grows in j order
+  const double dg = L(tt, tt);
+  double sum = 0.0;
+  int buf = 0;
+  for (int j0 = 0; j0 < n; j0 += 4, buf ^= 1) {
+    const int nc = n - j0 < 4 ? n - j0 : 4;
+    if (row && t >= j0 && t < j0 + 4) sh.pubs[buf][t - j0][0] = sum;
+    __syncthreads();
+    double uu[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      if (c < nc) {
+        double sc = sh.pubs[buf][c][0];
+#pragma unroll
+        for (int e = 0; e < c; e++) sc = __builtin_fma(L(j0 + c, j0 + e), uu[e], sc);
+        uu[c] = (sh.g[j0 + c] - sc) / L(j0 + c, j0 + c);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      if (c < nc) {
+        if (t == j0 + c) sh.u[t] = uu[c];
+        if (row && t > j0 + c) sum = __builtin_fma(L(t, j0 + c), uu[c], sum);
+      }
+    }
+  }
+  (void)dg;
+  __syncthreads();  // u complete; the exchange buffers are free again
+  // ---- backsolve_inplace_t (:270-281), the inner sums taken from j = n-1 down to i+1
+  sum = 0.0;
+  double mine_b = 0.0;
+  buf = 0;
+  for (int j0 = ((n - 1) >> 2) << 2; j0 >= 0; j0 -= 4, buf ^= 1) {
+    const int nc = n - j0 < 4 ? n - j0 : 4;
+    if (row && t >= j0 && t < j0 + 4) sh.pubs[buf][t - j0][0] = sum;
+    __syncthreads();
+    double bb[4];
+#pragma unroll
+    for (int c = 3; c >= 0; c--) {
+      if (c < nc) {
+        double sc = sh.pubs[buf][c][0];
+#pragma unroll
+        for (int e = 3; e > c; e--)
+          if (e < nc) sc = __builtin_fma(L(j0 + e, j0 + c), bb[e], sc);
+        bb[c] = (sh.u[j0 + c] - sc) / L(j0 + c, j0 + c);
+      }
+    }
+#pragma unroll
+    for (int c = 3; c >= 0; c--) {
+      if (c < nc) {
+        if (t == j0 + c) mine_b = bb[c];
+        if (row && t < j0 + c) sum = __builtin_fma(L(j0 + c, t), bb[c], sum);
+      }
+    }
+  }
+  if (row) th[t] = th[t] - mine_b;  // :3534
+}
+
 // ---- The same functors for 64 < n <= 128 on the matrix cores: ONE pass over A. A workgroup of
 // four waves per problem; per sixteen rows: global -> registers (the group after next is in flight)
 // -> z_i = A_i theta (a half-wave per row: the 32-lane chains and butterfly of the order-1 oracle)
@@ -1379,6 +1562,270 @@ __global__ __launch_bounds__(256, 2) void lm_wide128_tanh_eval_kernel(LmParams p
     case 1: lm_wide128_run<1>(p, first, pid, sh, vec); break;
     case 2: lm_wide128_run<2>(p, first, pid, sh, vec); break;
     default: lm_wide128_run<3>(p, first, pid, sh, vec); break;
+  }
+}
+
+// ---- 128 < n <= 1024 on the matrix cores. H no longer fits one set of accumulators, so the rows
+// are passed over once per 128 x 128 super-block of its lower triangle (as lm_wide_tanh_eval_kernel
+// does on the VALU), after a first phase that needs them all: z = A theta, tanh, residuals r and
+// weights (kept in global memory, rw) and f. A pass (bj, bk) stages, sixteen rows at a time, the
+// scaled Jacobian columns of block bj (and of bk, if another) in LDS and feeds v_mfma_f64_16x16x4:
+// a diagonal super-block exactly as lm_wide128_tanh_eval_kernel does (its 36 lower tiles, nine per
+// wave), any other one as four 64 x 64 quadrants of sixteen tiles, one per wave; g rides on the
+// operands of the passes (bj, 0). Every H_jk is still one k-ordered fma chain over the rows, g_j
+// four chains by row mod 4, f eight chains, z the 32-lane chains of the order-1 oracle: same bits.
+struct LmWideMfmaShared {
+  double Jj[16 * kLmW128Stride];  // phase 1 keeps theta (up to 1024 doubles) here
+  double Jk[16 * kLmW128Stride];
+  double r[16];
+  double part[8];
+};
+
+template <int W, bool DIAG>
+__device__ __attribute__((noinline)) void lm_wide_mfma_pass(const LmParams &p, uint64_t pid, LmWideMfmaShared &sh, uint64_t bj,
+                                         uint64_t bk, bool vec) {
+  constexpr int S = kLmW128Stride;
+  constexpr int R = 7 - W;                  // DIAG: the wave's long tile row (its short one is W)
+  constexpr int QJ = W >> 1, QK = W & 1;    // !DIAG: the wave's 64 x 64 quadrant
+  constexpr int NACC = DIAG ? 9 : 16;
+  const int lane = lane_id();
+  const int half = lane >> 5, lp = lane & 31, kk = lane >> 4, cc = lane & 15;
+  const uint64_t n = p.n, m = p.m;
+  const double *A = p.Aw + pid * m * n;
+  const double *rg = p.rw + pid * 2 * m, *wg = rg + m;
+  const uint64_t nstep = (m + 15) / 16;
+  const int rr[2] = {2 * W + half, 2 * (W + 4) + half};
+  const bool with_g = bk == 0;
+  double aj[2][4], ak[2][4], wv[2], rv2[2];
+  auto fetch = [&](uint64_t s) {
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const uint64_t i = 16 * s + rr[q];
+      const bool in = i < m;
+      const double *row = A + (in ? i : 0) * n;
+      auto get4 = [&](uint64_t base, double (&out)[4]) {
+        const uint64_t e0 = base + 2 * static_cast<uint64_t>(lp), e2 = e0 + 64;
+        if (vec) {
+          const v2d_nt u = *reinterpret_cast<const v2d_nt *>(row + (e0 < n ? e0 : 0));
+          const v2d_nt v = *reinterpret_cast<const v2d_nt *>(row + (e2 < n ? e2 : 0));
+          out[0] = (in && e0 < n) ? u.x : 0.0;
+          out[1] = (in && e0 < n) ? u.y : 0.0;
+          out[2] = (in && e2 < n) ? v.x : 0.0;
+          out[3] = (in && e2 < n) ? v.y : 0.0;
+        } else {
+          out[0] = (in && e0 < n) ? row[e0 < n ? e0 : 0] : 0.0;
+          out[1] = (in && e0 + 1 < n) ? row[e0 + 1 < n ? e0 + 1 : 0] : 0.0;
+          out[2] = (in && e2 < n) ? row[e2 < n ? e2 : 0] : 0.0;
+          out[3] = (in && e2 + 1 < n) ? row[e2 + 1 < n ? e2 + 1 : 0] : 0.0;
+        }
+      };
+      get4(128 * bj, aj[q]);
+      if constexpr (!DIAG) get4(128 * bk, ak[q]);
+      wv[q] = in ? wg[i] : 0.0;
+      rv2[q] = in ? rg[i] : 0.0;
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const double wgt = wv[q];
+      double2 lo, hi;
+      lo.x = -(wgt * aj[q][0]);
+      lo.y = -(wgt * aj[q][1]);
+      hi.x = -(wgt * aj[q][2]);
+      hi.y = -(wgt * aj[q][3]);
+      *reinterpret_cast<double2 *>(&sh.Jj[rr[q] * S + 2 * lp]) = lo;
+      *reinterpret_cast<double2 *>(&sh.Jj[rr[q] * S + 64 + 2 * lp]) = hi;
+      if constexpr (!DIAG) {
+        lo.x = -(wgt * ak[q][0]);
+        lo.y = -(wgt * ak[q][1]);
+        hi.x = -(wgt * ak[q][2]);
+        hi.y = -(wgt * ak[q][3]);
+        *reinterpret_cast<double2 *>(&sh.Jk[rr[q] * S + 2 * lp]) = lo;
+        *reinterpret_cast<double2 *>(&sh.Jk[rr[q] * S + 64 + 2 * lp]) = hi;
+      }
+      if (lp == 0) sh.r[rr[q]] = rv2[q];
+    }
+  };
+  v4d acc[NACC];
+#pragma unroll
+  for (int c = 0; c < NACC; c++) acc[c] = v4d{0.0, 0.0, 0.0, 0.0};
+  double gacc[4] = {0.0, 0.0, 0.0, 0.0};
+  fetch(0);
+  for (uint64_t s = 0; s < nstep; s++) {
+    stage();
+    if (s + 1 < nstep) fetch(s + 1);
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      const double rv = sh.r[4 * ks + kk];
+      if constexpr (DIAG) {
+        constexpr int GB = 6 - 2 * W;
+        const double *row = &sh.Jj[(4 * ks + kk) * S];
+        double op[R + 1];
+#pragma unroll
+        for (int b = 0; b <= R; b++) op[b] = row[16 * b + cc];
+        if (with_g) {
+          gacc[0] = __builtin_fma(op[GB], rv, gacc[0]);
+          gacc[1] = __builtin_fma(op[GB + 1], rv, gacc[1]);
+        }
+#pragma unroll
+        for (int c = 0; c <= R; c++) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[R], op[c], acc[c], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c <= W; c++)
+          acc[R + 1 + c] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[W], op[c], acc[R + 1 + c], 0, 0, 0);
+      } else {
+        const double *rowj = &sh.Jj[(4 * ks + kk) * S + 64 * QJ], *rowk = &sh.Jk[(4 * ks + kk) * S + 64 * QK];
+        double opj[4], opk[4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+          opj[b] = rowj[16 * b + cc];
+          opk[b] = rowk[16 * b + cc];
+        }
+        if (with_g && QK == 0) {
+#pragma unroll
+          for (int b = 0; b < 4; b++) gacc[b] = __builtin_fma(opj[b], rv, gacc[b]);
+        }
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+          for (int b = 0; b < 4; b++)
+            acc[4 * a + b] = __builtin_amdgcn_mfma_f64_16x16x4f64(opj[a], opk[b], acc[4 * a + b], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // ---- publish the super-block (and its mirror image), and g for the columns of block bj
+  double *H = p.Hw + pid * n * n;
+  auto put_tile = [&](uint64_t rb, uint64_t cb, const v4d &tile, bool mirror) {
+#pragma unroll
+    for (int rg4 = 0; rg4 < 4; rg4++) {
+      const uint64_t row = 128 * bj + 16 * rb + kk + 4 * rg4, col = 128 * bk + 16 * cb + cc;
+      if (row < n && col < n) {
+        const double v = 2 * tile[rg4];
+        H[row * n + col] = v;
+        if (mirror) H[col * n + row] = v;
+      }
+    }
+  };
+  auto put_g = [&](double gv, uint64_t colblock) {
+    const double g0 = __shfl(gv, cc, 64), g1 = __shfl(gv, cc + 16, 64);
+    const double g2 = __shfl(gv, cc + 32, 64), g3 = __shfl(gv, cc + 48, 64);
+    const uint64_t col = 128 * bj + 16 * colblock + cc;
+    if (kk == 0 && col < n) p.gg[pid * n + col] = 2 * (((g0 + g1) + g2) + g3);
+  };
+  if constexpr (DIAG) {
+#pragma unroll
+    for (int c = 0; c <= R; c++) put_tile(R, c, acc[c], R != c);
+#pragma unroll
+    for (int c = 0; c <= W; c++) put_tile(W, c, acc[R + 1 + c], W != c);
+    if (with_g) {
+      put_g(gacc[0], 6 - 2 * W);
+      put_g(gacc[1], 7 - 2 * W);
+    }
+  } else {
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+      for (int b = 0; b < 4; b++) put_tile(4 * QJ + a, 4 * QK + b, acc[4 * a + b], true);
+    if (with_g && QK == 0) {
+#pragma unroll
+      for (int b = 0; b < 4; b++) put_g(gacc[b], 4 * QJ + b);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void lm_wide_mfma_tanh_eval_kernel(LmParams p, int first) {
+  __shared__ __align__(16) LmWideMfmaShared sh;
+  const uint64_t pid = blockIdx.x;
+  LmProblem *pr = p.prob + pid;
+  if (!first && pr->done) return;
+  const int t = threadIdx.x, lane = lane_id();
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int half = lane >> 5, lp = lane & 31;
+  const uint64_t n = p.n, m = p.m;
+  const bool vec = (n & 1) == 0;
+  const double *A = p.Aw + pid * m * n, *y = p.yw + pid * m, *th = p.theta + pid * n;
+  double *rg = p.rw + pid * 2 * m, *wg = rg + m;
+  // ---- phase 1: z_i = A_i theta (a half-wave per row: each lane's fma chain runs over its column
+  // pair of every 64-column block, then the butterfly 16 .. 1), tanh, r, weights, f. Wave w takes
+  // the sixteen-row groups s = w (mod 4): the f chain (s mod 4, row parity) then lives in one
+  // half-wave's registers, rows in order.
+  double *theta = sh.Jj;
+  for (uint64_t j = t; j < kLmWideMaxN; j += 256) theta[j] = j < n ? th[j] : 0.0;
+  __syncthreads();
+  const uint64_t nstep = (m + 15) / 16, nblk = (n + 63) / 64;
+  double fw = 0.0;
+  for (uint64_t s = w; s < nstep; s += 4) {
+    for (int k0 = 0; k0 < 8; k0 += 2) {  // two rows of the half at a time: their chains interleave
+      double z[2], yv[2];
+      bool in[2];
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        const uint64_t i = 16 * s + 2 * (k0 + q) + half;
+        in[q] = i < m;
+        const double *row = A + (in[q] ? i : 0) * n;
+        yv[q] = y[in[q] ? i : 0];
+        double acc = 0.0;
+        for (uint64_t c = 0; c < nblk; c++) {
+          const uint64_t e0 = 64 * c + 2 * static_cast<uint64_t>(lp);
+          double a0, a1;
+          if (vec) {
+            const v2d_nt u = *reinterpret_cast<const v2d_nt *>(row + (e0 < n ? e0 : 0));
+            a0 = (in[q] && e0 < n) ? u.x : 0.0;
+            a1 = (in[q] && e0 < n) ? u.y : 0.0;
+          } else {
+            a0 = (in[q] && e0 < n) ? row[e0 < n ? e0 : 0] : 0.0;
+            a1 = (in[q] && e0 + 1 < n) ? row[e0 + 1 < n ? e0 + 1 : 0] : 0.0;
+          }
+          const double2 tv = *reinterpret_cast<const double2 *>(&theta[e0]);
+          acc = c == 0 ? __builtin_fma(a1, tv.y, a0 * tv.x) : __builtin_fma(a1, tv.y, __builtin_fma(a0, tv.x, acc));
+        }
+        z[q] = acc;
+      }
+      butterfly_levels<16>([&](auto off) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) z[q] = z[q] + lane_xor<decltype(off)::value>(z[q]);
+      });
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        const uint64_t i = 16 * s + 2 * (k0 + q) + half;
+        const double tz = det_tanh(z[q]);
+        const double res = in[q] ? yv[q] - tz : 0.0;
+        if (lp == 0 && in[q]) {
+          rg[i] = res;
+          wg[i] = 1 - tz * tz;
+        }
+        fw = __builtin_fma(res, res, fw);
+      }
+    }
+  }
+  if (lp == 0) sh.part[2 * w + half] = fw;
+  __syncthreads();  // r and the weights of every row are in place; theta's space is free
+  // ---- phase 2: the super-blocks of the lower triangle
+  const uint64_t SB = (n + 127) / 128;
+  for (uint64_t bj = 0; bj < SB; bj++)
+    for (uint64_t bk = 0; bk <= bj; bk++) {
+      if (bj == bk) {
+        switch (w) {
+          case 0: lm_wide_mfma_pass<0, true>(p, pid, sh, bj, bk, vec); break;
+          case 1: lm_wide_mfma_pass<1, true>(p, pid, sh, bj, bk, vec); break;
+          case 2: lm_wide_mfma_pass<2, true>(p, pid, sh, bj, bk, vec); break;
+          default: lm_wide_mfma_pass<3, true>(p, pid, sh, bj, bk, vec); break;
+        }
+      } else {
+        switch (w) {
+          case 0: lm_wide_mfma_pass<0, false>(p, pid, sh, bj, bk, vec); break;
+          case 1: lm_wide_mfma_pass<1, false>(p, pid, sh, bj, bk, vec); break;
+          case 2: lm_wide_mfma_pass<2, false>(p, pid, sh, bj, bk, vec); break;
+          default: lm_wide_mfma_pass<3, false>(p, pid, sh, bj, bk, vec); break;
+        }
+      }
+    }
+  if (t == 0) {
+    double f = 0.0;
+    for (int k = 0; k < 8; k++) f = f + sh.part[k];
+    lm_publish_state(p, pr, first, f);
   }
 }
 

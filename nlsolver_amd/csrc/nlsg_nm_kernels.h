@@ -404,40 +404,101 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_kernel(NmParams p) {
 // the bits of nm_solve_kernel and of the oracle.
 constexpr int kNmCmdShrink = 1, kNmCmdEnd = 2;
 
+// The shrink (2009-2035) and rescoring (2288-2294) of the rows a wave owns, four at a time: rows
+// wid + nwaves q, q = 0 .. 3, then the same 4 nwaves further on. The four objectives are reduced
+// together (wave_sum4: the butterflies' own pairs, a third of their instructions — the rescoring
+// is bound by vector issue: n objective evaluations of ~60 instructions each per shrink).
+// VEC: n even — a lane's pair is 16-byte aligned in every row: one 128-bit LDS access each way
+template <int OBJ, bool VEC>
+__device__ inline void nm_shrink_rows_impl(double *S, double *scores, uint64_t n, uint64_t nv, uint64_t best,
+                                           double sigma, double fmul, int wid, uint64_t nwaves) {
+  using O = Objective<OBJ>;
+  const int lane = lane_id();
+  const uint64_t e0 = 2 * static_cast<uint64_t>(lane);
+  const bool in0 = e0 < n, in1 = e0 + 1 < n;
+  auto load_pair = [&](const double *row, double (&v)[1][2]) {
+    if constexpr (VEC) {
+      const double2 q = *reinterpret_cast<const double2 *>(row + (in0 ? e0 : 0));
+      v[0][0] = in0 ? q.x : 0.0;
+      v[0][1] = in0 ? q.y : 0.0;
+    } else {
+      nm_load_point<1>(row, n, v);
+    }
+  };
+  auto store_pair = [&](double *row, double a, double b) {
+    if constexpr (VEC) {
+      if (in0) *reinterpret_cast<double2 *>(row + e0) = make_double2(a, b);
+    } else {
+      if (in0) row[e0] = a;
+      if (in1) row[e0 + 1] = b;
+    }
+  };
+  double bv[1][2];
+  load_pair(S + best * n, bv);
+  // a tail of at most one row per wave (n = 128: row 128 of 129) is not worth a pass of four on
+  // the wave that would get it: those rows go one each to the LAST waves, scored on their own
+  const uint64_t full = nv / (4 * nwaves) * (4 * nwaves);
+  const uint64_t tail = nv - full <= nwaves ? nv - full : 0;
+  if (tail && static_cast<uint64_t>(wid) + tail >= nwaves) {
+    const uint64_t v = full + (nwaves - 1 - static_cast<uint64_t>(wid));
+    if (v != best) {
+      double *row = S + v * n;
+      double ov[1][2];
+      load_pair(row, ov);
+      double pt[1][2];
+      pt[0][0] = bv[0][0] + sigma * (ov[0][0] - bv[0][0]);
+      pt[0][1] = bv[0][1] + sigma * (ov[0][1] - bv[0][1]);
+      store_pair(row, pt[0][0], pt[0][1]);
+      if (!in0) pt[0][0] = 0.0;
+      if (!in1) pt[0][1] = 0.0;
+      const double fv = fmul * wave_objective<OBJ, 1>(pt, n);
+      if (lane == 0) scores[v] = fv;
+    }
+  }
+  const uint64_t end = tail ? full : nv;
+  for (uint64_t v0 = wid; v0 < end; v0 += 4 * nwaves) {
+    double xv[4][2];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const uint64_t v = v0 + nwaves * q;
+      const bool live = v < end && v != best;
+      double *row = S + (live ? v : best) * n;
+      double ov[1][2];
+      load_pair(row, ov);
+      xv[q][0] = bv[0][0] + sigma * (ov[0][0] - bv[0][0]);
+      xv[q][1] = bv[0][1] + sigma * (ov[0][1] - bv[0][1]);
+      if (live) store_pair(row, xv[q][0], xv[q][1]);
+      if (!in0) xv[q][0] = 0.0;
+      if (!in1) xv[q][1] = 0.0;
+    }
+    double f;
+    if constexpr (O::kWhole) {  // a whole-vector user objective reduces inside its own body
+      double fq[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const double pt[1][2] = {{xv[q][0], xv[q][1]}};
+        fq[q] = fmul * wave_objective<OBJ, 1>(pt, n);
+      }
+      const int g = lane >> 4;
+      f = g == 0 ? fq[0] : g == 1 ? fq[1] : g == 2 ? fq[2] : fq[3];
+    } else {
+      double part[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) part[q] = wave_objective_partial<OBJ>(xv[q][0], xv[q][1], n);
+      f = fmul * O::finish(wave_sum4(part[0], part[1], part[2], part[3]), n);
+    }
+    // lanes 16 q .. 16 q + 15 hold row q's value
+    const uint64_t v = v0 + nwaves * static_cast<uint64_t>(lane >> 4);
+    if ((lane & 15) == 0 && v < end && v != best) scores[v] = f;
+  }
+}
 template <int OBJ>
 __device__ inline void nm_shrink_rows(double *S, double *scores, uint64_t n, uint64_t nv, uint64_t best,
                                       double sigma, double fmul, int wid, uint64_t nwaves) {
-  constexpr int ROWS = 4;
-  const int lane = lane_id();
-  double bv[1][2];
-  nm_load_point<1>(S + best * n, n, bv);
-  for (uint64_t v0 = wid; v0 < nv; v0 += ROWS * nwaves) {
-    double xv[ROWS][1][2];
-#pragma unroll
-    for (int q = 0; q < ROWS; q++) {
-      const uint64_t v = v0 + nwaves * q;
-      const bool live = v < nv && v != best;
-      double *row = S + (live ? v : best) * n;
-      double ov[1][2];
-      nm_load_point<1>(row, n, ov);
-      const uint64_t e0 = 2 * static_cast<uint64_t>(lane);
-      const bool in0 = e0 < n, in1 = e0 + 1 < n;
-      xv[q][0][0] = bv[0][0] + sigma * (ov[0][0] - bv[0][0]);
-      xv[q][0][1] = bv[0][1] + sigma * (ov[0][1] - bv[0][1]);
-      if (live && in0) row[e0] = xv[q][0][0];
-      if (live && in1) row[e0 + 1] = xv[q][0][1];
-      if (!in0) xv[q][0][0] = 0.0;
-      if (!in1) xv[q][0][1] = 0.0;
-    }
-    double f[ROWS];
-#pragma unroll
-    for (int q = 0; q < ROWS; q++) f[q] = fmul * wave_objective<OBJ, 1>(xv[q], n);
-#pragma unroll
-    for (int q = 0; q < ROWS; q++) {
-      const uint64_t v = v0 + nwaves * q;
-      if (lane == 0 && v < nv && v != best) scores[v] = f[q];
-    }
-  }
+  if ((n & 1) == 0)
+    nm_shrink_rows_impl<OBJ, true>(S, scores, n, nv, best, sigma, fmul, wid, nwaves);
+  else
+    nm_shrink_rows_impl<OBJ, false>(S, scores, n, nv, best, sigma, fmul, wid, nwaves);
 }
 
 template <int OBJ>
@@ -451,6 +512,9 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_driver_kernel(NmParams p)
   double *centroid = scores + ((nv + 1) & ~1ull);         // (layout of nm_lds_bytes; unused vectors stay)
   double *x0 = centroid + 4 * n, *up = x0 + n, *lo = up + n;
   NmCtl *ctl = reinterpret_cast<NmCtl *>(lo + n);
+  // phase counters (measurement aid) live in LDS behind the control block: the workgroup's size
+  // caps a thread at 128 registers and the driver wave needs them all
+  unsigned long long *ph = reinterpret_cast<unsigned long long *>(ctl + 1);
   const int t = threadIdx.x;
   const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
   const int lane = lane_id();
@@ -466,11 +530,11 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_driver_kernel(NmParams p)
     ctl->eps = p.eps;
     ctl->fcalls = 0;
     ctl->iter = 0;
+    for (int k = 0; k < kNmPhases; k++) ph[k] = 0;
   }
   __syncthreads();
   uint64_t total_iter = 0;
   double final_f = 0.0;
-  unsigned long long ph[kNmPhases] = {0, 0, 0, 0, 0, 0, 0, 0};
 
   for (uint64_t run = 0; run <= p.restarts; run++) {
     // ---- simplex ctor (1910-1950) with the effective vertices of SURVEY B1
@@ -521,62 +585,89 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_driver_kernel(NmParams p)
       auto lap = [&](int k) {
         if (p.phase) {
           const unsigned long long now = __builtin_readcyclecounter();
-          ph[k] += now - tk;
+          if (lane == 0) ph[k] += now - tk;
           tk = now;
         }
       };
       auto clamp = [&](double v, double l, double u) { return v < l ? l : (u < v ? u : v); };
-      const double lo0 = p.bounded && in0 ? lo[e0] : 0.0, lo1 = p.bounded && in1 ? lo[e1] : 0.0;
-      const double up0 = p.bounded && in0 ? up[e0] : 0.0, up1 = p.bounded && in1 ? up[e1] : 0.0;
+      // (bounds are read from LDS where a bounded transform needs them: no registers held for them)
+      auto clamp2 = [&](double &a, double &b) {
+        const uint64_t i0 = in0 ? e0 : 0, i1 = in1 ? e1 : 0;
+        a = clamp(a, lo[i0], up[i0]);
+        b = clamp(b, lo[i1], up[i1]);
+      };
       auto score = [&](double a, double b) {
         const double xv[1][2] = {{in0 ? a : 0.0, in1 ? b : 0.0}};
         return p.fmul * wave_objective<OBJ, 1>(xv, n);
       };
       for (;;) {
-        // ---- std_err(scores) and the best / worst / second-worst scan (see nm_solve_kernel)
+        // ---- std_err(scores) and the best / worst / second-worst scan (the closed form of
+        // nm_solve_kernel). The extrema travel as VALUES only (one min / max per butterfly level
+        // instead of a value-and-index pair with its compound compare); the first index that holds
+        // an extremum is then read off three ballots: lane l holds indices l, l + 64, l + 128, so
+        // the lowest index is the lowest lane of the lowest round that has a holder. A NaN never
+        // equals anything and min / max skip it: NaN never wins, as in the serial scan.
+        auto first_holder = [&](double target, const double (&val)[3], uint32_t limit) -> uint32_t {
+          uint32_t found = ~0u;
+#pragma unroll
+          for (int q = 2; q >= 0; q--) {
+            const uint32_t i = static_cast<uint32_t>(lane) + 64u * q;
+            const uint64_t mask = __ballot(i < limit && val[q] == target);
+            if (mask) found = static_cast<uint32_t>(__builtin_ctzll(mask)) + 64u * q;
+          }
+          return found;
+        };
+        const uint32_t nv32 = static_cast<uint32_t>(nv);
         double acc = 0.0;
         double mnv = __builtin_inf(), mxv = -__builtin_inf();
-        uint64_t mni = ~0ull, mxi = ~0ull;
-        for (uint64_t i = lane; i < nv; i += 64) {
-          const double si = scores[i];
-          acc = acc + si;
-          argmin_combine(mnv, mni, si, i);
-          argmax_combine(mxv, mxi, si, i);
+        double sc[3] = {0.0, 0.0, 0.0};  // the lane's scores (nv <= 129: at most three)
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          const uint32_t i = static_cast<uint32_t>(lane) + 64u * q;
+          if (i < nv32) {
+            const double si = scores[i];
+            sc[q] = si;
+            acc = acc + si;
+            mnv = si < mnv ? si : mnv;
+            mxv = si > mxv ? si : mxv;
+          }
         }
         butterfly_levels<32>([&](auto off) {
           constexpr int o = decltype(off)::value;
           const double oa = lane_xor<o>(acc);
           const double omn = lane_xor<o>(mnv), omx = lane_xor<o>(mxv);
-          const uint64_t omni = lane_xor<o>(mni), omxi = lane_xor<o>(mxi);
           acc = acc + oa;
-          argmin_combine(mnv, mni, omn, omni);
-          argmax_combine(mxv, mxi, omx, omxi);
+          mnv = omn < mnv ? omn : mnv;
+          mxv = omx > mxv ? omx : mxv;
         });
         const double mean = acc / static_cast<double>(nv);
         const bool frozen = isnan(scores[0]);
-        const uint64_t worst_i = (frozen || mxi == ~0ull) ? 0 : mxi;
+        const uint32_t mni = first_holder(mnv, sc, nv32), mxi = first_holder(mxv, sc, nv32);
+        const uint32_t worst_i = (frozen || mxi == ~0u) ? 0 : mxi;
         acc = 0.0;
         double sv = -__builtin_inf();
-        uint64_t svi = ~0ull;
-        for (uint64_t i = lane; i < nv; i += 64) {
-          const double si = scores[i];
-          const double d = si - mean;
-          acc = acc + d * d;
-          if (i < worst_i) argmax_combine(sv, svi, si, i);
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          const uint32_t i = static_cast<uint32_t>(lane) + 64u * q;
+          if (i < nv32) {
+            const double d = sc[q] - mean;
+            acc = acc + d * d;
+            if (i < worst_i) sv = sc[q] > sv ? sc[q] : sv;
+          }
         }
         butterfly_levels<32>([&](auto off) {
           constexpr int o = decltype(off)::value;
           const double oa = lane_xor<o>(acc);
           const double osv = lane_xor<o>(sv);
-          const uint64_t osvi = lane_xor<o>(svi);
           acc = acc + oa;
-          argmax_combine(sv, svi, osv, osvi);
+          sv = osv > sv ? osv : sv;
         });
+        const uint32_t svi = first_holder(sv, sc, worst_i);
         const double se = sqrt(acc / static_cast<double>(nv - 1));
         prev_worst = worst;
-        best = (frozen || mni == ~0ull) ? 0 : mni;
+        best = (frozen || mni == ~0u) ? 0 : mni;
         worst = worst_i;
-        second = (svi == ~0ull) ? 0 : svi;
+        second = (svi == ~0u) ? 0 : svi;
         // the butterflies leave the same bits in every lane: make that visible to the compiler
         best = static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(best)));
         worst = static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(worst)));
@@ -594,17 +685,47 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_driver_kernel(NmParams p)
         // ---- centroid of all vertices but the worst (1965-1984), only when it can have changed:
         // per coordinate the vertices in order, two branch-free runs around the worst one
         if (prev_worst != worst || shrunk) {
-          const double *col0 = S + (in0 ? e0 : 0), *col1 = S + (in1 ? e1 : 0);
+          // the lane's two coordinates are adjacent: for an even n one 128-bit LDS read per vertex
+          // (conflict-free: the lanes' pairs tile the row), sixteen vertices in flight ahead of
+          // their additions; two branch-free runs around the worst vertex. The pair past the
+          // point's end is read and never used. 32-bit element indices.
+          const uint32_t n32 = static_cast<uint32_t>(n);
+          const uint32_t off0 = in0 ? static_cast<uint32_t>(e0) : 0u;
           double a0 = 0.0, a1 = 0.0;
-#pragma unroll 8
-          for (uint64_t v = 0; v < worst; v++) {
-            a0 += col0[v * n];
-            a1 += col1[v * n];
-          }
-#pragma unroll 8
-          for (uint64_t v = worst + 1; v < nv; v++) {
-            a0 += col0[v * n];
-            a1 += col1[v * n];
+          auto run = [&](auto vec, uint32_t lo_v, uint32_t hi_v) {
+            constexpr bool VEC = decltype(vec)::value != 0;
+            uint32_t v = lo_v, base = lo_v * n32 + off0;
+            for (; v + 16 <= hi_v; v += 16, base += 16 * n32) {
+              double q0[16], q1[16];
+#pragma unroll
+              for (int u = 0; u < 16; u++) {
+                if constexpr (VEC) {
+                  const double2 pr = *reinterpret_cast<const double2 *>(S + base + static_cast<uint32_t>(u) * n32);
+                  q0[u] = pr.x;
+                  q1[u] = pr.y;
+                } else {
+                  q0[u] = S[base + static_cast<uint32_t>(u) * n32];
+                  q1[u] = S[base + static_cast<uint32_t>(u) * n32 + 1];
+                }
+              }
+#pragma unroll
+              for (int u = 0; u < 16; u++) {
+                a0 += q0[u];
+                a1 += q1[u];
+              }
+            }
+            for (; v < hi_v; v++, base += n32) {
+              a0 += S[base];
+              a1 += S[base + 1];
+            }
+          };
+          const uint32_t w32 = static_cast<uint32_t>(worst), nv32c = static_cast<uint32_t>(nv);
+          if ((n32 & 1) == 0) {
+            run(int_c<1>{}, 0, w32);
+            run(int_c<1>{}, w32 + 1, nv32c);
+          } else {
+            run(int_c<0>{}, 0, w32);
+            run(int_c<0>{}, w32 + 1, nv32c);
           }
           c0 = a0 / static_cast<double>(nv - 1);
           c1 = a1 / static_cast<double>(nv - 1);
@@ -614,10 +735,7 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_driver_kernel(NmParams p)
         double *wrow = S + worst * n;
         const double w0 = in0 ? wrow[e0] : 0.0, w1 = in1 ? wrow[e1] : 0.0;
         double r0 = c0 + p.alpha * (c0 - w0), r1 = c1 + p.alpha * (c1 - w1);
-        if (p.bounded) {
-          r0 = clamp(r0, lo0, up0);
-          r1 = clamp(r1, lo1, up1);
-        }
+        if (p.bounded) clamp2(r0, r1);
         const double rs = score(r0, r1);
         fcalls++;
         shrunk = 0;
@@ -631,10 +749,7 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_driver_kernel(NmParams p)
           if (lane == 0) scores[worst] = rs;
         } else if (action == 1) {  // expand, 2255-2265: c + gamma (reflected - c)
           double x0e = c0 + p.gamma * (r0 - c0), x1e = c1 + p.gamma * (r1 - c1);
-          if (p.bounded) {
-            x0e = clamp(x0e, lo0, up0);
-            x1e = clamp(x1e, lo1, up1);
-          }
+          if (p.bounded) clamp2(x0e, x1e);
           const double es = score(x0e, x1e);
           fcalls++;
           const bool take_exp = es < rs;
@@ -645,10 +760,7 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_driver_kernel(NmParams p)
         } else {  // contraction, 2266-2297 (B4: the reflect transform for both kinds)
           const bool outside = rs < sw;
           double x0c = c0 + p.rho * (c0 - (outside ? r0 : w0)), x1c = c1 + p.rho * (c1 - (outside ? r1 : w1));
-          if (p.bounded) {
-            x0c = clamp(x0c, lo0, up0);
-            x1c = clamp(x1c, lo1, up1);
-          }
+          if (p.bounded) clamp2(x0c, x1c);
           const double cs = score(x0c, x1c);
           fcalls++;
           if (cs < (outside ? rs : sw)) {
@@ -667,7 +779,7 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_driver_kernel(NmParams p)
             __syncthreads();  // (B)
             fcalls += nv - 1;
             shrunk = 1;
-            ph[7] += p.phase ? 1 : 0;
+            if (p.phase && lane == 0) ph[7] += 1;
             lap(4);
           }
         }
@@ -679,7 +791,7 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_driver_kernel(NmParams p)
         ctl->eps = eps;
         ctl->cmd = kNmCmdEnd;
       }
-      ph[6] += p.phase ? iter : 0;
+      if (p.phase && lane == 0) ph[6] += iter;
       __syncthreads();  // (A) with the end request
     }
     __syncthreads();  // ctl as the driver left it, for every wave
@@ -707,7 +819,8 @@ __host__ __device__ inline int nm_chunks(uint64_t n) { return n <= 128 ? 1 : n <
 inline size_t nm_lds_bytes(uint64_t n) {
   const uint64_t nv = n + 1;
   const uint64_t rows = nm_chunks(n) == 1 ? nv * n : 0;
-  return (rows + ((nv + 1) & ~1ull) + 7 * n) * sizeof(double) + sizeof(NmCtl) + 16;
+  return (rows + ((nv + 1) & ~1ull) + 7 * n) * sizeof(double) + sizeof(NmCtl) + 16 +
+         kNmPhases * sizeof(unsigned long long);  // (the driver kernel's phase counters)
 }
 
 }  // namespace nlsg

@@ -24,10 +24,13 @@ for (mm, n, B, iters) in ((512, 128, 1024, 10), (1024, 256, 256, 6)):
     y = np.tanh(np.einsum("bmn,bn->bm", A, star))
     th0 = 0.5 * star + 0.05 * (2 * rng.random((B, n)) - 1)
     with m.LMEngine(m.TanhRegression(A, y), lam=10.0, max_iter=iters, f_delta=0.0) as eng:
-        eng.minimize(th0.copy())
-        dt, (th, st, lam) = timed(lambda: eng.minimize(th0.copy()))
-    print(f"LM tanh m={mm} n={n} batch={B}: {dt / iters * 1e3:8.3f} ms per iteration, "
-          f"{B * iters / dt:.3e} iteration-problems/s, max f {max(s.f_value for s in st):.2e}", flush=True)
+        th, st, lam = eng.minimize(th0.copy())
+        eng.time_solve(th0, 2)  # (clocks up)
+        dt = eng.time_solve(th0, 3) / 3 * 1e-3  # HIP events around the whole solve, data resident
+        ev = eng.time_eval_kernel(th0, 10) / 10
+    print(f"LM tanh m={mm} n={n} batch={B}: {dt / iters * 1e3:8.3f} ms per iteration (evaluation kernel "
+          f"{ev:.3f} ms), {B * iters / dt:.3e} iteration-problems/s, max f {max(s.f_value for s in st):.2e}",
+          flush=True)
 for (obj, n, B, iters) in (("rosenbrock", 100, 1, 2), ("rosenbrock", 100, 64, 2), ("sphere", 256, 8, 1)):
     x0 = 0.5 + 0.3 * (rng.random((B, n)) - 0.5)
     with m.lm.LMEngine(obj, batch=B, n=n, lam=1.0, max_iter=iters, f_delta=0.0) as eng:

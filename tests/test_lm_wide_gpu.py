@@ -128,12 +128,16 @@ def test_lm_wide_diagonal_shortcut_and_limits(mod, oracle):
 
 
 @pytest.mark.parametrize("m,n,batch", [(512, 128, 4), (33, 127, 2), (16, 65, 2), (100, 101, 3), (257, 112, 2),
-                                       (64, 96, 2), (1, 66, 2)])
+                                       (64, 96, 2), (1, 66, 2),
+                                       (200, 129, 2), (130, 257, 2), (96, 400, 1), (300, 256, 2), (50, 513, 1)])
 def test_lm_wide_matrix_core_kernel_bit_exact(mod, oracle, monkeypatch, m, n, batch):
-    """64 < n <= 128: the one-pass kernel with J^T J on the matrix cores (lm_wide128_tanh_eval_kernel)
-    against the order-1 oracle AND against the VALU contraction it replaces (NLSG_LM_WIDE_MFMA=0):
-    the benchmark size, odd n (scalar loads), m not a multiple of sixteen, fewer rows than a group,
-    column blocks that are entirely padding. An fp64 MFMA is a k-ordered fma chain: same bits."""
+    """n > 64 with J^T J on the matrix cores — the one-pass kernel up to 128 parameters
+    (lm_wide128_tanh_eval_kernel, with the LDS-resident step lm_wide128_step_kernel), the super-block
+    kernel beyond (lm_wide_mfma_tanh_eval_kernel: two, three and five column blocks, diagonal and
+    off-diagonal passes) — against the order-1 oracle AND against the VALU kernels they replace
+    (NLSG_LM_WIDE_MFMA=0): the benchmark size, odd n (scalar loads), m not a multiple of sixteen,
+    fewer rows than a group, column blocks that are entirely padding. An fp64 MFMA is a k-ordered
+    fma chain: same bits."""
     kw = dict(lam=10.0, max_iter=5, f_delta=0.0)
     A, y, t0 = problems(oracle, 11, batch, m, n)
     out = {}
