@@ -260,7 +260,7 @@ def ref_baseline(cmd, key, unit, sample):
             "sample": f"{sample} ({r['seconds']:.1f} s), 1 thread (library is single-threaded by design)"}
 
 
-PMC_DIRS = ("profiles/r02", "profiles/r01")  # newest first
+PMC_DIRS = ("profiles/r03", "profiles/r02", "profiles/r01")  # newest first
 
 
 def pmc_traffic(pop_local):

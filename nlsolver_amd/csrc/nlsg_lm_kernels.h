@@ -262,6 +262,8 @@ __device__ inline void lm_solve_qr(LmQrShared &qs, int n) {
   constexpr int S = kLmQrStride;
   static_assert(SPAN >= 32, "chains that share a slot must never be active together");
   const int t = threadIdx.x, lane = lane_id();
+  // (Rotating the Givens role over the workgroup's waves with the workgroup index — in case the
+  // four Givens waves of a CU's four workgroups shared a SIMD — changed nothing: 0.812 vs 0.815 ms.)
   const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
   const int last = 2 * n - 4;  // last wavefront step
   // rotation of chain j at step k: rows i-1, i with i = n-1-(k-2j); exists for 2j <= k <= j+n-2
@@ -921,7 +923,10 @@ __global__ __launch_bounds__(kLmWideThreads) void lm_wide_step_kernel(LmParams p
     return;
   }
   // cholesky (:251-269), column by column: L[i][j] = 1 / L[j][j] * (A[i][j] - sum_k<j L[i][k] L[j][k]),
-  // each sum one fma chain in k order (the diagonal's is the same chain on its own row)
+  // each sum one fma chain in k order (the diagonal's is the same chain on its own row).
+  // (A transposed second copy of L in the upper triangle, so that a thread's walk along its row
+  // is coalesced across threads, was measured SLOWER — 4.5 -> 4.9 ms at n = 256: the row walk
+  // reuses each of its cache lines for sixteen consecutive k, the column walk none.)
   double s[R];
   for (int j = 0; j < n; j++) {
     for (int k = t; k < j; k += T) piv[k] = H[static_cast<uint64_t>(j) * n + k];

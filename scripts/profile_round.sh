@@ -5,7 +5,7 @@
 # gpurun_out/prof_ROUND/. Summarised afterwards, off the box, by profiles/summarize_pmc.py into
 # profiles/ROUND/{pmc_summary,de_pmc_summary}.json; the csv / json files are copied there as they are.
 # scripts/profile_round.sh ROUND "tag tag ..." limits the run to those workloads.
-round=${1:-r02}
+round=${1:-r03}
 only=" ${2:-} "
 root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 out=$root/gpurun_out/prof_$round
@@ -35,6 +35,7 @@ run bfgs_sym --workload bfgs --bfgs-symmetric --no-cpu-baseline &&
 run lm --workload lm &&
 run lm_qr --workload lm --lm-solver qr --no-cpu-baseline &&
 run nm --workload nm && run sann --workload sann && run nmpso --workload nmpso &&
-run bfgs_fd --workload bfgs-fd && run lm_fd --workload lm-fd
+run bfgs_fd --workload bfgs-fd && run lm_fd --workload lm-fd &&
+run lm_n128 --workload lm --lm-n 128 && run tinyqr --workload tinyqr
 echo "rc=$?"
 du -sh "$out"
