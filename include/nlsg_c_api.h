@@ -324,7 +324,7 @@ typedef enum {
  * engine reproduces the reference's own runs bit for bit, the default finite-difference gradient
  * included (fin_diff divides differences of objective values by 12 eps, which turns the last bit
  * of a tree sum into 1e-8 .. 1e-6 of the result). A parity mode: a sum costs n dependent
- * additions; dim <= 256, literal update only, objectives given by their terms. */
+ * additions; literal update only, objectives given by their terms. */
 #define NLSG_BFGS_REFERENCE_ORDER 2
 
 typedef struct {

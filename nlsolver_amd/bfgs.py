@@ -39,7 +39,7 @@ class BFGSEngine:
     56 % of the memory and traffic at dim = 1024; results agree with the literal update to rounding.
     reference_order=True: every sum in index order, as the reference's sequential loops take it
     (NLSG_BFGS_REFERENCE_ORDER): the reference's own runs bit for bit, default gradient included;
-    a parity mode, dim <= 256."""
+    a parity mode (a sum costs dim dependent additions)."""
 
     def __init__(self, objective, batch, *, dim=None, max_iter=100, grad_eps=5e-3, alpha=1.0,
                  device=0, stream=None, symmetric=False, reference_order=False):

@@ -41,7 +41,7 @@ namespace {
     }                                                                                            \
   } while (0)
 
-// reference-order mode (n <= 256): the H passes with every row's dot in index order
+// reference-order mode: the H passes with every row's dot in index order
 #define BFGS_DISPATCH_SEQ(KERNEL, grid, ...)                                                          \
   do {                                                                                                \
     const dim3 g_(grid), b_(256);                                                                     \
@@ -50,6 +50,10 @@ namespace {
       case 3: hipLaunchKernelGGL((KERNEL<1, true, true>), g_, b_, 0, e->stream, __VA_ARGS__); break;  \
       case 4: hipLaunchKernelGGL((KERNEL<2, false, true>), g_, b_, 0, e->stream, __VA_ARGS__); break; \
       case 5: hipLaunchKernelGGL((KERNEL<2, true, true>), g_, b_, 0, e->stream, __VA_ARGS__); break;  \
+      case 8: hipLaunchKernelGGL((KERNEL<4, false, true>), g_, b_, 0, e->stream, __VA_ARGS__); break; \
+      case 9: hipLaunchKernelGGL((KERNEL<4, true, true>), g_, b_, 0, e->stream, __VA_ARGS__); break;  \
+      case 16: hipLaunchKernelGGL((KERNEL<8, false, true>), g_, b_, 0, e->stream, __VA_ARGS__); break; \
+      case 17: hipLaunchKernelGGL((KERNEL<8, true, true>), g_, b_, 0, e->stream, __VA_ARGS__); break;  \
       default: break;                                                                                 \
     }                                                                                                 \
   } while (0)
@@ -166,8 +170,6 @@ static int bfgs_create(const nlsg_bfgs_config *cfg, const double *diag_host, con
     return fail(NLSG_ERR_INVALID_ARG,
                 "NLSG_BFGS_REFERENCE_ORDER reproduces the reference's literal arithmetic; the symmetric "
                 "restatement is a different one");
-  if (seq && cfg->dim > 256)
-    return fail(NLSG_ERR_UNSUPPORTED, "NLSG_BFGS_REFERENCE_ORDER (a parity mode) covers dim <= 256");
   if (seq && custom && custom->chain == NLSG_CUSTOM_VECTOR)
     return fail(NLSG_ERR_UNSUPPORTED,
                 "NLSG_BFGS_REFERENCE_ORDER needs an objective given by its terms (x.sum() of a "

@@ -578,7 +578,7 @@ __device__ inline void bfgs_store_h_row(double *__restrict__ row, uint64_t D, co
 constexpr int kBfgsRowsPerWave = 8;  // rows a wave streams per launch (vector kept in regs)
 
 // t = H y (first loop of update_inverse_hessian, 3139-3142). Block = 4 waves = 32 rows.
-// SEQ: the reference-order mode (every row's dot in index order; parity mode, n <= 256)
+// SEQ: the reference-order mode (every row's dot in index order; a parity mode)
 template <int CHUNKS, bool VEC, bool SEQ = false>
 __global__ __launch_bounds__(256) void bfgs_hy_kernel(BfgsParams p, uint32_t blocks_per_problem) {
   const uint64_t pid = blockIdx.x / blocks_per_problem;

@@ -21,6 +21,7 @@ struct nlsg_lm {
   bool has_data = false;
   bool wide = false;   // n > 64: the workgroup-per-problem kernels (lm_wide_*)
   bool wide_valu = false;  // NLSG_LM_WIDE_MFMA=0: the VALU contraction at every n > 64 (A/B switch)
+  int wide128_waves = 8;   // NLSG_LM_WIDE128_WAVES=4: the four-wave form of the n <= 128 evaluation (A/B switch)
   uint64_t ldt = kLmN; // row stride of theta / gg on the device: 64, or n when wide
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   LmRtcKernels rtc;  // objective == NLSG_OBJ_CUSTOM: the kernel hiprtc built for it
@@ -109,8 +110,10 @@ void launch_wide_eval(nlsg_lm *e, int first) {
     // up to 128 parameters: one pass over A, J^T J on the matrix cores
     if (e->wide_valu)
       hipLaunchKernelGGL(lm_wide_tanh_eval_kernel, grid, dim3(kLmWideThreads), 0, e->stream, e->p, first);
-    else if (e->p.n <= 128)
+    else if (e->p.n <= 128 && e->wide128_waves == 4)
       hipLaunchKernelGGL(lm_wide128_tanh_eval_kernel, grid, dim3(256), 0, e->stream, e->p, first);
+    else if (e->p.n <= 128)
+      hipLaunchKernelGGL(lm_wide128x8_tanh_eval_kernel, grid, dim3(512), 0, e->stream, e->p, first);
     else  // super-blocks of 128 x 128, each on the matrix cores
       hipLaunchKernelGGL(lm_wide_mfma_tanh_eval_kernel, grid, dim3(256), 0, e->stream, e->p, first);
     return;
@@ -234,6 +237,8 @@ static int lm_create(const nlsg_lm_config *cfg, const nlsg_custom_objective *cus
   {
     const char *sw = std::getenv("NLSG_LM_WIDE_MFMA");
     e->wide_valu = sw && sw[0] == '0';
+    const char *ww = std::getenv("NLSG_LM_WIDE128_WAVES");
+    e->wide128_waves = ww && ww[0] == '4' ? 4 : 8;
   }
   e->ldt = wide ? cfg->n : kLmN;
   if (cfg->stream) {

@@ -1570,6 +1570,191 @@ __global__ __launch_bounds__(256, 2) void lm_wide128_tanh_eval_kernel(LmParams p
   }
 }
 
+// ---- The same kernel with EIGHT waves per problem (the default; NLSG_LM_WIDE128_WAVES=4 keeps the
+// four-wave form for the A/B). With four waves a SIMD holds two of them and each carries nine
+// MFMAs plus ~60 vector instructions of staging per k-step group; eight waves halve a wave's
+// staging (one row per half-wave and group instead of two), need ~110 registers instead of 196
+// (four waves per SIMD) and so leave the matrix pipe fewer gaps. Tiles: 36 = 4 x 5 + 4 x 4, waves
+// w and w + 4 (which share a SIMD) together nine:
+//   w0 (7,0..4)  w1 (6,0..4)  w2 (5,0..4)  w3 (4,0..4)
+//   w4 (7,5)(7,6)(7,7)(6,5)   w5 (6,6)(5,5)(3,3)(2,2)   w6 (3,0)(3,1)(3,2)(2,0)   w7 (2,1)(1,0)(1,1)(0,0)
+// g: wave w < 4 takes column block 7 - w (its long row's own operand), w5 block 3, w6 block 2, w7
+// blocks 1 and 0; f on wave 4. Same chains, same bits.
+struct LmW128Tiles {
+  int nt;         // tiles
+  int tr[5], tc[5];  // (row block, column block)
+  int nop;        // distinct operands
+  int ops[6];     // their column blocks
+  int ng;         // g column blocks (taken from the wave's operands)
+  int gb[2];
+};
+__host__ __device__ constexpr LmW128Tiles lm_w128_tiles(int w) {
+  switch (w) {
+    case 0: return {5, {7, 7, 7, 7, 7}, {0, 1, 2, 3, 4}, 6, {7, 0, 1, 2, 3, 4}, 1, {7, 0}};
+    case 1: return {5, {6, 6, 6, 6, 6}, {0, 1, 2, 3, 4}, 6, {6, 0, 1, 2, 3, 4}, 1, {6, 0}};
+    case 2: return {5, {5, 5, 5, 5, 5}, {0, 1, 2, 3, 4}, 6, {5, 0, 1, 2, 3, 4}, 1, {5, 0}};
+    case 3: return {5, {4, 4, 4, 4, 4}, {0, 1, 2, 3, 4}, 5, {4, 0, 1, 2, 3, 0}, 1, {4, 0}};
+    case 4: return {4, {7, 7, 7, 6, 0}, {5, 6, 7, 5, 0}, 3, {7, 5, 6, 0, 0, 0}, 0, {0, 0}};
+    case 5: return {4, {6, 5, 3, 2, 0}, {6, 5, 3, 2, 0}, 4, {6, 5, 3, 2, 0, 0}, 1, {3, 0}};
+    case 6: return {4, {3, 3, 3, 2, 0}, {0, 1, 2, 0, 0}, 4, {3, 0, 1, 2, 0, 0}, 1, {2, 0}};
+    default: return {4, {2, 1, 1, 0, 0}, {1, 0, 1, 0, 0}, 3, {2, 1, 0, 0, 0, 0}, 2, {1, 0}};
+  }
+}
+// the slot of column block b among the wave's operands
+__host__ __device__ constexpr int lm_w128_slot(const LmW128Tiles &t, int b) {
+  for (int i = 0; i < t.nop; i++)
+    if (t.ops[i] == b) return i;
+  return 0;
+}
+
+template <int W>
+__device__ inline void lm_wide128_run8(const LmParams &p, int first, uint64_t pid, LmWide128Shared &sh,
+                                       bool vec) {
+  constexpr LmW128Tiles T = lm_w128_tiles(W);
+  constexpr int S = kLmW128Stride;
+  LmProblem *pr = p.prob + pid;
+  const int lane = lane_id();
+  const int half = lane >> 5, lp = lane & 31, kk = lane >> 4, cc = lane & 15;
+  const uint64_t n = p.n, m = p.m;
+  const double *A = p.Aw + pid * m * n, *y = p.yw + pid * m, *th = p.theta + pid * n;
+  const uint64_t e0 = 2 * static_cast<uint64_t>(lp), e1 = e0 + 1, e2 = 64 + e0, e3 = e2 + 1;
+  const double t0 = e0 < n ? th[e0] : 0.0, t1 = e1 < n ? th[e1] : 0.0;
+  const double t2 = e2 < n ? th[e2] : 0.0, t3 = e3 < n ? th[e3] : 0.0;
+  const uint64_t nstep = (m + 15) / 16;
+  const int rr = 2 * W + half;  // the row of a group this lane's half stages
+  double a[4], yv;
+  auto fetch = [&](uint64_t s) {
+    const uint64_t i = 16 * s + rr;
+    const bool in = i < m;
+    const double *row = A + (in ? i : 0) * n;
+    if (vec) {  // n even: rows start 16-byte aligned; the matrix is read once: streamed (nt)
+      const v2d_nt u = __builtin_nontemporal_load(reinterpret_cast<const v2d_nt *>(row + (e0 < n ? e0 : 0)));
+      const v2d_nt v = __builtin_nontemporal_load(reinterpret_cast<const v2d_nt *>(row + (e2 < n ? e2 : 0)));
+      a[0] = (in && e0 < n) ? u.x : 0.0;
+      a[1] = (in && e0 < n) ? u.y : 0.0;
+      a[2] = (in && e2 < n) ? v.x : 0.0;
+      a[3] = (in && e2 < n) ? v.y : 0.0;
+    } else {
+      a[0] = (in && e0 < n) ? __builtin_nontemporal_load(row + (e0 < n ? e0 : 0)) : 0.0;
+      a[1] = (in && e1 < n) ? __builtin_nontemporal_load(row + (e1 < n ? e1 : 0)) : 0.0;
+      a[2] = (in && e2 < n) ? __builtin_nontemporal_load(row + (e2 < n ? e2 : 0)) : 0.0;
+      a[3] = (in && e3 < n) ? __builtin_nontemporal_load(row + (e3 < n ? e3 : 0)) : 0.0;
+    }
+    yv = y[in ? i : 0];
+  };
+  auto stage = [&](uint64_t s, int buf) {
+    double z = __builtin_fma(a[3], t3, __builtin_fma(a[2], t2, __builtin_fma(a[1], t1, a[0] * t0)));
+    butterfly_levels<16>([&](auto off) { z = z + lane_xor<decltype(off)::value>(z); });
+    const bool in = 16 * s + rr < m;
+    const double tz = det_tanh(z);
+    const double res = in ? yv - tz : 0.0;
+    const double wgt = 1 - tz * tz;
+    double *row = &sh.J[buf][rr * S];
+    double2 lo, hi;
+    lo.x = -(wgt * a[0]);
+    lo.y = -(wgt * a[1]);
+    hi.x = -(wgt * a[2]);
+    hi.y = -(wgt * a[3]);
+    *reinterpret_cast<double2 *>(row + e0) = lo;
+    *reinterpret_cast<double2 *>(row + e2) = hi;
+    if (lp == 0) sh.r[buf][rr] = res;
+  };
+  v4d acc[T.nt];
+#pragma unroll
+  for (int c = 0; c < T.nt; c++) acc[c] = v4d{0.0, 0.0, 0.0, 0.0};
+  double gacc[2] = {0.0, 0.0};
+  double facc[4] = {0.0, 0.0, 0.0, 0.0};
+
+  fetch(0);
+  stage(0, 0);
+  if (nstep > 1) fetch(1);
+  __syncthreads();
+  for (uint64_t s = 0; s < nstep; s++) {
+    const int buf = static_cast<int>(s & 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      const double *row = &sh.J[buf][(4 * ks + kk) * S];
+      double op[T.nop];
+#pragma unroll
+      for (int b = 0; b < T.nop; b++) op[b] = row[16 * T.ops[b] + cc];
+      if constexpr (T.ng > 0) {  // g: chain kk of column 16 b + cc takes the rows = kk (mod 4) in order
+        const double rv = sh.r[buf][4 * ks + kk];
+#pragma unroll
+        for (int q = 0; q < T.ng; q++) gacc[q] = __builtin_fma(op[lm_w128_slot(T, T.gb[q])], rv, gacc[q]);
+      }
+#pragma unroll
+      for (int c = 0; c < T.nt; c++)
+        acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[lm_w128_slot(T, T.tr[c])], op[lm_w128_slot(T, T.tc[c])],
+                                                      acc[c], 0, 0, 0);
+    }
+    if constexpr (W == 4) {  // f: chain (s mod 4, parity) takes its rows of the group in order
+      const int sm = static_cast<int>(s & 3);
+      double fw = sm == 0 ? facc[0] : sm == 1 ? facc[1] : sm == 2 ? facc[2] : facc[3];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const double rv = sh.r[buf][2 * k + half];
+        fw = __builtin_fma(rv, rv, fw);
+      }
+      facc[0] = sm == 0 ? fw : facc[0];
+      facc[1] = sm == 1 ? fw : facc[1];
+      facc[2] = sm == 2 ? fw : facc[2];
+      facc[3] = sm == 3 ? fw : facc[3];
+    }
+    if (s + 1 < nstep) {
+      stage(s + 1, buf ^ 1);
+      if (s + 2 < nstep) fetch(s + 2);
+    }
+    __syncthreads();
+  }
+  // ---- publish H = 2 J^T J (both triangles), g = 2 J^T r, f
+  double *H = p.Hw + pid * n * n;
+#pragma unroll
+  for (int c = 0; c < T.nt; c++) {
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) {
+      const uint64_t row = 16 * T.tr[c] + kk + 4 * rg, col = 16 * T.tc[c] + cc;
+      if (row < n && col < n) {
+        const double v = 2 * acc[c][rg];
+        H[row * n + col] = v;
+        if (T.tr[c] != T.tc[c]) H[col * n + row] = v;
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < T.ng; q++) {
+    const double g0 = __shfl(gacc[q], cc, 64), g1 = __shfl(gacc[q], cc + 16, 64);
+    const double g2 = __shfl(gacc[q], cc + 32, 64), g3 = __shfl(gacc[q], cc + 48, 64);
+    const uint64_t col = 16 * T.gb[q] + cc;
+    if (kk == 0 && col < n) p.gg[pid * n + col] = 2 * (((g0 + g1) + g2) + g3);
+  }
+  if constexpr (W == 4) {
+    double f = 0.0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      f = f + __shfl(facc[w], 0, 64);
+      f = f + __shfl(facc[w], 32, 64);
+    }
+    if (lane == 0) lm_publish_state(p, pr, first, f);
+  }
+}
+
+__global__ __launch_bounds__(512, 4) void lm_wide128x8_tanh_eval_kernel(LmParams p, int first) {
+  __shared__ __align__(16) LmWide128Shared sh;
+  const uint64_t pid = blockIdx.x;
+  if (!first && p.prob[pid].done) return;
+  const bool vec = (p.n & 1) == 0;
+  switch (__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6)) {
+    case 0: lm_wide128_run8<0>(p, first, pid, sh, vec); break;
+    case 1: lm_wide128_run8<1>(p, first, pid, sh, vec); break;
+    case 2: lm_wide128_run8<2>(p, first, pid, sh, vec); break;
+    case 3: lm_wide128_run8<3>(p, first, pid, sh, vec); break;
+    case 4: lm_wide128_run8<4>(p, first, pid, sh, vec); break;
+    case 5: lm_wide128_run8<5>(p, first, pid, sh, vec); break;
+    case 6: lm_wide128_run8<6>(p, first, pid, sh, vec); break;
+    default: lm_wide128_run8<7>(p, first, pid, sh, vec); break;
+  }
+}
+
 // ---- 128 < n <= 1024 on the matrix cores. H no longer fits one set of accumulators, so the rows
 // are passed over once per 128 x 128 super-block of its lower triangle (as lm_wide_tanh_eval_kernel
 // does on the VALU), after a first phase that needs them all: z = A theta, tanh, residuals r and

@@ -151,3 +151,19 @@ def test_lm_wide_matrix_core_kernel_bit_exact(mod, oracle, monkeypatch, m, n, ba
         check(st[b], ref, th[b], xr, lam[b], lam_r, (m, n, b))
     assert np.array_equal(out["0"][0], th, equal_nan=True) and np.array_equal(out["0"][2], lam, equal_nan=True)
     assert [s.f_value for s in out["0"][1]] == [s.f_value for s in st]
+
+
+def test_lm_wide_bench_configuration_sampled_parity(mod, oracle):
+    """The configuration `bench.py --workload lm --lm-n 128` times — m = 512, n = 128, 1024 problems,
+    20 iterations, lambda 10 — at its full batch: six sampled problems (first and last included)
+    equal the order-1 oracle bit for bit, every problem converges to the planted solution."""
+    m, n, batch = 512, 128, 1024
+    kw = dict(lam=10.0, max_iter=20, f_delta=0.0)
+    A, y, t0 = problems(oracle, 5, batch, m, n)
+    with mod.LMEngine(mod.TanhRegression(A, y), **kw) as eng:
+        th, st, lam = eng.minimize(t0.copy())
+    for b in (0, 1, 257, 511, 1000, batch - 1):
+        ref, xr, lam_r, _ = O.lm_solve(oracle, A[b], y[b], t0[b], order=1, **kw)
+        check(st[b], ref, th[b], xr, lam[b], lam_r, b)
+    assert all(s.iteration == 20 and s.done == 1 for s in st)
+    assert max(s.f_value for s in st) < 1e-20

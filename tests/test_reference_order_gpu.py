@@ -45,10 +45,11 @@ def test_bfgs_default_gradient_equals_the_reference_run(mod, golden, name):
 
 
 @pytest.mark.parametrize("name", ["n8", "n64", "n64_default_stop", "n100_ragged_start",
-                                  "n130_alpha_half", "n256_max_iter_5"])
+                                  "n130_alpha_half", "n256_max_iter_5", "n1024"])
 def test_bfgs_analytic_gradient_equals_the_reference_run(mod, golden, name):
     """The G6 quadratic with its analytic gradient functor (tests/golden/bfgs.json), reference
-    order: counts and the final value of the reference's run bit for bit."""
+    order: counts and the final value of the reference's run bit for bit — n = 1024, the dimension of
+    BASELINE configs[2], included (37 iterations, 158 function and gradient calls)."""
     g = golden("bfgs.json")[name]
     n = g["n"]
     d, b, c = O.quad_problem(n)
@@ -60,6 +61,10 @@ def test_bfgs_analytic_gradient_equals_the_reference_run(mod, golden, name):
         (g["iters"], g["fcalls"], g["gcalls"])
     assert st[0].f_value == hx(g["f"])
     assert x[0][:8].tolist() == [hx(v) for v in g["x_head"]]
+    h = 1469598103934665603  # FNV-1a over the bytes of the whole x, as the reference driver hashed it
+    for byte in np.ascontiguousarray(x[0]).view(np.uint8).tobytes():
+        h = ((h ^ byte) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    assert h == int(g["x_fnv"])
 
 
 @pytest.mark.parametrize("obj,n,batch", [("rosenbrock", 3, 5), ("rosenbrock", 31, 4), ("sphere", 129, 3),
@@ -80,9 +85,7 @@ def test_bfgs_reference_order_batches_equal_the_serial_oracle(mod, oracle, obj, 
 
 
 def test_bfgs_reference_order_limits(mod):
-    d, b, c = O.quad_problem(300)
-    for args, kw in (((mod.QuadDiagRank1(d, b, c), 1), {}),                    # dim > 256
-                     (("rastrigin", 1), dict(dim=4)),                          # no libm cosine on the device
+    for args, kw in ((("rastrigin", 1), dict(dim=4)),                          # no libm cosine on the device
                      (("rosenbrock", 1), dict(dim=4, symmetric=True))):        # a different arithmetic
         with pytest.raises(mod.NlsgError):
             mod.BFGSEngine(*args, reference_order=True, **kw)
