@@ -1216,6 +1216,10 @@ __global__ __launch_bounds__(kLmWideThreads) void lm_wide_tanh_eval_kernel(LmPar
 // solves the four unknowns) itself — the same arithmetic on the same inputs, hence the same bits
 // — so a panel costs two barriers (one in the substitutions), not two per column. Every sum is
 // the k-ordered fma chain of the order-1 oracle; back-substitution sums run from j = n-1 down.
+// (Four threads per row — each accumulating one column's panel sum, the sums meeting in LDS, the
+// rest replicated — was built and measured: 0.54 ms against 0.39. The replicated block factorisation
+// and substitutions then run on eight waves instead of two: more instructions in total on SIMDs
+// that two workgroups of lone waves already keep half busy. Not kept.)
 constexpr int kLmW128Tri = lm_tri_row(128);
 struct LmWide128StepShared {
   double tri[kLmW128Tri];
