@@ -934,6 +934,11 @@ def other_configs_pass():
              "BASELINE words: tinyqr::lm on J^T J + lambda I)", ["--workload", "lm", "--lm-solver", "qr"]),
             ("configs[3] Levenberg-Marquardt m=512 n=64 batch=8192, Cholesky damped solve (the "
              "reference class's own get_update_with_hessian)", ["--workload", "lm", "--lm-solver", "cholesky"]),
+            ("configs[3] past the one-wave size: Levenberg-Marquardt m=512 n=128 batch=1024 (J^T J on fp64 "
+             "MFMA in the workgroup-per-problem kernels; no BASELINE config names it)",
+             ["--workload", "lm", "--lm-n", "128"]),
+            ("configs[3]'s solver as a surface of its own: tinyqr::lm on 8192 systems of 576 x 64 (SURVEY "
+             "row a25; latency-bound, not roofline-graded)", ["--workload", "tinyqr", "--steps", "2"]),
             ("configs[4] PSO Accelerated, one GPU's shard 131072 x 256",
              ["--workload", "pso-accel", "--steps", "100", "--warmup", "300"]),
             ("configs[4] PSO Vanilla, one GPU's shard 131072 x 256",

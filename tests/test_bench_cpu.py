@@ -49,8 +49,10 @@ def test_other_configs_pass_summarises_children_and_survives_failures(monkeypatc
     assert all(e["config"].startswith("configs[") for e in out)
     # BASELINE words configs[3] with the tinyqr solve: that solver is an entry of its own, and it
     # comes before the Cholesky one
-    lm = [c for c in calls if "lm" in c]
+    lm = [c for c in calls if "lm" in c and "--lm-n" not in c]
     assert len(lm) == 2 and "qr" in lm[0] and "cholesky" in lm[1]
+    # the sizes past the one-wave kernels and the tinyqr surface are measured in the same line
+    assert any("--lm-n" in c and "128" in c for c in calls) and any("tinyqr" in c for c in calls)
     assert any("tinyqr" in e["config"] for e in out)
 
 
