@@ -101,6 +101,14 @@ typedef struct {
 /* DE::solve<minimize> (nlsolver.h:2414-2476), strategy 0 = best, 1 = random
  * (enum order of nlsolver.h:2377). `gen` is the caller's generator and is
  * advanced exactly as the reference advances it. x is in/out. */
+/* The reference's donor pick (generate_indices, nlsolver.h:2331-2355) and proposal
+ * (propose_new_agent, :2357-2375) — the code orc_de_serial runs — for ONE agent, fed with given
+ * draws; lets a test show that the synchronous restatement's donors / forced dimension / trial
+ * are what the reference's logic makes of the same draws. */
+size_t orc_de_serial_proposal_from_draws(const double *agents, size_t pop, size_t D, size_t fixed,
+                                         double CR, double F, const double *donor_draws,
+                                         size_t n_donor, const double *cross_draws, size_t *ids_out,
+                                         size_t *donor_used, double *proposal);
 orc_status orc_de_serial(int obj, int minimize, int strategy, double *x, size_t D,
                          orc_xorshift *gen, double CR, double F, double eps,
                          size_t pop, size_t max_iter, size_t best_val_no_change,

@@ -18,14 +18,27 @@ static void log_eval(orc_eval_log *log, const double *x, double f) {
   log->count++;
 }
 
+/* Where the reference's generator draws come from: the xorshift stream (orc_de_serial, pinned to
+ * the goldens) or a replayed list (orc_de_serial_proposal_from_draws: the SAME code below fed
+ * with the keyed draws of the synchronous restatement, tests/test_oracle_properties.py). */
+typedef struct {
+  orc_xorshift *g;
+  const double *replay;
+  size_t pos, n;
+} draw_src;
+static double next_draw(draw_src *d) {
+  if (d->g) return orc_xorshift_next(d->g);
+  return d->pos < d->n ? d->replay[d->pos++] : (d->pos++, 0.0);
+}
+
 /* generate_index, nlsolver.h:2325-2329: size_t(u * max). */
-static size_t gen_index(size_t max, orc_xorshift *g) {
-  return (size_t)(orc_xorshift_next(g) * (double)max);
+static size_t gen_index(size_t max, draw_src *g) {
+  return (size_t)(next_draw(g) * (double)max);
 }
 
 /* generate_indices, nlsolver.h:2331-2355: three distinct proposals != fixed by
  * rejection; the unordered_set is a membership test over <= 3 values. */
-static void gen_indices(size_t fixed, size_t max, orc_xorshift *g, size_t out[4]) {
+static void gen_indices(size_t fixed, size_t max, draw_src *g, size_t out[4]) {
   out[0] = fixed;
   size_t samples = 1;
   for (;;) {
@@ -39,6 +52,37 @@ static void gen_indices(size_t fixed, size_t max, orc_xorshift *g, size_t out[4]
   }
 }
 
+/* propose_new_agent, nlsolver.h:2357-2375: forced dimension, then per coordinate one draw
+ * (always taken: the left operand of ||) and the mutant or the base agent's coordinate */
+static size_t propose(const double *agents, const size_t ids[4], size_t D, double CR, double F,
+                      draw_src *g, double *proposal) {
+  const size_t dim = gen_index(D, g);
+  for (size_t d = 0; d < D; d++) {
+    const double u = next_draw(g);
+    if (u < CR || d == dim) {
+      proposal[d] = agents[ids[1] * D + d] + F * (agents[ids[2] * D + d] - agents[ids[3] * D + d]);
+    } else {
+      proposal[d] = agents[ids[0] * D + d];
+    }
+  }
+  return dim;
+}
+
+/* The reference's donor pick and proposal for one agent, fed with given draws instead of the
+ * xorshift stream: donor_draws (consumed until three distinct donors != fixed are found; returns
+ * how many in *donor_used), then cross_draws[0] for the forced dimension and cross_draws[1 .. D]
+ * for the coordinates. ids_out[4] = {fixed, r1, r2, r3}; returns the forced dimension. */
+size_t orc_de_serial_proposal_from_draws(const double *agents, size_t pop, size_t D, size_t fixed,
+                                         double CR, double F, const double *donor_draws,
+                                         size_t n_donor, const double *cross_draws, size_t *ids_out,
+                                         size_t *donor_used, double *proposal) {
+  draw_src dd = {NULL, donor_draws, 0, n_donor};
+  gen_indices(fixed, pop, &dd, ids_out);
+  *donor_used = dd.pos;
+  draw_src dc = {NULL, cross_draws, 0, D + 1};
+  return propose(agents, ids_out, D, CR, F, &dc, proposal);
+}
+
 orc_status orc_de_serial(int obj, int minimize, int strategy, double *x, size_t D,
                          orc_xorshift *gen, double CR, double F, double eps,
                          size_t pop, size_t max_iter, size_t best_val_no_change,
@@ -48,9 +92,10 @@ orc_status orc_de_serial(int obj, int minimize, int strategy, double *x, size_t 
   double *proposal = (double *)malloc(D * sizeof(double));
   /* init_agents / generate_sequence, nlsolver.h:2302-2323: (u - 0.5) * x0[i],
    * agent-major draw order. */
+  draw_src src = {gen, NULL, 0, 0};
   for (size_t a = 0; a < pop; a++)
     for (size_t i = 0; i < D; i++)
-      agents[a * D + i] = (orc_xorshift_next(gen) - 0.5) * x[i];
+      agents[a * D + i] = (next_draw(&src) - 0.5) * x[i];
   const double fm = minimize ? 1.0 : -1.0; /* :2418 */
   for (size_t a = 0; a < pop; a++) {       /* :2423-2425 */
     const double f = orc_objective_seq(obj, agents + a * D, D);
@@ -78,18 +123,8 @@ orc_status orc_de_serial(int obj, int minimize, int strategy, double *x, size_t 
     }
     for (size_t i = 0; i < pop; i++) { /* :2449 */
       size_t ids[4];
-      gen_indices(strategy == 1 ? i : best_id, pop, gen, ids); /* :2451-2457 */
-      /* propose_new_agent, :2357-2375 */
-      const size_t dim = gen_index(D, gen);
-      for (size_t d = 0; d < D; d++) {
-        const double u = orc_xorshift_next(gen); /* always drawn (left operand) */
-        if (u < CR || d == dim) {
-          proposal[d] = agents[ids[1] * D + d] +
-                        F * (agents[ids[2] * D + d] - agents[ids[3] * D + d]);
-        } else {
-          proposal[d] = agents[ids[0] * D + d];
-        }
-      }
+      gen_indices(strategy == 1 ? i : best_id, pop, &src, ids); /* :2451-2457 */
+      propose(agents, ids, D, CR, F, &src, proposal);           /* :2357-2375 */
       const double f = orc_objective_seq(obj, proposal, D);
       log_eval(log, proposal, f);
       const double score = fm * f; /* :2463 */

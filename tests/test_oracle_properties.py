@@ -65,3 +65,51 @@ def test_omp_variant_is_bit_identical(oracle):
     a.step(3)
     b.step(3, threads=4)
     assert np.array_equal(a.population, b.population) and np.array_equal(a.scores, b.scores)
+
+
+@pytest.mark.parametrize("strategy", [1, 0])
+@pytest.mark.parametrize("pop,D", [(64, 16), (256, 128), (37, 5)])
+def test_sync_donors_and_trials_are_the_reference_logic_on_the_same_draws(oracle, strategy, pop, D):
+    """The link between the two parity chains (device == synchronous restatement bit for bit;
+    serial restatement == the reference bit for bit): the synchronous generation's donors, forced
+    dimension and trial vector are what the REFERENCE'S OWN code path — generate_indices
+    (nlsolver.h:2331-2355) and propose_new_agent (:2357-2375) as orc_de_serial runs them, pinned to
+    the goldens — makes of the same uniform draws. The keyed draws of agent a (slots D + 1 + k:
+    donor proposals, D: forced dimension, 0 .. D - 1: crossover) are replayed into that code."""
+    import ctypes as C
+    x0 = np.full(D, 0.6) * (1.0 + 0.001 * np.arange(D))
+    run = O.DESyncRun(oracle, "rosenbrock", pop, D, x0, strategy=strategy, CR=0.2, F=0.5, eps=0.0,
+                      max_iter=1000, best_val_no_change=1000, trace=True)
+    run.step(2)                               # generation 2 has seen acceptances
+    before = run.population.copy()
+    scores_before = run.scores.copy()
+    gen = run.s.iter + 1                      # the generation about to run
+    run.step(1)
+    after, trace = run.population, run.trace
+    best_of_turn = run.s.best_id              # found by the turn's scan, before its generation (:2432-2437)
+    kg = oracle.orc_ctr_key(run.s.seed, gen)
+    sz = C.c_size_t
+    fn = oracle.orc_de_serial_proposal_from_draws
+    fn.restype = sz
+    fn.argtypes = [O.pd, sz, sz, sz, C.c_double, C.c_double, O.pd, sz, O.pd, C.POINTER(sz),
+                   C.POINTER(sz), O.pd]
+    accepted = 0
+    for a in range(pop):
+        ka = oracle.orc_ctr_key(kg, a)
+        donor = np.array([oracle.orc_u01(oracle.orc_ctr_key(ka, D + 1 + k)) for k in range(64)])
+        cross = np.array([oracle.orc_u01(oracle.orc_ctr_key(ka, D))] +
+                         [oracle.orc_u01(oracle.orc_ctr_key(ka, d)) for d in range(D)])
+        ids, used, prop = (sz * 4)(), sz(), np.zeros(D)
+        fixed = a if strategy == 1 else best_of_turn
+        dim = fn(O._ptr(before), pop, D, fixed, 0.2, 0.5, O._ptr(donor), donor.size, O._ptr(cross), ids,
+                 C.byref(used), O._ptr(prop))
+        assert used.value <= 64
+        assert [ids[1], ids[2], ids[3]] == trace[a, :3].tolist(), a
+        assert dim == trace[a, 3], a
+        if trace[a, 4]:                       # accepted: the survivor is the trial vector
+            accepted += 1
+            assert np.array_equal(after[a], prop), a
+            assert run.scores[a] < scores_before[a]
+        else:
+            assert np.array_equal(after[a], before[a]), a
+    assert accepted > 0
