@@ -152,6 +152,11 @@ void orc_de_sync_step_omp(orc_de_sync *s, int threads);
 /* -------------------------------------------------------------------- PSO --- */
 /* PSO::solve and helpers (nlsolver.h:2479-2742), literal (incl. the sentinels B8,
  * the best_index rule B9 and, for Vanilla, B7). type 0 = Vanilla, 1 = Accelerated. */
+/* update_positions (Accelerated, nlsolver.h:2687-2699) + threshold_positions (2701-2715) of one
+ * particle from given normal variates: the code both PSO restatements share. */
+void orc_pso_accel_move_from_normals(double *pos, const double *normals, const double *gbest,
+                                     const double *lower, const double *upper, size_t D,
+                                     double inertia, double cog, double soc, int bounded);
 orc_status orc_pso_serial(int obj, int minimize, int type, int bounded, double *x, size_t D,
                           const double *lower, const double *upper, orc_xorshift *gen,
                           double inertia, double cog, double soc, size_t n, size_t max_iter,

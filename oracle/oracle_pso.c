@@ -26,6 +26,29 @@ static double rnorm_serial(orc_xorshift *g) {
   return sqrt(-2 * log(u1)) * cos(2 * pi_ * u2);
 }
 
+/* update_positions, Accelerated (nlsolver.h:2687-2699), and threshold_positions (2701-2715) for one
+ * coordinate: the ONE piece of code both the serial restatement (pinned to the reference's runs)
+ * and the synchronous one (what the GPU executes) run; they differ in where `normal` comes from. */
+static double apso_position(double inertia, double normal, double cog, double pos, double soc,
+                            double gbest_j) {
+  return inertia * normal + (1 - cog) * pos + soc * gbest_j;
+}
+static double clamp_position(double p, double lower, double upper) {
+  p = p < lower ? lower : p;
+  p = p > upper ? upper : p;
+  return p;
+}
+/* the same for a whole particle, as a probe for tests */
+void orc_pso_accel_move_from_normals(double *pos, const double *normals, const double *gbest,
+                                     const double *lower, const double *upper, size_t D,
+                                     double inertia, double cog, double soc, int bounded) {
+  for (size_t j = 0; j < D; j++) {
+    double p = apso_position(inertia, normals[j], cog, pos[j], soc, gbest[j]);
+    if (bounded) p = clamp_position(p, lower[j], upper[j]);
+    pos[j] = p;
+  }
+}
+
 /* PSO::solve (nlsolver.h:2593-2624) with init_solver_state (2626-2657),
  * update_velocities (2658-2677, literal incl. B7), update_positions (2678-2700),
  * threshold_positions (2701-2715), update_best_positions (2716-2741).
@@ -110,16 +133,11 @@ orc_status orc_pso_serial(int obj, int minimize, int type, int bounded, double *
       inertia = pow(init_inertia, (double)iter); /* :2613 */
       for (size_t i = 0; i < n; i++)
         for (size_t j = 0; j < D; j++) /* :2687-2699 */
-          pos[i * D + j] = inertia * rnorm_serial(gen) + (1 - cog) * pos[i * D + j] + soc * gbest[j];
+          pos[i * D + j] = apso_position(inertia, rnorm_serial(gen), cog, pos[i * D + j], soc, gbest[j]);
     }
     if (bounded) { /* :2701-2715 */
       for (size_t i = 0; i < n; i++)
-        for (size_t j = 0; j < D; j++) {
-          double p = pos[i * D + j];
-          p = p < lower[j] ? lower[j] : p;
-          p = p > upper[j] ? upper[j] : p;
-          pos[i * D + j] = p;
-        }
+        for (size_t j = 0; j < D; j++) pos[i * D + j] = clamp_position(pos[i * D + j], lower[j], upper[j]);
     }
     iter++;
   }
@@ -247,7 +265,7 @@ static void pso_particle(orc_pso_sync *s, uint64_t kg, size_t i) {
   for (size_t j = 0; j < D; j++) {
     double p;
     if (s->type == 1) { /* Accelerated, :2687-2699 */
-      p = s->inertia * rnorm_ctr(kp, j) + (1 - s->cog) * row[j] + s->soc * s->gbest_x[j];
+      p = apso_position(s->inertia, rnorm_ctr(kp, j), s->cog, row[j], s->soc, s->gbest_x[j]);
     } else { /* Vanilla with the intended update (B7 repaired): pbest[j]-pos, gbest[j]-pos */
       const double r_p = orc_u01(orc_ctr_key(kp, 2 * j)), r_g = orc_u01(orc_ctr_key(kp, 2 * j + 1));
       double *v = s->vel + i * D + j;
@@ -255,10 +273,7 @@ static void pso_particle(orc_pso_sync *s, uint64_t kg, size_t i) {
            s->soc * r_g * (s->gbest_x[j] - row[j]);
       p = row[j] + *v; /* :2683 */
     }
-    if (s->bounded) { /* :2701-2715 */
-      p = p < s->lower[j] ? s->lower[j] : p;
-      p = p > s->upper[j] ? s->upper[j] : p;
-    }
+    if (s->bounded) p = clamp_position(p, s->lower[j], s->upper[j]); /* :2701-2715 */
     row[j] = p;
   }
   const double fm = s->minimize ? 1.0 : -1.0;

@@ -113,3 +113,33 @@ def test_sync_donors_and_trials_are_the_reference_logic_on_the_same_draws(oracle
         else:
             assert np.array_equal(after[a], before[a]), a
     assert accepted > 0
+
+
+@pytest.mark.parametrize("bounded", [False, True])
+def test_sync_pso_move_is_the_reference_update_on_the_same_normals(oracle, bounded):
+    """Accelerated PSO: a particle's new position in the synchronous restatement (what the GPU
+    executes) is the reference's update_positions + threshold_positions (nlsolver.h:2687-2715) — the
+    code the serial restatement, pinned to the reference's runs, executes — applied to the same
+    normal variates; the two restatements differ only in where the variates come from (one keyed
+    64-bit draw each instead of two xorshift draws)."""
+    import ctypes as C
+    n, D = 48, 24
+    kw = dict(type=O.PSO_ACCELERATED, bounded=bounded, eps=0.0, max_iter=1000, best_val_no_change=1000)
+    run = O.PSOSyncRun(oracle, "rosenbrock", n, D, -1.5, 2.0, **kw)
+    run.step(3)
+    before = run.pos.copy()
+    it = run.s.iter
+    run.step(1)
+    gbest = run.gbest_x.copy()  # as the move of this turn saw it (the head ran first)
+    kg = oracle.orc_ctr_key(run.s.seed, it + 1)
+    fn = oracle.orc_pso_accel_move_from_normals
+    fn.restype = None
+    fn.argtypes = [O.pd, O.pd, O.pd, O.pd, O.pd, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_int]
+    import math
+    for i in range(n):
+        kp = oracle.orc_ctr_key(kg, i)
+        normals = np.array([oracle.orc_rnorm(oracle.orc_ctr_key(kp, 2 * j)) for j in range(D)])
+        p = before[i].copy()
+        fn(O._ptr(p), O._ptr(normals), O._ptr(gbest), O._ptr(run.lower), O._ptr(run.upper), D,
+           math.pow(0.8, it), 1.8, 1.8, int(bounded))
+        assert np.array_equal(p, run.pos[i]), i  # inertia = pow(init_inertia, iter), :2613
