@@ -22,6 +22,7 @@ struct nlsg_lm {
   bool wide = false;   // n > 64: the workgroup-per-problem kernels (lm_wide_*)
   bool wide_valu = false;  // NLSG_LM_WIDE_MFMA=0: the VALU contraction at every n > 64 (A/B switch)
   int wide128_waves = 8;   // NLSG_LM_WIDE128_WAVES=4: the four-wave form of the n <= 128 evaluation (A/B switch)
+  bool wide_chol = true;   // NLSG_LM_WIDE_CHOL=0: the column-by-column step at n > 128 (A/B switch)
   uint64_t ldt = kLmN; // row stride of theta / gg on the device: 64, or n when wide
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   LmRtcKernels rtc;  // objective == NLSG_OBJ_CUSTOM: the kernel hiprtc built for it
@@ -101,6 +102,18 @@ void launch_wide_fd(nlsg_lm *e, dim3 grid, int first) {
     default: hipLaunchKernelGGL((lm_wide_fd_eval_kernel<OBJ, 8>), grid, dim3(lm_wide_fd_threads(8)), 0, e->stream, e->p, first); break;
   }
 }
+template <bool EVEN>
+void launch_wide_chol_step_t(nlsg_lm *e, dim3 grid) {
+  switch (lm_wchol_threads(e->p.n)) {
+    case 256: hipLaunchKernelGGL((lm_wide_chol_step_kernel<256, EVEN>), grid, dim3(256), lm_wchol_lds_bytes(256), e->stream, e->p); break;
+    case 512: hipLaunchKernelGGL((lm_wide_chol_step_kernel<512, EVEN>), grid, dim3(512), lm_wchol_lds_bytes(512), e->stream, e->p); break;
+    default: hipLaunchKernelGGL((lm_wide_chol_step_kernel<1024, EVEN>), grid, dim3(1024), lm_wchol_lds_bytes(1024), e->stream, e->p); break;
+  }
+}
+void launch_wide_chol_step(nlsg_lm *e, dim3 grid) {
+  if (e->p.n & 1) launch_wide_chol_step_t<false>(e, grid);
+  else launch_wide_chol_step_t<true>(e, grid);
+}
 void launch_wide_eval(nlsg_lm *e, int first) {
   // finite-difference model: enough workgroups per problem to fill the device when the batch is small
   const unsigned split = e->p.fd ? static_cast<unsigned>(std::min<uint64_t>(
@@ -151,6 +164,8 @@ int launch_solve(nlsg_lm *e) {
         if (e->p.n <= 128 && !e->wide_valu)  // the damped matrix fits LDS: one thread per row
           hipLaunchKernelGGL(lm_wide128_step_kernel, grid, dim3(128), sizeof(LmWide128StepShared),
                              e->stream, e->p);
+        else if (e->wide_chol && !e->wide_valu)  // blocked, the panel sums on the matrix cores
+          launch_wide_chol_step(e, grid);
         else
           hipLaunchKernelGGL(lm_wide_step_kernel, grid, dim3(kLmWideThreads), 0, e->stream, e->p);
         launch_wide_eval(e, 0);
@@ -239,6 +254,8 @@ static int lm_create(const nlsg_lm_config *cfg, const nlsg_custom_objective *cus
     e->wide_valu = sw && sw[0] == '0';
     const char *ww = std::getenv("NLSG_LM_WIDE128_WAVES");
     e->wide128_waves = ww && ww[0] == '4' ? 4 : 8;
+    const char *wc = std::getenv("NLSG_LM_WIDE_CHOL");
+    e->wide_chol = !(wc && wc[0] == '0');
   }
   e->ldt = wide ? cfg->n : kLmN;
   if (cfg->stream) {
@@ -284,6 +301,15 @@ static int lm_create(const nlsg_lm_config *cfg, const nlsg_custom_objective *cus
   if (he == hipSuccess)
     he = hipFuncSetAttribute(reinterpret_cast<const void *>(lm_wide128_step_kernel),
                              hipFuncAttributeMaxDynamicSharedMemorySize, sizeof(LmWide128StepShared));
+  for (int ev = 0; ev < 2 && he == hipSuccess; ev++) {  // 139 KB at 1024 threads, 70 KB at 512
+    he = hipFuncSetAttribute(ev ? reinterpret_cast<const void *>(lm_wide_chol_step_kernel<1024, true>)
+                                : reinterpret_cast<const void *>(lm_wide_chol_step_kernel<1024, false>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, lm_wchol_lds_bytes(1024));
+    if (he == hipSuccess)
+      he = hipFuncSetAttribute(ev ? reinterpret_cast<const void *>(lm_wide_chol_step_kernel<512, true>)
+                                  : reinterpret_cast<const void *>(lm_wide_chol_step_kernel<512, false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, lm_wchol_lds_bytes(512));
+  }
   if (he != hipSuccess) {
     nlsg_lm_destroy(e);
     return fail(he == hipErrorOutOfMemory ? NLSG_ERR_OOM : NLSG_ERR_HIP,

@@ -994,6 +994,296 @@ __global__ __launch_bounds__(kLmWideThreads) void lm_wide_step_kernel(LmParams p
   for (int i = t; i < n; i += T) th[i] = th[i] - piv[i];  // :3534
 }
 
+// ---- The step for 128 < n <= 1024 as a BLOCKED left-looking Cholesky with the panel sums on the
+// matrix cores. Element (i, j) of the factor is 1 / L_jj (A_ij - sum_{k<j} L_ik L_jk) with the sum
+// one k-ordered fma chain starting at zero (cholesky, :251-269, order 1 of the oracle) — which is
+// what v_mfma_f64_16x16x4_f64 computes for a 16 x 16 tile of (i, j) at once when it is fed
+// k = 0, 1, 2, ... in order. So, per panel J of sixteen columns:
+//   P1  S_IJ = L[I rows][0 .. 16J) L[J rows][0 .. 16J)^T for every row block I >= J, one tile per
+//       wave at a time (4J MFMAs each), into LDS; wave 0 takes the diagonal tile and then factors
+//       the 16 x 16 diagonal block (a lane per row, the other rows' entries by v_readlane) while
+//       the other waves are on the matrix cores; it publishes the block and the 1 / L_jj;
+//   P2  thread t = row t below the block continues its sixteen chains through the panel's own
+//       columns (k = 16J .. 16J + c - 1, from the published block) and writes its sixteen entries.
+// Two barriers per panel (32 at n = 256) where lm_wide_step_kernel has three per column (768), and
+// the n^3 / 3 flops run at MFMA rate instead of from uncoalesced row walks.
+// L overwrites the lower triangle of H in a PERMUTED layout: inside every full 16-column block,
+// column c sits at position 4 (c mod 4) + c / 4, so that the four values a lane feeds to four
+// consecutive MFMAs (k = g, g + 4, g + 8, g + 12 for lane group g) are 32 contiguous bytes and a
+// tile's operand load touches sixteen full cache lines. H is scratch of the iteration (the next
+// evaluation rewrites it), so the layout never leaves this kernel.
+// The substitutions are blocked the same way: the wave that owns a block's rows solves its
+// sixteen unknowns in sequence (lane broadcasts), publishes them, and after ONE barrier every
+// thread extends its running sum by the sixteen products, in the order-1 oracle's order (forward
+// sums grow with j, backward sums run from j = n-1 down).
+__host__ __device__ constexpr int lm_wchol_threads(uint64_t n) { return n <= 256 ? 256 : n <= 512 ? 512 : 1024; }
+__host__ __device__ constexpr size_t lm_wchol_lds_bytes(int threads) {
+  return (static_cast<size_t>(threads) * 17 + 16 * 16 + 16 + 2 * 16) * sizeof(double);
+}
+__device__ inline int lm_wchol_pos(int c) { return ((c & 3) << 2) | (c >> 2); }
+
+#ifdef NLSG_WCHOL_PROFILE
+#define WCHOL_T(k) do { const long long now_ = __builtin_readcyclecounter(); prof_[k] += now_ - last_; last_ = now_; } while (0)
+#else
+#define WCHOL_T(k) do { } while (0)
+#endif
+template <int THREADS, bool EVEN>  // EVEN: n is even, rows start on 16-byte boundaries (128-bit loads)
+__global__ __launch_bounds__(THREADS, 4) void lm_wide_chol_step_kernel(LmParams p) {
+#ifdef NLSG_WCHOL_PROFILE
+  long long prof_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_readcyclecounter();
+#endif
+  extern __shared__ __align__(16) double lm_wchol_smem[];
+  constexpr int W = THREADS / 64;
+  double *S = lm_wchol_smem;                  // [THREADS][17]: the panel sums, row t for thread t
+  double *ld = S + THREADS * 17;              // [16][16]: the factored diagonal block
+  double *rinv = ld + 256;                    // [16]: 1 / L_jj
+  double *xbuf = rinv + 16;                   // [2][16]: a block's unknowns in the substitutions
+  const uint64_t pid = blockIdx.x;
+  LmProblem *pr = p.prob + pid;
+  if (pr->done) return;
+  const int t = threadIdx.x, lane = t & 63, n = static_cast<int>(p.n);
+  const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+  const double prev = pr->prev, cur = pr->f;
+  if (pr->iter >= p.max_iter || fabs(prev - cur) < p.f_delta || isnan(prev)) {  // :3520-3527
+    __syncthreads();  // every thread has read `done` before it flips
+    if (t == 0) pr->done = 1;
+    return;
+  }
+  double *H = p.Hw + pid * p.n * p.n;
+  const double *g = p.gg + pid * p.n;
+  double *th = p.theta + pid * p.n;
+  const double lambda = pr->lambda;
+  const int tr = t < n ? t : n - 1;  // threads past n alias the last row for their (unused) reads
+  for (int i = t; i < n; i += THREADS) H[static_cast<uint64_t>(i) * n + i] += lambda;  // :3529-3531
+#pragma unroll
+  for (int c = 0; c < 16; c++) S[t * 17 + c] = 0.0;  // the first panel's sums
+  __syncthreads();
+  bool off = false;  // is_diagonal (:295-307); column t of eight rows in flight
+  for (int i0 = 0; i0 < n; i0 += 8) {
+    double v[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) v[q] = H[static_cast<uint64_t>(i0 + q < n ? i0 + q : n - 1) * n + tr];
+#pragma unroll
+    for (int q = 0; q < 8; q++) off |= (i0 + q != t) && (i0 + q < n) && (t < n) && v[q] > 2.220446049250313e-16 * 1e12;
+  }
+  if (!__syncthreads_or(off)) {  // :310-318
+    if (t < n) th[t] = th[t] - g[t] / H[static_cast<uint64_t>(t) * n + t];
+    return;
+  }
+  const int NB = (n + 15) >> 4;
+  WCHOL_T(0);
+  auto load4 = [&](const double *src, double (&v)[4]) {
+    if constexpr (EVEN) {
+      const double2 a = *reinterpret_cast<const double2 *>(src), b = *reinterpret_cast<const double2 *>(src + 2);
+      v[0] = a.x, v[1] = a.y, v[2] = b.x, v[3] = b.y;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; q++) v[q] = src[q];
+    }
+  };
+  const int cc = lane & 15, kk = lane >> 4;
+  double *Hrow = H + static_cast<uint64_t>(tr) * n;
+  // ---- cholesky (:251-269)
+  for (int J = 0; J < NB; J++) {
+    const int j0 = 16 * J, nc = n - j0 < 16 ? n - j0 : 16;
+    const bool full = nc == 16;
+    if (J > 0) {
+      // P1: wave 0 the diagonal tile, waves 1 .. W-1 the tiles below it
+      const double *pb = H + static_cast<uint64_t>(j0 + cc < n ? j0 + cc : n - 1) * n + 4 * kk;
+      for (int I = wid == 0 ? J : J + wid; I < NB; I += wid == 0 ? NB : W - 1) {
+        const int ra = 16 * I + cc;
+        const double *pa = H + static_cast<uint64_t>(ra < n ? ra : n - 1) * n + 4 * kk;
+        v4d acc = {0.0, 0.0, 0.0, 0.0};
+        // four column blocks per batch of loads (the entries come from HBM or the far cache: the
+        // other waves of the SIMD cover the wait)
+        int kb = 0;
+        for (; kb + 4 <= J; kb += 4) {
+          double a[4][4], b[4][4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            load4(pa + 16 * (kb + u), a[u]);
+            load4(pb + 16 * (kb + u), b[u]);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][s], b[u][s], acc, 0, 0, 0);
+        }
+        if (kb < J) {
+          double a[3][4], b[3][4];
+#pragma unroll
+          for (int u = 0; u < 3; u++) {
+            const int k2 = kb + u < J ? kb + u : J - 1;
+            load4(pa + 16 * k2, a[u]);
+            load4(pb + 16 * k2, b[u]);
+          }
+#pragma unroll
+          for (int u = 0; u < 3; u++)
+            if (kb + u < J) {
+#pragma unroll
+              for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][s], b[u][s], acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) S[(16 * I + kk + 4 * rg) * 17 + cc] = acc[rg];
+      }
+    }
+    WCHOL_T(1);
+    if (wid == 0) {
+      // the diagonal block: lane a = row j0 + a; L[c][e] of another row comes from lane c
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const int a = lane < nc ? lane : nc - 1;
+      const double *hr = H + static_cast<uint64_t>(j0 + a) * n + j0;
+      // column by column; a finished column extends the sums of all later ones at once (each sum
+      // still grows in k order), so only the square root and the reciprocal are a serial chain
+      double mine[16], sv[16], hv[16];
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+        hv[c] = hr[c < nc ? c : 0];
+        sv[c] = S[(j0 + a) * 17 + c];
+      }
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+        if (c < nc) {  // uniform
+          const double x = hv[c] - sv[c];
+          const double d = sqrt(lane_broadcast(x, c));
+          const double ri = 1.0 / d;
+          mine[c] = lane == c ? d : (ri * x);
+          if (lane == 0) rinv[c] = ri;
+#pragma unroll
+          for (int e = c + 1; e < 16; e++) sv[e] = __builtin_fma(mine[c], lane_broadcast(mine[c], e), sv[e]);
+        }
+      }
+      if (lane < nc) {
+        double *wr = H + static_cast<uint64_t>(j0 + lane) * n + j0;
+#pragma unroll
+        for (int c = 0; c < 16; c++)
+          if (c <= lane) {
+            ld[lane * 16 + c] = mine[c];
+            wr[full ? lm_wchol_pos(c) : c] = mine[c];
+          }
+      }
+    }
+    WCHOL_T(2);
+    __syncthreads();
+    WCHOL_T(3);
+    // P2: the rows below the block (then the block is full)
+    if (t >= j0 + 16 && t < n) {
+      double h[16], mine[16];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        double v[4];
+        load4(Hrow + j0 + 4 * q, v);
+#pragma unroll
+        for (int e = 0; e < 4; e++) h[4 * q + e] = v[e];
+      }
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+        double sv = S[t * 17 + c];
+#pragma unroll
+        for (int e = 0; e < c; e++) sv = __builtin_fma(mine[e], ld[c * 16 + e], sv);
+        mine[c] = (rinv[c] * (h[c] - sv));
+        __builtin_amdgcn_sched_barrier(0);  // (keeps the 136 block entries from being loaded up front)
+      }
+      // position 4 g + s holds column 4 s + g
+#pragma unroll
+      for (int gq = 0; gq < 4; gq++) {
+        if constexpr (EVEN) {
+          *reinterpret_cast<double2 *>(Hrow + j0 + 4 * gq) = make_double2(mine[gq], mine[4 + gq]);
+          *reinterpret_cast<double2 *>(Hrow + j0 + 4 * gq + 2) = make_double2(mine[8 + gq], mine[12 + gq]);
+        } else {
+#pragma unroll
+          for (int s = 0; s < 4; s++) Hrow[j0 + 4 * gq + s] = mine[4 * s + gq];
+        }
+      }
+    }
+    WCHOL_T(4);
+    __syncthreads();
+    WCHOL_T(5);
+  }
+  // position of column j in its row
+  auto col = [&](int j) { return (j | 15) < n ? (j & ~15) + lm_wchol_pos(j & 15) : j; };
+  // ---- forwardsolve_inplace (:282-294)
+  double sum = 0.0, own = 0.0;  // own: u_t, then the step's component t
+  const double gt = g[tr];
+  for (int J = 0; J < NB; J++) {
+    const int j0 = 16 * J, nc = n - j0 < 16 ? n - j0 : 16;
+    double *xb = xbuf + 16 * (J & 1);
+    double lrow[16];  // the thread's entries in this block's columns
+#pragma unroll
+    for (int c = 0; c < 16; c++) lrow[c] = (c < nc && t >= j0) ? Hrow[col(j0 + c)] : 1.0;
+    if (wid == (j0 >> 6)) {  // the wave that holds the block's rows: lanes b .. b + 15
+      const int b = j0 & 63;
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+        if (c < nc) {
+          // lane b + c: its sum is complete
+          const double uc = lane_broadcast((gt - sum) / lrow[c], b + c);
+          if (lane == b + c) own = uc;
+          if (lane > b + c && lane < b + 16) sum = __builtin_fma(lrow[c], uc, sum);
+          if (lane == 0) xb[c] = uc;
+        }
+      }
+    }
+    __syncthreads();  // (the next block's unknowns go to the other buffer)
+    if (t >= j0 + 16 && t < n) {
+#pragma unroll
+      for (int c = 0; c < 16; c++) sum = __builtin_fma(lrow[c], xb[c], sum);
+    }
+  }
+  WCHOL_T(6);
+  // ---- backsolve_inplace_t (:270-281), the inner sums taken from j = n-1 down to i+1
+  sum = 0.0;
+  const double ut = own;
+  for (int J = NB - 1; J >= 0; J--) {
+    const int j0 = 16 * J, nc = n - j0 < 16 ? n - j0 : 16;
+    double *xb = xbuf + 16 * (J & 1);
+    if (wid == (j0 >> 6)) {
+      const int b = j0 & 63;
+      const int a = lane - b;  // column inside the block for lanes b .. b + 15
+      const bool in = a >= 0 && a < nc;
+      // L[j0 + c][j0 + a]: row j0 + c across the lanes (one cache line)
+      double lc[16];
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+        const int c2 = c < nc ? c : nc - 1;
+        lc[c] = in ? H[static_cast<uint64_t>(j0 + c2) * n + col(j0 + (a <= c2 ? a : c2))] : 1.0;
+      }
+#pragma unroll
+      for (int c = 15; c >= 0; c--) {
+        if (c < nc) {
+          const double lca = lc[c];
+          const double xc = lane_broadcast((ut - sum) / lca, b + c);  // lane b + c divides by L_cc
+          if (a == c) own = xc;
+          if (in && a < c) sum = __builtin_fma(lca, xc, sum);
+          if (lane == 0) xb[c] = xc;
+        }
+      }
+    }
+    double lt[16];  // column t of the block's rows, requested before the wait
+    if (t < j0) {   // (t < n)
+      const int ct = col(t);
+#pragma unroll
+      for (int c = 0; c < 16; c++) lt[c] = H[static_cast<uint64_t>(j0 + (c < nc ? c : nc - 1)) * n + ct];
+    }
+    __syncthreads();
+    if (t < j0) {
+#pragma unroll
+      for (int c = 15; c >= 0; c--)
+        if (c < nc) sum = __builtin_fma(lt[c], xb[c], sum);
+    }
+  }
+  if (t < n) th[t] = th[t] - own;  // :3534
+  WCHOL_T(7);
+#ifdef NLSG_WCHOL_PROFILE
+  if (pid == 5 && lane == 0 && (wid == 0 || wid == 1 || wid == W - 1))
+    printf("wchol wave %d: setup %lld | P1 %lld diag %lld wait %lld P2 %lld wait %lld | fwd %lld bwd %lld\n", wid,
+           prof_[0], prof_[1], prof_[2], prof_[3], prof_[4], prof_[5], prof_[6], prof_[7]);
+#endif
+}
+#undef WCHOL_T
+
 // The default functors (fin_diff, fin_diff_h; see lm_fd_eval_groups above) for n > 64: sixteen
 // (n > 512: eight) waves per problem, a probe point per wave (CHUNKS x 128 coordinates in registers), gradient
 // coordinates and Hessian entries dealt to the waves round robin. Every probe is a full
