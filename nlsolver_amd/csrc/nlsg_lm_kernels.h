@@ -2219,7 +2219,7 @@ __device__ __attribute__((noinline)) void lm_wide_mfma_pass(const LmParams &p, u
   }
 }
 
-__global__ __launch_bounds__(256) void lm_wide_mfma_tanh_eval_kernel(LmParams p, int first) {
+__global__ __launch_bounds__(256, 2) void lm_wide_mfma_tanh_eval_kernel(LmParams p, int first) {
   __shared__ __align__(16) LmWideMfmaShared sh;
   const uint64_t pid = blockIdx.x;
   LmProblem *pr = p.prob + pid;
