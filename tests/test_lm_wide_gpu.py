@@ -135,8 +135,9 @@ def test_lm_wide_matrix_core_kernel_bit_exact(mod, oracle, monkeypatch, m, n, ba
     """n > 64 with J^T J on the matrix cores — the one-pass kernel up to 128 parameters
     (lm_wide128_tanh_eval_kernel, with the LDS-resident step lm_wide128_step_kernel), the super-block
     kernel beyond (lm_wide_mfma_tanh_eval_kernel: two, three and five column blocks, diagonal and
-    off-diagonal passes) — against the order-1 oracle AND against the VALU kernels they replace
-    (NLSG_LM_WIDE_MFMA=0): the benchmark size, odd n (scalar loads), m not a multiple of sixteen,
+    off-diagonal passes), with the blocked matrix-core Cholesky step lm_wide_chol_step_kernel (256, 512
+    and 1024 threads, odd n, a last block of one column, n = 1024) — against the order-1 oracle AND
+    against the VALU kernels and the column-wise step they replace (NLSG_LM_WIDE_MFMA=0): the benchmark size, odd n (scalar loads), m not a multiple of sixteen,
     fewer rows than a group, column blocks that are entirely padding. An fp64 MFMA is a k-ordered
     fma chain: same bits."""
     kw = dict(lam=10.0, max_iter=5, f_delta=0.0)
