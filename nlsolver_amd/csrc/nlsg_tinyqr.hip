@@ -14,6 +14,8 @@ int check_shape(uint64_t batch, uint64_t n, uint64_t p) {
     return fail(NLSG_ERR_INVALID_ARG, "n = %llu rows < p = %llu columns: tinyqr::lm needs n >= p",
                 (unsigned long long)n, (unsigned long long)p);
   if (batch > 0x7fffffffull) return fail(NLSG_ERR_UNSUPPORTED, "batch too large for one launch grid");
+  if (n >= (1ull << 30))  // the kernel counts steps (n + p - 2 of them) in 32 bits
+    return fail(NLSG_ERR_UNSUPPORTED, "n = %llu rows is past the device path's 2^30", (unsigned long long)n);
   return NLSG_OK;
 }
 

@@ -27,8 +27,12 @@
 //    applied to the entries that are read.
 // One workgroup per system. Wave 0 computes the step's Givens pairs (one chain per lane) while
 // waves 1 and 2 move the entering row; then all waves apply the rotations (chain j on wave
-// j mod W, one column per lane). Two barriers per step; latency-bound (the Givens pair is ~45
-// dependent fp64 instructions), not roofline-graded.
+// j mod W — one chain per (wave, slot) for the whole run —, one column per lane). A chain's
+// rotation at step k+1 reads the row its rotation at step k wrote as `lower'`, and nothing else
+// reads that row's columns right of the pivot in between, so the wave keeps it in a register
+// (`carry`): per rotation one row read, one written. Lanes without a column work on a padding
+// column (index p + 1) instead of being masked off. Two barriers per step; bound by instruction
+// issue and the Givens pair's ~45 dependent fp64 instructions, not roofline-graded.
 #pragma once
 #include "nlsg_common.h"
 #include "nlsg_math.h"
@@ -43,12 +47,12 @@ struct TqrParams {
   const double *y;  // [batch][n]
   double *beta;     // [batch][p]
   uint64_t batch, n;
-  uint32_t p, ring, stride;  // ring rows (2p + 4), doubles per ring row ((p + 1) | 1: odd)
+  uint32_t p, ring, stride;  // ring rows (2p + 4), doubles per ring row ((p + 2) | 1: odd, >= p + 2)
   double tol;
 };
 
 __host__ __device__ inline uint32_t tqr_ring_rows(uint32_t p) { return 2 * p + 4; }
-__host__ __device__ inline uint32_t tqr_stride(uint32_t p) { return (p + 1) | 1u; }
+__host__ __device__ inline uint32_t tqr_stride(uint32_t p) { return (p + 2) | 1u; }  // columns 0 .. p-1, y, padding
 __host__ __device__ inline size_t tqr_lds_bytes(uint32_t p) {
   return (static_cast<size_t>(tqr_ring_rows(p)) * tqr_stride(p) + 2 * kTqrMaxP) * sizeof(double);
 }
@@ -60,20 +64,20 @@ __global__ __launch_bounds__(THREADS) void tinyqr_lm_kernel(TqrParams q) {
   const int t = threadIdx.x, lane = lane_id();
   const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
   const int p = static_cast<int>(q.p), S = static_cast<int>(q.stride), RING = static_cast<int>(q.ring);
-  const long long n = static_cast<long long>(q.n);
+  const int n = static_cast<int>(q.n);  // (the host side admits n < 2^30)
   double *ring = tqr_smem;                                              // [RING][S]
   double2 *cs = reinterpret_cast<double2 *>(tqr_smem + RING * S);       // [64]
   const uint64_t sys = blockIdx.x;
   const double *X = q.X + sys * q.n * q.p, *y = q.y + sys * q.n;
-  const int nch = static_cast<int>(n - 1 < p ? n - 1 : p);  // chains: columns that have a row below the diagonal
-  const long long last = nch > 0 ? static_cast<long long>(nch - 1) + n - 2 : -1;  // last step
+  const int nch = n - 1 < p ? n - 1 : p;  // chains: columns that have a row below the diagonal
+  const int last = nch > 0 ? nch - 1 + n - 2 : -1;  // last step
 
   // element `c` of row r (c < p: X, c == p: y) — what the loader lanes fetch
-  auto fetch = [&](long long r, int c) -> double {
+  auto fetch = [&](int r, int c) -> double {
     if (r < 0) return 0.0;
-    return c < p ? X[static_cast<uint64_t>(c) * q.n + r] : y[r];
+    return c < p ? X[static_cast<uint64_t>(c) * q.n + static_cast<uint64_t>(r)] : y[r];
   };
-  auto slot_of = [&](long long r) -> int { return static_cast<int>(r % RING); };
+  auto slot_of = [&](int r) -> int { return r % RING; };
 
   // prologue: rows n-1 and n-2 (step 0), row n-3 waits in a register for step 1
   const bool loader = (wid == 1 && lane <= p) || (wid == 2 && lane == 0 && p == 64);
@@ -84,11 +88,21 @@ __global__ __launch_bounds__(THREADS) void tinyqr_lm_kernel(TqrParams q) {
     if (n >= 2) ring[slot_of(n - 2) * S + lcol] = fetch(n - 2, lcol);
     pending = fetch(n - 3, lcol);
   }
+  // the apply waves' chains: slot u of wave `wid` follows chain j = wid + u W
+  constexpr int SL = (kTqrMaxP + W - 1) / W;
+  int col[SL];
+  double carry[SL];
+#pragma unroll
+  for (int u = 0; u < SL; u++) {
+    const int c = wid + u * W + 1 + lane;
+    col[u] = c <= p ? c : p + 1;
+    carry[u] = 0.0;
+  }
   __syncthreads();
 
   int s0 = slot_of(n - 1);  // slot of row i0 = n-1-k, chain 0's lower row at step k
   int sin = slot_of(n >= 3 ? n - 3 : 0);  // slot of the row entering for step k+1: n-3-k
-  for (long long k = 0; k <= last; k++) {
+  for (int k = 0; k <= last; k++) {
     // ---- phase A: Givens pairs of this step (wave 0), the entering row (waves 1, 2)
     if (wid == 0) {
       const int j = lane;
@@ -114,34 +128,34 @@ __global__ __launch_bounds__(THREADS) void tinyqr_lm_kernel(TqrParams q) {
       pending = fetch(n - 4 - k, lcol);
     }
     __syncthreads();
-    // ---- phase B: rotate_matrix (tinyqr.h:126-139) on the columns right of each chain's pivot
-    double t1[(kTqrMaxP + W - 1) / W], t2[(kTqrMaxP + W - 1) / W];
-    double2 g[(kTqrMaxP + W - 1) / W];
-    int om[(kTqrMaxP + W - 1) / W], oi[(kTqrMaxP + W - 1) / W];
+    // ---- phase B: rotate_matrix (tinyqr.h:126-139) on the columns right of each chain's pivot;
+    // two passes, so that every active slot's LDS reads are in flight before the first is used
+    double2 g[SL];
+    double t1[SL];
 #pragma unroll
-    for (int u = 0; u < (kTqrMaxP + W - 1) / W; u++) {
-      const int j = wid + u * W;  // wave-uniform
-      const bool act = j < nch && k >= 2 * j && k <= j + n - 2;
-      const int col = j + 1 + lane;
-      if (act && col <= p) {
+    for (int u = 0; u < SL; u++) {
+      const int j = wid + u * W;  // wave-uniform, like everything here but `col`
+      if (j < nch && static_cast<unsigned>(k - 2 * j) <= static_cast<unsigned>(n - 2 - j)) {
         int si = s0 + 2 * j;
         si -= si >= RING ? RING : 0;
         const int sm = si == 0 ? RING - 1 : si - 1;
-        om[u] = sm * S + col;
-        oi[u] = si * S + col;
         g[u] = cs[j];
-        t1[u] = ring[om[u]];
-        t2[u] = ring[oi[u]];
-      } else {
-        om[u] = -1;
+        t1[u] = ring[sm * S + col[u]];
+        if (k == 2 * j) carry[u] = ring[si * S + col[u]];  // the chain starts: row n-1
       }
     }
 #pragma unroll
-    for (int u = 0; u < (kTqrMaxP + W - 1) / W; u++) {
-      if (om[u] >= 0) {
-        const double c = g[u].x, s = g[u].y;
-        ring[om[u]] = __builtin_fma(c, t1[u], s * t2[u]);
-        ring[oi[u]] = __builtin_fma(c, t2[u], (-s) * t1[u]);
+    for (int u = 0; u < SL; u++) {
+      const int j = wid + u * W;
+      if (j < nch && static_cast<unsigned>(k - 2 * j) <= static_cast<unsigned>(n - 2 - j)) {
+        int si = s0 + 2 * j;
+        si -= si >= RING ? RING : 0;
+        const int sm = si == 0 ? RING - 1 : si - 1;
+        const double c = g[u].x, s = g[u].y, t2 = carry[u];
+        const double lo = __builtin_fma(c, t1[u], s * t2);
+        ring[si * S + col[u]] = __builtin_fma(c, t2, (-s) * t1[u]);
+        carry[u] = lo;
+        if (k == j + n - 2) ring[sm * S + col[u]] = lo;  // the chain ends: row j of R is final
       }
     }
     s0 = s0 == 0 ? RING - 1 : s0 - 1;
