@@ -36,6 +36,6 @@ run lm --workload lm &&
 run lm_qr --workload lm --lm-solver qr --no-cpu-baseline &&
 run nm --workload nm && run sann --workload sann && run nmpso --workload nmpso &&
 run bfgs_fd --workload bfgs-fd && run lm_fd --workload lm-fd &&
-run lm_n128 --workload lm --lm-n 128 && run tinyqr --workload tinyqr
+run lm_n128 --workload lm --lm-n 128 && run lm_n256 --workload lm --lm-n 256 && run tinyqr --workload tinyqr
 echo "rc=$?"
 du -sh "$out"
