@@ -22,7 +22,8 @@ struct nlsg_lm {
   bool wide = false;   // n > 64: the workgroup-per-problem kernels (lm_wide_*)
   bool wide_valu = false;  // NLSG_LM_WIDE_MFMA=0: the VALU contraction at every n > 64 (A/B switch)
   int wide128_waves = 8;   // NLSG_LM_WIDE128_WAVES=4: the four-wave form of the n <= 128 evaluation (A/B switch)
-  bool wide_chol = true;   // NLSG_LM_WIDE_CHOL=0: the column-by-column step at n > 128 (A/B switch)
+  bool wide_chol = true;   // NLSG_LM_WIDE_CHOL=0: the steps before the blocked one — LDS-resident at
+                           // n <= 128, column by column beyond (A/B switch)
   uint64_t ldt = kLmN; // row stride of theta / gg on the device: 64, or n when wide
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   LmRtcKernels rtc;  // objective == NLSG_OBJ_CUSTOM: the kernel hiprtc built for it
@@ -161,11 +162,11 @@ int launch_solve(nlsg_lm *e) {
     const uint64_t chunk = left < 8 ? left : 8;
     for (uint64_t i = 0; i < chunk; i++) {
       if (e->wide) {
-        if (e->p.n <= 128 && !e->wide_valu)  // the damped matrix fits LDS: one thread per row
+        if (e->wide_chol && !e->wide_valu)  // blocked, the panel sums on the matrix cores
+          launch_wide_chol_step(e, grid);
+        else if (e->p.n <= 128 && !e->wide_valu)  // the damped matrix in LDS, one thread per row
           hipLaunchKernelGGL(lm_wide128_step_kernel, grid, dim3(128), sizeof(LmWide128StepShared),
                              e->stream, e->p);
-        else if (e->wide_chol && !e->wide_valu)  // blocked, the panel sums on the matrix cores
-          launch_wide_chol_step(e, grid);
         else
           hipLaunchKernelGGL(lm_wide_step_kernel, grid, dim3(kLmWideThreads), 0, e->stream, e->p);
         launch_wide_eval(e, 0);

@@ -133,26 +133,34 @@ def test_lm_wide_diagonal_shortcut_and_limits(mod, oracle):
                                        (40, 144, 2), (64, 700, 1), (24, 1024, 1), (30, 1009, 1)])
 def test_lm_wide_matrix_core_kernel_bit_exact(mod, oracle, monkeypatch, m, n, batch):
     """n > 64 with J^T J on the matrix cores — the one-pass kernel up to 128 parameters
-    (lm_wide128_tanh_eval_kernel, with the LDS-resident step lm_wide128_step_kernel), the super-block
+    (lm_wide128x8_tanh_eval_kernel), the super-block
     kernel beyond (lm_wide_mfma_tanh_eval_kernel: two, three and five column blocks, diagonal and
-    off-diagonal passes), with the blocked matrix-core Cholesky step lm_wide_chol_step_kernel (256, 512
-    and 1024 threads, odd n, a last block of one column, n = 1024) — against the order-1 oracle AND
-    against the VALU kernels and the column-wise step they replace (NLSG_LM_WIDE_MFMA=0): the benchmark size, odd n (scalar loads), m not a multiple of sixteen,
+    off-diagonal passes), with the blocked matrix-core Cholesky step lm_wide_chol_step_kernel at every
+    n > 64 (256, 512 and 1024 threads, odd n, a last block of one column, n = 1024) — against the
+    order-1 oracle AND against the kernels they replace (NLSG_LM_WIDE_CHOL=0: the LDS-resident step
+    lm_wide128_step_kernel up to n = 128, the column-wise one beyond; NLSG_LM_WIDE_MFMA=0: the VALU
+    evaluations with the column-wise step): the benchmark size, odd n (scalar loads), m not a multiple of sixteen,
     fewer rows than a group, column blocks that are entirely padding. An fp64 MFMA is a k-ordered
     fma chain: same bits."""
     kw = dict(lam=10.0, max_iter=5, f_delta=0.0)
     A, y, t0 = problems(oracle, 11, batch, m, n)
     out = {}
-    for sw in ("1", "0"):
-        monkeypatch.setenv("NLSG_LM_WIDE_MFMA", sw)
+    # default; the steps the blocked one replaced (LDS-resident up to n = 128, column-wise beyond)
+    # under the same evaluations; VALU evaluations with the column-wise step
+    for tag, env in (("1", {}), ("step", {"NLSG_LM_WIDE_CHOL": "0"}), ("0", {"NLSG_LM_WIDE_MFMA": "0"})):
+        for k in ("NLSG_LM_WIDE_CHOL", "NLSG_LM_WIDE_MFMA"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
         with mod.LMEngine(mod.TanhRegression(A, y), **kw) as eng:
-            out[sw] = eng.minimize(t0.copy())
+            out[tag] = eng.minimize(t0.copy())
     th, st, lam = out["1"]
     for b in range(batch):
         ref, xr, lam_r, _ = O.lm_solve(oracle, A[b], y[b], t0[b], order=1, **kw)
         check(st[b], ref, th[b], xr, lam[b], lam_r, (m, n, b))
-    assert np.array_equal(out["0"][0], th, equal_nan=True) and np.array_equal(out["0"][2], lam, equal_nan=True)
-    assert [s.f_value for s in out["0"][1]] == [s.f_value for s in st]
+    for tag in ("step", "0"):
+        assert np.array_equal(out[tag][0], th, equal_nan=True) and np.array_equal(out[tag][2], lam, equal_nan=True)
+        assert [s.f_value for s in out[tag][1]] == [s.f_value for s in st]
 
 
 def test_lm_wide_bench_configuration_sampled_parity(mod, oracle):
