@@ -994,7 +994,7 @@ __global__ __launch_bounds__(kLmWideThreads) void lm_wide_step_kernel(LmParams p
   for (int i = t; i < n; i += T) th[i] = th[i] - piv[i];  // :3534
 }
 
-// ---- The step for 128 < n <= 1024 as a BLOCKED left-looking Cholesky with the panel sums on the
+// ---- The step for 64 < n <= 1024 (the default) as a BLOCKED left-looking Cholesky with the panel sums on the
 // matrix cores. Element (i, j) of the factor is 1 / L_jj (A_ij - sum_{k<j} L_ik L_jk) with the sum
 // one k-ordered fma chain starting at zero (cholesky, :251-269, order 1 of the oracle) — which is
 // what v_mfma_f64_16x16x4_f64 computes for a 16 x 16 tile of (i, j) at once when it is fed
@@ -1495,7 +1495,8 @@ __global__ __launch_bounds__(kLmWideThreads) void lm_wide_tanh_eval_kernel(LmPar
   }
 }
 
-// ---- The step for 64 < n <= 128 with the damped matrix in LDS. lm_wide_step_kernel keeps H in
+// ---- The step for 64 < n <= 128 with the damped matrix in LDS (NLSG_LM_WIDE_CHOL=0; the blocked
+// kernel above replaced it as the default: 0.18 against 0.38 ms at n = 128). lm_wide_step_kernel keeps H in
 // global memory and walks it row-wise from every thread (uncoalesced, three barriers per column):
 // at n = 128 it took 0.72 ms for 1024 problems, 2.4 x the evaluation beside it. Here the packed
 // lower triangle (66.5 KB: two workgroups per CU) is loaded once, column-coalesced, and thread t
