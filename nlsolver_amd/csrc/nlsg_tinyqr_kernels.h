@@ -92,12 +92,20 @@ __global__ __launch_bounds__(THREADS) void tinyqr_lm_kernel(TqrParams q) {
   constexpr int SL = (kTqrMaxP + W - 1) / W;
   int col[SL];
   double carry[SL];
+  // wave-uniform per chain: first step (never, for a slot without a chain), last - first step, and
+  // the ring offsets of the rotation's rows i-1 and i, followed from step to step while it runs
+  int first[SL], span[SL], om[SL], oi[SL];
 #pragma unroll
   for (int u = 0; u < SL; u++) {
-    const int c = wid + u * W + 1 + lane;
+    const int j = wid + u * W;
+    const int c = j + 1 + lane;
     col[u] = c <= p ? c : p + 1;
     carry[u] = 0.0;
+    first[u] = j < nch ? 2 * j : 0x40000000;
+    span[u] = j < nch ? n - 2 - j : 0;
+    om[u] = oi[u] = 0;
   }
+  const int om_start = n >= 2 ? slot_of(n - 2) * S : 0, oi_start = slot_of(n - 1) * S;
   __syncthreads();
 
   int s0 = slot_of(n - 1);  // slot of row i0 = n-1-k, chain 0's lower row at step k
@@ -129,33 +137,26 @@ __global__ __launch_bounds__(THREADS) void tinyqr_lm_kernel(TqrParams q) {
     }
     __syncthreads();
     // ---- phase B: rotate_matrix (tinyqr.h:126-139) on the columns right of each chain's pivot;
-    // two passes, so that every active slot's LDS reads are in flight before the first is used
-    double2 g[SL];
-    double t1[SL];
+    // one pass per chain (the ring slots are computed once; the SIMD's other waves cover the LDS
+    // round trip)
 #pragma unroll
     for (int u = 0; u < SL; u++) {
-      const int j = wid + u * W;  // wave-uniform, like everything here but `col`
-      if (j < nch && static_cast<unsigned>(k - 2 * j) <= static_cast<unsigned>(n - 2 - j)) {
-        int si = s0 + 2 * j;
-        si -= si >= RING ? RING : 0;
-        const int sm = si == 0 ? RING - 1 : si - 1;
-        g[u] = cs[j];
-        t1[u] = ring[sm * S + col[u]];
-        if (k == 2 * j) carry[u] = ring[si * S + col[u]];  // the chain starts: row n-1
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < SL; u++) {
-      const int j = wid + u * W;
-      if (j < nch && static_cast<unsigned>(k - 2 * j) <= static_cast<unsigned>(n - 2 - j)) {
-        int si = s0 + 2 * j;
-        si -= si >= RING ? RING : 0;
-        const int sm = si == 0 ? RING - 1 : si - 1;
-        const double c = g[u].x, s = g[u].y, t2 = carry[u];
-        const double lo = __builtin_fma(c, t1[u], s * t2);
-        ring[si * S + col[u]] = __builtin_fma(c, t2, (-s) * t1[u]);
+      const unsigned d = static_cast<unsigned>(k - first[u]);  // wave-uniform, like everything here but `col`
+      if (d <= static_cast<unsigned>(span[u])) {
+        if (d == 0) {  // the chain starts at the bottom: rows n-2, n-1
+          om[u] = om_start;
+          oi[u] = oi_start;
+          carry[u] = ring[oi_start + col[u]];
+        }
+        const double2 g = cs[wid + u * W];
+        const double t1 = ring[om[u] + col[u]];
+        const double c = g.x, s = g.y, t2 = carry[u];
+        const double lo = __builtin_fma(c, t1, s * t2);
+        ring[oi[u] + col[u]] = __builtin_fma(c, t2, (-s) * t1);
         carry[u] = lo;
-        if (k == j + n - 2) ring[sm * S + col[u]] = lo;  // the chain ends: row j of R is final
+        if (d == static_cast<unsigned>(span[u])) ring[om[u] + col[u]] = lo;  // the chain ends: row j of R is final
+        oi[u] = om[u];
+        om[u] = om[u] == 0 ? (RING - 1) * S : om[u] - S;
       }
     }
     s0 = s0 == 0 ? RING - 1 : s0 - 1;
