@@ -42,8 +42,13 @@ void launch(const double *X, const double *y, double *beta, uint64_t batch, uint
   q.ring = tqr_ring_rows(q.p);
   q.stride = tqr_stride(q.p);
   q.tol = tol;
-  hipLaunchKernelGGL(tinyqr_lm_kernel<kTqrThreads>, dim3(static_cast<unsigned>(batch)),
-                     dim3(kTqrThreads), tqr_lds_bytes(q.p), stream, q);
+  const dim3 grid(static_cast<unsigned>(batch));
+  if (p <= 8)
+    hipLaunchKernelGGL((tinyqr_lm_kernel<128, 8>), grid, dim3(128), tqr_lds_bytes(q.p), stream, q);
+  else if (p <= 32)
+    hipLaunchKernelGGL((tinyqr_lm_kernel<256, 32>), grid, dim3(256), tqr_lds_bytes(q.p), stream, q);
+  else
+    hipLaunchKernelGGL(tinyqr_lm_kernel<kTqrThreads>, grid, dim3(kTqrThreads), tqr_lds_bytes(q.p), stream, q);
 }
 
 }  // namespace

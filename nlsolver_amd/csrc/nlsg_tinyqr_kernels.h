@@ -57,9 +57,12 @@ __host__ __device__ inline size_t tqr_lds_bytes(uint32_t p) {
   return (static_cast<size_t>(tqr_ring_rows(p)) * tqr_stride(p) + 2 * kTqrMaxP) * sizeof(double);
 }
 
-template <int THREADS>
+// THREADS / 64 waves serve systems of up to MAXP columns: (512, 64), (256, 32), (128, 8) — a small
+// system gets a small workgroup, so that many of them share a CU (the host side picks by p)
+template <int THREADS, int MAXP = kTqrMaxP>
 __global__ __launch_bounds__(THREADS) void tinyqr_lm_kernel(TqrParams q) {
   constexpr int W = THREADS / 64;
+  static_assert(W >= 2 && MAXP <= kTqrMaxP, "wave 1 loads the entering row");
   extern __shared__ __align__(16) double tqr_smem[];
   const int t = threadIdx.x, lane = lane_id();
   const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(THREADS) void tinyqr_lm_kernel(TqrParams q) {
     pending = fetch(n - 3, lcol);
   }
   // the apply waves' chains: slot u of wave `wid` follows chain j = wid + u W
-  constexpr int SL = (kTqrMaxP + W - 1) / W;
+  constexpr int SL = (MAXP + W - 1) / W;
   int col[SL];
   double carry[SL];
   // wave-uniform per chain: first step (never, for a slot without a chain), last - first step, and
