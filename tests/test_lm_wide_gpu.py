@@ -177,3 +177,17 @@ def test_lm_wide_bench_configuration_sampled_parity(mod, oracle):
         check(st[b], ref, th[b], xr, lam[b], lam_r, b)
     assert all(s.iteration == 20 and s.done == 1 for s in st)
     assert max(s.f_value for s in st) < 1e-20
+
+
+def test_lm_wide_blocked_step_every_width(mod, oracle):
+    """Every n from 65 to 176 (all positions of the last, partial sixteen-column block; odd and even
+    row strides; two to eleven panels) through the blocked step and the matrix-core evaluations:
+    each problem equals the order-1 oracle bit for bit after three iterations."""
+    kw = dict(lam=2.0, max_iter=3, f_delta=0.0)
+    for n in range(65, 177):
+        m = 24 + (n % 5) * 7
+        A, y, t0 = problems(oracle, 100 + n, 1, m, n)
+        with mod.LMEngine(mod.TanhRegression(A, y), **kw) as eng:
+            th, st, lam = eng.minimize(t0.copy())
+        ref, xr, lam_r, _ = O.lm_solve(oracle, A[0], y[0], t0[0], order=1, **kw)
+        check(st[0], ref, th[0], xr, lam[0], lam_r, (m, n))
