@@ -104,7 +104,7 @@ __global__ __launch_bounds__(THREADS) void tinyqr_lm_kernel(TqrParams q) {
     const int c = j + 1 + lane;
     col[u] = c <= p ? c : p + 1;
     carry[u] = 0.0;
-    first[u] = j < nch ? 2 * j : 0x40000000;
+    first[u] = j < nch ? 2 * j : 0x7fffffff;  // (k - first stays negative: never inside a window)
     span[u] = j < nch ? n - 2 - j : 0;
     om[u] = oi[u] = 0;
   }
