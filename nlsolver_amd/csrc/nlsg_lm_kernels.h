@@ -251,7 +251,8 @@ constexpr int kLmQrStride = 65;  // doubles per row: 64 columns + the right-hand
 struct LmQrShared {              // LDS of the QR step (one workgroup per problem)
   double R[64 * kLmQrStride];    // working R (row-major), column 64 = co-rotated right-hand side
   double scr[64 + kLmQrStride];  // where the apply waves' lanes without a column load and store
-  double2 cs[2][32];             // Givens pairs (c, s) by step parity and chain j mod 32
+  double2 cs[2][33];             // Givens pairs (c, s) by step parity and chain j mod 32; [32]: where
+                                 // the Givens lanes without a rotation put theirs
   double upd[64];
 };
 static_assert(__builtin_offsetof(LmQrShared, scr) == 64 * kLmQrStride * sizeof(double), "scr follows R");
@@ -273,68 +274,86 @@ __device__ inline void lm_solve_qr(LmQrShared &qs, int n) {
     // chain of dependent fp64 instructions (two divisions and a square root, IEEE-correct: ~45 of
     // them, ~1000 cycles with the LDS round trip and the barrier) and it is the workgroup's
     // critical path (raising its issue priority over the apply waves changed nothing: measured).
+    // A lone wave issues an instruction every 5 - 8 cycles whatever it is, so the phase costs what
+    // its instruction COUNT costs, not only its ~45 dependent links: the chain's step window is
+    // one unsigned compare against per-lane constants, and the addresses of the tracked elements
+    // are followed from step to step in bytes instead of being rebuilt from (k, j).
+    char *const Rb = reinterpret_cast<char *>(qs.R);
+    constexpr int S8 = S * 8;
+    constexpr int kNever = 0x40000000;
     int j = lane;                          // current chain (lanes >= 32 never have one)
+    auto has_chain = [&](int jj) { return lane < 32 && jj <= n - 2; };
+    int kstart = has_chain(j) ? 2 * j : kNever;  // first step of my chain (kNever: no chain)
+    int kspan = has_chain(j) ? n - 2 - j : 0;    // last step - first step (compared unsigned: never negative)
+    int bst = ((n - 1) * S + (j < 63 ? j : 62)) * 8;  // R[n-1][j], R[n-1][j+1]: where my chain starts
+    int t1off = 0;                         // R[i-1][j+1] of my chain's rotation at the step just applied
+    int t1start = ((n - 2) * S + j + 1) * 8;  // ... at its first step (rows n-2, n-1)
+    int a0off = (n - 2 > 0 ? n - 2 : 0) * S8;  // chain 0's a for the pair of step k+1 = R[n-3-k][0], k = -1
     double bp = 0.0, bq = 0.0, cp = 0.0, sp = 0.0;
     bool had = false;                      // my chain had a rotation at the step just applied
-    int pend = -1;                         // a finished chain whose row-j elements are still to be stored
+    int dprev = 0;                         // ... which was its step number dprev
+    const int nowhere = (64 * S + 2 * lane) * 8;  // LmQrShared::scr, a pair per lane
+    int pend = nowhere;                    // byte offset of R[j][j] of a finished chain still to be stored
     double pend_p = 0.0, pend_q = 0.0;
     for (int k = -1; k <= last + 1; k++) {  // one phase past the last step: the last chain's store
       // Every LDS read of the phase is issued here, before anything waits: the phase is a chain
       // of dependent fp64 instructions behind ONE read round trip (what a read returns is only
       // used where the comments below say so; the addresses are always inside R).
-      const int jr = j < 63 ? j : 62;
-      const int i_k = n - 1 - (k - 2 * jr);
-      const double t1q = qs.R[(had ? i_k - 1 : 0) * S + jr + 1];  // (1): row i-1 of step k, column j+1
-      const double b_start = qs.R[(n - 1) * S + jr];              // (2) if my chain starts: row n-1
-      const double bq_start = qs.R[(n - 1) * S + jr + 1];
-      const int r0 = n - 3 - k;                                   // (2) chain 0: a = R[i-1][0], i = n-2-k
-      const double a_col0 = qs.R[(r0 > 0 ? r0 : 0) * S];
-      if (pend >= 0) {  // R[j][j], R[j][j+1] of the chain that ended in the previous phase — one
-                        // phase late: the apply lane of column j+1 read the old R[j][j+1] then
-        qs.R[pend * S + pend] = pend_p;
-        qs.R[pend * S + pend + 1] = pend_q;
-        pend = -1;
-      }
+      const double t1q = *reinterpret_cast<const double *>(Rb + t1off);       // (1): row i-1 of step k, column j+1
+      const double b_start = *reinterpret_cast<const double *>(Rb + bst);     // (2) if my chain starts: row n-1
+      const double bq_start = *reinterpret_cast<const double *>(Rb + bst + 8);
+      const double a_col0 = *reinterpret_cast<const double *>(Rb + a0off);    // (2) chain 0: a = R[i-1][0], i = n-2-k
+      a0off = a0off >= S8 ? a0off - S8 : 0;
+      // R[j][j], R[j][j+1] of the chain that ended in the previous phase — one phase late: the
+      // apply lane of column j+1 read the old R[j][j+1] then (no chain ended: a scratch pair)
+      *reinterpret_cast<double *>(Rb + pend) = pend_p;
+      *reinterpret_cast<double *>(Rb + pend + 8) = pend_q;
+      pend = nowhere;
       // (1) step k's rotation of my chain, on the two tracked columns j and j+1; its inputs
       //     were written by step k-1's rotations (complete: barrier)
-      double upq = 0.0;
-      if (had) {
-        upq = __builtin_fma(cp, bq, (-sp) * t1q);  // = R[i][j+1] after the step: chain j+1's next a
-        bq = __builtin_fma(cp, t1q, sp * bq);
-        if (i_k - 1 == j) {  // the chain ended with this step: row j of R is final in these columns
-          pend = j;
-          pend_p = bp;
-          pend_q = bq;
-          j += 32;
-        }
+      // (Computed by every lane, rotation or not: what a lane without one produces is never read —
+      // chain j+1 has a rotation at step k+1 only if chain j had one at step k, and a chain
+      // reloads its tracked elements when it starts — and the loop stays free of divergent
+      // branches, whose merges cost more instructions than the arithmetic they would skip.)
+      const double upq = __builtin_fma(cp, bq, (-sp) * t1q);  // = R[i][j+1] after the step: chain j+1's next a
+      bq = __builtin_fma(cp, t1q, sp * bq);
+      if (had && dprev == kspan) {  // the chain ended with this step: row j of R is final in these columns
+        pend = (j * S + j) * 8;
+        pend_p = bp;
+        pend_q = bq;
+        j += 32;
+        kstart = has_chain(j) ? 2 * j : kNever;
+        kspan = has_chain(j) ? n - 2 - j : 0;
+        bst = ((n - 1) * S + (j < 63 ? j : 62)) * 8;
+        t1start += 32 * 8;
       }
       // chain j's `a` is chain j-1's upq: lane L from lane L-1 (a DPP wave shift), lane 0 from lane 31
       double a_in = lane_up1(upq);
       const double a_wrap = lane_broadcast(upq, 31);
       if (lane == 0) a_in = a_wrap;
       // (2) the Givens pair of my chain's rotation at step k+1 (givens_rotation, tinyqr.h:86-97)
-      had = lane < 32 && j <= n - 2 && k + 1 <= last && k + 1 >= 2 * j && k + 1 <= j + n - 2;
-      if (had) {
-        double b = bp;
-        if (k + 1 == 2 * j) {  // the chain starts: row n-1
-          b = b_start;
-          bq = bq_start;
-        }
-        const double a = j == 0 ? a_col0 : a_in;
-        // both branches of the reference are r = small / large, t = 1 / sqrt(r^2 + 1), {t, t r}:
-        // one division, one square root, one reciprocal — selected, not branched
-        const bool swap = fabs(b) > fabs(a);
-        const double r = (swap ? a : b) / (swap ? b : a);
-        // r^2 + 1 lies in [1, 2] (or is NaN): the square root and the reciprocal without the
-        // compiler's operand scaling and fix-up steps — nine instructions off the chain that is
-        // the workgroup's critical path, same correctly rounded values
-        const double tt = div_unscaled(1.0, sqrt_unscaled(r * r + 1.0));
-        const double tr = tt * r;
-        cp = swap ? tr : tt;
-        sp = swap ? tt : tr;
-        bp = __builtin_fma(cp, a, sp * b);  // the chain's new pivot element
-        qs.cs[(k + 1) & 1][j & 31] = make_double2(cp, sp);
-      }
+      const int d = k + 1 - kstart;
+      had = static_cast<uint32_t>(d) <= static_cast<uint32_t>(kspan);
+      dprev = d;
+      const bool starts = d == 0;  // the chain starts: rows n-2, n-1
+      const double b = starts ? b_start : bp;
+      bq = starts ? bq_start : bq;
+      const int t1next = starts ? t1start : t1off - S8;
+      t1off = had ? t1next : t1off;
+      const double a = j == 0 ? a_col0 : a_in;
+      // both branches of the reference are r = small / large, t = 1 / sqrt(r^2 + 1), {t, t r}:
+      // one division, one square root, one reciprocal — selected, not branched
+      const bool swap = fabs(b) > fabs(a);
+      const double r = (swap ? a : b) / (swap ? b : a);
+      // r^2 + 1 lies in [1, 2] (or is NaN): the square root and the reciprocal without the
+      // compiler's operand scaling and fix-up steps — nine instructions off the chain that is
+      // the workgroup's critical path, same correctly rounded values
+      const double tt = div_unscaled(1.0, sqrt_unscaled(r * r + 1.0));
+      const double tr = tt * r;
+      cp = swap ? tr : tt;
+      sp = swap ? tt : tr;
+      bp = __builtin_fma(cp, a, sp * b);  // the chain's new pivot element
+      qs.cs[(k + 1) & 1][had ? (j & 31) : 32] = make_double2(cp, sp);
       __syncthreads();
     }
   } else {
