@@ -274,10 +274,12 @@ __device__ inline void lm_solve_qr(LmQrShared &qs, int n) {
     // chain of dependent fp64 instructions (two divisions and a square root, IEEE-correct: ~45 of
     // them, ~1000 cycles with the LDS round trip and the barrier) and it is the workgroup's
     // critical path (raising its issue priority over the apply waves changed nothing: measured).
-    // A lone wave issues an instruction every 5 - 8 cycles whatever it is, so the phase costs what
-    // its instruction COUNT costs, not only its ~45 dependent links: the chain's step window is
-    // one unsigned compare against per-lane constants, and the addresses of the tracked elements
-    // are followed from step to step in bytes instead of being rebuilt from (k, j).
+    // Around that chain the loop is kept short (112 instructions per step; 163 when the step window
+    // and the tracked elements' addresses were rebuilt from (k, j) every step and the two halves sat
+    // behind divergent branches): the window is one unsigned compare against per-lane constants,
+    // the addresses are followed in bytes, and every lane computes a pair — lanes without a rotation
+    // store theirs to a spare slot. Worth 1 % alone (off-chain instructions issue in the chain's
+    // shadow), 4 % between the evaluation launches of a real iteration.
     char *const Rb = reinterpret_cast<char *>(qs.R);
     constexpr int S8 = S * 8;
     constexpr int kNever = 0x40000000;
