@@ -131,6 +131,10 @@ __device__ inline void lm_solve_cholesky_wave(Rows H, const double *g, double *u
   for (int j0 = 0; j0 < n; j0 += 4) {
     double s4[4] = {0.0, 0.0, 0.0, 0.0};
     const bool act = row && t >= j0;
+    // rows above the panel's sixteen-row group are finished: whole groups of sixteen lanes sit the
+    // sums out. (A partly enabled wave issues its fp64 instructions cheaper — the SIMD skips the
+    // sixteen-lane passes without an enabled lane: measured, 0.170 -> 0.157 ms for the step.)
+    if (t >= (j0 & ~15))
     for (int k = 0; k < j0; k += 4) {  // j0 is a multiple of 4
       // (rows start at even offsets: a pair of columns is one 128-bit LDS read)
       const double2 xa = H.pair(t, k), xb = H.pair(t, k + 2);  // lanes t < j0: in-buffer, unused
