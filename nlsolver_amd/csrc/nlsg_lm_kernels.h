@@ -156,11 +156,16 @@ __device__ inline void lm_solve_cholesky_wave(Rows H, const double *g, double *u
     for (int c = 0; c < 4; c++) {
       const int j = j0 + c;
       if (j < n) {  // wave-uniform
-        // diagonal first (lane j: sum = sum_k L[j][k]^2), then the column below it
-        double v = 0.0;
-        if (t == j) v = sqrt(hd[c] - s4[c]);
-        const double d = lane_broadcast(v, j);
-        if (act && t > j) v = (1.0 / d * (hd[c] - s4[c]));
+        // diagonal first (lane j: sum = sum_k L[j][k]^2), then the column below it. Root AND
+        // reciprocal are taken by lane j alone — one enabled lane: one sixteen-lane pass per
+        // instruction instead of four — and the reciprocal travels through scalar registers
+        double v = 0.0, rinv = 0.0;
+        if (t == j) {
+          v = sqrt(hd[c] - s4[c]);
+          rinv = 1.0 / v;
+        }
+        const double ri = lane_broadcast(rinv, j);
+        if (act && t > j) v = (ri * (hd[c] - s4[c]));
         if (act && t >= j) H(t, j) = v;
         // the panel's later columns continue their sums with k = j
 #pragma unroll
