@@ -307,6 +307,7 @@ __device__ inline void lm_solve_qr(LmQrShared &qs, int n) {
     int pend = nowhere;                    // byte offset of R[j][j] of a finished chain still to be stored
     double pend_p = 0.0, pend_q = 0.0;
     for (int k = -1; k <= last + 1; k++) {  // one phase past the last step: the last chain's store
+      if (lane < 32) {  // (chains live in lanes 0 .. 31: half the sixteen-lane passes per instruction)
       // Every LDS read of the phase is issued here, before anything waits: the phase is a chain
       // of dependent fp64 instructions behind ONE read round trip (what a read returns is only
       // used where the comments below say so; the addresses are always inside R).
@@ -365,6 +366,7 @@ __device__ inline void lm_solve_qr(LmQrShared &qs, int n) {
       sp = swap ? tt : tr;
       bp = __builtin_fma(cp, a, sp * b);  // the chain's new pivot element
       qs.cs[(k + 1) & 1][had ? (j & 31) : 32] = make_double2(cp, sp);
+      }
       __syncthreads();
     }
   } else {
