@@ -22,6 +22,7 @@ struct nlsg_lm {
   bool wide = false;   // n > 64: the workgroup-per-problem kernels (lm_wide_*)
   bool wide_valu = false;  // NLSG_LM_WIDE_MFMA=0: the VALU contraction at every n > 64 (A/B switch)
   int wide128_waves = 8;   // NLSG_LM_WIDE128_WAVES=4: the four-wave form of the n <= 128 evaluation (A/B switch)
+  bool wide256 = true;     // NLSG_LM_WIDE256=0: the super-block evaluation at 128 < n <= 256 too (A/B switch)
   bool wide_chol = true;   // NLSG_LM_WIDE_CHOL=0: the steps before the blocked one — LDS-resident at
                            // n <= 128, column by column beyond (A/B switch)
   uint64_t ldt = kLmN; // row stride of theta / gg on the device: 64, or n when wide
@@ -128,6 +129,8 @@ void launch_wide_eval(nlsg_lm *e, int first) {
       hipLaunchKernelGGL(lm_wide128_tanh_eval_kernel, grid, dim3(256), 0, e->stream, e->p, first);
     else if (e->p.n <= 128)
       hipLaunchKernelGGL(lm_wide128x8_tanh_eval_kernel, grid, dim3(512), 0, e->stream, e->p, first);
+    else if (e->p.n <= 256 && e->wide256)  // one pass over A still: 136 tiles on eight waves
+      hipLaunchKernelGGL(lm_wide256x8_tanh_eval_kernel, grid, dim3(512), sizeof(LmWide256Shared), e->stream, e->p, first);
     else  // super-blocks of 128 x 128, each on the matrix cores
       hipLaunchKernelGGL(lm_wide_mfma_tanh_eval_kernel, grid, dim3(256), 0, e->stream, e->p, first);
     return;
@@ -255,6 +258,8 @@ static int lm_create(const nlsg_lm_config *cfg, const nlsg_custom_objective *cus
     e->wide_valu = sw && sw[0] == '0';
     const char *ww = std::getenv("NLSG_LM_WIDE128_WAVES");
     e->wide128_waves = ww && ww[0] == '4' ? 4 : 8;
+    const char *w2 = std::getenv("NLSG_LM_WIDE256");
+    e->wide256 = !(w2 && w2[0] == '0');
     const char *wc = std::getenv("NLSG_LM_WIDE_CHOL");
     e->wide_chol = !(wc && wc[0] == '0');
   }
@@ -302,6 +307,9 @@ static int lm_create(const nlsg_lm_config *cfg, const nlsg_custom_objective *cus
   if (he == hipSuccess)
     he = hipFuncSetAttribute(reinterpret_cast<const void *>(lm_wide128_step_kernel),
                              hipFuncAttributeMaxDynamicSharedMemorySize, sizeof(LmWide128StepShared));
+  if (he == hipSuccess)
+    he = hipFuncSetAttribute(reinterpret_cast<const void *>(lm_wide256x8_tanh_eval_kernel),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, sizeof(LmWide256Shared));
   for (int ev = 0; ev < 2 && he == hipSuccess; ev++) {  // 139 KB at 1024 threads, 70 KB at 512
     he = hipFuncSetAttribute(ev ? reinterpret_cast<const void *>(lm_wide_chol_step_kernel<1024, true>)
                                 : reinterpret_cast<const void *>(lm_wide_chol_step_kernel<1024, false>),

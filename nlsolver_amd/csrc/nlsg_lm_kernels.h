@@ -2091,6 +2091,180 @@ __global__ __launch_bounds__(512, 4) void lm_wide128x8_tanh_eval_kernel(LmParams
   }
 }
 
+// ---- 128 < n <= 256 in ONE pass over A too: the 136 lower tiles of the sixteen column blocks fit
+// the accumulators of eight waves, seventeen each — wave w carries the tile rows 15 - w (16 - w
+// tiles) and w (w + 1 tiles), whose operands are the column blocks 0 .. 15 - w of the staged rows.
+// Otherwise lm_wide128x8_tanh_eval_kernel: a half-wave computes one row's z per group (its lanes'
+// fma chains over their column pair of the four 64-column blocks, then the butterfly 16 .. 1 — the
+// chains of lm_wide_mfma_tanh_eval_kernel's first phase, which this kernel replaces at these
+// sizes), scales the row into a double-buffered LDS tile (stride 272 doubles: conflict-free
+// ds_read_b64 for the MFMA operand pattern), g rides on the wave's two row-block operands, f on
+// wave 4. A is read once; 1.42 -> X ms at n = 256, m = 512, batch 1024.
+constexpr int kLmW256Stride = 272;
+struct LmWide256Shared {  // 70 KB: dynamic LDS
+  double J[2][16 * kLmW256Stride];
+  double r[2][16];
+};
+
+template <int W>
+__device__ inline void lm_wide256_run8(const LmParams &p, int first, uint64_t pid, LmWide256Shared &sh,
+                                       bool vec) {
+  constexpr int S = kLmW256Stride;
+  constexpr int RL = 15 - W, NOP = 16 - W;  // the long tile row; operands = column blocks 0 .. RL
+  constexpr int NT = 17;                    // tiles: (RL, 0 .. RL), then (W, 0 .. W)
+  LmProblem *pr = p.prob + pid;
+  const int lane = lane_id();
+  const int half = lane >> 5, lp = lane & 31, kk = lane >> 4, cc = lane & 15;
+  const uint64_t n = p.n, m = p.m;
+  const double *A = p.Aw + pid * m * n, *y = p.yw + pid * m, *th = p.theta + pid * n;
+  double tv[8];  // theta at the lane's column pair of the four 64-column blocks
+#pragma unroll
+  for (int b = 0; b < 4; b++) {
+    const uint64_t e = 64 * b + 2 * static_cast<uint64_t>(lp);
+    tv[2 * b] = e < n ? th[e] : 0.0;
+    tv[2 * b + 1] = e + 1 < n ? th[e + 1] : 0.0;
+  }
+  const uint64_t nstep = (m + 15) / 16;
+  const int rr = 2 * W + half;  // the row of a group this lane's half stages
+  double a[8], yv;
+  auto fetch = [&](uint64_t s) {
+    const uint64_t i = 16 * s + rr;
+    const bool in = i < m;
+    const double *row = A + (in ? i : 0) * n;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      const uint64_t e = 64 * b + 2 * static_cast<uint64_t>(lp);
+      if (vec) {  // n even: rows start 16-byte aligned; the matrix is read once: streamed (nt)
+        const v2d_nt u = __builtin_nontemporal_load(reinterpret_cast<const v2d_nt *>(row + (e < n ? e : 0)));
+        a[2 * b] = (in && e < n) ? u.x : 0.0;
+        a[2 * b + 1] = (in && e < n) ? u.y : 0.0;
+      } else {
+        a[2 * b] = (in && e < n) ? __builtin_nontemporal_load(row + (e < n ? e : 0)) : 0.0;
+        a[2 * b + 1] = (in && e + 1 < n) ? __builtin_nontemporal_load(row + (e + 1 < n ? e + 1 : 0)) : 0.0;
+      }
+    }
+    yv = y[in ? i : 0];
+  };
+  auto stage = [&](uint64_t s, int buf) {
+    double z = __builtin_fma(a[1], tv[1], a[0] * tv[0]);
+#pragma unroll
+    for (int b = 1; b < 4; b++) z = __builtin_fma(a[2 * b + 1], tv[2 * b + 1], __builtin_fma(a[2 * b], tv[2 * b], z));
+    butterfly_levels<16>([&](auto off) { z = z + lane_xor<decltype(off)::value>(z); });
+    const bool in = 16 * s + rr < m;
+    const double tz = det_tanh(z);
+    const double res = in ? yv - tz : 0.0;
+    const double wgt = 1 - tz * tz;
+    double *row = &sh.J[buf][rr * S];
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      double2 jv;
+      jv.x = -(wgt * a[2 * b]);
+      jv.y = -(wgt * a[2 * b + 1]);
+      *reinterpret_cast<double2 *>(row + 64 * b + 2 * lp) = jv;
+    }
+    if (lp == 0) sh.r[buf][rr] = res;
+  };
+  v4d acc[NT];
+#pragma unroll
+  for (int c = 0; c < NT; c++) acc[c] = v4d{0.0, 0.0, 0.0, 0.0};
+  double gacc[2] = {0.0, 0.0};  // column blocks RL and W
+  double facc[4] = {0.0, 0.0, 0.0, 0.0};
+
+  fetch(0);
+  stage(0, 0);
+  if (nstep > 1) fetch(1);
+  __syncthreads();
+  for (uint64_t s = 0; s < nstep; s++) {
+    const int buf = static_cast<int>(s & 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      const double *row = &sh.J[buf][(4 * ks + kk) * S];
+      double op[NOP];
+#pragma unroll
+      for (int b = 0; b < NOP; b++) op[b] = row[16 * b + cc];
+      // g: chain kk of column 16 b + cc takes the rows = kk (mod 4) in order
+      const double rv = sh.r[buf][4 * ks + kk];
+      gacc[0] = __builtin_fma(op[RL], rv, gacc[0]);
+      gacc[1] = __builtin_fma(op[W], rv, gacc[1]);
+#pragma unroll
+      for (int c = 0; c <= RL; c++) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[RL], op[c], acc[c], 0, 0, 0);
+#pragma unroll
+      for (int c = 0; c <= W; c++)
+        acc[RL + 1 + c] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[W], op[c], acc[RL + 1 + c], 0, 0, 0);
+    }
+    if constexpr (W == 4) {  // f: chain (s mod 4, parity) takes its rows of the group in order
+      const int sm = static_cast<int>(s & 3);
+      double fw = sm == 0 ? facc[0] : sm == 1 ? facc[1] : sm == 2 ? facc[2] : facc[3];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const double rq = sh.r[buf][2 * k + half];
+        fw = __builtin_fma(rq, rq, fw);
+      }
+      facc[0] = sm == 0 ? fw : facc[0];
+      facc[1] = sm == 1 ? fw : facc[1];
+      facc[2] = sm == 2 ? fw : facc[2];
+      facc[3] = sm == 3 ? fw : facc[3];
+    }
+    if (s + 1 < nstep) {
+      stage(s + 1, buf ^ 1);
+      if (s + 2 < nstep) fetch(s + 2);
+    }
+    __syncthreads();
+  }
+  // ---- publish H = 2 J^T J (both triangles), g = 2 J^T r, f
+  double *H = p.Hw + pid * n * n;
+  auto put_tile = [&](int tr, int tc, const v4d &tile) {
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) {
+      const uint64_t row = 16 * static_cast<uint64_t>(tr) + kk + 4 * rg, col = 16 * static_cast<uint64_t>(tc) + cc;
+      if (row < n && col < n) {
+        const double v = 2 * tile[rg];
+        H[row * n + col] = v;
+        if (tr != tc) H[col * n + row] = v;
+      }
+    }
+  };
+#pragma unroll
+  for (int c = 0; c <= RL; c++) put_tile(RL, c, acc[c]);
+#pragma unroll
+  for (int c = 0; c <= W; c++) put_tile(W, c, acc[RL + 1 + c]);
+  auto put_g = [&](double gv, int b) {
+    const double g0 = __shfl(gv, cc, 64), g1 = __shfl(gv, cc + 16, 64);
+    const double g2 = __shfl(gv, cc + 32, 64), g3 = __shfl(gv, cc + 48, 64);
+    const uint64_t col = 16 * static_cast<uint64_t>(b) + cc;
+    if (kk == 0 && col < n) p.gg[pid * n + col] = 2 * (((g0 + g1) + g2) + g3);
+  };
+  put_g(gacc[0], RL);
+  put_g(gacc[1], W);
+  if constexpr (W == 4) {
+    double f = 0.0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      f = f + __shfl(facc[w], 0, 64);
+      f = f + __shfl(facc[w], 32, 64);
+    }
+    if (lane == 0) lm_publish_state(p, pr, first, f);
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void lm_wide256x8_tanh_eval_kernel(LmParams p, int first) {
+  extern __shared__ __align__(16) unsigned char lm_w256_smem[];
+  LmWide256Shared &sh = *reinterpret_cast<LmWide256Shared *>(lm_w256_smem);
+  const uint64_t pid = blockIdx.x;
+  if (!first && p.prob[pid].done) return;
+  const bool vec = (p.n & 1) == 0;
+  switch (__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6)) {
+    case 0: lm_wide256_run8<0>(p, first, pid, sh, vec); break;
+    case 1: lm_wide256_run8<1>(p, first, pid, sh, vec); break;
+    case 2: lm_wide256_run8<2>(p, first, pid, sh, vec); break;
+    case 3: lm_wide256_run8<3>(p, first, pid, sh, vec); break;
+    case 4: lm_wide256_run8<4>(p, first, pid, sh, vec); break;
+    case 5: lm_wide256_run8<5>(p, first, pid, sh, vec); break;
+    case 6: lm_wide256_run8<6>(p, first, pid, sh, vec); break;
+    default: lm_wide256_run8<7>(p, first, pid, sh, vec); break;
+  }
+}
+
 // ---- 128 < n <= 1024 on the matrix cores. H no longer fits one set of accumulators, so the rows
 // are passed over once per 128 x 128 super-block of its lower triangle (as lm_wide_tanh_eval_kernel
 // does on the VALU), after a first phase that needs them all: z = A theta, tanh, residuals r and
