@@ -650,8 +650,8 @@ def main_lm(args):
     # the evaluation launch (both solvers share it), timed on its own: ten lower 16 x 16 tiles of
     # J^T J per 4-row k-step are what the matrix cores execute (the matrix is symmetric)
     eng.time_eval_kernel(theta0, 60)  # untimed: clocks back up after the host-side pauses
-    kname = ("lm_wide128x8_tanh_eval_kernel" if 64 < n <= 128 else "lm_wide_mfma_tanh_eval_kernel" if wide
-             else "lm_iter_kernel (evaluation-only launches)")
+    kname = ("lm_wide128x8_tanh_eval_kernel" if 64 < n <= 128 else "lm_wide256x8_tanh_eval_kernel" if 128 < n <= 256
+             else "lm_wide_mfma_tanh_eval_kernel" if wide else "lm_iter_kernel (evaluation-only launches)")
     kms = eng.time_eval_kernel(theta0, 20) / 20
     # executed on the matrix cores: the lower 16 x 16 tiles of J^T J (the matrix is bitwise
     # symmetric), 2 * 16 * 16 flop per tile and row — 10 tiles at n = 64, 36 at n = 128

@@ -133,7 +133,7 @@ def test_lm_wide_diagonal_shortcut_and_limits(mod, oracle):
                                        (40, 144, 2), (64, 700, 1), (24, 1024, 1), (30, 1009, 1)])
 def test_lm_wide_matrix_core_kernel_bit_exact(mod, oracle, monkeypatch, m, n, batch):
     """n > 64 with J^T J on the matrix cores — the one-pass kernel up to 128 parameters
-    (lm_wide128x8_tanh_eval_kernel), the super-block
+    (lm_wide128x8_tanh_eval_kernel), up to 256 (lm_wide256x8_tanh_eval_kernel), the super-block
     kernel beyond (lm_wide_mfma_tanh_eval_kernel: two, three and five column blocks, diagonal and
     off-diagonal passes), with the blocked matrix-core Cholesky step lm_wide_chol_step_kernel at every
     n > 64 (256, 512 and 1024 threads, odd n, a last block of one column, n = 1024) — against the
