@@ -147,8 +147,9 @@ def test_lm_wide_matrix_core_kernel_bit_exact(mod, oracle, monkeypatch, m, n, ba
     out = {}
     # default; the steps the blocked one replaced (LDS-resident up to n = 128, column-wise beyond)
     # under the same evaluations; VALU evaluations with the column-wise step
-    for tag, env in (("1", {}), ("step", {"NLSG_LM_WIDE_CHOL": "0"}), ("0", {"NLSG_LM_WIDE_MFMA": "0"})):
-        for k in ("NLSG_LM_WIDE_CHOL", "NLSG_LM_WIDE_MFMA"):
+    for tag, env in (("1", {}), ("step", {"NLSG_LM_WIDE_CHOL": "0"}), ("0", {"NLSG_LM_WIDE_MFMA": "0"}),
+                     ("sb", {"NLSG_LM_WIDE256": "0"})):  # (the super-block evaluation at 128 < n <= 256)
+        for k in ("NLSG_LM_WIDE_CHOL", "NLSG_LM_WIDE_MFMA", "NLSG_LM_WIDE256"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -158,7 +159,7 @@ def test_lm_wide_matrix_core_kernel_bit_exact(mod, oracle, monkeypatch, m, n, ba
     for b in range(batch):
         ref, xr, lam_r, _ = O.lm_solve(oracle, A[b], y[b], t0[b], order=1, **kw)
         check(st[b], ref, th[b], xr, lam[b], lam_r, (m, n, b))
-    for tag in ("step", "0"):
+    for tag in ("step", "0", "sb"):
         assert np.array_equal(out[tag][0], th, equal_nan=True) and np.array_equal(out[tag][2], lam, equal_nan=True)
         assert [s.f_value for s in out[tag][1]] == [s.f_value for s in st]
 
