@@ -44,7 +44,8 @@ struct LmProblem {
   double f, lambda, prev;
   uint64_t iter, fcalls;
   int32_t done;
-  int32_t upper;  // finite-difference model: an upper off-diagonal of H exceeds eps * 1e12
+  int32_t upper;  // finite-difference model: an upper off-diagonal of H exceeds eps * 1e12; the one-pass
+                  // evaluations past 64 parameters: 2 | (some off-diagonal of H exceeds it) (LmParams::verdict)
 };
 
 struct LmParams {
@@ -59,7 +60,8 @@ struct LmParams {
   double *Hg;        // [batch][kLmTri] lower triangle of 2 J^T J, packed by rows
   double *gg;        // [batch][64] 2 J^T r
   double eps_h;      // finite-difference model: step of fin_diff_h, pow(DBL_EPSILON, 1/4)
-  int32_t fd, pad;   // 1: the functors are the reference's defaults on a built-in objective
+  int32_t fd;        // 1: the functors are the reference's defaults on a built-in objective
+  int32_t verdict;   // 1: the evaluation kernel leaves is_diagonal's verdict on H in LmProblem::upper (2 | any)
   // n > 64 (the lm_wide_* kernels below; theta and gg are then [batch][n]):
   double *Hw;        // [batch][n][n] the Hessian as evaluated, row-major, both triangles
   const double *Aw;  // [batch][m][n] design matrices in the caller's layout
@@ -1099,13 +1101,20 @@ __global__ __launch_bounds__(THREADS, 4) void lm_wide_chol_step_kernel(LmParams 
 #pragma unroll
   for (int c = 0; c < 16; c++) S[t * 17 + c] = 0.0;  // the first panel's sums
   __syncthreads();
-  bool off = false;  // is_diagonal (:295-307); column t of eight rows in flight
-  for (int i0 = 0; i0 < n; i0 += 8) {
-    double v[8];
+  // is_diagonal (:295-307): the one-pass evaluations leave their verdict on the matrix they publish
+  // (the damping only touches the diagonal); otherwise column t of eight rows in flight
+  bool off = false;
+  const int verdict = p.verdict ? pr->upper : 0;  // wave-uniform
+  if (verdict & 2) {
+    off = (verdict & 1) != 0;
+  } else {
+    for (int i0 = 0; i0 < n; i0 += 8) {
+      double v[8];
 #pragma unroll
-    for (int q = 0; q < 8; q++) v[q] = H[static_cast<uint64_t>(i0 + q < n ? i0 + q : n - 1) * n + tr];
+      for (int q = 0; q < 8; q++) v[q] = H[static_cast<uint64_t>(i0 + q < n ? i0 + q : n - 1) * n + tr];
 #pragma unroll
-    for (int q = 0; q < 8; q++) off |= (i0 + q != t) && (i0 + q < n) && (t < n) && v[q] > 2.220446049250313e-16 * 1e12;
+      for (int q = 0; q < 8; q++) off |= (i0 + q != t) && (i0 + q < n) && (t < n) && v[q] > 2.220446049250313e-16 * 1e12;
+    }
   }
   if (!__syncthreads_or(off)) {  // :310-318
     if (t < n) th[t] = th[t] - g[t] / H[static_cast<uint64_t>(t) * n + t];
@@ -1943,8 +1952,9 @@ __host__ __device__ constexpr int lm_w128_slot(const LmW128Tiles &t, int b) {
   return 0;
 }
 
+// returns: some off-diagonal entry this wave published exceeds is_diagonal's threshold (:295-307)
 template <int W>
-__device__ inline void lm_wide128_run8(const LmParams &p, int first, uint64_t pid, LmWide128Shared &sh,
+__device__ inline bool lm_wide128_run8(const LmParams &p, int first, uint64_t pid, LmWide128Shared &sh,
                                        bool vec) {
   constexpr LmW128Tiles T = lm_w128_tiles(W);
   constexpr int S = kLmW128Stride;
@@ -2044,6 +2054,7 @@ __device__ inline void lm_wide128_run8(const LmParams &p, int first, uint64_t pi
   }
   // ---- publish H = 2 J^T J (both triangles), g = 2 J^T r, f
   double *H = p.Hw + pid * n * n;
+  bool offd = false;
 #pragma unroll
   for (int c = 0; c < T.nt; c++) {
 #pragma unroll
@@ -2053,6 +2064,7 @@ __device__ inline void lm_wide128_run8(const LmParams &p, int first, uint64_t pi
         const double v = 2 * acc[c][rg];
         H[row * n + col] = v;
         if (T.tr[c] != T.tc[c]) H[col * n + row] = v;
+        offd |= row != col && v > 2.220446049250313e-16 * 1e12;
       }
     }
   }
@@ -2072,6 +2084,7 @@ __device__ inline void lm_wide128_run8(const LmParams &p, int first, uint64_t pi
     }
     if (lane == 0) lm_publish_state(p, pr, first, f);
   }
+  return offd;
 }
 
 __global__ __launch_bounds__(512, 4) void lm_wide128x8_tanh_eval_kernel(LmParams p, int first) {
@@ -2079,16 +2092,20 @@ __global__ __launch_bounds__(512, 4) void lm_wide128x8_tanh_eval_kernel(LmParams
   const uint64_t pid = blockIdx.x;
   if (!first && p.prob[pid].done) return;
   const bool vec = (p.n & 1) == 0;
+  bool offd;
   switch (__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6)) {
-    case 0: lm_wide128_run8<0>(p, first, pid, sh, vec); break;
-    case 1: lm_wide128_run8<1>(p, first, pid, sh, vec); break;
-    case 2: lm_wide128_run8<2>(p, first, pid, sh, vec); break;
-    case 3: lm_wide128_run8<3>(p, first, pid, sh, vec); break;
-    case 4: lm_wide128_run8<4>(p, first, pid, sh, vec); break;
-    case 5: lm_wide128_run8<5>(p, first, pid, sh, vec); break;
-    case 6: lm_wide128_run8<6>(p, first, pid, sh, vec); break;
-    default: lm_wide128_run8<7>(p, first, pid, sh, vec); break;
+    case 0: offd = lm_wide128_run8<0>(p, first, pid, sh, vec); break;
+    case 1: offd = lm_wide128_run8<1>(p, first, pid, sh, vec); break;
+    case 2: offd = lm_wide128_run8<2>(p, first, pid, sh, vec); break;
+    case 3: offd = lm_wide128_run8<3>(p, first, pid, sh, vec); break;
+    case 4: offd = lm_wide128_run8<4>(p, first, pid, sh, vec); break;
+    case 5: offd = lm_wide128_run8<5>(p, first, pid, sh, vec); break;
+    case 6: offd = lm_wide128_run8<6>(p, first, pid, sh, vec); break;
+    default: offd = lm_wide128_run8<7>(p, first, pid, sh, vec); break;
   }
+  // is_diagonal's verdict on the matrix just published, for the step (it saves the step a pass over H)
+  const int any = __syncthreads_or(offd);
+  if (threadIdx.x == 0) p.prob[pid].upper = 2 | (any ? 1 : 0);
 }
 
 // ---- 128 < n <= 256 in ONE pass over A too: the 136 lower tiles of the sixteen column blocks fit
@@ -2107,7 +2124,7 @@ struct LmWide256Shared {  // 70 KB: dynamic LDS
 };
 
 template <int W>
-__device__ inline void lm_wide256_run8(const LmParams &p, int first, uint64_t pid, LmWide256Shared &sh,
+__device__ inline bool lm_wide256_run8(const LmParams &p, int first, uint64_t pid, LmWide256Shared &sh,
                                        bool vec) {
   constexpr int S = kLmW256Stride;
   constexpr int RL = 15 - W, NOP = 16 - W;  // the long tile row; operands = column blocks 0 .. RL
@@ -2213,6 +2230,7 @@ __device__ inline void lm_wide256_run8(const LmParams &p, int first, uint64_t pi
   }
   // ---- publish H = 2 J^T J (both triangles), g = 2 J^T r, f
   double *H = p.Hw + pid * n * n;
+  bool offd = false;  // some off-diagonal entry exceeds is_diagonal's threshold (:295-307)
   auto put_tile = [&](int tr, int tc, const v4d &tile) {
 #pragma unroll
     for (int rg = 0; rg < 4; rg++) {
@@ -2221,6 +2239,7 @@ __device__ inline void lm_wide256_run8(const LmParams &p, int first, uint64_t pi
         const double v = 2 * tile[rg];
         H[row * n + col] = v;
         if (tr != tc) H[col * n + row] = v;
+        offd |= row != col && v > 2.220446049250313e-16 * 1e12;
       }
     }
   };
@@ -2245,6 +2264,7 @@ __device__ inline void lm_wide256_run8(const LmParams &p, int first, uint64_t pi
     }
     if (lane == 0) lm_publish_state(p, pr, first, f);
   }
+  return offd;
 }
 
 __global__ __launch_bounds__(512, 2) void lm_wide256x8_tanh_eval_kernel(LmParams p, int first) {
@@ -2253,16 +2273,19 @@ __global__ __launch_bounds__(512, 2) void lm_wide256x8_tanh_eval_kernel(LmParams
   const uint64_t pid = blockIdx.x;
   if (!first && p.prob[pid].done) return;
   const bool vec = (p.n & 1) == 0;
+  bool offd;
   switch (__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6)) {
-    case 0: lm_wide256_run8<0>(p, first, pid, sh, vec); break;
-    case 1: lm_wide256_run8<1>(p, first, pid, sh, vec); break;
-    case 2: lm_wide256_run8<2>(p, first, pid, sh, vec); break;
-    case 3: lm_wide256_run8<3>(p, first, pid, sh, vec); break;
-    case 4: lm_wide256_run8<4>(p, first, pid, sh, vec); break;
-    case 5: lm_wide256_run8<5>(p, first, pid, sh, vec); break;
-    case 6: lm_wide256_run8<6>(p, first, pid, sh, vec); break;
-    default: lm_wide256_run8<7>(p, first, pid, sh, vec); break;
+    case 0: offd = lm_wide256_run8<0>(p, first, pid, sh, vec); break;
+    case 1: offd = lm_wide256_run8<1>(p, first, pid, sh, vec); break;
+    case 2: offd = lm_wide256_run8<2>(p, first, pid, sh, vec); break;
+    case 3: offd = lm_wide256_run8<3>(p, first, pid, sh, vec); break;
+    case 4: offd = lm_wide256_run8<4>(p, first, pid, sh, vec); break;
+    case 5: offd = lm_wide256_run8<5>(p, first, pid, sh, vec); break;
+    case 6: offd = lm_wide256_run8<6>(p, first, pid, sh, vec); break;
+    default: offd = lm_wide256_run8<7>(p, first, pid, sh, vec); break;
   }
+  const int any = __syncthreads_or(offd);  // is_diagonal's verdict, for the step
+  if (threadIdx.x == 0) p.prob[pid].upper = 2 | (any ? 1 : 0);
 }
 
 // ---- 128 < n <= 1024 on the matrix cores. H no longer fits one set of accumulators, so the rows
