@@ -2143,6 +2143,7 @@ __device__ inline bool lm_wide256_run8(const LmParams &p, int first, uint64_t pi
   }
   const uint64_t nstep = (m + 15) / 16;
   const int rr = 2 * W + half;  // the row of a group this lane's half stages
+  const bool long_row = 16 * static_cast<uint64_t>(RL) < n;  // tile row 15 - W has columns below n
   double a[8], yv;
   auto fetch = [&](uint64_t s) {
     const uint64_t i = 16 * s + rr;
@@ -2198,13 +2199,17 @@ __device__ inline bool lm_wide256_run8(const LmParams &p, int first, uint64_t pi
       const double *row = &sh.J[buf][(4 * ks + kk) * S];
       double op[NOP];
 #pragma unroll
-      for (int b = 0; b < NOP; b++) op[b] = row[16 * b + cc];
+      for (int b = 0; b <= W; b++) op[b] = row[16 * b + cc];
       // g: chain kk of column 16 b + cc takes the rows = kk (mod 4) in order
       const double rv = sh.r[buf][4 * ks + kk];
-      gacc[0] = __builtin_fma(op[RL], rv, gacc[0]);
       gacc[1] = __builtin_fma(op[W], rv, gacc[1]);
+      if (long_row) {  // (wave-uniform: a tile row past n is all zeros and stays out of the matrix pipe)
 #pragma unroll
-      for (int c = 0; c <= RL; c++) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[RL], op[c], acc[c], 0, 0, 0);
+        for (int b = W + 1; b < NOP; b++) op[b] = row[16 * b + cc];
+        gacc[0] = __builtin_fma(op[RL], rv, gacc[0]);
+#pragma unroll
+        for (int c = 0; c <= RL; c++) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[RL], op[c], acc[c], 0, 0, 0);
+      }
 #pragma unroll
       for (int c = 0; c <= W; c++)
         acc[RL + 1 + c] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[W], op[c], acc[RL + 1 + c], 0, 0, 0);
