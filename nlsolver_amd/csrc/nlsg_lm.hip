@@ -347,9 +347,8 @@ static int lm_create(const nlsg_lm_config *cfg, const nlsg_custom_objective *cus
   p.down = cfg->down;
   p.f_delta = cfg->f_delta;
   p.fd = fd ? 1 : 0;
-  // the one-pass matrix-core evaluations hand is_diagonal's verdict to the step
-  p.verdict = (wide && !fd && !e->wide_valu &&
-               ((cfg->n <= 128 && e->wide128_waves == 8) || (cfg->n > 128 && cfg->n <= 256 && e->wide256))) ? 1 : 0;
+  // the matrix-core evaluations (but the four-wave A/B form) hand is_diagonal's verdict to the step
+  p.verdict = (wide && !fd && !e->wide_valu && !(cfg->n <= 128 && e->wide128_waves != 8)) ? 1 : 0;
   p.eps_h = std::pow(DBL_EPSILON, 1.0 / 4.0);  // fin_diff_h's step (:1454)
   e->has_data = fd;  // the model is the objective itself
   *out = e;

@@ -2310,7 +2310,7 @@ struct LmWideMfmaShared {
 };
 
 template <int W, bool DIAG>
-__device__ __attribute__((noinline)) void lm_wide_mfma_pass(const LmParams &p, uint64_t pid, LmWideMfmaShared &sh, uint64_t bj,
+__device__ __attribute__((noinline)) bool lm_wide_mfma_pass(const LmParams &p, uint64_t pid, LmWideMfmaShared &sh, uint64_t bj,
                                          uint64_t bk, bool vec) {
   constexpr int S = kLmW128Stride;
   constexpr int R = 7 - W;                  // DIAG: the wave's long tile row (its short one is W)
@@ -2425,6 +2425,7 @@ __device__ __attribute__((noinline)) void lm_wide_mfma_pass(const LmParams &p, u
   }
   // ---- publish the super-block (and its mirror image), and g for the columns of block bj
   double *H = p.Hw + pid * n * n;
+  bool offd = false;  // some off-diagonal entry published here exceeds is_diagonal's threshold (:295-307)
   auto put_tile = [&](uint64_t rb, uint64_t cb, const v4d &tile, bool mirror) {
 #pragma unroll
     for (int rg4 = 0; rg4 < 4; rg4++) {
@@ -2433,6 +2434,7 @@ __device__ __attribute__((noinline)) void lm_wide_mfma_pass(const LmParams &p, u
         const double v = 2 * tile[rg4];
         H[row * n + col] = v;
         if (mirror) H[col * n + row] = v;
+        offd |= row != col && v > 2.220446049250313e-16 * 1e12;
       }
     }
   };
@@ -2461,6 +2463,7 @@ __device__ __attribute__((noinline)) void lm_wide_mfma_pass(const LmParams &p, u
       for (int b = 0; b < 4; b++) put_g(gacc[b], 4 * QJ + b);
     }
   }
+  return offd;
 }
 
 __global__ __launch_bounds__(256, 2) void lm_wide_mfma_tanh_eval_kernel(LmParams p, int first) {
@@ -2532,28 +2535,31 @@ __global__ __launch_bounds__(256, 2) void lm_wide_mfma_tanh_eval_kernel(LmParams
   __syncthreads();  // r and the weights of every row are in place; theta's space is free
   // ---- phase 2: the super-blocks of the lower triangle
   const uint64_t SB = (n + 127) / 128;
+  bool offd = false;
   for (uint64_t bj = 0; bj < SB; bj++)
     for (uint64_t bk = 0; bk <= bj; bk++) {
       if (bj == bk) {
         switch (w) {
-          case 0: lm_wide_mfma_pass<0, true>(p, pid, sh, bj, bk, vec); break;
-          case 1: lm_wide_mfma_pass<1, true>(p, pid, sh, bj, bk, vec); break;
-          case 2: lm_wide_mfma_pass<2, true>(p, pid, sh, bj, bk, vec); break;
-          default: lm_wide_mfma_pass<3, true>(p, pid, sh, bj, bk, vec); break;
+          case 0: offd |= lm_wide_mfma_pass<0, true>(p, pid, sh, bj, bk, vec); break;
+          case 1: offd |= lm_wide_mfma_pass<1, true>(p, pid, sh, bj, bk, vec); break;
+          case 2: offd |= lm_wide_mfma_pass<2, true>(p, pid, sh, bj, bk, vec); break;
+          default: offd |= lm_wide_mfma_pass<3, true>(p, pid, sh, bj, bk, vec); break;
         }
       } else {
         switch (w) {
-          case 0: lm_wide_mfma_pass<0, false>(p, pid, sh, bj, bk, vec); break;
-          case 1: lm_wide_mfma_pass<1, false>(p, pid, sh, bj, bk, vec); break;
-          case 2: lm_wide_mfma_pass<2, false>(p, pid, sh, bj, bk, vec); break;
-          default: lm_wide_mfma_pass<3, false>(p, pid, sh, bj, bk, vec); break;
+          case 0: offd |= lm_wide_mfma_pass<0, false>(p, pid, sh, bj, bk, vec); break;
+          case 1: offd |= lm_wide_mfma_pass<1, false>(p, pid, sh, bj, bk, vec); break;
+          case 2: offd |= lm_wide_mfma_pass<2, false>(p, pid, sh, bj, bk, vec); break;
+          default: offd |= lm_wide_mfma_pass<3, false>(p, pid, sh, bj, bk, vec); break;
         }
       }
     }
+  const int any = __syncthreads_or(offd);  // is_diagonal's verdict on the published matrix, for the step
   if (t == 0) {
     double f = 0.0;
     for (int k = 0; k < 8; k++) f = f + sh.part[k];
     lm_publish_state(p, pr, first, f);
+    pr->upper = 2 | (any ? 1 : 0);
   }
 }
 
