@@ -192,3 +192,26 @@ def test_lm_wide_blocked_step_every_width(mod, oracle):
             th, st, lam = eng.minimize(t0.copy())
         ref, xr, lam_r, _ = O.lm_solve(oracle, A[0], y[0], t0[0], order=1, **kw)
         check(st[0], ref, th[0], xr, lam[0], lam_r, (m, n))
+
+
+@pytest.mark.parametrize("n", [70, 130, 300])
+def test_lm_wide_diagonal_hessian_takes_the_shortcut_on_the_evaluations_verdict(mod, oracle, n):
+    """Design matrices with one non-zero per row make J^T J diagonal: get_update_with_hessian's
+    shortcut (nlsolver.h:310-318) must fire, and past 64 parameters it does so on the verdict the
+    evaluation kernel leaves for the step (one-pass kernels up to 256, super-blocks beyond) — as in
+    the oracle; a second problem of the batch keeps a dense matrix, so both branches run side by side."""
+    m, kw = 2 * n, dict(lam=2.0, max_iter=4, f_delta=0.0)
+    A, y, t0 = problems(oracle, 900 + n, 2, m, n)
+    rng = np.random.default_rng(n)
+    D = np.zeros((m, n))
+    D[np.arange(m), np.arange(m) % n] = 0.5 + rng.random(m)
+    A[0] = D
+    y[0] = np.tanh(D @ (0.3 * (2 * rng.random(n) - 1)))
+    with mod.LMEngine(mod.TanhRegression(A, y), **kw) as eng:
+        th, st, lam = eng.minimize(t0.copy())
+    for b in range(2):
+        ref, xr, lam_r, _ = O.lm_solve(oracle, A[b], y[b], t0[b], order=1, **kw)
+        check(st[b], ref, th[b], xr, lam[b], lam_r, (n, b))
+    # the diagonal problem really is one: a dense solve would have mixed the coordinates
+    H = 2 * (A[0].T @ A[0])
+    assert np.count_nonzero(H - np.diag(np.diag(H))) == 0
