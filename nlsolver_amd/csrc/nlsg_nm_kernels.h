@@ -410,11 +410,15 @@ constexpr int kNmCmdShrink = 1, kNmCmdEnd = 2;
 // is bound by vector issue: n objective evaluations of ~60 instructions each per shrink).
 // VEC: n even — a lane's pair is 16-byte aligned in every row: one 128-bit LDS access each way
 template <int OBJ, bool VEC>
-__device__ inline void nm_shrink_rows_impl(double *S, double *scores, uint64_t n, uint64_t nv, uint64_t best,
-                                           double sigma, double fmul, int wid, uint64_t nwaves) {
+__device__ inline void nm_shrink_rows_impl(double *S, double *scores, uint64_t n64, uint64_t nv64, uint64_t best64,
+                                           double sigma, double fmul, int wid, uint64_t nwaves64) {
   using O = Objective<OBJ>;
   const int lane = lane_id();
-  const uint64_t e0 = 2 * static_cast<uint64_t>(lane);
+  // 32-bit indices (n <= 1024: a row offset fits easily): 64-bit products and compares for every
+  // row were a third of this loop's scalar instructions
+  const uint32_t n = static_cast<uint32_t>(n64), nv = static_cast<uint32_t>(nv64);
+  const uint32_t best = static_cast<uint32_t>(best64), nwaves = static_cast<uint32_t>(nwaves64);
+  const uint32_t e0 = 2 * static_cast<uint32_t>(lane);
   const bool in0 = e0 < n, in1 = e0 + 1 < n;
   auto load_pair = [&](const double *row, double (&v)[1][2]) {
     if constexpr (VEC) {
@@ -437,10 +441,10 @@ __device__ inline void nm_shrink_rows_impl(double *S, double *scores, uint64_t n
   load_pair(S + best * n, bv);
   // a tail of at most one row per wave (n = 128: row 128 of 129) is not worth a pass of four on
   // the wave that would get it: those rows go one each to the LAST waves, scored on their own
-  const uint64_t full = nv / (4 * nwaves) * (4 * nwaves);
-  const uint64_t tail = nv - full <= nwaves ? nv - full : 0;
-  if (tail && static_cast<uint64_t>(wid) + tail >= nwaves) {
-    const uint64_t v = full + (nwaves - 1 - static_cast<uint64_t>(wid));
+  const uint32_t full = nv / (4 * nwaves) * (4 * nwaves);
+  const uint32_t tail = nv - full <= nwaves ? nv - full : 0;
+  if (tail && static_cast<uint32_t>(wid) + tail >= nwaves) {
+    const uint32_t v = full + (nwaves - 1 - static_cast<uint32_t>(wid));
     if (v != best) {
       double *row = S + v * n;
       double ov[1][2];
@@ -449,18 +453,17 @@ __device__ inline void nm_shrink_rows_impl(double *S, double *scores, uint64_t n
       pt[0][0] = bv[0][0] + sigma * (ov[0][0] - bv[0][0]);
       pt[0][1] = bv[0][1] + sigma * (ov[0][1] - bv[0][1]);
       store_pair(row, pt[0][0], pt[0][1]);
-      if (!in0) pt[0][0] = 0.0;
-      if (!in1) pt[0][1] = 0.0;
+      // (coordinates past n are zero in both loaded points, so their transform is +0 already)
       const double fv = fmul * wave_objective<OBJ, 1>(pt, n);
       if (lane == 0) scores[v] = fv;
     }
   }
-  const uint64_t end = tail ? full : nv;
-  for (uint64_t v0 = wid; v0 < end; v0 += 4 * nwaves) {
+  const uint32_t end = tail ? full : nv;
+  for (uint32_t v0 = static_cast<uint32_t>(wid); v0 < end; v0 += 4 * nwaves) {
     double xv[4][2];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      const uint64_t v = v0 + nwaves * q;
+      const uint32_t v = v0 + nwaves * static_cast<uint32_t>(q);
       const bool live = v < end && v != best;
       double *row = S + (live ? v : best) * n;
       double ov[1][2];
@@ -468,8 +471,6 @@ __device__ inline void nm_shrink_rows_impl(double *S, double *scores, uint64_t n
       xv[q][0] = bv[0][0] + sigma * (ov[0][0] - bv[0][0]);
       xv[q][1] = bv[0][1] + sigma * (ov[0][1] - bv[0][1]);
       if (live) store_pair(row, xv[q][0], xv[q][1]);
-      if (!in0) xv[q][0] = 0.0;
-      if (!in1) xv[q][1] = 0.0;
     }
     double f;
     if constexpr (O::kWhole) {  // a whole-vector user objective reduces inside its own body
@@ -488,7 +489,7 @@ __device__ inline void nm_shrink_rows_impl(double *S, double *scores, uint64_t n
       f = fmul * O::finish(wave_sum4(part[0], part[1], part[2], part[3]), n);
     }
     // lanes 16 q .. 16 q + 15 hold row q's value
-    const uint64_t v = v0 + nwaves * static_cast<uint64_t>(lane >> 4);
+    const uint32_t v = v0 + nwaves * static_cast<uint32_t>(lane >> 4);
     if ((lane & 15) == 0 && v < end && v != best) scores[v] = f;
   }
 }
