@@ -696,10 +696,12 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_driver_kernel(NmParams p)
           auto run = [&](auto vec, uint32_t lo_v, uint32_t hi_v) {
             constexpr bool VEC = decltype(vec)::value != 0;
             uint32_t v = lo_v, base = lo_v * n32 + off0;
-            for (; v + 16 <= hi_v; v += 16, base += 16 * n32) {
-              double q0[16], q1[16];
+            // C consecutive vertices: their reads in flight together, then their additions in order
+            auto block = [&](auto count) {
+              constexpr int C = decltype(count)::value;
+              double q0[C], q1[C];
 #pragma unroll
-              for (int u = 0; u < 16; u++) {
+              for (int u = 0; u < C; u++) {
                 if constexpr (VEC) {
                   const double2 pr = *reinterpret_cast<const double2 *>(S + base + static_cast<uint32_t>(u) * n32);
                   q0[u] = pr.x;
@@ -710,15 +712,21 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_driver_kernel(NmParams p)
                 }
               }
 #pragma unroll
-              for (int u = 0; u < 16; u++) {
+              for (int u = 0; u < C; u++) {
                 a0 += q0[u];
                 a1 += q1[u];
               }
-            }
-            for (; v < hi_v; v++, base += n32) {
-              a0 += S[base];
-              a1 += S[base + 1];
-            }
+              v += C;
+              base += C * n32;
+            };
+            while (v + 16 <= hi_v) block(int_c<16>{});
+            // the rest of the run in blocks of 8, 4, 2, 1 by the bits of its length (a tail walked
+            // vertex by vertex paid an LDS round trip per vertex)
+            const uint32_t rest = hi_v - v;
+            if (rest & 8) block(int_c<8>{});
+            if (rest & 4) block(int_c<4>{});
+            if (rest & 2) block(int_c<2>{});
+            if (rest & 1) block(int_c<1>{});
           };
           const uint32_t w32 = static_cast<uint32_t>(worst), nv32c = static_cast<uint32_t>(nv);
           if ((n32 & 1) == 0) {
