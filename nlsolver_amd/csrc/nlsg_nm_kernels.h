@@ -693,9 +693,13 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_driver_kernel(NmParams p)
           const uint32_t n32 = static_cast<uint32_t>(n);
           const uint32_t off0 = in0 ? static_cast<uint32_t>(e0) : 0u;
           double a0 = 0.0, a1 = 0.0;
-          auto run = [&](auto vec, uint32_t lo_v, uint32_t hi_v) {
+          // STRIDE: the row length when it is known at compile time (128, 64: the offsets of a
+          // block's reads are then immediates of the instructions), 0: n32
+          auto run = [&](auto vec, auto stride, uint32_t lo_v, uint32_t hi_v) {
             constexpr bool VEC = decltype(vec)::value != 0;
-            uint32_t v = lo_v, base = lo_v * n32 + off0;
+            constexpr uint32_t STRIDE = decltype(stride)::value;
+            const uint32_t rs = STRIDE ? STRIDE : n32;
+            uint32_t v = lo_v, base = lo_v * rs + off0;
             // C consecutive vertices: their reads in flight together, then their additions in order
             auto block = [&](auto count) {
               constexpr int C = decltype(count)::value;
@@ -703,12 +707,12 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_driver_kernel(NmParams p)
 #pragma unroll
               for (int u = 0; u < C; u++) {
                 if constexpr (VEC) {
-                  const double2 pr = *reinterpret_cast<const double2 *>(S + base + static_cast<uint32_t>(u) * n32);
+                  const double2 pr = *reinterpret_cast<const double2 *>(S + base + static_cast<uint32_t>(u) * rs);
                   q0[u] = pr.x;
                   q1[u] = pr.y;
                 } else {
-                  q0[u] = S[base + static_cast<uint32_t>(u) * n32];
-                  q1[u] = S[base + static_cast<uint32_t>(u) * n32 + 1];
+                  q0[u] = S[base + static_cast<uint32_t>(u) * rs];
+                  q1[u] = S[base + static_cast<uint32_t>(u) * rs + 1];
                 }
               }
 #pragma unroll
@@ -717,7 +721,7 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_driver_kernel(NmParams p)
                 a1 += q1[u];
               }
               v += C;
-              base += C * n32;
+              base += C * rs;
             };
             while (v + 16 <= hi_v) block(int_c<16>{});
             // the rest of the run in blocks of 8, 4, 2, 1 by the bits of its length (a tail walked
@@ -729,12 +733,18 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_driver_kernel(NmParams p)
             if (rest & 1) block(int_c<1>{});
           };
           const uint32_t w32 = static_cast<uint32_t>(worst), nv32c = static_cast<uint32_t>(nv);
-          if ((n32 & 1) == 0) {
-            run(int_c<1>{}, 0, w32);
-            run(int_c<1>{}, w32 + 1, nv32c);
+          if (n32 == 128) {
+            run(int_c<1>{}, int_c<128>{}, 0, w32);
+            run(int_c<1>{}, int_c<128>{}, w32 + 1, nv32c);
+          } else if (n32 == 64) {
+            run(int_c<1>{}, int_c<64>{}, 0, w32);
+            run(int_c<1>{}, int_c<64>{}, w32 + 1, nv32c);
+          } else if ((n32 & 1) == 0) {
+            run(int_c<1>{}, int_c<0>{}, 0, w32);
+            run(int_c<1>{}, int_c<0>{}, w32 + 1, nv32c);
           } else {
-            run(int_c<0>{}, 0, w32);
-            run(int_c<0>{}, w32 + 1, nv32c);
+            run(int_c<0>{}, int_c<0>{}, 0, w32);
+            run(int_c<0>{}, int_c<0>{}, w32 + 1, nv32c);
           }
           c0 = a0 / static_cast<double>(nv - 1);
           c1 = a1 / static_cast<double>(nv - 1);
