@@ -409,17 +409,19 @@ constexpr int kNmCmdShrink = 1, kNmCmdEnd = 2;
 // together (wave_sum4: the butterflies' own pairs, a third of their instructions — the rescoring
 // is bound by vector issue: n objective evaluations of ~60 instructions each per shrink).
 // VEC: n even — a lane's pair is 16-byte aligned in every row: one 128-bit LDS access each way
-template <int OBJ, bool VEC>
+// FULL: n = 128 — every lane holds two coordinates and the row length is a compile-time constant
+// (no masks on the loads, the objective's own lane tests fold away)
+template <int OBJ, bool VEC, bool FULL = false>
 __device__ inline void nm_shrink_rows_impl(double *S, double *scores, uint64_t n64, uint64_t nv64, uint64_t best64,
                                            double sigma, double fmul, int wid, uint64_t nwaves64) {
   using O = Objective<OBJ>;
   const int lane = lane_id();
   // 32-bit indices (n <= 1024: a row offset fits easily): 64-bit products and compares for every
   // row were a third of this loop's scalar instructions
-  const uint32_t n = static_cast<uint32_t>(n64), nv = static_cast<uint32_t>(nv64);
+  const uint32_t n = FULL ? 128u : static_cast<uint32_t>(n64), nv = FULL ? 129u : static_cast<uint32_t>(nv64);
   const uint32_t best = static_cast<uint32_t>(best64), nwaves = static_cast<uint32_t>(nwaves64);
   const uint32_t e0 = 2 * static_cast<uint32_t>(lane);
-  const bool in0 = e0 < n, in1 = e0 + 1 < n;
+  const bool in0 = FULL || e0 < n, in1 = FULL || e0 + 1 < n;
   auto load_pair = [&](const double *row, double (&v)[1][2]) {
     if constexpr (VEC) {
       const double2 q = *reinterpret_cast<const double2 *>(row + (in0 ? e0 : 0));
@@ -496,7 +498,9 @@ __device__ inline void nm_shrink_rows_impl(double *S, double *scores, uint64_t n
 template <int OBJ>
 __device__ inline void nm_shrink_rows(double *S, double *scores, uint64_t n, uint64_t nv, uint64_t best,
                                       double sigma, double fmul, int wid, uint64_t nwaves) {
-  if ((n & 1) == 0)
+  if (n == 128)
+    nm_shrink_rows_impl<OBJ, true, true>(S, scores, n, nv, best, sigma, fmul, wid, nwaves);
+  else if ((n & 1) == 0)
     nm_shrink_rows_impl<OBJ, true>(S, scores, n, nv, best, sigma, fmul, wid, nwaves);
   else
     nm_shrink_rows_impl<OBJ, false>(S, scores, n, nv, best, sigma, fmul, wid, nwaves);
