@@ -633,8 +633,8 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_driver_kernel(NmParams p)
             const double si = scores[i];
             sc[q] = si;
             acc = acc + si;
-            mnv = si < mnv ? si : mnv;
-            mxv = si > mxv ? si : mxv;
+            mnv = __builtin_fmin(mnv, si);  // (one instruction; a NaN never wins, as in the compare-and-keep form)
+            mxv = __builtin_fmax(mxv, si);
           }
         }
         butterfly_levels<32>([&](auto off) {
@@ -642,8 +642,8 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_driver_kernel(NmParams p)
           const double oa = lane_xor<o>(acc);
           const double omn = lane_xor<o>(mnv), omx = lane_xor<o>(mxv);
           acc = acc + oa;
-          mnv = omn < mnv ? omn : mnv;
-          mxv = omx > mxv ? omx : mxv;
+          mnv = __builtin_fmin(mnv, omn);
+          mxv = __builtin_fmax(mxv, omx);
         });
         const double mean = acc / static_cast<double>(nv);
         const bool frozen = isnan(scores[0]);
@@ -657,7 +657,7 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_driver_kernel(NmParams p)
           if (i < nv32) {
             const double d = sc[q] - mean;
             acc = acc + d * d;
-            if (i < worst_i) sv = sc[q] > sv ? sc[q] : sv;
+            if (i < worst_i) sv = __builtin_fmax(sv, sc[q]);
           }
         }
         butterfly_levels<32>([&](auto off) {
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_driver_kernel(NmParams p)
           const double oa = lane_xor<o>(acc);
           const double osv = lane_xor<o>(sv);
           acc = acc + oa;
-          sv = osv > sv ? osv : sv;
+          sv = __builtin_fmax(sv, osv);
         });
         const uint32_t svi = first_holder(sv, sc, worst_i);
         const double se = sqrt(acc / static_cast<double>(nv - 1));
