@@ -582,8 +582,10 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_driver_kernel(NmParams p)
       // ---- the driver wave. Everything below is wave-uniform except the coordinates.
       double eps = ctl->eps;
       eps = eps * (scores[0] * eps);  // 2189 (B2)
-      uint64_t fcalls = ctl->fcalls + nv, iter = 0, worst = 0, prev_worst = 0, best = 0, second = 0;
-      uint64_t last_best = 99999999, no_change = 0;
+      uint64_t fcalls = ctl->fcalls + nv, iter = 0, no_change = 0;
+      // (vertex indices in 32 bits: the lone driver wave pays an issue slot for every scalar
+      // instruction of a 64-bit product or compare as well)
+      uint32_t worst = 0, prev_worst = 0, best = 0, second = 0, last_best = 99999999u;
       int shrunk = 0;
       double c0 = 0.0, c1 = 0.0;  // the centroid, zeroed at :2195
       unsigned long long tk = p.phase ? __builtin_readcyclecounter() : 0;
@@ -674,9 +676,9 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_driver_kernel(NmParams p)
         worst = worst_i;
         second = (svi == ~0u) ? 0 : svi;
         // the butterflies leave the same bits in every lane: make that visible to the compiler
-        best = static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(best)));
-        worst = static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(worst)));
-        second = static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(second)));
+        best = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(best)));
+        worst = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(worst)));
+        second = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(second)));
         if (last_best == best) {  // 2223-2230
           no_change++;
         } else {
@@ -755,7 +757,7 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_driver_kernel(NmParams p)
         }
         lap(1);
         // ---- reflect (2245): c + alpha (c - p), clamped when bounded
-        double *wrow = S + worst * n;
+        double *wrow = S + worst * static_cast<uint32_t>(n);
         const double w0 = in0 ? wrow[e0] : 0.0, w1 = in1 ? wrow[e1] : 0.0;
         double r0 = c0 + p.alpha * (c0 - w0), r1 = c1 + p.alpha * (c1 - w1);
         if (p.bounded) clamp2(r0, r1);
