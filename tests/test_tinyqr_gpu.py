@@ -51,7 +51,7 @@ def test_reference_systems_on_the_device(tq, oracle, golden, n, p, seed):
 
 @pytest.mark.parametrize("n,p,batch", [(576, 64, 24), (64, 64, 40), (65, 64, 7), (130, 63, 9),
                                        (1000, 3, 33), (2, 1, 5), (1, 1, 3), (7, 7, 11), (33, 32, 6),
-                                       (300, 17, 13), (129, 2, 4), (200, 62, 5), (64, 33, 4), (9, 8, 3)])
+                                       (300, 17, 13), (129, 2, 4), (200, 62, 5), (64, 33, 4), (9, 8, 3), (40, 9, 3), (100, 31, 2), (8, 8, 2)])
 def test_random_batches_bit_exact(tq, oracle, n, p, batch):
     """Batches of random systems incl. the augmented damped system of configs[3] (576 x 64), square
     ones, one column, one row: every system equals the order-1 oracle bit for bit, the literal
