@@ -19,7 +19,7 @@ run() {  # tag, bench args...
     python3 "$root/bench.py" "$@" > "$out/${tag}_bench.json" 2> "$out/${tag}_bench.err" || return 1
   cp "$(find "$out/${tag}_stats" -name '*kernel_stats.csv' | head -1)" "$out/${tag}_kernel_stats.csv"
   for ctr in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$out/${tag}_$ctr" -o "$tag" -- \
+    NLSG_BENCH_NO_CONSISTENCY_CHECK=1 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$out/${tag}_$ctr" -o "$tag" -- \
       python3 "$root/bench.py" "$@" --steps 20 --warmup 2 --no-cpu-baseline --no-north-star --no-other-configs \
       > /dev/null 2> "$out/${tag}_$ctr.err" || return 1
     # keep only the counter csv (the traces are large)
