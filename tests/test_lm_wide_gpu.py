@@ -130,7 +130,7 @@ def test_lm_wide_diagonal_shortcut_and_limits(mod, oracle):
 @pytest.mark.parametrize("m,n,batch", [(512, 128, 4), (33, 127, 2), (16, 65, 2), (100, 101, 3), (257, 112, 2),
                                        (64, 96, 2), (1, 66, 2),
                                        (200, 129, 2), (130, 257, 2), (96, 400, 1), (300, 256, 2), (50, 513, 1),
-                                       (40, 144, 2), (64, 700, 1), (24, 1024, 1), (30, 1009, 1)])
+                                       (40, 144, 2), (64, 700, 1), (24, 1024, 1), (30, 1009, 1), (10, 150, 2), (1, 200, 1), (17, 255, 2)])
 def test_lm_wide_matrix_core_kernel_bit_exact(mod, oracle, monkeypatch, m, n, batch):
     """n > 64 with J^T J on the matrix cores — the one-pass kernel up to 128 parameters
     (lm_wide128x8_tanh_eval_kernel), up to 256 (lm_wide256x8_tanh_eval_kernel), the super-block
