@@ -941,6 +941,8 @@ def other_configs_pass():
              ["--workload", "lm", "--lm-n", "128"]),
             ("configs[3]'s solver as a surface of its own: tinyqr::lm on 8192 systems of 576 x 64 (SURVEY "
              "row a25; latency-bound, not roofline-graded)", ["--workload", "tinyqr", "--steps", "2"]),
+            ("north_star's NelderMead simplex reflect / expand / contract: Rosenbrock-128D, 4096 starts x "
+             "2000 iterations (SURVEY rows a16-a17; latency-bound, not roofline-graded)", ["--workload", "nm"]),
             ("configs[4] PSO Accelerated, one GPU's shard 131072 x 256",
              ["--workload", "pso-accel", "--steps", "100", "--warmup", "300"]),
             ("configs[4] PSO Vanilla, one GPU's shard 131072 x 256",

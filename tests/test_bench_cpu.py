@@ -46,7 +46,7 @@ def test_other_configs_pass_summarises_children_and_survives_failures(monkeypatc
         assert e["other_solver"] == {"solver": "qr", "value": 1.0, "ms_per_step": 2.0}
         # every entry states whether its dominant kernel fits into its step (0.1 <= 0.4 here)
         assert e["kernel_within_step"] is True and e["solver"] == "qr" and e["whole_run"] == {"value": 3.0}
-    assert all(e["config"].startswith("configs[") for e in out)
+    assert all(e["config"].startswith(("configs[", "north_star")) for e in out)
     # BASELINE words configs[3] with the tinyqr solve: that solver is an entry of its own, and it
     # comes before the Cholesky one
     lm = [c for c in calls if "lm" in c and "--lm-n" not in c]
