@@ -792,6 +792,111 @@ def main_nm(args):
     eng.close()
     ranks.close()
 
+TTS_BIN = os.path.join(ROOT, "tests", "cpp", "bin", "tts")
+
+
+def tts_device(argv, timeout=600):
+    """One case through the drop-in header in a FRESH process (so `cold` is a process's first
+    device call): tests/cpp/tts.cpp -> include/nlsolver_mi/nlsolver.h -> dlopen -> C-ABI."""
+    env = dict(os.environ, NLSG_LIBRARY=os.path.join(ROOT, "nlsolver_amd", "libnlsolver_hip.so"))
+    r = subprocess.run([TTS_BIN, *map(str, argv)], capture_output=True, text=True, env=env,
+                       timeout=timeout)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not line:
+        raise RuntimeError(f"tts {argv}: rc={r.returncode} {r.stdout.strip()[-200:]} {r.stderr.strip()[-200:]}")
+    return json.loads(line[-1])
+
+
+def tts_reference(argv, scale=1.0):
+    """The unmodified reference solving the same problem on one core (oracle/_ref/ref_driver
+    tts-*), or a bounded sample of the batch scaled up (`scale`); None without the binary."""
+    drv = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    if not os.path.exists(drv):
+        return None
+    r = json.loads(subprocess.check_output([drv, *map(str, argv)], text=True))
+    r["ms"] = r["seconds"] * 1e3 * scale
+    r["scaled_by"] = scale
+    return r
+
+
+def main_tts(args):
+    """Time-to-solution through the drop-in header ("honest end-to-end minimize()
+    latency, not only kernel throughput"; the reference's loop nlsolver.h:2429-2447).
+
+    Every case: `Solver<device objective, ...>(f, gen, ctor defaults).minimize(x)` to its DEFAULT
+    stop rule, cold (first device call of a process) and warm (the same call again), with the
+    library's phase laps; beside it the reference itself on one core solving the same problem to
+    the same stop rule. `value` = warm wall time of BASELINE configs[1]'s shape (pop 65536 x D 128);
+    the table's point is the break-even: below which pop x D the host path is the faster one."""
+    grid = [(2, 40), (2, 4096), (2, 65536), (128, 40), (128, 4096), (128, 65536)]
+    if args.tts_grid:
+        grid = [(Dd, n) for Dd in (2, 16, 128) for n in (40, 256, 1024, 4096, 16384, 65536)]
+    cases = []
+    for Dd, n in grid:
+        x0 = "5,7" if Dd == 2 else "4.096"
+        dev = tts_device(["de", Dd, n])
+        ref = None if args.no_cpu_baseline else tts_reference(
+            ["tts-de", Dd, n, 1000, 10e-4, 50, x0])
+        cases.append({"solver": "DE<device::Rosenbrock, xorshift, double, random>", "D": Dd, "pop": n,
+                      "cold": dev["cold"], "warm": dev["warm"],
+                      "reference_1core_ms": ref and ref["ms"], "reference_iters": ref and ref["iters"],
+                      "warm_speedup": ref and ref["ms"] / dev["warm"]["wall_ms"]})
+    pso = []
+    for Dd, n in ([(2, 40), (128, 4096), (128, 65536)] if not args.tts_grid else
+                  [(Dd, n) for Dd in (2, 16, 128) for n in (40, 1024, 16384, 65536)]):
+        dev = tts_device(["pso", Dd, n])
+        ref = None if args.no_cpu_baseline else tts_reference(
+            ["tts-pso", Dd, n, 5000, 10e-4, 50, "2.048"])
+        pso.append({"solver": "PSO<device::Rosenbrock, xorshift, double, Accelerated>", "D": Dd,
+                    "particles": n, "cold": dev["cold"], "warm": dev["warm"],
+                    "reference_1core_ms": ref and ref["ms"], "reference_iters": ref and ref["iters"],
+                    "warm_speedup": ref and ref["ms"] / dev["warm"]["wall_ms"]})
+    batch = []
+    dev = tts_device(["bfgs", 1024, 4096])
+    sample = 4
+    ref = None if args.no_cpu_baseline else tts_reference(["tts-bfgs", 1024, sample, 100, 5e-3],
+                                                          4096 / sample)
+    batch.append({"solver": "BFGS<device::QuadDiagRank1>::minimize_batch (configs[2]: n 1024 x 4096 "
+                            "starts, defaults max_iter 100 grad_eps 5e-3)",
+                  "cold": dev["cold"], "warm": dev["warm"], "reference_1core_ms": ref and ref["ms"],
+                  "reference_sample": f"{sample} of 4096 problems, scaled",
+                  "warm_speedup": ref and ref["ms"] / dev["warm"]["wall_ms"]})
+    dev = tts_device(["lm", 512, 64, 8192])
+    sample = 16
+    ref = None if args.no_cpu_baseline else tts_reference(["tts-lm", 512, 64, sample, 100, 1e-12],
+                                                          8192 / sample)
+    batch.append({"solver": "LevenbergMarquardt<device::TanhRegression>::minimize_batch (configs[3]: "
+                            "m 512 n 64 x 8192 problems, defaults max_iter 100 f_delta 1e-12)",
+                  "cold": dev["cold"], "warm": dev["warm"], "reference_1core_ms": ref and ref["ms"],
+                  "reference_sample": f"{sample} of 8192 problems, scaled",
+                  "warm_speedup": ref and ref["ms"] / dev["warm"]["wall_ms"]})
+    head = next(c for c in cases if c["D"] == 128 and c["pop"] == 65536)
+    # break-even: the smallest population per D at which the warm device call beats the reference
+    breakeven = {}
+    for c in cases:
+        if c["warm_speedup"] and c["warm_speedup"] >= 1.0:
+            key = f"D={c['D']}"
+            breakeven[key] = min(breakeven.get(key, c["pop"]), c["pop"])
+    print(json.dumps({
+        "metric": "time-to-solution of minimize() through the drop-in header, default stop rule",
+        "value": head["warm"]["wall_ms"], "unit": "ms", "n_gpus": 1, "steps": 1, "warmup": 1,
+        "ms_per_step": head["warm"]["wall_ms"], "higher_is_better": False, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "DE Rosenbrock-128D pop=65536 to the default stop (value); table: DE "
+                               "pop {40, 4096, 65536} x D {2, 128}, Accelerated PSO, BFGS configs[2], "
+                               "LM configs[3] — each cold (first device call of a process) and warm",
+                   "phases": "create / upload / init / iterate / readback / destroy = host wall-clock "
+                             "laps inside the library (nlsg_call_timing); wall_ms = the whole call",
+                   "break_even_pop": breakeven},
+        "cases": cases, "pso_cases": pso, "batch_cases": batch,
+        "roofline": {"bound": "latency", "achieved": None, "peak": None, "unit": None, "frac": None,
+                     "traffic": None, "kernel": None,
+                     "note": "an end-to-end latency line, not a kernel line"},
+        **({} if args.no_cpu_baseline else {"cpu_baseline": {
+            "value": head["reference_1core_ms"], "unit": "ms", "cores": 1, "kind": "reference",
+            "sample": "the reference's DE<random> solving the same problem to the same stop rule "
+                      "(oracle/_ref/ref_driver tts-de 128 65536)"}})}))
+
 
 def rehearsal_device(local_rank):
     """NLSG_BENCH_REHEARSAL=1: every rank uses GPU 0 and the ranks talk over gloo — the N > 1
@@ -1004,11 +1109,15 @@ def main():
     ap.add_argument("--bfgs-symmetric", action="store_true",
                     help="bfgs workload: the symmetric restatement of the rank-2 update (streams "
                          "the upper blocks of H only) instead of the reference's literal one")
-    ap.add_argument("--workload", choices=["de", "pso-accel", "pso-vanilla", "bfgs", "bfgs-fd", "lm", "lm-fd", "nm", "sann", "nmpso", "tinyqr"],
+    ap.add_argument("--workload", choices=["de", "pso-accel", "pso-vanilla", "bfgs", "bfgs-fd", "lm", "lm-fd", "nm", "sann", "nmpso", "tinyqr", "tts"],
                     default="de",
                     help="de = the headline benchmark (BASELINE metric); pso-* = config 5's "
                          "per-GPU shard (secondary, same JSON shape)")
+    ap.add_argument("--tts-grid", action="store_true",
+                    help="tts workload: the full pop x D grid instead of the six DE cases")
     args = ap.parse_args()
+    if args.workload == "tts":
+        return main_tts(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args)  # before torch is imported or a GPU is touched
     if args.workload == "bfgs":

@@ -94,6 +94,12 @@ const char *nlsg_last_error(void);
 int nlsg_abi_version(void);
 /* Number of visible HIP devices whose arch is gfx950 (0 if none / no runtime). */
 int nlsg_device_count(void);
+/* Host wall-clock (ms) of the calling thread's most recent DE / PSO / BFGS / LM calls:
+ * ms_out6 = {create, upload (nlsg_lm_set_data), init, iterate, read-back, destroy}. The last four
+ * are the phases of nlsg_*_minimize — the reference's minimize() (nlsolver.h:2404, 2553, 3188,
+ * 3457) is one call; this is where its time goes once the loops run on the device. Host-side laps
+ * without extra synchronisation (bench.py --workload tts reports them). */
+int nlsg_call_timing(double *ms_out6);
 
 /* The device's deterministic math primitives (the log / cos of rnorm nlsolver.h:2479-2485, the
  * exp / tanh of the NLLS model, the cosine of Rastrigin test_functions.h:74-76) evaluated on n

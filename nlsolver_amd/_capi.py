@@ -118,6 +118,7 @@ SYMBOLS = {
     "nlsg_last_error": (C.c_char_p, []),
     "nlsg_abi_version": (C.c_int, []),
     "nlsg_device_count": (C.c_int, []),
+    "nlsg_call_timing": (C.c_int, [pd]),
     "nlsg_probe_math": (C.c_int, [C.c_int32, pu, pu, u64, C.c_int32]),
     "nlsg_de_create": (C.c_int, [C.POINTER(DEConfig), C.POINTER(_H)]),
     "nlsg_de_destroy": (C.c_int, [_H]),

@@ -134,7 +134,10 @@ int nlsg_bfgs_create(const nlsg_bfgs_config *cfg, const double *diag_host, const
                      nlsg_bfgs **out) {
   if (cfg && cfg->objective == NLSG_OBJ_CUSTOM)
     return fail(NLSG_ERR_INVALID_ARG, "NLSG_OBJ_CUSTOM engines are made by nlsg_bfgs_create_custom");
-  return bfgs_create(cfg, diag_host, lin_host, nullptr, out);
+  PhaseClock clk;
+  const int rc = bfgs_create(cfg, diag_host, lin_host, nullptr, out);
+  call_timing().create_ms = clk.lap();
+  return rc;
 }
 
 int nlsg_bfgs_create_custom(const nlsg_bfgs_config *cfg, const nlsg_custom_objective *obj,
@@ -142,7 +145,10 @@ int nlsg_bfgs_create_custom(const nlsg_bfgs_config *cfg, const nlsg_custom_objec
   if (!cfg || !obj) return fail(NLSG_ERR_INVALID_ARG, "null argument");
   if (cfg->objective != NLSG_OBJ_CUSTOM)
     return fail(NLSG_ERR_INVALID_ARG, "cfg.objective must be NLSG_OBJ_CUSTOM");
-  return bfgs_create(cfg, nullptr, nullptr, obj, out);
+  PhaseClock clk;
+  const int rc = bfgs_create(cfg, nullptr, nullptr, obj, out);
+  call_timing().create_ms = clk.lap();
+  return rc;
 }
 
 static int bfgs_create(const nlsg_bfgs_config *cfg, const double *diag_host, const double *lin_host,
@@ -269,6 +275,7 @@ static int bfgs_create(const nlsg_bfgs_config *cfg, const double *diag_host, con
 
 int nlsg_bfgs_destroy(nlsg_bfgs *e) {
   if (!e) return NLSG_OK;
+  PhaseClock clk;
   hipSetDevice(e->cfg.device);
   if (e->stream) hipStreamSynchronize(e->stream);
   hipFree(e->p.H);
@@ -290,6 +297,7 @@ int nlsg_bfgs_destroy(nlsg_bfgs *e) {
     if (ev) hipEventDestroy(ev);
   if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
   delete e;
+  call_timing().destroy_ms = clk.lap();
   return NLSG_OK;
 }
 
@@ -405,8 +413,10 @@ int nlsg_bfgs_download_state(nlsg_bfgs *e, double *g_host, double *h_host) {
 
 int nlsg_bfgs_minimize(nlsg_bfgs *e, double *x_inout_host, nlsg_status *status_host) {
   if (!e || !x_inout_host) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  PhaseClock clk;
   int rc = nlsg_bfgs_init(e, x_inout_host);
   if (rc) return rc;
+  call_timing().init_ms = clk.lap();
   // every problem stops after at most max_iter + 1 turns (the last one only fires the stop test)
   uint64_t left = e->cfg.max_iter + 1;
   for (;;) {
@@ -419,7 +429,10 @@ int nlsg_bfgs_minimize(nlsg_bfgs *e, double *x_inout_host, nlsg_status *status_h
     if (rc) return rc;
     if (open == 0) break;
   }
-  return nlsg_bfgs_download(e, x_inout_host, status_host);
+  call_timing().iterate_ms = clk.lap();
+  rc = nlsg_bfgs_download(e, x_inout_host, status_host);
+  call_timing().readback_ms = clk.lap();
+  return rc;
 }
 
 int nlsg_bfgs_time_steps(nlsg_bfgs *e, uint64_t iters, float *ms_total, float *ms_hessian) {

@@ -19,6 +19,7 @@ typedef int int32_t;
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -44,6 +45,27 @@ inline int fail(int code, const char *fmt, ...) {
   va_end(ap);
   return code;
 }
+// Host wall-clock of the calling thread's last create / minimize / destroy, read back through
+// nlsg_call_timing (include/nlsg_c_api.h): what a call through the drop-in header costs beyond its
+// kernels. Phases are host-side laps, without extra synchronisation: device work queued by `init`
+// that is still running when the lap is taken is counted under `iterate`; `upload` is
+// nlsg_lm_set_data (the model's design matrices crossing PCIe).
+struct CallTiming {
+  double create_ms, upload_ms, init_ms, iterate_ms, readback_ms, destroy_ms;
+};
+inline CallTiming &call_timing() {
+  static thread_local CallTiming t = {0, 0, 0, 0, 0, 0};
+  return t;
+}
+struct PhaseClock {
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  double lap() {  // milliseconds since construction or the previous lap
+    const auto t1 = std::chrono::steady_clock::now();
+    const double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    t0 = t1;
+    return ms;
+  }
+};
 #define NLSG_HIP(call)                                                          \
   do {                                                                          \
     hipError_t e_ = (call);                                                     \

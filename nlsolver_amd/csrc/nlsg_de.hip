@@ -298,6 +298,17 @@ extern "C" {
 
 const char *nlsg_last_error(void) { return err_buf(); }
 int nlsg_abi_version(void) { return NLSG_ABI_VERSION; }
+int nlsg_call_timing(double *ms_out6) {
+  if (!ms_out6) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  const CallTiming &t = call_timing();
+  ms_out6[0] = t.create_ms;
+  ms_out6[1] = t.upload_ms;
+  ms_out6[2] = t.init_ms;
+  ms_out6[3] = t.iterate_ms;
+  ms_out6[4] = t.readback_ms;
+  ms_out6[5] = t.destroy_ms;
+  return NLSG_OK;
+}
 
 int nlsg_device_count(void) {
   int n = 0;
@@ -317,14 +328,20 @@ static int de_create(const nlsg_de_config *cfg, const nlsg_custom_objective *cus
 int nlsg_de_create(const nlsg_de_config *cfg, nlsg_de **out) {
   if (cfg && cfg->objective == NLSG_OBJ_CUSTOM)
     return fail(NLSG_ERR_INVALID_ARG, "NLSG_OBJ_CUSTOM engines are made by nlsg_de_create_custom");
-  return de_create(cfg, nullptr, out);
+  PhaseClock clk;
+  const int rc = de_create(cfg, nullptr, out);
+  call_timing().create_ms = clk.lap();
+  return rc;
 }
 
 int nlsg_de_create_custom(const nlsg_de_config *cfg, const nlsg_custom_objective *obj, nlsg_de **out) {
   if (!cfg || !obj) return fail(NLSG_ERR_INVALID_ARG, "null argument");
   if (cfg->objective != NLSG_OBJ_CUSTOM)
     return fail(NLSG_ERR_INVALID_ARG, "cfg.objective must be NLSG_OBJ_CUSTOM");
-  return de_create(cfg, obj, out);
+  PhaseClock clk;
+  const int rc = de_create(cfg, obj, out);
+  call_timing().create_ms = clk.lap();
+  return rc;
 }
 
 static int de_create(const nlsg_de_config *cfg, const nlsg_custom_objective *custom, nlsg_de **out) {
@@ -467,6 +484,7 @@ static int de_create(const nlsg_de_config *cfg, const nlsg_custom_objective *cus
 
 int nlsg_de_destroy(nlsg_de *e) {
   if (!e) return NLSG_OK;
+  PhaseClock clk;
   hipSetDevice(e->cfg.device);
   if (e->stream) hipStreamSynchronize(e->stream);
   hipFree(e->p.buf[0]);
@@ -495,6 +513,7 @@ int nlsg_de_destroy(nlsg_de *e) {
   if (e->ev1) hipEventDestroy(e->ev1);
   if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
   delete e;
+  call_timing().destroy_ms = clk.lap();
   return NLSG_OK;
 }
 
@@ -594,8 +613,10 @@ int nlsg_de_upload(nlsg_de *e, const double *pop_host, const double *scores_host
 
 int nlsg_de_minimize(nlsg_de *e, double *x_inout_host, uint64_t poll_every, nlsg_status *out) {
   if (!e || !x_inout_host) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  PhaseClock clk;
   int rc = nlsg_de_init(e, x_inout_host);
   if (rc) return rc;
+  call_timing().init_ms = clk.lap();
   if (poll_every == 0) poll_every = 32;
   DeState s;
   for (;;) {
@@ -605,9 +626,11 @@ int nlsg_de_minimize(nlsg_de *e, double *x_inout_host, uint64_t poll_every, nlsg
     if (rc) return rc;
     if (s.done) break;
   }
+  call_timing().iterate_ms = clk.lap();
   // x = agents[best_id] (nlsolver.h:2444)
   NLSG_HIP(hipMemcpy(x_inout_host, e->p.best_x, e->p.D * sizeof(double), hipMemcpyDeviceToHost));
   if (out) fill_status(s, out);
+  call_timing().readback_ms = clk.lap();
   return NLSG_OK;
 }
 

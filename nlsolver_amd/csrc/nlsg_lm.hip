@@ -204,14 +204,20 @@ extern "C" {
 int nlsg_lm_create(const nlsg_lm_config *cfg, nlsg_lm **out) {
   if (cfg && cfg->objective == NLSG_OBJ_CUSTOM)
     return fail(NLSG_ERR_INVALID_ARG, "NLSG_OBJ_CUSTOM engines are made by nlsg_lm_create_custom");
-  return lm_create(cfg, nullptr, out);
+  PhaseClock clk;
+  const int rc = lm_create(cfg, nullptr, out);
+  call_timing().create_ms = clk.lap();
+  return rc;
 }
 
 int nlsg_lm_create_custom(const nlsg_lm_config *cfg, const nlsg_custom_objective *obj, nlsg_lm **out) {
   if (!cfg || !obj) return fail(NLSG_ERR_INVALID_ARG, "null argument");
   if (cfg->objective != NLSG_OBJ_CUSTOM)
     return fail(NLSG_ERR_INVALID_ARG, "cfg.objective must be NLSG_OBJ_CUSTOM");
-  return lm_create(cfg, obj, out);
+  PhaseClock clk;
+  const int rc = lm_create(cfg, obj, out);
+  call_timing().create_ms = clk.lap();
+  return rc;
 }
 
 }  // extern "C"
@@ -359,6 +365,7 @@ extern "C" {
 
 int nlsg_lm_destroy(nlsg_lm *e) {
   if (!e) return NLSG_OK;
+  PhaseClock clk;
   hipSetDevice(e->cfg.device);
   if (e->stream) hipStreamSynchronize(e->stream);
   hipFree(e->A_dev);
@@ -376,6 +383,7 @@ int nlsg_lm_destroy(nlsg_lm *e) {
   rtc_release(&e->rtc);
   if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
   delete e;
+  call_timing().destroy_ms = clk.lap();
   return NLSG_OK;
 }
 
@@ -383,11 +391,13 @@ int nlsg_lm_set_data(nlsg_lm *e, const double *a_host, const double *y_host) {
   if (!e || !a_host || !y_host) return fail(NLSG_ERR_INVALID_ARG, "null argument");
   if (e->p.fd) return fail(NLSG_ERR_STATE, "this engine minimises a built-in objective: no data");
   NLSG_HIP(hipSetDevice(e->cfg.device));
+  PhaseClock clk;
   const uint64_t B = e->p.batch, m = e->p.m, n = e->p.n;
   if (e->wide) {  // kept as handed over
     NLSG_HIP(hipMemcpy(e->A_dev, a_host, B * m * n * 8, hipMemcpyHostToDevice));
     NLSG_HIP(hipMemcpy(e->y_dev, y_host, B * m * 8, hipMemcpyHostToDevice));
     e->has_data = true;
+    call_timing().upload_ms = clk.lap();
     return NLSG_OK;
   }
   // host layout [problem][m][n] -> device layout [row group][problem][16][64] (zero padded):
@@ -438,6 +448,7 @@ int nlsg_lm_set_data(nlsg_lm *e, const double *a_host, const double *y_host) {
   if (copy) hipStreamDestroy(copy);
   NLSG_HIP(he);
   e->has_data = true;
+  call_timing().upload_ms = clk.lap();
   return NLSG_OK;
 }
 
@@ -473,12 +484,15 @@ int nlsg_lm_minimize(nlsg_lm *e, double *theta_inout_host, nlsg_status *status_h
   if (!e || !theta_inout_host) return fail(NLSG_ERR_INVALID_ARG, "null argument");
   if (!e->has_data) return fail(NLSG_ERR_STATE, "nlsg_lm_set_data has not been called");
   NLSG_HIP(hipSetDevice(e->cfg.device));
+  PhaseClock clk;
   int rc = upload_theta(e, theta_inout_host);
   if (rc) return rc;
+  call_timing().init_ms = clk.lap();
   rc = launch_solve(e);
   if (rc) return rc;
   NLSG_HIP(launches_status());
   NLSG_HIP(hipStreamSynchronize(e->stream));
+  call_timing().iterate_ms = clk.lap();
   const uint64_t B = e->p.batch, n = e->p.n;
   if (e->wide) {
     NLSG_HIP(hipMemcpy(theta_inout_host, e->p.theta, B * n * 8, hipMemcpyDeviceToHost));
@@ -508,6 +522,7 @@ int nlsg_lm_minimize(nlsg_lm *e, double *theta_inout_host, nlsg_status *status_h
     }
     if (lambda_out_host) lambda_out_host[b] = pr[b].lambda;
   }
+  call_timing().readback_ms = clk.lap();
   return NLSG_OK;
 }
 

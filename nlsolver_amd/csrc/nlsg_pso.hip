@@ -236,7 +236,10 @@ static int pso_create(const nlsg_pso_config *cfg, const nlsg_custom_objective *c
 int nlsg_pso_create(const nlsg_pso_config *cfg, nlsg_pso **out) {
   if (cfg && cfg->objective == NLSG_OBJ_CUSTOM)
     return fail(NLSG_ERR_INVALID_ARG, "NLSG_OBJ_CUSTOM engines are made by nlsg_pso_create_custom");
-  return pso_create(cfg, nullptr, out);
+  PhaseClock clk;
+  const int rc = pso_create(cfg, nullptr, out);
+  call_timing().create_ms = clk.lap();
+  return rc;
 }
 
 int nlsg_pso_create_custom(const nlsg_pso_config *cfg, const nlsg_custom_objective *obj,
@@ -244,7 +247,10 @@ int nlsg_pso_create_custom(const nlsg_pso_config *cfg, const nlsg_custom_objecti
   if (!cfg || !obj) return fail(NLSG_ERR_INVALID_ARG, "null argument");
   if (cfg->objective != NLSG_OBJ_CUSTOM)
     return fail(NLSG_ERR_INVALID_ARG, "cfg.objective must be NLSG_OBJ_CUSTOM");
-  return pso_create(cfg, obj, out);
+  PhaseClock clk;
+  const int rc = pso_create(cfg, obj, out);
+  call_timing().create_ms = clk.lap();
+  return rc;
 }
 
 static int pso_create(const nlsg_pso_config *cfg, const nlsg_custom_objective *custom, nlsg_pso **out) {
@@ -382,6 +388,7 @@ static int pso_create(const nlsg_pso_config *cfg, const nlsg_custom_objective *c
 
 int nlsg_pso_destroy(nlsg_pso *e) {
   if (!e) return NLSG_OK;
+  PhaseClock clk;
   hipSetDevice(e->cfg.device);
   if (e->stream) hipStreamSynchronize(e->stream);
   hipFree(e->p.pos);
@@ -405,6 +412,7 @@ int nlsg_pso_destroy(nlsg_pso *e) {
   if (e->ev1) hipEventDestroy(e->ev1);
   if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
   delete e;
+  call_timing().destroy_ms = clk.lap();
   return NLSG_OK;
 }
 
@@ -481,8 +489,10 @@ int nlsg_pso_download(nlsg_pso *e, double *pos_host, double *vel_host, double *p
 int nlsg_pso_minimize(nlsg_pso *e, double *x_out_host, const double *lower_host,
                       const double *upper_host, uint64_t poll_every, nlsg_status *out) {
   if (!e || !x_out_host) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  PhaseClock clk;
   int rc = nlsg_pso_init(e, lower_host, upper_host);
   if (rc) return rc;
+  call_timing().init_ms = clk.lap();
   if (poll_every == 0) poll_every = 32;
   PsoState s;
   for (;;) {
@@ -492,9 +502,11 @@ int nlsg_pso_minimize(nlsg_pso *e, double *x_out_host, const double *lower_host,
     if (rc) return rc;
     if (s.done) break;
   }
+  call_timing().iterate_ms = clk.lap();
   // x = swarm_best_position (nlsolver.h:2601)
   NLSG_HIP(hipMemcpy(x_out_host, e->p.gbest_x, e->p.D * sizeof(double), hipMemcpyDeviceToHost));
   if (out) fill_status(s, out);
+  call_timing().readback_ms = clk.lap();
   return NLSG_OK;
 }
 

@@ -229,6 +229,7 @@ static int bench_de(size_t D, size_t pop, size_t gens) {
 }
 
 #include "ref_driver_more.inc"
+#include "ref_driver_stat.inc"
 
 int main(int argc, char **argv) {
   if (argc < 2) {
@@ -264,6 +265,11 @@ int main(int argc, char **argv) {
     const size_t pop = argc > 3 ? std::strtoull(argv[3], nullptr, 10) : 65536;
     const size_t gens = argc > 4 ? std::strtoull(argv[4], nullptr, 10) : 10;
     return bench_de(D, pop, gens);
+  }
+  {
+    bool handled = false;
+    const int rc = stat_main(cmd, argc, argv, handled);
+    if (handled) return rc;
   }
   return more_main(cmd, argc, argv);
 }

@@ -182,7 +182,9 @@ def test_c1_on_device_reaches_reference_result(eng_mod, golden):
     fcalls, iters, f, g, h = st.get_summary()
     assert np.all(np.abs(x - 1.0) <= 0.05) and f < 1e-3  # the reference's own pass criterion
     assert fcalls == 40 * (iters + 1) and g == 0 and h == 0
-    assert 0.3 * ref["iters"] <= iters <= 3 * ref["iters"]
+    # how many generations the device needs against the reference's 45 is a distribution, tested as
+    # one over 128 seeds against 128 reference runs: tests/test_stat_gpu.py (pop40_D2)
+    assert ref["iters"] == 45
 
 
 def test_full_size_config2_bit_exact_and_deterministic(eng_mod, oracle):
