@@ -100,6 +100,13 @@ int nlsg_device_count(void);
  * 3457) is one call; this is where its time goes once the loops run on the device. Host-side laps
  * without extra synchronisation (bench.py --workload tts reports them). */
 int nlsg_call_timing(double *ms_out6);
+/* Engines recycle their device blocks and streams through a per-process cache (what one
+ * minimize() releases the next one takes: the reference's one-call-per-solve API would otherwise
+ * pay a dozen hipMalloc / hipFree pairs per call). At most $NLSG_POOL_BYTES (default 4 GiB; 0
+ * turns the cache off) sit idle per device. nlsg_release_cached frees all of it now;
+ * nlsg_cached_bytes reports how much is parked. */
+int nlsg_release_cached(void);
+uint64_t nlsg_cached_bytes(void);
 
 /* The device's deterministic math primitives (the log / cos of rnorm nlsolver.h:2479-2485, the
  * exp / tanh of the NLLS model, the cosine of Rastrigin test_functions.h:74-76) evaluated on n

@@ -119,6 +119,8 @@ SYMBOLS = {
     "nlsg_abi_version": (C.c_int, []),
     "nlsg_device_count": (C.c_int, []),
     "nlsg_call_timing": (C.c_int, [pd]),
+    "nlsg_release_cached": (C.c_int, []),
+    "nlsg_cached_bytes": (u64, []),
     "nlsg_probe_math": (C.c_int, [C.c_int32, pu, pu, u64, C.c_int32]),
     "nlsg_de_create": (C.c_int, [C.POINTER(DEConfig), C.POINTER(_H)]),
     "nlsg_de_destroy": (C.c_int, [_H]),

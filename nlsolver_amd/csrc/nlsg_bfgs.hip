@@ -203,7 +203,7 @@ static int bfgs_create(const nlsg_bfgs_config *cfg, const double *diag_host, con
   if (cfg->stream) {
     e->stream = borrowed_stream(cfg->stream);
   } else {
-    hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    hipError_t he = pool_stream_get(&e->stream);
     if (he != hipSuccess) {
       delete e;
       return fail(NLSG_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(he));
@@ -212,7 +212,7 @@ static int bfgs_create(const nlsg_bfgs_config *cfg, const double *diag_host, con
   }
   BfgsParams &p = e->p;
   std::memset(&p, 0, sizeof p);
-  auto alloc = [&](void **ptr, size_t bytes) { return hipMalloc(ptr, bytes ? bytes : 8); };
+  auto alloc = [&](void **ptr, size_t bytes) { return pool_malloc(ptr, bytes ? bytes : 8); };
   hipError_t he = hipSuccess;
   const size_t vec_bytes = B * n * sizeof(double);
   if (he == hipSuccess && !e->symmetric)
@@ -278,24 +278,24 @@ int nlsg_bfgs_destroy(nlsg_bfgs *e) {
   PhaseClock clk;
   hipSetDevice(e->cfg.device);
   if (e->stream) hipStreamSynchronize(e->stream);
-  hipFree(e->p.H);
-  hipFree(e->p.Hs);
-  hipFree(e->p.part);
-  hipFree(e->p.x);
-  hipFree(e->p.g);
-  hipFree(e->p.dir);
-  hipFree(e->p.s);
-  hipFree(e->p.y);
-  hipFree(e->p.t);
-  hipFree(e->p.prob);
+  pool_free(e->p.H);
+  pool_free(e->p.Hs);
+  pool_free(e->p.part);
+  pool_free(e->p.x);
+  pool_free(e->p.g);
+  pool_free(e->p.dir);
+  pool_free(e->p.s);
+  pool_free(e->p.y);
+  pool_free(e->p.t);
+  pool_free(e->p.prob);
   rtc_release(&e->rtc);
-  hipFree(e->qd_dev);
-  hipFree(e->qb_dev);
-  hipFree(e->zero_dev);
-  hipFree(e->count_dev);
+  pool_free(e->qd_dev);
+  pool_free(e->qb_dev);
+  pool_free(e->zero_dev);
+  pool_free(e->count_dev);
   for (hipEvent_t ev : {e->ev0, e->ev1, e->ev2, e->ev3})
     if (ev) hipEventDestroy(ev);
-  if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
+  if (e->own_stream && e->stream) pool_stream_put(e->cfg.device, e->stream);
   delete e;
   call_timing().destroy_ms = clk.lap();
   return NLSG_OK;

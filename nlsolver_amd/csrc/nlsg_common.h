@@ -19,6 +19,7 @@ typedef int int32_t;
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -27,6 +28,9 @@ typedef int int32_t;
 
 #include "../../include/nlsg_c_api.h"
 #include "nlsg_math.h"
+#ifndef __HIPCC_RTC__
+#include "nlsg_pool.h"
+#endif
 
 namespace nlsg {
 
@@ -76,6 +80,10 @@ struct PhaseClock {
   } while (0)
 // every engine's first question: is `device` a gfx950 this process can see?
 inline int check_device(int device) {
+  // the verdict on a device does not change while the process lives: asked once (the property
+  // query costs about a millisecond, every minimize() through the header creates an engine)
+  static std::atomic<unsigned long long> ok_mask{0};
+  if (device >= 0 && device < 64 && ((ok_mask.load(std::memory_order_relaxed) >> device) & 1ull)) return NLSG_OK;
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
     return fail(NLSG_ERR_NO_DEVICE, "no HIP device visible");
@@ -86,6 +94,7 @@ inline int check_device(int device) {
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(NLSG_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only",
                 device, prop.gcnArchName);
+  if (device < 64) ok_mask.fetch_or(1ull << device, std::memory_order_relaxed);
   return NLSG_OK;
 }
 

@@ -298,6 +298,11 @@ extern "C" {
 
 const char *nlsg_last_error(void) { return err_buf(); }
 int nlsg_abi_version(void) { return NLSG_ABI_VERSION; }
+int nlsg_release_cached(void) {
+  pool_release_all();
+  return NLSG_OK;
+}
+uint64_t nlsg_cached_bytes(void) { return pool_idle_bytes(); }
 int nlsg_call_timing(double *ms_out6) {
   if (!ms_out6) return fail(NLSG_ERR_INVALID_ARG, "null argument");
   const CallTiming &t = call_timing();
@@ -384,7 +389,7 @@ static int de_create(const nlsg_de_config *cfg, const nlsg_custom_objective *cus
   if (cfg->stream) {
     e->stream = borrowed_stream(cfg->stream);
   } else {
-    hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    hipError_t he = pool_stream_get(&e->stream);
     if (he != hipSuccess) {
       delete e;
       return fail(NLSG_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(he));
@@ -393,7 +398,7 @@ static int de_create(const nlsg_de_config *cfg, const nlsg_custom_objective *cus
   }
   DeParams &p = e->p;
   std::memset(&p, 0, sizeof p);
-  auto alloc = [&](void **ptr, size_t bytes) { return hipMalloc(ptr, bytes ? bytes : 8); };
+  auto alloc = [&](void **ptr, size_t bytes) { return pool_malloc(ptr, bytes ? bytes : 8); };
   hipError_t he = hipSuccess;
   const size_t rows = n * D * sizeof(double);
   if (he == hipSuccess) he = alloc(reinterpret_cast<void **>(&p.buf[0]), rows);
@@ -426,7 +431,7 @@ static int de_create(const nlsg_de_config *cfg, const nlsg_custom_objective *cus
   e->fused = cfg->strategy == NLSG_DE_RANDOM && cfg->shard_n == cfg->pop && !e->long_rows &&
              !e->overlap && !cfg->trace && !(fu && fu[0] == '0');  // the trace buffer is not double-buffered
   if (e->overlap) {
-    if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking);
+    if (he == hipSuccess) he = pool_stream_get(&e->side);
     for (int i = 0; i < 4; i++) {
       if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_gen[i], hipEventDisableTiming);
       if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_head[i], hipEventDisableTiming);
@@ -487,31 +492,31 @@ int nlsg_de_destroy(nlsg_de *e) {
   PhaseClock clk;
   hipSetDevice(e->cfg.device);
   if (e->stream) hipStreamSynchronize(e->stream);
-  hipFree(e->p.buf[0]);
-  hipFree(e->p.buf[1]);
-  hipFree(e->p.scores[0]);
-  hipFree(e->p.scores[1]);
+  pool_free(e->p.buf[0]);
+  pool_free(e->p.buf[1]);
+  pool_free(e->p.scores[0]);
+  pool_free(e->p.scores[1]);
   if (e->side) {
     hipStreamSynchronize(e->side);
-    hipStreamDestroy(e->side);
+    pool_stream_put(e->cfg.device, e->side);
   }
   for (int i = 0; i < 4; i++) {
     if (e->ev_gen[i]) hipEventDestroy(e->ev_gen[i]);
     if (e->ev_head[i]) hipEventDestroy(e->ev_head[i]);
   }
-  hipFree(e->p.best_x);
-  hipFree(e->p.trace);
-  hipFree(e->p.state);
-  hipFree(e->p.part);
-  hipFree(e->p.ticket);
+  pool_free(e->p.best_x);
+  pool_free(e->p.trace);
+  pool_free(e->p.state);
+  pool_free(e->p.part);
+  pool_free(e->p.ticket);
   comm_detach(e->comm);
   rtc_release(&e->rtc);
-  hipFree(e->x0_dev);
-  hipFree(e->zero_dev);
-  hipFree(e->rec);
+  pool_free(e->x0_dev);
+  pool_free(e->zero_dev);
+  pool_free(e->rec);
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
-  if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
+  if (e->own_stream && e->stream) pool_stream_put(e->cfg.device, e->stream);
   delete e;
   call_timing().destroy_ms = clk.lap();
   return NLSG_OK;

@@ -273,7 +273,7 @@ static int lm_create(const nlsg_lm_config *cfg, const nlsg_custom_objective *cus
   if (cfg->stream) {
     e->stream = borrowed_stream(cfg->stream);
   } else {
-    hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    hipError_t he = pool_stream_get(&e->stream);
     if (he != hipSuccess) {
       delete e;
       return fail(NLSG_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(he));
@@ -287,23 +287,23 @@ static int lm_create(const nlsg_lm_config *cfg, const nlsg_custom_objective *cus
   const uint64_t nstep = wide ? 0 : (m + 15) / 16;
   p.nstep = nstep;
   if (he == hipSuccess && nstep)
-    he = hipMalloc(reinterpret_cast<void **>(&e->A_dev), nstep * B * 16 * kLmN * 8);
+    he = pool_malloc(reinterpret_cast<void **>(&e->A_dev), nstep * B * 16 * kLmN * 8);
   if (he == hipSuccess && nstep)
-    he = hipMalloc(reinterpret_cast<void **>(&e->y_dev), nstep * B * 16 * 8);
+    he = pool_malloc(reinterpret_cast<void **>(&e->y_dev), nstep * B * 16 * 8);
   if (he == hipSuccess && wide && m) {  // the caller's layout, [batch][m][n]
-    he = hipMalloc(reinterpret_cast<void **>(&e->A_dev), B * m * cfg->n * 8);
-    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&e->y_dev), B * m * 8);
-    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p.rw), B * 2 * m * 8);
+    he = pool_malloc(reinterpret_cast<void **>(&e->A_dev), B * m * cfg->n * 8);
+    if (he == hipSuccess) he = pool_malloc(reinterpret_cast<void **>(&e->y_dev), B * m * 8);
+    if (he == hipSuccess) he = pool_malloc(reinterpret_cast<void **>(&p.rw), B * 2 * m * 8);
   }
   if (he == hipSuccess && wide)
-    he = hipMalloc(reinterpret_cast<void **>(&p.Hw), B * cfg->n * cfg->n * 8);
-  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p.theta), B * e->ldt * 8);
-  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p.prob), B * sizeof(LmProblem));
-  if (he == hipSuccess && !wide) he = hipMalloc(reinterpret_cast<void **>(&p.Hg), B * kLmTri * 8);
+    he = pool_malloc(reinterpret_cast<void **>(&p.Hw), B * cfg->n * cfg->n * 8);
+  if (he == hipSuccess) he = pool_malloc(reinterpret_cast<void **>(&p.theta), B * e->ldt * 8);
+  if (he == hipSuccess) he = pool_malloc(reinterpret_cast<void **>(&p.prob), B * sizeof(LmProblem));
+  if (he == hipSuccess && !wide) he = pool_malloc(reinterpret_cast<void **>(&p.Hg), B * kLmTri * 8);
   if (he == hipSuccess && !wide) he = hipMemset(p.Hg, 0, B * kLmTri * 8);  // rows past n are never written
-  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p.gg), B * e->ldt * 8);
-  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&e->count_dev), 8);
-  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&e->zero_dev), 16);
+  if (he == hipSuccess) he = pool_malloc(reinterpret_cast<void **>(&p.gg), B * e->ldt * 8);
+  if (he == hipSuccess) he = pool_malloc(reinterpret_cast<void **>(&e->count_dev), 8);
+  if (he == hipSuccess) he = pool_malloc(reinterpret_cast<void **>(&e->zero_dev), 16);
   if (he == hipSuccess) he = hipMemset(e->zero_dev, 0, 16);
   if (he == hipSuccess) he = hipEventCreate(&e->ev0);
   if (he == hipSuccess) he = hipEventCreate(&e->ev1);
@@ -368,20 +368,20 @@ int nlsg_lm_destroy(nlsg_lm *e) {
   PhaseClock clk;
   hipSetDevice(e->cfg.device);
   if (e->stream) hipStreamSynchronize(e->stream);
-  hipFree(e->A_dev);
-  hipFree(e->y_dev);
-  hipFree(e->p.theta);
-  hipFree(e->p.prob);
-  hipFree(e->p.Hg);
-  hipFree(e->p.Hw);
-  hipFree(e->p.rw);
-  hipFree(e->p.gg);
-  hipFree(e->count_dev);
-  hipFree(e->zero_dev);
+  pool_free(e->A_dev);
+  pool_free(e->y_dev);
+  pool_free(e->p.theta);
+  pool_free(e->p.prob);
+  pool_free(e->p.Hg);
+  pool_free(e->p.Hw);
+  pool_free(e->p.rw);
+  pool_free(e->p.gg);
+  pool_free(e->count_dev);
+  pool_free(e->zero_dev);
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
   rtc_release(&e->rtc);
-  if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
+  if (e->own_stream && e->stream) pool_stream_put(e->cfg.device, e->stream);
   delete e;
   call_timing().destroy_ms = clk.lap();
   return NLSG_OK;
@@ -412,13 +412,13 @@ int nlsg_lm_set_data(nlsg_lm *e, const double *a_host, const double *y_host) {
   double *raw[2] = {nullptr, nullptr}, *y_raw = nullptr;
   hipStream_t copy = nullptr;
   hipEvent_t landed[2] = {nullptr, nullptr}, packed[2] = {nullptr, nullptr};
-  hipError_t he = hipStreamCreateWithFlags(&copy, hipStreamNonBlocking);
+  hipError_t he = pool_stream_get(&copy);
   for (int k = 0; k < 2 && he == hipSuccess; k++) {
-    he = hipMalloc(reinterpret_cast<void **>(&raw[k]), chunk * per);
+    he = pool_malloc(reinterpret_cast<void **>(&raw[k]), chunk * per);
     if (he == hipSuccess) he = hipEventCreateWithFlags(&landed[k], hipEventDisableTiming);
     if (he == hipSuccess) he = hipEventCreateWithFlags(&packed[k], hipEventDisableTiming);
   }
-  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&y_raw), B * m * 8);
+  if (he == hipSuccess) he = pool_malloc(reinterpret_cast<void **>(&y_raw), B * m * 8);
   if (he == hipSuccess) he = hipMemcpyAsync(y_raw, y_host, B * m * 8, hipMemcpyHostToDevice, copy);
   uint64_t k = 0;
   for (uint64_t b0 = 0; b0 < B && he == hipSuccess; b0 += chunk, k++) {
@@ -440,12 +440,12 @@ int nlsg_lm_set_data(nlsg_lm *e, const double *a_host, const double *y_host) {
   if (he == hipSuccess) he = hipStreamSynchronize(e->stream);  // the host buffers are borrowed for this call only
   if (copy) hipStreamSynchronize(copy);
   for (int q = 0; q < 2; q++) {
-    hipFree(raw[q]);
+    pool_free(raw[q]);
     if (landed[q]) hipEventDestroy(landed[q]);
     if (packed[q]) hipEventDestroy(packed[q]);
   }
-  hipFree(y_raw);
-  if (copy) hipStreamDestroy(copy);
+  pool_free(y_raw);
+  if (copy) pool_stream_put(e->cfg.device, copy);
   NLSG_HIP(he);
   e->has_data = true;
   call_timing().upload_ms = clk.lap();

@@ -124,7 +124,7 @@ static int nm_create(const nlsg_nm_config *cfg, const nlsg_custom_objective *cus
   if (cfg->stream) {
     e->stream = borrowed_stream(cfg->stream);
   } else {
-    hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    hipError_t he = pool_stream_get(&e->stream);
     if (he != hipSuccess) {
       delete e;
       return fail(NLSG_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(he));
@@ -138,18 +138,18 @@ static int nm_create(const nlsg_nm_config *cfg, const nlsg_custom_objective *cus
   hipError_t he = hipSuccess;
   const int chunks = nm_chunks(n);
   if (he == hipSuccess && chunks > 1)  // the simplexes themselves: past what LDS holds
-    he = hipMalloc(reinterpret_cast<void **>(&p.simplex), B * (n + 1) * n * 8);
-  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p.x), B * n * 8);
-  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p.prob), B * sizeof(NmProblem));
-  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&e->upper_dev), n * 8);
-  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&e->lower_dev), n * 8);
+    he = pool_malloc(reinterpret_cast<void **>(&p.simplex), B * (n + 1) * n * 8);
+  if (he == hipSuccess) he = pool_malloc(reinterpret_cast<void **>(&p.x), B * n * 8);
+  if (he == hipSuccess) he = pool_malloc(reinterpret_cast<void **>(&p.prob), B * sizeof(NmProblem));
+  if (he == hipSuccess) he = pool_malloc(reinterpret_cast<void **>(&e->upper_dev), n * 8);
+  if (he == hipSuccess) he = pool_malloc(reinterpret_cast<void **>(&e->lower_dev), n * 8);
   if (he == hipSuccess) he = hipEventCreate(&e->ev0);
   if (he == hipSuccess) he = hipEventCreate(&e->ev1);
   {
     const char *sw = std::getenv("NLSG_NM_DRIVER");
     e->driver = chunks == 1 && !(sw && sw[0] == '0');
   }
-  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&e->phase_dev), B * kNmPhases * 8);
+  if (he == hipSuccess) he = pool_malloc(reinterpret_cast<void **>(&e->phase_dev), B * kNmPhases * 8);
   if (he == hipSuccess) he = prepare_driver<NLSG_OBJ_ROSENBROCK>();
   if (he == hipSuccess) he = prepare_driver<NLSG_OBJ_SPHERE>();
   if (he == hipSuccess) he = prepare_driver<NLSG_OBJ_STYBLINSKI_TANG>();
@@ -197,15 +197,15 @@ int nlsg_nm_destroy(nlsg_nm *e) {
   hipSetDevice(e->cfg.device);
   if (e->stream) hipStreamSynchronize(e->stream);
   rtc_release(&e->rtc);
-  hipFree(e->p.simplex);
-  hipFree(e->p.x);
-  hipFree(e->p.prob);
-  hipFree(e->upper_dev);
-  hipFree(e->lower_dev);
-  hipFree(e->phase_dev);
+  pool_free(e->p.simplex);
+  pool_free(e->p.x);
+  pool_free(e->p.prob);
+  pool_free(e->upper_dev);
+  pool_free(e->lower_dev);
+  pool_free(e->phase_dev);
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
-  if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
+  if (e->own_stream && e->stream) pool_stream_put(e->cfg.device, e->stream);
   delete e;
   return NLSG_OK;
 }

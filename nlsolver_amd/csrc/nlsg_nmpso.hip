@@ -136,7 +136,7 @@ static int hyb_create(const nlsg_nmpso_config *cfg, const nlsg_custom_objective 
   if (cfg->stream) {
     e->stream = borrowed_stream(cfg->stream);
   } else {
-    hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    hipError_t he = pool_stream_get(&e->stream);
     if (he != hipSuccess) {
       delete e;
       return fail(NLSG_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(he));
@@ -147,13 +147,13 @@ static int hyb_create(const nlsg_nmpso_config *cfg, const nlsg_custom_objective 
   std::memset(&p, 0, sizeof p);
   const uint64_t B = cfg->batch, n = cfg->dim, rows = B * (3 * n + 1);
   hipError_t he = hipSuccess;
-  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p.x), B * n * 8);
-  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p.pos), rows * n * 8);
-  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p.vel), rows * n * 8);
-  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p.prob), B * sizeof(HybProblem));
-  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&e->upper_dev), n * 8);
-  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&e->lower_dev), n * 8);
-  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&e->zero_dev), 16);
+  if (he == hipSuccess) he = pool_malloc(reinterpret_cast<void **>(&p.x), B * n * 8);
+  if (he == hipSuccess) he = pool_malloc(reinterpret_cast<void **>(&p.pos), rows * n * 8);
+  if (he == hipSuccess) he = pool_malloc(reinterpret_cast<void **>(&p.vel), rows * n * 8);
+  if (he == hipSuccess) he = pool_malloc(reinterpret_cast<void **>(&p.prob), B * sizeof(HybProblem));
+  if (he == hipSuccess) he = pool_malloc(reinterpret_cast<void **>(&e->upper_dev), n * 8);
+  if (he == hipSuccess) he = pool_malloc(reinterpret_cast<void **>(&e->lower_dev), n * 8);
+  if (he == hipSuccess) he = pool_malloc(reinterpret_cast<void **>(&e->zero_dev), 16);
   if (he == hipSuccess) he = hipMemset(e->zero_dev, 0, 16);
   if (he == hipSuccess) he = hipEventCreate(&e->ev0);
   if (he == hipSuccess) he = hipEventCreate(&e->ev1);
@@ -207,16 +207,16 @@ int nlsg_nmpso_destroy(nlsg_nmpso *e) {
   hipSetDevice(e->cfg.device);
   if (e->stream) hipStreamSynchronize(e->stream);
   rtc_release(&e->rtc);
-  hipFree(e->p.x);
-  hipFree(e->p.pos);
-  hipFree(e->p.vel);
-  hipFree(e->p.prob);
-  hipFree(e->upper_dev);
-  hipFree(e->lower_dev);
-  hipFree(e->zero_dev);
+  pool_free(e->p.x);
+  pool_free(e->p.pos);
+  pool_free(e->p.vel);
+  pool_free(e->p.prob);
+  pool_free(e->upper_dev);
+  pool_free(e->lower_dev);
+  pool_free(e->zero_dev);
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
-  if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
+  if (e->own_stream && e->stream) pool_stream_put(e->cfg.device, e->stream);
   delete e;
   return NLSG_OK;
 }

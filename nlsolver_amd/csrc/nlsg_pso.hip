@@ -296,7 +296,7 @@ static int pso_create(const nlsg_pso_config *cfg, const nlsg_custom_objective *c
   if (cfg->stream) {
     e->stream = borrowed_stream(cfg->stream);
   } else {
-    hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    hipError_t he = pool_stream_get(&e->stream);
     if (he != hipSuccess) {
       delete e;
       return fail(NLSG_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(he));
@@ -305,7 +305,7 @@ static int pso_create(const nlsg_pso_config *cfg, const nlsg_custom_objective *c
   }
   PsoParams &p = e->p;
   std::memset(&p, 0, sizeof p);
-  auto alloc = [&](void **ptr, size_t bytes) { return hipMalloc(ptr, bytes ? bytes : 8); };
+  auto alloc = [&](void **ptr, size_t bytes) { return pool_malloc(ptr, bytes ? bytes : 8); };
   const bool vanilla = cfg->type == NLSG_PSO_VANILLA;
   const size_t rows = n * D * sizeof(double);
   hipError_t he = hipSuccess;
@@ -391,26 +391,26 @@ int nlsg_pso_destroy(nlsg_pso *e) {
   PhaseClock clk;
   hipSetDevice(e->cfg.device);
   if (e->stream) hipStreamSynchronize(e->stream);
-  hipFree(e->p.pos);
-  hipFree(e->p.vel);
-  hipFree(e->p.pbest_pos);
-  hipFree(e->p.pbest_val);
-  hipFree(e->p.cur_val);
-  hipFree(e->p.gbest_x);
-  hipFree(e->p.state);
-  hipFree(e->p.part);
-  hipFree(e->p.ticket);
-  hipFree(e->lower_dev);
-  hipFree(e->upper_dev);
-  hipFree(e->zero_dev);
-  hipFree(e->tab_dev);
-  hipFree(e->loc);
+  pool_free(e->p.pos);
+  pool_free(e->p.vel);
+  pool_free(e->p.pbest_pos);
+  pool_free(e->p.pbest_val);
+  pool_free(e->p.cur_val);
+  pool_free(e->p.gbest_x);
+  pool_free(e->p.state);
+  pool_free(e->p.part);
+  pool_free(e->p.ticket);
+  pool_free(e->lower_dev);
+  pool_free(e->upper_dev);
+  pool_free(e->zero_dev);
+  pool_free(e->tab_dev);
+  pool_free(e->loc);
   comm_detach(e->comm);
   rtc_release(&e->rtc);
-  hipFree(e->rec);
+  pool_free(e->rec);
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
-  if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
+  if (e->own_stream && e->stream) pool_stream_put(e->cfg.device, e->stream);
   delete e;
   call_timing().destroy_ms = clk.lap();
   return NLSG_OK;

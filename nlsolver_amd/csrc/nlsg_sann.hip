@@ -177,7 +177,7 @@ static int sann_create(const nlsg_sann_config *cfg, const nlsg_custom_objective 
   if (cfg->stream) {
     e->stream = borrowed_stream(cfg->stream);
   } else {
-    hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    hipError_t he = pool_stream_get(&e->stream);
     if (he != hipSuccess) {
       delete e;
       return fail(NLSG_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(he));
@@ -190,11 +190,11 @@ static int sann_create(const nlsg_sann_config *cfg, const nlsg_custom_objective 
   SannParams &p = e->p;
   std::memset(&p, 0, sizeof p);
   hipError_t he = hipSuccess;
-  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p.x), B * D * 8);
-  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p.p), B * D * 8);
-  if (he == hipSuccess && D > 1024) he = hipMalloc(reinterpret_cast<void **>(&p.trial), B * D * 8);
-  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&p.prob), B * sizeof(SannProblem));
-  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&e->zero_dev), 16);
+  if (he == hipSuccess) he = pool_malloc(reinterpret_cast<void **>(&p.x), B * D * 8);
+  if (he == hipSuccess) he = pool_malloc(reinterpret_cast<void **>(&p.p), B * D * 8);
+  if (he == hipSuccess && D > 1024) he = pool_malloc(reinterpret_cast<void **>(&p.trial), B * D * 8);
+  if (he == hipSuccess) he = pool_malloc(reinterpret_cast<void **>(&p.prob), B * sizeof(SannProblem));
+  if (he == hipSuccess) he = pool_malloc(reinterpret_cast<void **>(&e->zero_dev), 16);
   if (he == hipSuccess) he = hipMemset(e->zero_dev, 0, 16);
   if (he == hipSuccess) he = hipEventCreate(&e->ev0);
   if (he == hipSuccess) he = hipEventCreate(&e->ev1);
@@ -229,14 +229,14 @@ int nlsg_sann_destroy(nlsg_sann *e) {
   hipSetDevice(e->cfg.device);
   if (e->stream) hipStreamSynchronize(e->stream);
   rtc_release(&e->rtc);
-  hipFree(e->p.x);
-  hipFree(e->p.p);
-  hipFree(e->p.trial);
-  hipFree(e->p.prob);
-  hipFree(e->zero_dev);
+  pool_free(e->p.x);
+  pool_free(e->p.p);
+  pool_free(e->p.trial);
+  pool_free(e->p.prob);
+  pool_free(e->zero_dev);
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
-  if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
+  if (e->own_stream && e->stream) pool_stream_put(e->cfg.device, e->stream);
   delete e;
   return NLSG_OK;
 }

@@ -82,9 +82,9 @@ int nlsg_tinyqr_lm(const double *X_host, const double *y_host, uint64_t batch, u
   if (rc) return rc;
   double *X = nullptr, *y = nullptr, *beta = nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  hipError_t he = hipMalloc(reinterpret_cast<void **>(&X), batch * n * p * sizeof(double));
-  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&y), batch * n * sizeof(double));
-  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void **>(&beta), batch * p * sizeof(double));
+  hipError_t he = pool_malloc(reinterpret_cast<void **>(&X), batch * n * p * sizeof(double));
+  if (he == hipSuccess) he = pool_malloc(reinterpret_cast<void **>(&y), batch * n * sizeof(double));
+  if (he == hipSuccess) he = pool_malloc(reinterpret_cast<void **>(&beta), batch * p * sizeof(double));
   if (he == hipSuccess) he = hipEventCreate(&e0);
   if (he == hipSuccess) he = hipEventCreate(&e1);
   if (he == hipSuccess) he = hipMemcpy(X, X_host, batch * n * p * sizeof(double), hipMemcpyHostToDevice);
@@ -98,9 +98,9 @@ int nlsg_tinyqr_lm(const double *X_host, const double *y_host, uint64_t batch, u
   if (he == hipSuccess) he = hipEventSynchronize(e1);
   if (he == hipSuccess && ms_kernel) he = hipEventElapsedTime(ms_kernel, e0, e1);
   if (he == hipSuccess) he = hipMemcpy(beta_host, beta, batch * p * sizeof(double), hipMemcpyDeviceToHost);
-  hipFree(X);
-  hipFree(y);
-  hipFree(beta);
+  pool_free(X);
+  pool_free(y);
+  pool_free(beta);
   if (e0) hipEventDestroy(e0);
   if (e1) hipEventDestroy(e1);
   if (he != hipSuccess)
