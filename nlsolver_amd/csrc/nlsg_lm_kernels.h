@@ -268,7 +268,10 @@ struct LmQrShared {              // LDS of the QR step (one workgroup per proble
 };
 static_assert(__builtin_offsetof(LmQrShared, scr) == 64 * kLmQrStride * sizeof(double), "scr follows R");
 
-template <int THREADS>
+// PROBE (scripts/ubench/qr_phases.hip only): 1 = the apply waves keep their barriers and skip their
+// rotations, 2 = the Givens wave keeps its barriers and skips its phase — what each side of a
+// step costs when the other is absent. The product instantiates PROBE = 0.
+template <int THREADS, int PROBE = 0>
 __device__ inline void lm_solve_qr(LmQrShared &qs, int n) {
   constexpr int W = THREADS / 64, AW = W - 1, SLOTS = (32 + AW - 1) / AW, SPAN = AW * SLOTS;
   constexpr int S = kLmQrStride;
@@ -309,7 +312,7 @@ __device__ inline void lm_solve_qr(LmQrShared &qs, int n) {
     int pend = nowhere;                    // byte offset of R[j][j] of a finished chain still to be stored
     double pend_p = 0.0, pend_q = 0.0;
     for (int k = -1; k <= last + 1; k++) {  // one phase past the last step: the last chain's store
-      if (lane < 32) {  // (chains live in lanes 0 .. 31: half the sixteen-lane passes per instruction)
+      if (PROBE != 2 && lane < 32) {  // (chains live in lanes 0 .. 31: half the sixteen-lane passes per instruction)
       // Every LDS read of the phase is issued here, before anything waits: the phase is a chain
       // of dependent fp64 instructions behind ONE read round trip (what a read returns is only
       // used where the comments below say so; the addresses are always inside R).
@@ -373,65 +376,99 @@ __device__ inline void lm_solve_qr(LmQrShared &qs, int n) {
     }
   } else {
     // ---- an apply wave: rotate_matrix on rows i-1, i (tinyqr.h:126-139), one chain per slot.
-    // The loop below is bound by instruction issue (a CU has one scalar unit for its four
-    // SIMDs), so a slot's per-step state is kept incrementally in vector registers: `off` the
-    // lane's LDS index of R[i-1][col] (minus one row per step), and lanes without a column
-    // (`dead`) are pointed at a per-lane scratch pair instead of being masked off — no exec
-    // juggling around the loads and the store; what they compute is never read.
-    // One pass per slot (the other waves of the SIMD cover the LDS round trip), the step's distance
-    // into the chain `d` computed once and compared three times, offsets kept in bytes, the Givens
-    // pair's address in a vector register, the step parity (which pair buffer) a template argument
-    // of an unrolled-by-two loop: 7 scalar instructions and 4 branches per rotation where the
-    // two-pass form had 13 and 5. Measured: 816 against 826 us for 8192 problems, 68 against 72 us
-    // for one problem per CU — the CU's scalar unit was NOT what bound the step; the Givens wave's
-    // dependent chain (~70 links with the tracking and the exchange, ~1100 cycles a step) is, and
-    // four problems per CU (LDS) overlap it only 1.6-fold.
-    int ts[SLOTS], span[SLOTS], jnext[SLOTS];  // wave-uniform: first step, last - first, next chain
-    int off[SLOTS], dec[SLOTS], csb[SLOTS];    // per lane: byte offsets into R / into a pair buffer
+    // WHAT BOUNDS THIS SIDE (round 4, scripts/ubench/qr_phases.hip + rocprofv3 SQ counters): not the
+    // vector unit (40 % busy) and not the Givens wave (its side alone takes 56 us per round of four
+    // problems on a CU whatever the residency) but the CU's ONE scalar unit: the apply waves of four
+    // resident problems issued 281 scalar instructions per problem and step (13 per rotation, 4 per
+    // idle slot: window compares, start / end tests, lane-mask copies), 78 % of what the unit can
+    // issue, and the step stretched with every workgroup added (54.6 -> 103.6 us per round from one
+    // to four problems per CU). So the per-slot bookkeeping is EVENT DRIVEN now:
+    //  * a wave's chains j = wid, wid + AW, ... start at steps 2j — an arithmetic sequence — and
+    //    end at steps j + n - 2 — another: two compares per step find "a chain of mine starts now"
+    //    and "a chain of mine ended in the previous step"; the (rare) bodies open the chain in its
+    //    slot (lane addresses, the carried row n-1 loaded right there) or store the finished row j
+    //    (one step late: nobody reads it before the back-substitution) and flip the slot's bit in
+    //    a wave-uniform mask;
+    //  * the hot path of a slot is a bit test, two LDS reads, four fp64 instructions, one LDS
+    //    write and one address decrement — no window arithmetic, no start / end tests.
+    // A slot's per-step state is kept in vector registers: `off` the lane's LDS byte offset of
+    // R[i-1][col] (minus one row per step), lanes without a column are pointed at a per-lane
+    // scratch pair instead of being masked off; the step parity (which pair buffer) is a template
+    // argument of an unrolled-by-two loop. Same rotations in the same order on the same bits.
+    int off[SLOTS], dec[SLOTS], csb[SLOTS], fin[SLOTS];  // per lane: byte offsets into R / a pair buffer
     double carry[SLOTS];
-    bool tail[SLOTS];  // lanes that store the chain's final row (all its columns but j+1)
     const int scratch = (64 * S + lane) * 8;  // LmQrShared::scr: [lane] and [lane + S]
-    auto open_chain = [&](int sl, int j) {
-      const bool any = j <= n - 2;
-      ts[sl] = any ? 2 * j : 0x40000000;            // first step
-      span[sl] = any ? n - 2 - j : 0;               // last step - first step
-      const int col = j + 1 + lane;
-      const bool live = col < n || col == 64;
-      off[sl] = live ? ((n - 2) * S + col) * 8 : scratch;  // R[i-1][col] at the chain's first step (i = n-1)
-      dec[sl] = live ? S * 8 : 0;
-      tail[sl] = live && lane != 0;
-      int c = (j & 31) * 16;
-      asm volatile("" : "+v"(c));  // (a wave-uniform value, kept in a vector register on purpose)
-      csb[sl] = c;
-      jnext[sl] = j + SPAN;
+    char *const Rb = reinterpret_cast<char *>(qs.R);
+    constexpr int kNever = 0x40000000;
+    uint32_t amask = 0;                       // bit sl: slot sl has a rotation at this step
+    int js = wid, je = wid;                   // next chain of mine to start / to be finished
+    int next_start = js <= n - 2 ? 2 * js : kNever;      // its first step
+    int next_fin = je <= n - 2 ? je + n - 1 : kNever;    // the step after its last one
+    uint32_t ss = 0, se = 0;                  // their slots (chain number mod SLOTS)
+    auto on_slot = [&](uint32_t sl, auto &&f) {  // f(int_c<sl>) for a wave-uniform sl: static register indices
+      if constexpr (SLOTS > 0) if (sl == 0) f(int_c<0>{});
+      if constexpr (SLOTS > 1) if (sl == 1) f(int_c<1>{});
+      if constexpr (SLOTS > 2) if (sl == 2) f(int_c<2>{});
+      if constexpr (SLOTS > 3) if (sl == 3) f(int_c<3>{});
+      if constexpr (SLOTS > 4) if (sl == 4) f(int_c<4>{});
+      if constexpr (SLOTS > 5) if (sl == 5) f(int_c<5>{});
+      if constexpr (SLOTS > 6) if (sl == 6) f(int_c<6>{});
+      if constexpr (SLOTS > 7) if (sl == 7) f(int_c<7>{});
     };
+    static_assert(SLOTS <= 8, "on_slot covers eight slots");
 #pragma unroll
     for (int sl = 0; sl < SLOTS; sl++) {
-      open_chain(sl, AW * sl + wid);
+      off[sl] = scratch;
+      dec[sl] = 0;
+      csb[sl] = 0;
+      fin[sl] = scratch;
       carry[sl] = 0.0;
     }
+    auto events = [&](int k) {
+      if (k == next_fin) {  // chain je ended in the previous step: row je of R is final (its columns
+                            // je, je+1 come from the Givens lane)
+        on_slot(se, [&](auto c) {
+          constexpr int sl = decltype(c)::value;
+          *reinterpret_cast<double *>(Rb + fin[sl]) = carry[sl];
+          amask &= ~(1u << sl);
+        });
+        je += AW;
+        se = se + 1 == SLOTS ? 0 : se + 1;
+        next_fin = je <= n - 2 ? je + n - 1 : kNever;
+      }
+      if (k == next_start) {  // chain js starts: rows n-2, n-1
+        on_slot(ss, [&](auto c) {
+          constexpr int sl = decltype(c)::value;
+          const int col = js + 1 + lane;
+          const bool live = col < n || col == 64;
+          off[sl] = live ? ((n - 2) * S + col) * 8 : scratch;  // R[i-1][col] at the first step (i = n-1)
+          dec[sl] = live ? S * 8 : 0;
+          fin[sl] = live && lane != 0 ? (js * S + col) * 8 : scratch;  // where the finished row goes
+          int cb = (js & 31) * 16;
+          asm volatile("" : "+v"(cb));  // (a wave-uniform value, kept in a vector register on purpose)
+          csb[sl] = cb;
+          carry[sl] = *reinterpret_cast<const double *>(Rb + off[sl] + S * 8);  // row n-1
+          amask |= 1u << sl;
+        });
+        js += AW;
+        ss = ss + 1 == SLOTS ? 0 : ss + 1;
+        next_start = js <= n - 2 ? 2 * js : kNever;
+      }
+    };
     __syncthreads();  // the prologue phase of the Givens wave (k = -1)
-    char *const Rb = reinterpret_cast<char *>(qs.R);
     auto step = [&](auto parity, int k) {
+      events(k);
       const char *csk = reinterpret_cast<const char *>(qs.cs[decltype(parity)::value]);
 #pragma unroll
       for (int sl = 0; sl < SLOTS; sl++) {
-        const uint32_t d = static_cast<uint32_t>(k - ts[sl]);
-        if (d <= static_cast<uint32_t>(span[sl])) {  // wave-uniform
+        if (PROBE != 1 && (amask >> sl & 1u)) {  // wave-uniform
           const double2 g = *reinterpret_cast<const double2 *>(csk + csb[sl]);
           const double t1 = *reinterpret_cast<const double *>(Rb + off[sl]);
-          if (d == 0) carry[sl] = *reinterpret_cast<const double *>(Rb + off[sl] + S * 8);  // the chain starts: row n-1
           const double c = g.x, sv = g.y, t2 = carry[sl];
           const double lo = __builtin_fma(c, t1, sv * t2);
           *reinterpret_cast<double *>(Rb + off[sl] + S * 8) = __builtin_fma(c, t2, (-sv) * t1);
           carry[sl] = lo;
-          if (d == static_cast<uint32_t>(span[sl])) {
-            // the chain ends: row j of R is final (its columns j, j+1 come from the Givens lane)
-            if (tail[sl]) *reinterpret_cast<double *>(Rb + off[sl]) = lo;
-            open_chain(sl, jnext[sl]);
-          } else {
-            off[sl] -= dec[sl];
-          }
+          off[sl] -= dec[sl];
         }
       }
       __syncthreads();
@@ -441,7 +478,11 @@ __device__ inline void lm_solve_qr(LmQrShared &qs, int n) {
       step(int_c<0>{}, k);
       step(int_c<1>{}, k + 1);
     }
-    if (k <= last) step(int_c<0>{}, k);
+    if (k <= last) {
+      step(int_c<0>{}, k);
+      k++;
+    }
+    events(k);  // k = last + 1: the last chain's finished row
     __syncthreads();  // the Givens wave's last phase
   }
   // back_solve (tinyqr.h:437-459) on R x = w, with lm()'s cleanup (tol = 1e-12, :278-282, 465)

@@ -333,14 +333,18 @@ __device__ inline double det_rnorm(uint64_t zbits, const double *tab) {  // tab:
   const double y = lo_d * (2 * 3.141593 * 0x1p-32);
   const double g = rint(__builtin_fma(y, invpi, -0.5));
   const double h = 2.0 * g + 1.0;
-  const double r = __builtin_fma(-h, pio2_1t, __builtin_fma(-h, pio2_1, y));
-  const double z = r * r;
+  // (the polynomial is evaluated at -r: every operation below is odd in r, so the result is -sin r
+  // bit for bit and the sign handling is one shift, one mask and one exclusive-or)
+  const double nr = __builtin_fma(h, pio2_1t, __builtin_fma(h, pio2_1, -y));
+  const double z = nr * nr;
   const double q = fma_k(z, fma_k(z, fma_k(z, fma_k(z, fma_k(z, fma_k(z, fma_k(z, __builtin_fma(z, Q8, Q7), Q6), Q5), Q4), Q3), Q2), Q1), Q0);
-  const double sn = __builtin_fma(z * r, q, r);
-  // g odd: sn, g even: -sn (the sign bit set by integer arithmetic)
-  const uint64_t flip = static_cast<uint64_t>(~static_cast<uint32_t>(static_cast<int>(g)) & 1u) << 63;
+  const double nsn = __builtin_fma(z * nr, q, nr);
+  // cos y = sin r for g odd, -sin r for g even: h = 2g + 1 is 1.0, 3.0 or 5.0 and only 3.0 has bit 19
+  // of its high word set, so that bit moved to the sign position flips -sin r back for odd g
+  const uint64_t hbits = static_cast<uint64_t>(__double_as_longlong(h));
+  const uint64_t flip = (hbits << 12) & 0x8000000000000000ull;
   const double cs = __longlong_as_double(static_cast<long long>(
-      static_cast<uint64_t>(__double_as_longlong(sn)) ^ flip));
+      static_cast<uint64_t>(__double_as_longlong(nsn)) ^ flip));
   return sqrt_unscaled(-2 * lg) * cs;  // -2 lg is 0, +inf or at least 2^-53
 }
 

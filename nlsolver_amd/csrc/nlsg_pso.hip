@@ -24,7 +24,7 @@ struct nlsg_pso {
   int chunks = 0;
   int group = 0;  // lanes per particle when several particles share a wave (D <= 64), else 0
   bool long_rows = false;  // D > 1024: rows streamed in segments (pso_*_long_kernel)
-  unsigned move_grid_cap = 2048;  // workgroups of the striding move kernel: 8 per CU
+  unsigned move_grid_cap = 2048;  // workgroups of the striding move kernel: 8 per CU (move_blocks_per_cu)
   bool initialised = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -180,6 +180,17 @@ void launch_move(nlsg_pso *e, int timing, uint64_t iter_ovr) {
 #undef CALL
 }
 
+// Workgroups per CU of the striding Accelerated move: eight (two more than the six a CU holds at
+// once with this kernel's 77 registers). Round 4 tried one exactly resident round instead (4 .. 8
+// per CU through this switch: 152 / 151 / 149 / 148 / 147 us per launch) — no tail effect to remove;
+// the kernel sits at the vector unit's issue rate (rocprofv3: the unit 91 % busy at the 2.0 GHz the
+// chip sustains under fp64 load), so only fewer instructions make it faster.
+unsigned move_blocks_per_cu() {
+  if (const char *b = std::getenv("NLSG_PSO_MOVE_BLOCKS_PER_CU"))  // A/B switch
+    if (std::atoi(b) > 0) return static_cast<unsigned>(std::atoi(b));
+  return 8;
+}
+
 void launch_local_summary(nlsg_pso *e, double *rec_dev) {
   hipLaunchKernelGGL(pso_scan_partial_kernel, dim3(e->p.ntiles), dim3(256), 0, e->stream, e->p);
   if (!(e->cfg.eps > 0)) {
@@ -285,11 +296,6 @@ static int pso_create(const nlsg_pso_config *cfg, const nlsg_custom_objective *c
   const uint64_t D = cfg->dim, n = cfg->shard_n;
   e->chunks = D <= 128 ? 1 : D <= 256 ? 2 : D <= 512 ? 4 : 8;
   e->long_rows = D > 1024;  // the reference has no limit (nlsolver.h:2498-2742)
-  {
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0)
-      e->move_grid_cap = 8u * static_cast<unsigned>(prop.multiProcessorCount);
-  }
   e->group = D <= 8 ? 4 : D <= 16 ? 8 : D <= 32 ? 16 : D <= 64 ? 32 : 0;
   if (const char *g = std::getenv("NLSG_PSO_GROUPS"))  // A/B switch: 0 = one particle per wave at any D
     if (g[0] == '0') e->group = 0;
@@ -381,6 +387,11 @@ static int pso_create(const nlsg_pso_config *cfg, const nlsg_custom_objective *c
       nlsg_pso_destroy(e);
       return rc2;
     }
+  }
+  if (cfg->type == NLSG_PSO_ACCELERATED && !e->group && !e->long_rows) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0)
+      e->move_grid_cap = move_blocks_per_cu() * static_cast<unsigned>(cus);
   }
   *out = e;
   return NLSG_OK;

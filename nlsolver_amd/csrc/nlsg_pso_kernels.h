@@ -169,12 +169,35 @@ __global__ __launch_bounds__(256) void pso_move_kernel(PsoParams p, int timing, 
                    p.soc * u2 * (gb[c][k] - xv[c][k]);
         pnew = xv[c][k] + vv[c][k];  // :2683
       }
-      if (p.bounded) {  // :2701-2715
+      xv[c][k] = pnew;
+    }
+  }
+  // thresholds (:2701-2715) and the zeros past the row's end, each behind ONE wave-uniform branch
+  // per particle: written per element the compiler turned both into compare-and-select pairs that
+  // every element paid for (10 of the 132 vector instructions per variate) although an unbounded
+  // run never thresholds and a row that fills its chunks has no lanes past its end. The empty asm
+  // keeps the blocks from being if-converted back.
+  if (p.bounded) {
+    asm volatile("");
+#pragma unroll
+    for (int c = 0; c < CHUNKS; c++)
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        double pnew = xv[c][k];
         pnew = pnew < lo[c][k] ? lo[c][k] : pnew;
         pnew = pnew > hi[c][k] ? hi[c][k] : pnew;
+        xv[c][k] = pnew;
       }
-      xv[c][k] = (e < D) ? pnew : 0.0;
-    }
+  }
+  if (D != 128u * CHUNKS) {
+    asm volatile("");
+#pragma unroll
+    for (int c = 0; c < CHUNKS; c++)
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const uint64_t e = static_cast<uint64_t>(c) * 128 + 2 * static_cast<uint64_t>(lane) + k;
+        xv[c][k] = (e < D) ? xv[c][k] : 0.0;
+      }
   }
   const double f = p.fmul * wave_objective<OBJ, CHUNKS>(xv, D);
   store_row_stream<CHUNKS, VEC>(row, D, xv);
