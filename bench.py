@@ -242,14 +242,43 @@ def cpu_baseline_all_cores():
                       f"{gens} generations ({dt:.1f} s), OpenMP over agents, {threads} threads"}
 
 
+CONSISTENCY_VIOLATIONS = []
+MIN_TIMED_S = 0.050  # every timed region is repeated until it covers at least this much wall time
+
+
 def check_kernel_within_step(kernel_ms, ms_per_step, what):
     """A line is self-consistent only if the dominant kernel fits into the step that contains it
-    (3 % for timer noise between the two measurements)."""
+    (3 % for timer noise between the two measurements). A violation is RECORDED — the line still
+    prints, carrying `kernel_within_step: false`, and the script exits non-zero after it."""
     if os.environ.get("NLSG_BENCH_NO_CONSISTENCY_CHECK") == "1":
-        return  # counter-collection passes of the profiler stretch launches unevenly
-    if kernel_ms > 1.03 * ms_per_step:
-        raise AssertionError(f"{what}: roofline.kernel_ms {kernel_ms:.4f} > ms_per_step "
-                             f"{ms_per_step:.4f}: the two describe different regimes")
+        return True  # counter-collection passes of the profiler stretch launches unevenly
+    ok = kernel_ms <= 1.03 * ms_per_step
+    if not ok:
+        CONSISTENCY_VIOLATIONS.append(f"{what}: roofline.kernel_ms {kernel_ms:.4f} > ms_per_step "
+                                      f"{ms_per_step:.4f}: the two describe different regimes")
+    return ok
+
+
+def timed_steps(ranks, stepper, steps):
+    """The contract's timed region — barrier + synchronize on both sides, max over ranks — around
+    `steps` steps, REPEATED until the region covers MIN_TIMED_S (a 20-step run of 47 us turns is
+    0.9 ms: one clock ramp away from noise). Every rank repeats the same number of times (agreed
+    on the slowest rank's first repetition). Returns (seconds, steps actually timed)."""
+    ranks.barrier()
+    t0 = time.perf_counter()
+    stepper(steps)
+    ranks.barrier()
+    dt = ranks.max_over_ranks(time.perf_counter() - t0)
+    total, done = dt, steps
+    extra = int(np.ceil(MIN_TIMED_S / max(dt, 1e-9))) - 1
+    if extra > 0:
+        ranks.barrier()
+        t0 = time.perf_counter()
+        stepper(steps * extra)
+        ranks.barrier()
+        total += ranks.max_over_ranks(time.perf_counter() - t0)
+        done += steps * extra
+    return total, done
 
 
 def ref_baseline(cmd, key, unit, sample):
@@ -262,7 +291,7 @@ def ref_baseline(cmd, key, unit, sample):
             "sample": f"{sample} ({r['seconds']:.1f} s), 1 thread (library is single-threaded by design)"}
 
 
-PMC_DIRS = ("profiles/r03", "profiles/r02", "profiles/r01")  # newest first
+PMC_DIRS = ("profiles/r04", "profiles/r03", "profiles/r02", "profiles/r01")  # newest first
 
 
 def pmc_traffic(pop_local):
@@ -377,9 +406,10 @@ def main_bfgs(args):
     bytes_per_iter = (eng.hessian_bytes_per_iteration() if args.bfgs_symmetric
                       else 3 * n * n * 8) * batch
     achieved = bytes_per_iter / (hess_ms * 1e-3) / 1e9
-    check_kernel_within_step(hess_ms, dt / steps * 1e3, "bfgs")
+    within = check_kernel_within_step(hess_ms, dt / steps * 1e3, "bfgs")
     if ranks.rank == 0:
         print(json.dumps({
+            "kernel_within_step": within,
             "metric": "BFGS iterations x problems / s (quadratic dim=1024)",
             "value": ranks.world * batch * steps / dt, "unit": "iteration-problems/s",
             "n_gpus": ranks.world, "steps": steps,
@@ -468,9 +498,14 @@ def timed_solves(ranks, eng, x0, reps):
     start points re-uploaded outside the events): barrier + synchronize on both sides, the
     slowest rank's milliseconds per solve."""
     ranks.barrier()
-    ms = eng.time_solve(x0, reps) / reps
+    ms = ranks.max_over_ranks(eng.time_solve(x0, reps) / reps)
     ranks.barrier()
-    return ranks.max_over_ranks(ms)
+    if ms * reps < MIN_TIMED_S * 1e3:  # too short a region: once more, long enough (same count on every rank)
+        reps = int(np.ceil(MIN_TIMED_S * 1e3 / max(ms, 1e-6)))
+        ms = ranks.max_over_ranks(eng.time_solve(x0, reps) / reps)
+        ranks.barrier()
+    ranks.solves_timed = reps
+    return ms
 
 
 def main_nmpso(args):
@@ -661,9 +696,10 @@ def main_lm(args):
     flops = 2.0 * m * (nb * (nb + 1) // 2) * 256 * batch
     tflops = flops / (kms * 1e-3) / 1e12
     hbm_gbps = hbm_eval / (kms * 1e-3) / 1e9
-    check_kernel_within_step(kms, ms / iters, "lm")
+    within = check_kernel_within_step(kms, ms / iters, "lm")
     if ranks.rank == 0:
         print(json.dumps({
+            "kernel_within_step": within, "solves_timed": getattr(ranks, "solves_timed", None),
             "metric": f"LM iterations x problems / s (NLLS m=512 n={n})",
             "value": ranks.world * batch * iters / (ms * 1e-3), "unit": "iteration-problems/s",
             "n_gpus": ranks.world,
@@ -690,11 +726,17 @@ def main_lm(args):
                                       else "page-locked host memory (nlsg_host_alloc)",
                        "pcie_inclusive_value": batch * iters / (upload_s + ms * 1e-3),
                        "parallelism": ranks.replicas()},
-            "roofline": {"bound": "mfma", "achieved": tflops, "peak": 78.6, "unit": "TFLOP/s",
-                         "frac": tflops / 78.6,
+            # achieved / frac are on SURVEY §8d's ALGORITHMIC count m n (n + 1) (J^T J exploiting
+            # symmetry); what the matrix cores execute — whole lower 16 x 16 tiles, 10 at n = 64, 36 at
+            # n = 128: 11 % more — is reported beside it
+            "roofline": {"bound": "mfma", "achieved": m * n * (n + 1) * batch / (kms * 1e-3) / 1e12,
+                         "peak": 78.6, "unit": "TFLOP/s",
+                         "frac": m * n * (n + 1) * batch / (kms * 1e-3) / 1e12 / 78.6,
+                         "frac_executed_tiles": tflops / 78.6,
                          **pmc_bytes("lm", ["lm_iter_kernel"], batch == 8192 and not wide),
                          "kernel": kname,
-                         "kernel_ms": kms, "algorithmic_flops_per_launch": flops,
+                         "kernel_ms": kms, "algorithmic_flops_per_launch": float(m * n * (n + 1) * batch),
+                         "executed_tile_flops_per_launch": flops,
                          # SURVEY §8d's counts: m n (n + 1) exploiting symmetry, 2 m n^2 without
                          "frac_on_m_n_n1": m * n * (n + 1) * batch / (kms * 1e-3) / 1e12 / 78.6,
                          "frac_on_2_m_n2": 2.0 * m * n * n * batch / (kms * 1e-3) / 1e12 / 78.6,
@@ -779,12 +821,16 @@ def main_nm(args):
             "value": ranks.world * batch * iters / (ms * 1e-3), "unit": "iteration-starts/s",
             "n_gpus": ranks.world,
             "steps": iters, "warmup": 1, "ms_per_step": ms / iters, "higher_is_better": True,
+            "solves_timed": getattr(ranks, "solves_timed", None),
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"Nelder-Mead Rosenbrock-{n}D, {iters} iterations, batch={batch} per GPU",
                        "objective_calls_per_s": ranks.world * fcalls / (ms * 1e-3),
                        "parallelism": ranks.replicas()},
             "roofline": {"bound": "latency", "achieved": None, "peak": None, "unit": None,
-                         "frac": None, "traffic": None, "kernel": "nm_solve_kernel", "kernel_ms": ms,
+                         # the whole solve is ONE launch of nm_solve_driver_kernel: its duration per
+                         # simplex iteration is the step
+                         "frac": None, "traffic": None, "kernel": "nm_solve_driver_kernel",
+                         "kernel_ms": ms / iters, "launch_ms": ms,
                          "note": "LDS-resident, decision chain; not roofline-graded (SURVEY §8d)"},
             **({} if (args.no_cpu_baseline or ranks.world > 1) else {"cpu_baseline": ref_baseline(
                 ["bench-nm", n, 400000], "iterations_per_s", "iteration-starts/s",
@@ -946,23 +992,23 @@ def main_pso(args):
     stepper(300)  # untimed device wake-up (see the DE benchmark), then start over
     eng.init(-2.048, 2.048)
     stepper(args.warmup)
-    ranks.barrier()
-    t0 = time.perf_counter()
-    stepper(args.steps)
-    ranks.barrier()
-    dt = ranks.max_over_ranks(time.perf_counter() - t0)
-    assert eng.status().iteration == args.warmup + args.steps
+    dt, steps_timed = timed_steps(ranks, stepper, args.steps)
+    assert eng.status().iteration == args.warmup + steps_timed
     stepper(200)  # untimed, every rank (a sharded turn is collective): clocks back up after the pauses
     if rank == 0:
         launches = max(min(args.steps, 200), 20)
         kern_ms = eng.time_move_kernel(launches) / launches
         bytes_per = (40 if vanilla else 16) * Dp + 24  # rows r/w + cur/pbest values
         achieved = bytes_per * n_local / (kern_ms * 1e-3) / 1e9
-        check_kernel_within_step(kern_ms, dt / args.steps * 1e3, args.workload)
+        hbm = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": achieved / HBM_PEAK_GBS}
+        valu = None if vanilla else valu_roofline(kern_ms, n_local, Dp)
+        within = check_kernel_within_step(kern_ms, dt / steps_timed * 1e3, args.workload)
         print(json.dumps({
-            "metric": "particle-evals/sec Rosenbrock-256D PSO", "value": n * args.steps / dt,
-            "unit": "particle-evals/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "metric": "particle-evals/sec Rosenbrock-256D PSO", "value": n * steps_timed / dt,
+            "unit": "particle-evals/s", "n_gpus": world, "steps": args.steps, "steps_timed": steps_timed,
+            "kernel_within_step": within,
+            "warmup": args.warmup, "ms_per_step": dt / steps_timed * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"Rosenbrock-{Dp}D PSO {'Vanilla' if vanilla else 'Accelerated'}"
@@ -971,8 +1017,10 @@ def main_pso(args):
                        "parallelism": f"swarm-sharded x{world} (one all-gather of the best record "
                                       "per iteration)",
                        "turn_driver": turn_driver(drv), "rccl_ranks": rccl_ranks(drv)},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            # The Accelerated move is bound by the vector unit ("fp64 vector ALU at the
+            # ridge"; its HBM traffic equals the algorithmic bytes), so its roof is instruction issue;
+            # the HBM figure rides along as `hbm`. Vanilla is HBM-bound.
+            "roofline": {**(valu if valu else hbm), **({"hbm": hbm} if valu else {}),
                          **pmc_bytes("pso_vanilla" if vanilla else "pso_accel",
                                      ["pso_move_kernel"], n_local == 131072),
                          "kernel": "pso_move_kernel", "kernel_ms": kern_ms,
@@ -984,6 +1032,39 @@ def main_pso(args):
         dist.barrier()  # no rank tears its communicator down while another is still measuring
     eng.close()
     ranks.close()
+
+
+VALU_WAVE_INSTR_PER_S = 256 * 4 * 2.4e9 / 4  # 1024 SIMDs, one 64-lane instruction per 4 cycles at 2.4 GHz
+
+
+def valu_roofline(kern_ms, n_local, Dp):
+    """Vector-issue roofline of pso_move_kernel<Accelerated>: frac = issued vector instructions x 4
+    cycles / (SIMDs x peak clock x kernel time). The instruction count per launch is read from the
+    committed rocprofv3 SQ_INSTS_VALU pass of this workload (profiles/rNN/pso_issue_summary.json,
+    made by scripts/pmc_pso_issue.sh); None-valued when no profile matches the size."""
+    insts = busy = None
+    src = None
+    for d in PMC_DIRS:
+        path = os.path.join(ROOT, d, "pso_issue_summary.json")
+        if os.path.exists(path) and n_local == 131072 and Dp == 256:
+            prof = json.load(open(path))
+            k = next((v for name, v in prof.items() if "pso_move_kernel" in name), None)
+            if k and "SQ_INSTS_VALU" in k:
+                insts = k["SQ_INSTS_VALU"]["mean"]
+                if "SQ_ACTIVE_INST_VALU" in k and "SQ_BUSY_CYCLES" in k:
+                    # quad-cycles the vector units were issuing / cycles x SIMDs available
+                    # (SQ_BUSY_CYCLES is summed over the chip's 32 shader-engine counters)
+                    busy = k["SQ_ACTIVE_INST_VALU"]["mean"] * 4 / (k["SQ_BUSY_CYCLES"]["mean"] / 32 * 1024)
+                src = f"{d}/pso_issue_summary.json (committed rocprofv3 --pmc passes of this workload)"
+                break
+    ach = None if insts is None else insts / (kern_ms * 1e-3)
+    return {"bound": "valu", "achieved": None if ach is None else ach / 1e9,
+            "peak": VALU_WAVE_INSTR_PER_S / 1e9, "unit": "G wave-instructions/s",
+            "frac": None if ach is None else ach / VALU_WAVE_INSTR_PER_S,
+            "valu_instructions_per_launch": insts, "valu_busy_measured": busy, "valu_source": src,
+            "frac_note": "frac prices every vector instruction at 4 cycles of a 2.4 GHz SIMD; under fp64 load "
+                         "the chip sustains about 2.0 GHz, which is why valu_busy_measured (the counter's own "
+                         "ratio, taken at the clock the run had) is the higher of the two"}
 
 
 def turn_driver(drv):
@@ -1003,14 +1084,14 @@ def rccl_ranks(drv):
     return drv.comm_ranks()[0]
 
 
-def north_star_pass(steps):
+def north_star_pass(steps, pop=1 << 20):
     """BASELINE north_star's size — pop = 2^20 x 128 fp64 (1 GiB per population buffer: out of
     reach of the 256 MiB Infinity Cache that holds configs[1]'s working set) — measured in the
     same process after the configs[1] pass: whole turns and the generation kernel alone, both by
-    HIP events on the engine's stream."""
+    HIP events on the engine's stream. pop = 2^22 (4 GiB per buffer, 16x the Infinity Cache) is
+    the point past ANY cache help: a quarter of a 2^20 population still fits the cache."""
     import nlsolver_amd
-    pop = 1 << 20
-    steps = max(20, min(steps, 200))
+    steps = max(20, min(steps, 200 if pop <= (1 << 20) else 60))
     with nlsolver_amd.DEEngine("rosenbrock", pop, D, minimize=True, strategy=nlsolver_amd.DE_RANDOM,
                                CR=0.9, F=0.8, eps=1e-300, max_iter=10**12,
                                best_val_no_change=10**12, seed=12374563468) as eng:
@@ -1058,8 +1139,8 @@ def other_configs_pass():
     for name, extra in runs:
         entry = {"config": name}
         try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-cpu-baseline"] + extra,
-                               capture_output=True, text=True, timeout=150, env=env)
+            r = subprocess.run([sys.executable, os.path.abspath(__file__)] + extra,
+                               capture_output=True, text=True, timeout=240, env=env)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             if r.returncode != 0 or not line:
                 raise RuntimeError(f"rc={r.returncode}: {r.stderr.strip()[-200:]}")
@@ -1072,6 +1153,11 @@ def other_configs_pass():
             # a line is self-consistent only if its dominant kernel fits into its step
             km, sm = entry["roofline"]["kernel_ms"], entry["ms_per_step"]
             entry["kernel_within_step"] = None if km is None else bool(km <= 1.03 * sm)
+            if d.get("cpu_baseline"):  # the reference binary on one core, timed by the child
+                entry["cpu_baseline"] = d["cpu_baseline"]
+            for k in ("steps_timed", "solves_timed"):
+                if d.get(k) is not None:
+                    entry[k] = d[k]
             for k in ("solver", "solve_ms_per_iteration", "whole_run", "timed_iterations"):
                 if k in d["config"]:
                     entry[k] = d["config"][k]
@@ -1082,6 +1168,33 @@ def other_configs_pass():
             entry["error"] = str(exc)[:300]
         out.append(entry)
     return out
+
+
+def tts_pass():
+    """`--workload tts` (minimize() through the drop-in header to its default stop, cold and warm,
+    beside the reference on one core) run by a child process and cut down to one row per case."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "tts"],
+                           capture_output=True, text=True, timeout=400, env=env)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not line:
+            raise RuntimeError(f"rc={r.returncode}: {r.stderr.strip()[-200:]}")
+        d = json.loads(line[-1])
+        rows = []
+        for c in d["cases"] + d["pso_cases"] + d["batch_cases"]:
+            rows.append({"solver": c["solver"], **{k: c[k] for k in ("D", "pop", "particles") if k in c},
+                         "cold_ms": c["cold"]["wall_ms"], "warm_ms": c["warm"]["wall_ms"],
+                         "warm_phases_ms": {k[:-3]: c["warm"][k] for k in
+                                            ("create_ms", "upload_ms", "init_ms", "iterate_ms",
+                                             "readback_ms", "destroy_ms")},
+                         "iters": c["warm"]["iters"], "reference_1core_ms": c["reference_1core_ms"],
+                         "warm_speedup": c["warm_speedup"]})
+        return {"metric": d["metric"], "unit": "ms", "break_even_pop": d["config"]["break_even_pop"],
+                "rows": rows}
+    except Exception as exc:
+        return {"error": str(exc)[:300]}
 
 
 def main():
@@ -1174,13 +1287,9 @@ def main():
     stepper(2000)
     eng.init(x0)
     stepper(args.warmup)
-    ranks.barrier()
-    t0 = time.perf_counter()
-    stepper(args.steps)
-    ranks.barrier()
-    dt = ranks.max_over_ranks(time.perf_counter() - t0)
+    dt, steps_timed = timed_steps(ranks, stepper, args.steps)
     st = eng.status()
-    assert st.iteration == args.warmup + args.steps, (st.iteration, args.warmup + args.steps)
+    assert st.iteration == args.warmup + steps_timed, (st.iteration, args.warmup + steps_timed)
     improved = float(np.mean(eng.download()[1] < scores_before))
 
     # the same pass in a regime where selection does accept (~10 % per generation: CR = 0.2,
@@ -1210,7 +1319,7 @@ def main():
         # dominant kernel: de_generation_kernel, timed alone with hipEvents on its stream
         launches = max(args.steps, 20)
         kern_ms = eng.time_generation_kernel(launches) / launches
-        if kern_ms > 1.03 * dt / args.steps * 1e3 and not distributed:
+        if kern_ms > 1.03 * dt / steps_timed * 1e3 and not distributed:
             # the kernel alone slower than the step that contains it: the clocks had dropped
             # between the two measurements — bring them back up and time it once more (the
             # kernel timing leaves the engine without a population: initialise it again first)
@@ -1221,13 +1330,15 @@ def main():
             except Exception as exc:  # never lose the line to the second attempt
                 print(f"bench.py: second kernel timing failed: {exc}", file=sys.stderr)
         achieved = BYTES_PER_CANDIDATE * pop_local / (kern_ms * 1e-3) / 1e9
-        check_kernel_within_step(kern_ms, dt / args.steps * 1e3, "de")
+        within = check_kernel_within_step(kern_ms, dt / steps_timed * 1e3, "de")
         out = {
             "metric": "candidate-evals/sec (pop x iters/s) Rosenbrock-128D DE",
-            "value": pop * args.steps / dt,
+            "value": pop * steps_timed / dt,
             "unit": "candidate-evals/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
+            # `steps` as requested; the timed region repeated that loop until it covered 50 ms
+            "n_gpus": world, "steps": args.steps, "steps_timed": steps_timed, "warmup": args.warmup,
+            "kernel_within_step": within,
+            "ms_per_step": dt / steps_timed * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"Rosenbrock-{D}D DE strategy=random CR=0.9 F=0.8, "
@@ -1256,6 +1367,10 @@ def main():
         if world == 1 and not args.no_north_star and pop_local == POP_PER_GPU:
             try:
                 out["north_star"] = north_star_pass(args.steps)
+                try:  # the same kernel where no cache can hold any useful share of the population
+                    out["north_star"]["pop_2p22"] = north_star_pass(args.steps, 1 << 22)
+                except Exception as exc:
+                    out["north_star"]["pop_2p22"] = {"error": str(exc)[:200]}
                 # the HBM-honest fraction next to the headline one: configs[1]'s 128 MiB working
                 # set lives in the 256 MiB Infinity Cache, the north-star population does not
                 ns = out["north_star"]["roofline"]
@@ -1275,6 +1390,7 @@ def main():
                 out["cpu_baseline_all_cores"] = {"error": str(exc)[:200]}
         if world == 1 and not args.no_other_configs and pop_local == POP_PER_GPU:
             out["other_configs"] = other_configs_pass()
+            out["time_to_solution"] = tts_pass()
     ranks.close()
     if rank == 0:
         print(json.dumps(out))
@@ -1297,3 +1413,7 @@ if __name__ == "__main__":
         print(l, file=sys.stderr)
     if _lines:
         os.write(1, (_lines[-1] + "\n").encode())
+    if CONSISTENCY_VIOLATIONS:  # after the line: it is never lost to this check
+        for v in CONSISTENCY_VIOLATIONS:
+            print("bench.py: " + v, file=sys.stderr)
+        sys.exit(3)

@@ -21,7 +21,6 @@ struct nlsg_lm {
   bool has_data = false;
   bool wide = false;   // n > 64: the workgroup-per-problem kernels (lm_wide_*)
   bool wide_valu = false;  // NLSG_LM_WIDE_MFMA=0: the VALU contraction at every n > 64 (A/B switch)
-  int wide128_waves = 8;   // NLSG_LM_WIDE128_WAVES=4: the four-wave form of the n <= 128 evaluation (A/B switch)
   bool wide256 = true;     // NLSG_LM_WIDE256=0: the super-block evaluation at 128 < n <= 256 too (A/B switch)
   bool wide_chol = true;   // NLSG_LM_WIDE_CHOL=0: the steps before the blocked one — LDS-resident at
                            // n <= 128, column by column beyond (A/B switch)
@@ -125,8 +124,6 @@ void launch_wide_eval(nlsg_lm *e, int first) {
     // up to 128 parameters: one pass over A, J^T J on the matrix cores
     if (e->wide_valu)
       hipLaunchKernelGGL(lm_wide_tanh_eval_kernel, grid, dim3(kLmWideThreads), 0, e->stream, e->p, first);
-    else if (e->p.n <= 128 && e->wide128_waves == 4)
-      hipLaunchKernelGGL(lm_wide128_tanh_eval_kernel, grid, dim3(256), 0, e->stream, e->p, first);
     else if (e->p.n <= 128)
       hipLaunchKernelGGL(lm_wide128x8_tanh_eval_kernel, grid, dim3(512), 0, e->stream, e->p, first);
     else if (e->p.n <= 256 && e->wide256)  // one pass over A still: 136 tiles on eight waves
@@ -262,8 +259,6 @@ static int lm_create(const nlsg_lm_config *cfg, const nlsg_custom_objective *cus
   {
     const char *sw = std::getenv("NLSG_LM_WIDE_MFMA");
     e->wide_valu = sw && sw[0] == '0';
-    const char *ww = std::getenv("NLSG_LM_WIDE128_WAVES");
-    e->wide128_waves = ww && ww[0] == '4' ? 4 : 8;
     const char *w2 = std::getenv("NLSG_LM_WIDE256");
     e->wide256 = !(w2 && w2[0] == '0');
     const char *wc = std::getenv("NLSG_LM_WIDE_CHOL");
@@ -354,7 +349,7 @@ static int lm_create(const nlsg_lm_config *cfg, const nlsg_custom_objective *cus
   p.f_delta = cfg->f_delta;
   p.fd = fd ? 1 : 0;
   // the matrix-core evaluations (but the four-wave A/B form) hand is_diagonal's verdict to the step
-  p.verdict = (wide && !fd && !e->wide_valu && !(cfg->n <= 128 && e->wide128_waves != 8)) ? 1 : 0;
+  p.verdict = (wide && !fd && !e->wide_valu) ? 1 : 0;
   p.eps_h = std::pow(DBL_EPSILON, 1.0 / 4.0);  // fin_diff_h's step (:1454)
   e->has_data = fd;  // the model is the objective itself
   *out = e;
@@ -470,6 +465,10 @@ int nlsg_lm_set_solver(nlsg_lm *e, int32_t solver) {
   if (solver != NLSG_LM_CHOLESKY && solver != NLSG_LM_QR)
     return fail(NLSG_ERR_INVALID_ARG, "unknown solver %d (the reference-order mode is chosen at creation)",
                 solver);
+  if (e->cfg.solver == NLSG_LM_CHOLESKY_REFERENCE_ORDER)  // the bit-for-bit parity mode is a property of
+    return fail(NLSG_ERR_STATE,                           // the engine: it is not left silently
+                "this engine was created in NLSG_LM_CHOLESKY_REFERENCE_ORDER; create another engine "
+                "for a different solver");
   if (e->wide && solver != NLSG_LM_CHOLESKY)
     return fail(NLSG_ERR_UNSUPPORTED, "the tinyqr solve is built for n <= 64");
   if (e->p.fd && solver != NLSG_LM_CHOLESKY)

@@ -1792,172 +1792,9 @@ struct LmWide128Shared {
   double r[2][16];
 };
 
-template <int W>
-__device__ inline void lm_wide128_run(const LmParams &p, int first, uint64_t pid, LmWide128Shared &sh,
-                                      bool vec) {
-  constexpr int R = 7 - W;  // the wave's long tile row; its short one is W
-  constexpr int S = kLmW128Stride;
-  LmProblem *pr = p.prob + pid;
-  const int lane = lane_id();
-  const int half = lane >> 5, lp = lane & 31, kk = lane >> 4, cc = lane & 15;
-  const uint64_t n = p.n, m = p.m;
-  const double *A = p.Aw + pid * m * n, *y = p.yw + pid * m, *th = p.theta + pid * n;
-  const uint64_t e0 = 2 * static_cast<uint64_t>(lp), e1 = e0 + 1, e2 = 64 + e0, e3 = e2 + 1;
-  const double t0 = e0 < n ? th[e0] : 0.0, t1 = e1 < n ? th[e1] : 0.0;
-  const double t2 = e2 < n ? th[e2] : 0.0, t3 = e3 < n ? th[e3] : 0.0;
-  const uint64_t nstep = (m + 15) / 16;
-  const int rr[2] = {2 * W + half, 2 * (W + 4) + half};  // the rows of a group this lane's half stages
-  double a[2][4], yv[2];
-  auto fetch = [&](uint64_t s) {
-#pragma unroll
-    for (int q = 0; q < 2; q++) {
-      const uint64_t i = 16 * s + rr[q];
-      const bool in = i < m;
-      const double *row = A + (in ? i : 0) * n;
-      if (vec) {  // n even: rows start 16-byte aligned; the matrix is read once: streamed (nt)
-        const v2d_nt u = __builtin_nontemporal_load(reinterpret_cast<const v2d_nt *>(row + (e0 < n ? e0 : 0)));
-        const v2d_nt v = __builtin_nontemporal_load(reinterpret_cast<const v2d_nt *>(row + (e2 < n ? e2 : 0)));
-        a[q][0] = (in && e0 < n) ? u.x : 0.0;
-        a[q][1] = (in && e0 < n) ? u.y : 0.0;
-        a[q][2] = (in && e2 < n) ? v.x : 0.0;
-        a[q][3] = (in && e2 < n) ? v.y : 0.0;
-      } else {
-        a[q][0] = (in && e0 < n) ? __builtin_nontemporal_load(row + (e0 < n ? e0 : 0)) : 0.0;
-        a[q][1] = (in && e1 < n) ? __builtin_nontemporal_load(row + (e1 < n ? e1 : 0)) : 0.0;
-        a[q][2] = (in && e2 < n) ? __builtin_nontemporal_load(row + (e2 < n ? e2 : 0)) : 0.0;
-        a[q][3] = (in && e3 < n) ? __builtin_nontemporal_load(row + (e3 < n ? e3 : 0)) : 0.0;
-      }
-      yv[q] = y[in ? i : 0];
-    }
-  };
-  auto stage = [&](uint64_t s, int buf) {
-    double z[2];
-#pragma unroll
-    for (int q = 0; q < 2; q++)  // two blocks of 64 columns: the second continues the lane's chain
-      z[q] = __builtin_fma(a[q][3], t3, __builtin_fma(a[q][2], t2, __builtin_fma(a[q][1], t1, a[q][0] * t0)));
-    butterfly_levels<16>([&](auto off) {
-#pragma unroll
-      for (int q = 0; q < 2; q++) z[q] = z[q] + lane_xor<decltype(off)::value>(z[q]);
-    });
-#pragma unroll
-    for (int q = 0; q < 2; q++) {
-      const bool in = 16 * s + rr[q] < m;
-      const double tz = det_tanh(z[q]);
-      const double res = in ? yv[q] - tz : 0.0;
-      const double wgt = 1 - tz * tz;
-      double *row = &sh.J[buf][rr[q] * S];
-      double2 lo, hi;
-      lo.x = -(wgt * a[q][0]);
-      lo.y = -(wgt * a[q][1]);
-      hi.x = -(wgt * a[q][2]);
-      hi.y = -(wgt * a[q][3]);
-      *reinterpret_cast<double2 *>(row + e0) = lo;
-      *reinterpret_cast<double2 *>(row + e2) = hi;
-      if (lp == 0) sh.r[buf][rr[q]] = res;
-    }
-  };
-  v4d accA[R + 1], accB[W + 1];
-#pragma unroll
-  for (int c = 0; c <= R; c++) accA[c] = v4d{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int c = 0; c <= W; c++) accB[c] = v4d{0.0, 0.0, 0.0, 0.0};
-  constexpr int GB = 6 - 2 * W;  // g: the wave's two column blocks (their operands are among its own)
-  double gacc[2] = {0.0, 0.0};
-  double facc[4] = {0.0, 0.0, 0.0, 0.0};
-
-  fetch(0);
-  stage(0, 0);
-  if (nstep > 1) fetch(1);
-  __syncthreads();
-  for (uint64_t s = 0; s < nstep; s++) {
-    const int buf = static_cast<int>(s & 1);
-#pragma unroll
-    for (int ks = 0; ks < 4; ks++) {
-      const double *row = &sh.J[buf][(4 * ks + kk) * S];
-      double op[R + 1];
-#pragma unroll
-      for (int b = 0; b <= R; b++) op[b] = row[16 * b + cc];
-      {  // g: chain kk of column 16 b + cc takes the rows = kk (mod 4) in order
-        const double rv = sh.r[buf][4 * ks + kk];
-        gacc[0] = __builtin_fma(op[GB], rv, gacc[0]);
-        gacc[1] = __builtin_fma(op[GB + 1], rv, gacc[1]);
-      }
-#pragma unroll
-      for (int c = 0; c <= R; c++)
-        accA[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[R], op[c], accA[c], 0, 0, 0);
-#pragma unroll
-      for (int c = 0; c <= W; c++)
-        accB[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[W], op[c], accB[c], 0, 0, 0);
-    }
-    if constexpr (W == 1) {  // f: chain (s mod 4, parity) takes its rows of the group in order
-      const int sm = static_cast<int>(s & 3);
-      double fw = sm == 0 ? facc[0] : sm == 1 ? facc[1] : sm == 2 ? facc[2] : facc[3];
-#pragma unroll
-      for (int k = 0; k < 8; k++) {
-        const double rv = sh.r[buf][2 * k + half];
-        fw = __builtin_fma(rv, rv, fw);
-      }
-      facc[0] = sm == 0 ? fw : facc[0];
-      facc[1] = sm == 1 ? fw : facc[1];
-      facc[2] = sm == 2 ? fw : facc[2];
-      facc[3] = sm == 3 ? fw : facc[3];
-    }
-    if (s + 1 < nstep) {
-      stage(s + 1, buf ^ 1);
-      if (s + 2 < nstep) fetch(s + 2);
-    }
-    __syncthreads();
-  }
-  // ---- publish H = 2 J^T J (both triangles), g = 2 J^T r, f
-  double *H = p.Hw + pid * n * n;
-  auto put_tile = [&](int rb, int cb, const v4d &acc) {
-#pragma unroll
-    for (int rg = 0; rg < 4; rg++) {
-      const uint64_t row = 16 * rb + kk + 4 * rg, col = 16 * cb + cc;
-      if (row < n && col < n) {
-        const double v = 2 * acc[rg];
-        H[row * n + col] = v;
-        if (rb != cb) H[col * n + row] = v;
-      }
-    }
-  };
-#pragma unroll
-  for (int c = 0; c <= R; c++) put_tile(R, c, accA[c]);
-#pragma unroll
-  for (int c = 0; c <= W; c++) put_tile(W, c, accB[c]);
-#pragma unroll
-  for (int b = 0; b < 2; b++) {
-    const double g0 = __shfl(gacc[b], cc, 64), g1 = __shfl(gacc[b], cc + 16, 64);
-    const double g2 = __shfl(gacc[b], cc + 32, 64), g3 = __shfl(gacc[b], cc + 48, 64);
-    const uint64_t col = 16 * (GB + b) + cc;
-    if (kk == 0 && col < n) p.gg[pid * n + col] = 2 * (((g0 + g1) + g2) + g3);
-  }
-  if constexpr (W == 1) {
-    double f = 0.0;
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-      f = f + __shfl(facc[w], 0, 64);
-      f = f + __shfl(facc[w], 32, 64);
-    }
-    if (lane == 0) lm_publish_state(p, pr, first, f);
-  }
-}
-
-__global__ __launch_bounds__(256, 2) void lm_wide128_tanh_eval_kernel(LmParams p, int first) {
-  __shared__ __align__(16) LmWide128Shared sh;
-  const uint64_t pid = blockIdx.x;
-  if (!first && p.prob[pid].done) return;
-  const bool vec = (p.n & 1) == 0;
-  switch (__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6)) {
-    case 0: lm_wide128_run<0>(p, first, pid, sh, vec); break;
-    case 1: lm_wide128_run<1>(p, first, pid, sh, vec); break;
-    case 2: lm_wide128_run<2>(p, first, pid, sh, vec); break;
-    default: lm_wide128_run<3>(p, first, pid, sh, vec); break;
-  }
-}
-
-// ---- The same kernel with EIGHT waves per problem (the default; NLSG_LM_WIDE128_WAVES=4 keeps the
-// four-wave form for the A/B). With four waves a SIMD holds two of them and each carries nine
+// ---- The kernel as it runs: EIGHT waves per problem. (The four-wave form described above was the
+// first build — 0.43 of the fp64 MFMA peak against 0.475 for eight waves, profiles/r03 — and was
+// removed in round 4 together with its switch.) With four waves a SIMD holds two of them and each carries nine
 // MFMAs plus ~60 vector instructions of staging per k-step group; eight waves halve a wave's
 // staging (one row per half-wave and group instead of two), need ~110 registers instead of 196
 // (four waves per SIMD) and so leave the matrix pipe fewer gaps. Tiles: 36 = 4 x 5 + 4 x 4, waves
@@ -2339,7 +2176,7 @@ __global__ __launch_bounds__(512, 2) void lm_wide256x8_tanh_eval_kernel(LmParams
 // does on the VALU), after a first phase that needs them all: z = A theta, tanh, residuals r and
 // weights (kept in global memory, rw) and f. A pass (bj, bk) stages, sixteen rows at a time, the
 // scaled Jacobian columns of block bj (and of bk, if another) in LDS and feeds v_mfma_f64_16x16x4:
-// a diagonal super-block exactly as lm_wide128_tanh_eval_kernel does (its 36 lower tiles, nine per
+// a diagonal super-block exactly as the n <= 128 kernel does (its 36 lower tiles, nine per
 // wave), any other one as four 64 x 64 quadrants of sixteen tiles, one per wave; g rides on the
 // operands of the passes (bj, 0). Every H_jk is still one k-ordered fma chain over the rows, g_j
 // four chains by row mod 4, f eight chains, z the 32-lane chains of the order-1 oracle: same bits.

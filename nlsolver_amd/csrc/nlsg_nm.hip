@@ -149,7 +149,6 @@ static int nm_create(const nlsg_nm_config *cfg, const nlsg_custom_objective *cus
     const char *sw = std::getenv("NLSG_NM_DRIVER");
     e->driver = chunks == 1 && !(sw && sw[0] == '0');
   }
-  if (he == hipSuccess) he = pool_malloc(reinterpret_cast<void **>(&e->phase_dev), B * kNmPhases * 8);
   if (he == hipSuccess) he = prepare_driver<NLSG_OBJ_ROSENBROCK>();
   if (he == hipSuccess) he = prepare_driver<NLSG_OBJ_SPHERE>();
   if (he == hipSuccess) he = prepare_driver<NLSG_OBJ_STYBLINSKI_TANG>();
@@ -247,6 +246,10 @@ int nlsg_nm_phase_cycles(nlsg_nm *e, const double *x0_host, uint64_t *cycles_hos
   if (!e || !x0_host || !cycles_host) return fail(NLSG_ERR_INVALID_ARG, "null argument");
   NLSG_HIP(hipSetDevice(e->cfg.device));
   const uint64_t B = e->p.batch;
+  // a measurement aid: its buffer exists from its first use on, and it profiles the unbounded
+  // solve only (a bounded engine would run on whatever bounds its last minimize left behind)
+  if (e->cfg.bounded) return fail(NLSG_ERR_UNSUPPORTED, "nlsg_nm_phase_cycles profiles unbounded engines");
+  if (!e->phase_dev) NLSG_HIP(pool_malloc(reinterpret_cast<void **>(&e->phase_dev), B * kNmPhases * 8));
   NLSG_HIP(hipMemcpy(e->p.x, x0_host, B * e->p.n * 8, hipMemcpyHostToDevice));
   NLSG_HIP(hipMemset(e->phase_dev, 0, B * kNmPhases * 8));
   e->p.phase = e->phase_dev;

@@ -150,8 +150,8 @@ __global__ __launch_bounds__(256) void pso_move_kernel(PsoParams p, int timing, 
   for (int c = 0; c < CHUNKS; c++) {
 #pragma unroll
     for (int k = 0; k < 2; k++) {
-      const uint64_t e = static_cast<uint64_t>(c) * 128 + 2 * static_cast<uint64_t>(lane) + k;
-      // Accelerated: one draw (slot 2e) feeds both uniforms of the element's normal variate;
+      // element e = 128 c + 2 lane + k. Accelerated: one draw (slot 2e) feeds both uniforms of the
+      // element's normal variate;
       // Vanilla: r_p and r_g are draws 2e and 2e + 1
       const uint64_t z1 = mix64(kp_lane + kGolden * static_cast<uint64_t>(256 * c + 2 * k));
       const double u1 = u01(z1);

@@ -19,14 +19,13 @@ int check_shape(uint64_t batch, uint64_t n, uint64_t p) {
   return NLSG_OK;
 }
 
-// The opt-in for more than 64 KiB of dynamic LDS belongs to the kernel, not to a call: set once
-// to the largest p the kernel serves.
+// The opt-in for more than 64 KiB of dynamic LDS, to the largest p the kernel serves. The
+// attribute applies to the device that is current when it is set, so it is set after every
+// hipSetDevice (cheap, constant value) — set once per process it left a second device without it.
 int allow_lds() {
-  static const hipError_t he =
-      hipFuncSetAttribute(reinterpret_cast<const void *>(tinyqr_lm_kernel<kTqrThreads>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize,
-                          static_cast<int>(tqr_lds_bytes(kTqrMaxP)));
-  NLSG_HIP(he);
+  NLSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(tinyqr_lm_kernel<kTqrThreads>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                               static_cast<int>(tqr_lds_bytes(kTqrMaxP))));
   return NLSG_OK;
 }
 

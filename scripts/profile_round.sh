@@ -5,7 +5,7 @@
 # gpurun_out/prof_ROUND/. Summarised afterwards, off the box, by profiles/summarize_pmc.py into
 # profiles/ROUND/{pmc_summary,de_pmc_summary}.json; the csv / json files are copied there as they are.
 # scripts/profile_round.sh ROUND "tag tag ..." limits the run to those workloads.
-round=${1:-r03}
+round=${1:-r04}
 only=" ${2:-} "
 root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 out=$root/gpurun_out/prof_$round
@@ -26,7 +26,7 @@ run() {  # tag, bench args...
     find "$out/${tag}_$ctr" -type f ! -name '*counter_collection.csv' -delete
   done
 }
-run de_c2 --steps 1000 --warmup 50 --no-other-configs &&
+run de_c2 --steps 1000 --warmup 50 --no-other-configs --no-north-star &&
 run de_ns --pop-per-gpu 1048576 --steps 100 --warmup 5 --no-cpu-baseline &&
 run pso_accel --workload pso-accel --steps 100 --warmup 10 &&
 run pso_vanilla --workload pso-vanilla --steps 100 --warmup 10 --no-cpu-baseline &&
@@ -36,6 +36,8 @@ run lm --workload lm &&
 run lm_qr --workload lm --lm-solver qr --no-cpu-baseline &&
 run nm --workload nm && run sann --workload sann && run nmpso --workload nmpso &&
 run bfgs_fd --workload bfgs-fd && run lm_fd --workload lm-fd &&
-run lm_n128 --workload lm --lm-n 128 && run lm_n256 --workload lm --lm-n 256 && run tinyqr --workload tinyqr
+run lm_n128 --workload lm --lm-n 128 && run lm_n256 --workload lm --lm-n 256 &&
+run lm_n512 --workload lm --lm-n 512 --no-cpu-baseline && run lm_n1024 --workload lm --lm-n 1024 --no-cpu-baseline &&
+run tinyqr --workload tinyqr
 echo "rc=$?"
 du -sh "$out"

@@ -33,6 +33,14 @@ def test_nm_batch_bit_exact_vs_kernel_order_oracle(mod, oracle, n, batch, kw):
     nm_bit_exact_case(mod, oracle, n, batch, kw)
 
 
+@pytest.mark.parametrize("n,batch", [(4, 5), (33, 3), (128, 3)])
+def test_nm_phase_per_barrier_kernel_bit_exact(mod, oracle, monkeypatch, n, batch):
+    """NLSG_NM_DRIVER=0 selects the kernel the driver-wave one replaced (kept as the A/B partner of
+    scripts/nm_phases.py): the switch is read at engine creation; same oracle, same bits."""
+    monkeypatch.setenv("NLSG_NM_DRIVER", "0")
+    nm_bit_exact_case(mod, oracle, n, batch, dict(max_iter=150, eps=0.0, no_change_best_tol=100000))
+
+
 @pytest.mark.parametrize("n,batch", [(129, 3), (200, 2), (256, 2), (257, 2), (600, 1), (1024, 2)])
 @pytest.mark.parametrize("kw", [dict(max_iter=60, eps=0.0, no_change_best_tol=100000),
                                 dict(max_iter=40, eps=1e-6, no_change_best_tol=20, step=0.4,

@@ -163,7 +163,7 @@ def test_pso_config5_shard_size_properties(mod, oracle):
         check_state(eng, ref, "config5 shard")
 
 
-@pytest.mark.parametrize("type_", [O.PSO_ACCELERATED])
+@pytest.mark.parametrize("type_", [O.PSO_ACCELERATED, O.PSO_VANILLA])
 def test_pso_config5_global_size_eight_shards_on_one_gpu(mod, oracle, type_):
     """BASELINE configs[4] AS WORDED: swarm = 2^20 particles x D = 256 sharded 8 x 131072, the best
     record exchanged every iteration — all eight shard engines on the one device (2 GiB of
@@ -198,6 +198,8 @@ def test_pso_config5_global_size_eight_shards_on_one_gpu(mod, oracle, type_):
         sl = slice(r * m, (r + 1) * m)
         assert np.array_equal(pos, ref.pos[sl]), f"shard {r}: positions"
         assert np.array_equal(pbest, ref.pbest_val[sl]), f"shard {r}: personal bests"
+        if type_ == O.PSO_VANILLA:
+            assert np.array_equal(vel, ref.vel[sl]), f"shard {r}: velocities"
         mins.append((pbest.min(), r * m + int(pbest.argmin())))
         st = e.status()
         stats.append((st.iteration, st.function_calls_used, st.val_no_change, st.done, st.best_index,
