@@ -592,6 +592,15 @@ int nlsg_tinyqr_lm(const double *X_host, const double *y_host, uint64_t batch, u
  * `stream` (NULL: the null stream), asynchronous. */
 int nlsg_tinyqr_lm_device(const double *X_dev, const double *y_dev, uint64_t batch, uint64_t n,
                           uint64_t p, double tol, int32_t device, void *stream, double *beta_dev);
+/* tinyqr::qr_decomposition (tinyqr.h:291-310) and lm (:461-470) in REFERENCE ORDER on the device — a
+ * parity mode, not the fast path: the reference's serial rotation order, Q formed, element updates
+ * as two products and an add, back_solve's sums in index order, so that Q, R and beta carry the
+ * reference's own bits (tests/golden/tinyqr.json). X as for nlsg_tinyqr_lm. Outputs, each optional
+ * (NULL): Q [batch][p][n] = the thin Q as the reference returns it (Q[i * n + j]), R [batch][p][p]
+ * with R[j * p + i] = R(i, j) after the cleanup |v| < tol -> 0, beta [batch][p] (needs y_host;
+ * p <= 64). n >= p, n + p <= 1280, any p. */
+int nlsg_tinyqr_qr(const double *X_host, const double *y_host, uint64_t batch, uint64_t n, uint64_t p,
+                   double tol, int32_t device, double *Q_host, double *R_host, double *beta_host);
 
 #ifdef __cplusplus
 }

@@ -183,6 +183,7 @@ SYMBOLS = {
     "nlsg_tinyqr_lm": (C.c_int, [pd, pd, u64, u64, u64, f64, i32, pd, C.POINTER(C.c_float)]),
     "nlsg_tinyqr_lm_device": (C.c_int, [C.c_void_p, C.c_void_p, u64, u64, u64, f64, i32, C.c_void_p,
                                         C.c_void_p]),
+    "nlsg_tinyqr_qr": (C.c_int, [pd, pd, u64, u64, u64, f64, i32, pd, pd, pd]),
     "nlsg_lm_create": (C.c_int, [C.POINTER(LMConfig), C.POINTER(_H)]),
     "nlsg_lm_destroy": (C.c_int, [_H]),
     "nlsg_lm_set_data": (C.c_int, [_H, pd, pd]),

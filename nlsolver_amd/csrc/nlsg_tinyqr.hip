@@ -1,6 +1,8 @@
 // nlsolver_amd/csrc/nlsg_tinyqr.hip — host side of the batched tinyqr::lm + C-ABI.
 #include "nlsg_tinyqr_kernels.h"
 
+#include <algorithm>
+
 using namespace nlsg;
 
 namespace {
@@ -104,6 +106,72 @@ int nlsg_tinyqr_lm(const double *X_host, const double *y_host, uint64_t batch, u
   if (e1) hipEventDestroy(e1);
   if (he != hipSuccess)
     return fail(he == hipErrorOutOfMemory ? NLSG_ERR_OOM : NLSG_ERR_HIP, "nlsg_tinyqr_lm failed: %s",
+                hipGetErrorString(he));
+  return NLSG_OK;
+}
+
+int nlsg_tinyqr_qr(const double *X_host, const double *y_host, uint64_t batch, uint64_t n, uint64_t p,
+                   double tol, int32_t device, double *Q_host, double *R_host, double *beta_host) {
+  if (!X_host || (!Q_host && !R_host && !beta_host)) return fail(NLSG_ERR_INVALID_ARG, "null argument");
+  if (beta_host && !y_host) return fail(NLSG_ERR_INVALID_ARG, "beta needs y");
+  if (batch < 1 || n < 1 || p < 1) return fail(NLSG_ERR_INVALID_ARG, "batch, n and p must be >= 1");
+  if (n < p)
+    return fail(NLSG_ERR_INVALID_ARG, "n = %llu rows < p = %llu columns: tinyqr needs n >= p",
+                (unsigned long long)n, (unsigned long long)p);
+  constexpr uint64_t kMaxCols = 64ull * 20;
+  if (n + p > kMaxCols)
+    return fail(NLSG_ERR_UNSUPPORTED, "n + p = %llu > %llu: the reference-order mode keeps a row of [R | Q] "
+                "in one wave's registers", (unsigned long long)(n + p), (unsigned long long)kMaxCols);
+  if (beta_host && p > 64)
+    return fail(NLSG_ERR_UNSUPPORTED, "reference-order beta is built for p <= 64 (Q and R: any p)");
+  int rc = check_device(device);
+  if (rc) return rc;
+  NLSG_HIP(hipSetDevice(device));
+  const uint64_t W = n + p, per = n * W * sizeof(double);
+  const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(batch, (2ull << 30) / per));
+  double *X = nullptr, *y = nullptr, *work = nullptr, *Q = nullptr, *R = nullptr, *beta = nullptr;
+  hipError_t he = pool_malloc(reinterpret_cast<void **>(&X), batch * n * p * sizeof(double));
+  if (he == hipSuccess && y_host) he = pool_malloc(reinterpret_cast<void **>(&y), batch * n * sizeof(double));
+  if (he == hipSuccess) he = pool_malloc(reinterpret_cast<void **>(&work), chunk * per);
+  if (he == hipSuccess && Q_host) he = pool_malloc(reinterpret_cast<void **>(&Q), batch * n * p * sizeof(double));
+  if (he == hipSuccess && R_host) he = pool_malloc(reinterpret_cast<void **>(&R), batch * p * p * sizeof(double));
+  if (he == hipSuccess && beta_host) he = pool_malloc(reinterpret_cast<void **>(&beta), batch * p * sizeof(double));
+  if (he == hipSuccess) he = hipMemcpy(X, X_host, batch * n * p * sizeof(double), hipMemcpyHostToDevice);
+  if (he == hipSuccess && y_host) he = hipMemcpy(y, y_host, batch * n * sizeof(double), hipMemcpyHostToDevice);
+  for (uint64_t s0 = 0; he == hipSuccess && s0 < batch; s0 += chunk) {
+    TqrRefParams q;
+    q.X = X;
+    q.y = y;
+    q.work = work;
+    q.Q = Q;
+    q.R = R;
+    q.beta = beta;
+    q.n = n;
+    q.p = p;
+    q.sys0 = s0;
+    q.tol = tol;
+    const dim3 grid(static_cast<unsigned>(std::min<uint64_t>(chunk, batch - s0)));
+    const size_t lds = beta_host ? (p * p + 2 * p) * sizeof(double) : 0;
+    if (W <= 128)
+      hipLaunchKernelGGL(tinyqr_reference_kernel<2>, grid, dim3(64), lds, nullptr, q);
+    else if (W <= 512)
+      hipLaunchKernelGGL(tinyqr_reference_kernel<8>, grid, dim3(64), lds, nullptr, q);
+    else
+      hipLaunchKernelGGL(tinyqr_reference_kernel<20>, grid, dim3(64), lds, nullptr, q);
+    he = launches_status();
+    if (he == hipSuccess) he = hipDeviceSynchronize();  // the workspace is reused by the next chunk
+  }
+  if (he == hipSuccess && Q_host) he = hipMemcpy(Q_host, Q, batch * n * p * sizeof(double), hipMemcpyDeviceToHost);
+  if (he == hipSuccess && R_host) he = hipMemcpy(R_host, R, batch * p * p * sizeof(double), hipMemcpyDeviceToHost);
+  if (he == hipSuccess && beta_host) he = hipMemcpy(beta_host, beta, batch * p * sizeof(double), hipMemcpyDeviceToHost);
+  pool_free(X);
+  pool_free(y);
+  pool_free(work);
+  pool_free(Q);
+  pool_free(R);
+  pool_free(beta);
+  if (he != hipSuccess)
+    return fail(he == hipErrorOutOfMemory ? NLSG_ERR_OOM : NLSG_ERR_HIP, "nlsg_tinyqr_qr failed: %s",
                 hipGetErrorString(he));
   return NLSG_OK;
 }

@@ -196,4 +196,131 @@ __global__ __launch_bounds__(THREADS) void tinyqr_lm_kernel(TqrParams q) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Reference-order mode (a PARITY mode, not the fast path): tinyqr::qr_decomposition and lm exactly
+// as the reference computes them (tinyqr.h:253-310, 437-470) — rotations in the serial order
+// (column by column, rows bottom-up), Q FORMED (every rotation applied to the n x n identity
+// too), an element update as two products and an add (rotate_matrix, :126-139: no fused
+// multiply-add), back_solve's sums in index order — so that Q, R and beta are the reference's own
+// bits (tests/golden/tinyqr.json holds them). One WAVE per system; lane l owns columns l, l + 64,
+// ... of the joint matrix [R | Q^T-in-progress] (n rows of p + n columns, a global workspace), so
+// a column's history stays within one lane and rows never need exchanging: per rotation the lane
+// that owns column j hands (a, b) to the others through v_readlane, everyone rotates its own
+// columns of rows i-1 and i. The row a chain pushes upwards stays in registers (`carry`).
+// n + p <= 64 * MAXCH columns; any p (the wavefront kernel above stops at 64).
+struct TqrRefParams {
+  const double *X;  // [batch][p][n] column-major systems
+  const double *y;  // [batch][n] or nullptr
+  double *work;     // [systems of this launch][n][p + n]
+  double *Q;        // [batch][p][n] (thin Q as the reference returns it: Q[i * n + j]) or nullptr
+  double *R;        // [batch][p][p] (R[j * p + i] = R(i, j), cleaned) or nullptr
+  double *beta;     // [batch][p] or nullptr (needs y; p <= 64)
+  uint64_t n, p, sys0;
+  double tol;
+};
+
+template <int MAXCH>
+__global__ __launch_bounds__(64) void tinyqr_reference_kernel(TqrRefParams q) {
+  extern __shared__ __align__(16) double tqr_ref_smem[];  // beta: R as it is returned (p * p), Q^T y, beta
+  const int lane = lane_id();
+  const uint64_t sys = q.sys0 + blockIdx.x;
+  const int n = static_cast<int>(q.n), p = static_cast<int>(q.p), W = n + p;
+  double *M = q.work + static_cast<uint64_t>(blockIdx.x) * q.n * static_cast<uint64_t>(W);
+  const double *X = q.X + sys * q.n * q.p;
+  auto row = [&](int r) { return M + static_cast<uint64_t>(r) * W; };
+  // R starts as X transposed (:298-303), Q as the identity (:295)
+  for (int r = 0; r < n; r++) {
+#pragma unroll
+    for (int m = 0; m < MAXCH; m++) {
+      const int c = lane + 64 * m;
+      if (c < W) row(r)[c] = c < p ? X[static_cast<uint64_t>(c) * q.n + r] : (c - p == r ? 1.0 : 0.0);
+    }
+  }
+  double carry[MAXCH], t1[MAXCH];
+  for (int j = 0; j < p && j < n - 1; j++) {  // qr_impl, :257-272
+    const int jm = j >> 6, jl = j & 63;       // (wave-uniform)
+#pragma unroll
+    for (int m = 0; m < MAXCH; m++) carry[m] = lane + 64 * m < W ? row(n - 1)[lane + 64 * m] : 0.0;
+    for (int i = n - 1; i > j; --i) {
+#pragma unroll
+      for (int m = 0; m < MAXCH; m++) t1[m] = lane + 64 * m < W ? row(i - 1)[lane + 64 * m] : 0.0;
+      double a = 0.0, b = 0.0;  // R[i-1][j], R[i][j]
+#pragma unroll
+      for (int m = 0; m < MAXCH; m++)
+        if (m == jm) {
+          a = lane_broadcast(t1[m], jl);
+          b = lane_broadcast(carry[m], jl);
+        }
+      // givens_rotation (:86-97); pow(r, 2) is r * r exactly
+      double c, s;
+      if (fabs(b) > fabs(a)) {
+        const double r = a / b;
+        const double sv = 1.0 / __builtin_sqrt(r * r + 1.0);
+        c = sv * r;
+        s = sv;
+      } else {
+        const double r = b / a;
+        const double cv = 1.0 / __builtin_sqrt(r * r + 1.0);
+        c = cv;
+        s = cv * r;
+      }
+      // rotate_matrix on R's p columns and on Q's n columns (:126-139, 269-270): lower = row i-1
+#pragma unroll
+      for (int m = 0; m < MAXCH; m++) {
+        const int col = lane + 64 * m;
+        if (col < W) {
+          const double lo = c * t1[m] + s * carry[m];
+          const double up = -s * t1[m] + c * carry[m];
+          row(i)[col] = up;
+          carry[m] = lo;
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < MAXCH; m++)
+      if (lane + 64 * m < W) row(j)[lane + 64 * m] = carry[m];
+  }
+  // outputs: every lane reads back its own columns only
+  const bool want_beta = q.beta && q.y;  // (p <= 64: checked by the host side)
+  double *Rl = tqr_ref_smem;
+#pragma unroll
+  for (int m = 0; m < MAXCH; m++) {
+    const int col = lane + 64 * m;
+    if (col < p) {  // column `col` of R: cleanup (:278-282), transposed leading block (:305-307)
+      for (int b = 0; b < p; b++) {
+        double v = row(b)[col];
+        v = fabs(v) < q.tol ? 0.0 : v;
+        if (q.R) q.R[sys * q.p * q.p + static_cast<uint64_t>(col) * p + b] = v;
+        if (want_beta) Rl[col * p + b] = v;
+      }
+    } else if (col < W && q.Q) {  // column col - p of Q's stored rows
+      for (int i = 0; i < p; i++) q.Q[sys * q.n * q.p + static_cast<uint64_t>(i) * n + (col - p)] = row(i)[col];
+    }
+  }
+  if (!want_beta) return;
+  // back_solve (:437-459): Q^T y coefficient by coefficient in index order — lane i sums its own
+  // row of Q, whose elements other lanes wrote: read past the vector L1 (agent-scope loads) after
+  // a fence — then the triangular solve, the sums in increasing j, by one lane
+  __threadfence();
+  double *qty = tqr_ref_smem + p * p, *res = qty + p;
+  const double *y = q.y + sys * q.n;
+  if (lane < p) {
+    double ytmp = 0.0;
+    const double *qr = row(lane) + p;
+    for (int jj = 0; jj < n; jj++)
+      ytmp += __hip_atomic_load(qr + jj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * y[jj];
+    qty[lane] = ytmp;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    for (int i = p; i-- > 0;) {
+      double temp = 0.0;
+      for (int jj = i + 1; jj < p; ++jj) temp += Rl[jj * p + i] * res[jj];
+      res[i] = (qty[i] - temp) / Rl[i * p + i];
+    }
+  }
+  __syncthreads();
+  if (lane < p) q.beta[sys * q.p + lane] = res[lane];
+}
+
 }  // namespace nlsg

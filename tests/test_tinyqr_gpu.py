@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from tests import _oracle as O
-from tests.test_oracle_lm_golden import RECT, hx, rect_system
+from tests.test_oracle_lm_golden import RECT, _fnv, hx, rect_system
 
 pytestmark = pytest.mark.gpu
 
@@ -119,3 +119,56 @@ def test_full_size_property_residual_is_orthogonal(tq):
     ortho = np.einsum("bpn,bn->bp", X, r)
     assert np.max(np.abs(ortho)) < 1e-9 * n
     assert ms > 0
+
+
+# ---- reference-order mode (nlsg_tinyqr_qr): the reference's own bits on the device ----------------
+
+@pytest.mark.parametrize("n,p,seed", RECT)
+def test_reference_order_q_r_beta_equal_the_reference_bit_for_bit(tq, oracle, golden, n, p, seed):
+    """tinyqr::qr_decomposition and lm on the device in the reference's order of operations
+    (serial rotation order, Q formed, two products and an add per element, index-order sums):
+    Q, R and beta equal the OUTPUTS OF THE UNMODIFIED REFERENCE (tests/golden/tinyqr.json: hashes
+    of Q and R for every system, the matrices themselves for the small ones) bit for bit — 0 ulp
+    where the co-rotated fast path agrees to rounding (rtol 1e-9 above)."""
+    g = golden("tinyqr.json")[f"rect_{n}x{p}"]
+    Xf, y = rect_system(oracle, n, p, seed)
+    X = Xf.reshape(p, n)
+    Q, R = tq.qr_decomposition(X, 1e-8)
+    assert Q.shape == (p, n) and R.shape == (p, p)
+    assert _fnv(Q.reshape(-1)) == int(g["Q_fnv"]) and _fnv(R.reshape(-1)) == int(g["R_fnv"])
+    if "Q" in g:
+        assert Q.reshape(-1).tolist() == [hx(v) for v in g["Q"]]
+        assert R.reshape(-1).tolist() == [hx(v) for v in g["R"]]
+    beta = tq.lm(X, y, reference_order=True)
+    assert beta.tolist() == [hx(v) for v in g["beta"]]
+    beta8 = tq.lm(X, y, 1e-8, reference_order=True)
+    assert beta8.tolist() == [hx(v) for v in g["beta_tol1e-8"]]
+
+
+@pytest.mark.parametrize("n,p,batch", [(64, 64, 9), (100, 70, 3), (300, 130, 2), (40, 9, 17), (1000, 200, 1)])
+def test_reference_order_batches_vs_literal_oracle(tq, oracle, n, p, batch):
+    """Batches, and column counts past the wavefront kernel's 64: Q and R equal the literal
+    (reference-pinned, order 0) oracle bit for bit; beta too where it is offered (p <= 64)."""
+    rng = np.random.default_rng(7 * n + p)
+    X = 2 * rng.random((batch, p, n)) - 1
+    y = 2 * rng.random((batch, n)) - 1
+    Q, R = tq.qr_decomposition(X, 1e-8)
+    for b in range(batch):
+        Qo, Ro = np.zeros(n * p), np.zeros(p * p)
+        oracle.orc_qr_decomposition(O._ptr(np.ascontiguousarray(X[b].reshape(-1))), n, p, 1e-8,
+                                    O._ptr(Qo), O._ptr(Ro))
+        assert np.array_equal(Q[b].reshape(-1), Qo) and np.array_equal(R[b].reshape(-1), Ro), b
+    if p <= 64:
+        beta = tq.lm(X, y, reference_order=True)
+        for b in range(batch):
+            assert np.array_equal(beta[b], oracle_lm(oracle, X[b], y[b], 0)), b
+
+
+def test_reference_order_limits(tq):
+    import nlsolver_amd
+    with pytest.raises(nlsolver_amd.NlsgError):  # n + p beyond one wave's registers
+        tq.qr_decomposition(np.zeros((10, 1300)))
+    with pytest.raises(nlsolver_amd.NlsgError):  # n < p
+        tq.qr_decomposition(np.zeros((5, 3)))
+    with pytest.raises(nlsolver_amd.NlsgError):  # reference-order beta: p <= 64
+        tq.lm(np.zeros((70, 100)), np.zeros(100), reference_order=True)
