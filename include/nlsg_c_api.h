@@ -102,7 +102,7 @@ int nlsg_device_count(void);
 int nlsg_call_timing(double *ms_out6);
 /* Engines recycle their device blocks and streams through a per-process cache (what one
  * minimize() releases the next one takes: the reference's one-call-per-solve API would otherwise
- * pay a dozen hipMalloc / hipFree pairs per call). At most $NLSG_POOL_BYTES (default 4 GiB; 0
+ * pay a dozen hipMalloc / hipFree pairs per call). At most $NLSG_POOL_BYTES (default 40 GiB; 0
  * turns the cache off) sit idle per device. nlsg_release_cached frees all of it now;
  * nlsg_cached_bytes reports how much is parked. */
 int nlsg_release_cached(void);

@@ -6,8 +6,8 @@
 // hipMalloc / hipFree pairs, the stream and the device query around it took 3.4 ms. So what an
 // engine releases stays with the process:
 //   * device blocks go to a per-device free list keyed by size (sizes repeat exactly from call to
-//     call) and are handed out again by pool_malloc; at most NLSG_POOL_BYTES (default 4 GiB) sit
-//     idle per device, larger blocks and the overflow are freed for real; a hipMalloc that runs
+//     call) and are handed out again by pool_malloc; at most NLSG_POOL_BYTES (default 40 GiB) sit
+//     idle per device (enough for configs[2]'s 32 GiB of inverse Hessians: a fresh hipMalloc of that size was seen to take 1.9 s), larger blocks and the overflow are freed for real; a hipMalloc that runs
 //     out of memory empties the cache and tries once more;
 //   * non-blocking streams are parked and reused;
 //   * the gfx950 check of a device is made once.
@@ -37,7 +37,7 @@ struct DevicePool {
   std::map<std::pair<int, size_t>, std::vector<void *>> idle;  // (device, bytes) -> parked blocks
   std::unordered_map<int, size_t> idle_bytes;                // per device
   std::unordered_map<int, std::vector<hipStream_t>> streams;  // parked non-blocking streams
-  size_t cap = 4ull << 30;
+  size_t cap = 40ull << 30;
   bool enabled = true;
   bool poison = false;  // NLSG_POOL_POISON=1 (tests): every block handed out is filled with 0xFF bytes
                         // (NaNs / huge integers), so an engine that reads what it never wrote shows
