@@ -87,12 +87,21 @@ __global__ __launch_bounds__(256) void sann_anneal_kernel(SannParams p, uint64_t
       for (int c = 0; c < CHUNKS; c++) {
 #pragma unroll
         for (int k = 0; k < 2; k++) {
-          const uint64_t e = static_cast<uint64_t>(c) * 128 + 2 * static_cast<uint64_t>(lane) + k;
           const uint64_t z1 = mix64(ks_lane + kGolden * static_cast<uint64_t>(256 * c + 2 * k));  // one draw (slot 2e) per normal variate
           // rnorm (:2479-2485): sqrt(-2 log u1) * cos(2 pi_ u2), pi_ = 3.141593
           const double rn = det_rnorm(z1, rn_tab);
-          pt[c][k] = (e < D) ? pc[c][k] + current_scale * rn : 0.0;  // :2800
+          pt[c][k] = pc[c][k] + current_scale * rn;  // :2800
         }
+      }
+      if (D != 128u * CHUNKS) {  // lanes past the point's end hold zeros: one wave-uniform branch per
+        asm volatile("");        // trial point instead of a select pair per element (as in pso_move_kernel)
+#pragma unroll
+        for (int c = 0; c < CHUNKS; c++)
+#pragma unroll
+          for (int k = 0; k < 2; k++) {
+            const uint64_t e = static_cast<uint64_t>(c) * 128 + 2 * static_cast<uint64_t>(lane) + k;
+            pt[c][k] = (e < D) ? pt[c][k] : 0.0;
+          }
       }
       const double current_val = p.fmul * wave_objective<OBJ, CHUNKS>(pt, D);
       fcalls++;
