@@ -1100,9 +1100,21 @@ def north_star_pass(steps, pop=1 << 20):
         turn_ms = eng.time_turns(steps) / steps
         assert eng.status().iteration == 60 + steps
         kern_ms = eng.time_generation_kernel(steps) / steps
+    # strategy best (nlsolver.h:2454-2457: every trial is built around the best agent) at the same
+    # size: the head decides the generation's base row, so head and generation are two launches
+    best = None
+    if pop == (1 << 20):
+        with nlsolver_amd.DEEngine("rosenbrock", pop, D, minimize=True, strategy=nlsolver_amd.DE_BEST,
+                                   CR=0.9, F=0.8, eps=1e-300, max_iter=10**12,
+                                   best_val_no_change=10**12, seed=12374563468) as eng:
+            eng.init(np.full(D, 4.096))
+            eng.step(30)  # untimed
+            tb = eng.time_turns(steps) / steps
+            best = {"turn_us": tb * 1e3, "value": pop / (tb * 1e-3), "unit": "candidate-evals/s"}
     achieved = BYTES_PER_CANDIDATE * pop / (kern_ms * 1e-3) / 1e9
     return {"pop": pop, "dim": D, "turns_timed": steps, "turn_us": turn_ms * 1e3,
             "value": pop / (turn_ms * 1e-3), "unit": "candidate-evals/s",
+            **({"strategy_best": best} if best else {}),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, **pmc_traffic(pop),
                          "kernel": "de_generation_kernel", "kernel_ms": kern_ms,
