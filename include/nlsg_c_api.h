@@ -405,7 +405,8 @@ typedef enum {
  * reference does (separate multiply and add, nlsolver.h:251-294) — so that the default-functor
  * model reproduces the reference's own runs bit for bit (fin_diff_h divides differences of
  * objective values by 600 eps^2 = 9e-6: the last bit of a tree sum is worth 1e-9 .. 1e-6 of the
- * result). A parity mode for the finite-difference model, n <= 64. */
+ * result). A parity mode for the finite-difference model (Rosenbrock / Sphere /
+ * Styblinski-Tang, any n the engine takes). */
 typedef enum { NLSG_LM_CHOLESKY = 0, NLSG_LM_QR = 1, NLSG_LM_CHOLESKY_REFERENCE_ORDER = 2 } nlsg_lm_solver;
 
 typedef struct {

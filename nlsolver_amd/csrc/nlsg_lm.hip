@@ -95,7 +95,20 @@ void launch_fd_iter(nlsg_lm *e, int first) {
 
 // n > 64: evaluation (f, g, H at the current point) as one launch, a workgroup per problem
 template <int OBJ>
+void launch_wide_fd_ref(nlsg_lm *e, dim3 grid, int first) {  // NLSG_LM_CHOLESKY_REFERENCE_ORDER past 64 parameters
+  switch (lm_wide_chunks(e->p.n)) {
+    case 1: hipLaunchKernelGGL((lm_wide_fd_eval_kernel<OBJ, 1, true>), grid, dim3(lm_wide_fd_threads(1)), 0, e->stream, e->p, first); break;
+    case 2: hipLaunchKernelGGL((lm_wide_fd_eval_kernel<OBJ, 2, true>), grid, dim3(lm_wide_fd_threads(2)), 0, e->stream, e->p, first); break;
+    case 4: hipLaunchKernelGGL((lm_wide_fd_eval_kernel<OBJ, 4, true>), grid, dim3(lm_wide_fd_threads(4)), 0, e->stream, e->p, first); break;
+    default: hipLaunchKernelGGL((lm_wide_fd_eval_kernel<OBJ, 8, true>), grid, dim3(lm_wide_fd_threads(8)), 0, e->stream, e->p, first); break;
+  }
+}
+template <int OBJ>
 void launch_wide_fd(nlsg_lm *e, dim3 grid, int first) {
+  if (e->cfg.solver == NLSG_LM_CHOLESKY_REFERENCE_ORDER) {
+    if constexpr (OBJ != NLSG_OBJ_RASTRIGIN) launch_wide_fd_ref<OBJ>(e, grid, first);  // (rejected at creation)
+    return;
+  }
   switch (lm_wide_chunks(e->p.n)) {
     case 1: hipLaunchKernelGGL((lm_wide_fd_eval_kernel<OBJ, 1>), grid, dim3(lm_wide_fd_threads(1)), 0, e->stream, e->p, first); break;
     case 2: hipLaunchKernelGGL((lm_wide_fd_eval_kernel<OBJ, 2>), grid, dim3(lm_wide_fd_threads(2)), 0, e->stream, e->p, first); break;
@@ -162,13 +175,15 @@ int launch_solve(nlsg_lm *e) {
     const uint64_t chunk = left < 8 ? left : 8;
     for (uint64_t i = 0; i < chunk; i++) {
       if (e->wide) {
-        if (e->wide_chol && !e->wide_valu)  // blocked, the panel sums on the matrix cores
+        if (e->cfg.solver == NLSG_LM_CHOLESKY_REFERENCE_ORDER)  // the reference's own order of operations
+          hipLaunchKernelGGL(lm_wide_step_kernel<true>, grid, dim3(kLmWideThreads), 0, e->stream, e->p);
+        else if (e->wide_chol && !e->wide_valu)  // blocked, the panel sums on the matrix cores
           launch_wide_chol_step(e, grid);
         else if (e->p.n <= 128 && !e->wide_valu)  // the damped matrix in LDS, one thread per row
           hipLaunchKernelGGL(lm_wide128_step_kernel, grid, dim3(128), sizeof(LmWide128StepShared),
                              e->stream, e->p);
         else
-          hipLaunchKernelGGL(lm_wide_step_kernel, grid, dim3(kLmWideThreads), 0, e->stream, e->p);
+          hipLaunchKernelGGL(lm_wide_step_kernel<false>, grid, dim3(kLmWideThreads), 0, e->stream, e->p);
         launch_wide_eval(e, 0);
       } else if (fd) {
         launch_fd_iter(e, 0);
@@ -234,11 +249,10 @@ static int lm_create(const nlsg_lm_config *cfg, const nlsg_custom_objective *cus
   if (fd && cfg->solver == NLSG_LM_QR)
     return fail(NLSG_ERR_UNSUPPORTED,
                 "the finite-difference model runs the reference's own solve (Cholesky) only");
-  if (ref_order && (!fd || cfg->objective == NLSG_OBJ_RASTRIGIN || cfg->objective == NLSG_OBJ_CUSTOM ||
-                    cfg->n > kLmN))
+  if (ref_order && (!fd || cfg->objective == NLSG_OBJ_RASTRIGIN || cfg->objective == NLSG_OBJ_CUSTOM))
     return fail(NLSG_ERR_UNSUPPORTED,
                 "NLSG_LM_CHOLESKY_REFERENCE_ORDER (a parity mode) covers the default functors on "
-                "Rosenbrock / Sphere / Styblinski-Tang with n <= 64");
+                "Rosenbrock / Sphere / Styblinski-Tang");
   if (cfg->n < 1 || (!fd && cfg->m < 1) || cfg->batch < 1)
     return fail(NLSG_ERR_INVALID_ARG, "need n >= 1, m >= 1, batch >= 1");
   const bool wide = cfg->n > kLmN;

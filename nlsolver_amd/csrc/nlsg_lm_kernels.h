@@ -977,8 +977,12 @@ __global__ void lm_repack_kernel(LmParams p, const double *a_raw, const double *
 constexpr int kLmWideThreads = 256;
 constexpr int kLmWideMaxN = 1024;
 
+// REF (NLSG_LM_CHOLESKY_REFERENCE_ORDER past 64 parameters, round 4): a product and an add instead of
+// a fused multiply-add, and backsolve_inplace_t's sums in increasing j — the reference's own bits.
+template <bool REF = false>
 __global__ __launch_bounds__(kLmWideThreads) void lm_wide_step_kernel(LmParams p) {
   __shared__ double piv[kLmWideMaxN];  // the pivot row of a column step / the solution vector
+  __shared__ double terms[REF ? kLmWideMaxN : 1];  // REF: the products of one backsolve row
   __shared__ double diag;
   const uint64_t pid = blockIdx.x;
   LmProblem *pr = p.prob + pid;
@@ -1021,7 +1025,7 @@ __global__ __launch_bounds__(kLmWideThreads) void lm_wide_step_kernel(LmParams p
       double sum = 0.0;
       if (i >= j && i < n) {
         const double *row = H + static_cast<uint64_t>(i) * n;
-        for (int k = 0; k < j; k++) sum = __builtin_fma(row[k], piv[k], sum);
+        for (int k = 0; k < j; k++) sum = lm_mad<REF>(row[k], piv[k], sum);
         if (i == j) diag = sqrt(row[j] - sum);
       }
       s[q] = sum;
@@ -1053,8 +1057,24 @@ __global__ __launch_bounds__(kLmWideThreads) void lm_wide_step_kernel(LmParams p
 #pragma unroll
     for (int q = 0; q < R; q++) {
       const int i = t + T * q;
-      if (i > j && i < n) s[q] = __builtin_fma(H[static_cast<uint64_t>(i) * n + j], uj, s[q]);
+      if (i > j && i < n) s[q] = lm_mad<REF>(H[static_cast<uint64_t>(i) * n + j], uj, s[q]);
     }
+  }
+  if constexpr (REF) {
+    // backsolve_inplace_t (:270-281) literally: component i from the sum over j = i+1 .. n-1 in
+    // that order. The products are made side by side (thread j: U[j][i] b[j]), one thread adds them.
+    for (int i = n - 1; i >= 0; i--) {
+      for (int j = i + 1 + t; j < n; j += T) terms[j] = H[static_cast<uint64_t>(j) * n + i] * piv[j];
+      __syncthreads();
+      if (t == 0) {
+        double sum = 0.0;
+        for (int j = i + 1; j < n; j++) sum = sum + terms[j];
+        piv[i] = (piv[i] - sum) / H[static_cast<uint64_t>(i) * n + i];
+      }
+      __syncthreads();
+    }
+    for (int i = t; i < n; i += T) th[i] = th[i] - piv[i];  // :3534
+    return;
   }
   // backsolve_inplace_t (:270-281), the inner sums taken from j = n-1 down to i+1
 #pragma unroll
@@ -1385,7 +1405,7 @@ __host__ __device__ constexpr int lm_wide_chunks(uint64_t n) { return n <= 128 ?
 __host__ __device__ constexpr int lm_wide_fd_threads(int chunks) {
   return chunks >= 8 ? 512 : 1024;  // the 1024-coordinate point needs more than 128 registers
 }
-template <int OBJ, int CHUNKS>
+template <int OBJ, int CHUNKS, bool REF = false>  // REF: every probe sums its objective in index order
 __global__ __launch_bounds__(lm_wide_fd_threads(CHUNKS)) void lm_wide_fd_eval_kernel(LmParams p, int first) {
   const uint64_t pid = blockIdx.x;
   LmProblem *pr = p.prob + pid;
@@ -1411,6 +1431,7 @@ __global__ __launch_bounds__(lm_wide_fd_threads(CHUNKS)) void lm_wide_fd_eval_ke
         const uint64_t e = static_cast<uint64_t>(c) * 128 + 2 * static_cast<uint64_t>(lane) + k;
         xp[c][k] = e == j ? vj : e == i ? vi : xv[c][k];
       }
+    if constexpr (REF) return wave_objective_seq<OBJ, CHUNKS>(xp, n);
     return wave_objective<OBJ, CHUNKS>(xp, n);
   };
   {  // fin_diff<1> (:1385-1413)
@@ -1467,7 +1488,7 @@ __global__ __launch_bounds__(lm_wide_fd_threads(CHUNKS)) void lm_wide_fd_eval_ke
     if (lane == 0) H[en] = result / denom;
   }
   if (w == 0) {
-    const double fx = wave_objective<OBJ, CHUNKS>(xv, n);
+    const double fx = REF ? wave_objective_seq<OBJ, CHUNKS>(xv, n) : wave_objective<OBJ, CHUNKS>(xv, n);
     if (lane == 0) lm_publish_state(p, pr, first, fx);
   }
 }

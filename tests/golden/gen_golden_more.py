@@ -58,6 +58,9 @@ def main():
         "sphere_n5": run("lm-fd", 1, 5, 50, 10, 1e-12, 3, -0.5, 64),
         "styblinski_tang_n8": run("lm-fd", 2, 8, 30, 10, 1e-12, -2.5, 0.1, 64),
         "sphere_n64_3iters_lambda1": run("lm-fd", 1, 64, 3, 1, 0, 1, 0.01, 64),
+        # past 64 parameters (the device's workgroup-per-problem kernels in reference order)
+        "rosenbrock_n100_2iters": run("lm-fd", 0, 100, 2, 10, 0, 0.95, 0.0005, 64),
+        "styblinski_tang_n130_2iters": run("lm-fd", 2, 130, 2, 10, 0, -2.5, 0.01, 64),
     }
     write("lm_fd.json", g8fd)
 

@@ -213,6 +213,10 @@ def test_lm_default_functors_match_reference_runs(mod, oracle, golden):
     from tests.test_oracle_golden import hx
     names = {0: "rosenbrock", 1: "sphere", 2: "styblinski_tang"}
     for name, g in golden("lm_fd.json").items():
+        if g["n"] > 64:
+            # the runs past 64 parameters (round 4) pin the REFERENCE-ORDER mode, bit for bit
+            # (tests/test_reference_order_gpu.py); the tolerances below were measured for n <= 64
+            continue
         x0 = hx(g["x0"]) + hx(g["x0_step"]) * np.arange(g["n"], dtype=np.float64)
         x = x0.copy()
         solver = mod.lm.LevenbergMarquardt(names[g["objective"]], hx(g["lambda"]), 10.0, 10.0,

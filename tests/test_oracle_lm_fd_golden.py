@@ -11,7 +11,8 @@ from tests.test_oracle_golden import hx
 
 OBJ_NAME = {0: "rosenbrock", 1: "sphere", 2: "styblinski_tang"}
 CASES = ["rosenbrock_n2_example_start", "rosenbrock_n4_near_minimum", "rosenbrock_n4_indefinite_nan",
-         "rosenbrock_n16_6iters", "sphere_n5", "styblinski_tang_n8", "sphere_n64_3iters_lambda1"]
+         "rosenbrock_n16_6iters", "sphere_n5", "styblinski_tang_n8", "sphere_n64_3iters_lambda1",
+         "rosenbrock_n100_2iters", "styblinski_tang_n130_2iters"]  # (past 64 parameters: round 4)
 
 
 def start(g):

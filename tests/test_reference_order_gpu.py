@@ -112,11 +112,14 @@ def test_lm_default_functors_equal_the_reference_runs(mod, golden):
 
 
 @pytest.mark.parametrize("obj,n,batch", [("rosenbrock", 3, 6), ("rosenbrock", 9, 4), ("sphere", 17, 3),
-                                         ("styblinski_tang", 33, 2), ("rosenbrock", 64, 2)])
+                                         ("styblinski_tang", 33, 2), ("rosenbrock", 64, 2),
+                                         # past 64 parameters: the workgroup-per-problem kernels (round 4)
+                                         ("rosenbrock", 65, 2), ("sphere", 129, 2),
+                                         ("styblinski_tang", 200, 1), ("rosenbrock", 257, 1)])
 def test_lm_reference_order_batches_equal_the_serial_oracle(mod, oracle, obj, n, batch):
     """Every group width (4, 8, 16, 32 lanes per probe point): device == oracle order 0."""
     from nlsolver_amd._capi import LM_CHOLESKY_REFERENCE_ORDER
-    kw = dict(lam=10.0, max_iter=3, f_delta=0.0)
+    kw = dict(lam=10.0, max_iter=3 if n <= 64 else 2, f_delta=0.0)
     rng = np.random.default_rng(500 + n)
     x0 = 0.9 + 0.2 * (rng.random((batch, n)) - 0.5)
     with mod.lm.LMEngine(obj, batch=batch, n=n, solver=LM_CHOLESKY_REFERENCE_ORDER, **kw) as eng:
@@ -129,7 +132,7 @@ def test_lm_reference_order_batches_equal_the_serial_oracle(mod, oracle, obj, n,
 
 def test_lm_reference_order_limits(mod):
     from nlsolver_amd._capi import LM_CHOLESKY_REFERENCE_ORDER, NlsgError
-    with pytest.raises(NlsgError):
-        mod.lm.LMEngine("rosenbrock", batch=1, n=70, solver=LM_CHOLESKY_REFERENCE_ORDER)
+    with pytest.raises(NlsgError):  # (n <= 1024 like every LM engine; 70 is served since round 4)
+        mod.lm.LMEngine("rosenbrock", batch=1, n=1100, solver=LM_CHOLESKY_REFERENCE_ORDER)
     with pytest.raises(NlsgError):
         mod.lm.LMEngine("rastrigin", batch=1, n=4, solver=LM_CHOLESKY_REFERENCE_ORDER)
