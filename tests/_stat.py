@@ -162,3 +162,46 @@ def compare(name, ref, smp, gens, report=None):
         }
     assert not bad, f"{name}: " + "; ".join(bad)
     return out
+
+
+# ---- the N4 rows (SANN, NelderMeadPSO): tests/golden/n4_stat.json ---------------------------------
+
+N4_SEED = 12374563468  # one seed, run k = chain / instance k: the device keys its draws by (seed, chain)
+
+
+def load_n4():
+    with open(os.path.join(HERE, "golden", "n4_stat.json")) as fh:
+        g = json.load(fh)
+    for fam in ("sann", "nmpso"):
+        for c in g[fam].values():
+            c["f"] = np.array([float.fromhex(v) for v in c["f"]])
+            c["iters"], c["fcalls"] = np.array(c["iters"]), np.array(c["fcalls"])
+    return g
+
+
+def significant(a, digits=12):
+    """Values to `digits` significant digits: a run that never leaves its start point returns f(x0),
+    which the reference sums in index order and the device as a lane tree — the same number to
+    north_star's 1e-12, not the same bits. Without this the KS test reads 128 identical values
+    against 128 identical values one ulp away as two different distributions (nmpso n = 32: every
+    reference run returns 9.8645556679802162)."""
+    a = np.asarray(a, dtype=np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        mag = np.where(a == 0, 1.0, 10.0 ** (digits - 1 - np.floor(np.log10(np.abs(a)))))
+    return np.round(a * mag) / mag
+
+
+def compare_n4(name, ref, f, iters, fcalls, report=None):
+    out, bad = [], []
+    for label, a, b in (("f", significant(f), significant(ref["f"])), ("iters", iters, ref["iters"]),
+                        ("fcalls", fcalls, ref["fcalls"])):
+        a, b = np.asarray(a), np.asarray(b)
+        p = 1.0 if np.array_equal(np.sort(a), np.sort(b)) else float(ks_2samp(a, b).pvalue)
+        out.append((label, p))
+        if p < P_MIN:
+            bad.append(f"{label}: KS p = {p:.3g} (medians {np.median(a):.6g} vs {np.median(b):.6g})")
+    if report is not None:
+        report[name] = {"median_f": [float(np.median(f)), float(np.median(ref["f"]))],
+                        "stats": [[a, "ks_p", b] for a, b in out]}
+    assert not bad, f"{name}: " + "; ".join(bad)
+    return out

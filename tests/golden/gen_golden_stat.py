@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Regenerate tests/golden/de_stat.json and pso_stat.json: K seeded runs of the UNMODIFIED
+"""Regenerate tests/golden/de_stat.json, pso_stat.json and n4_stat.json (SANN, NelderMeadPSO): K seeded runs of the UNMODIFIED
 reference per configuration (oracle/_ref/ref_driver de-stat / pso-stat, which reseed the
 reference's xorshift through its own set_state, nlsolver.h:1367).
 
@@ -43,6 +43,34 @@ PSO_CONFIGS = [
     ("n1024_D32", 32, 1024, 5000, 10e-4, 50, "2.048"),
     ("n4096_D128_fixed200", 128, 4096, 200, 0.0, 1000, "2.048"),
 ]
+
+
+# SANN (ctor defaults nlsolver.h:2759-2761: max_iter 5000, temperature_iter 10, temperature_max 10)
+# and NelderMeadPSO (3563-3569: eps 1e-6, max_iter 1000, no_change 20) on Rosenbrock from
+# x_i = 0.5 + 0.01 i: (name, n, args of the driver's *-stat command)
+SANN_CONFIGS = [
+    ("n2", 2, (5000, 10, 10.0)),
+    ("n16", 16, (5000, 10, 10.0)),
+    ("n128_2000iters", 128, (2000, 10, 10.0)),
+]
+NMPSO_CONFIGS = [
+    ("n2", 2, (1000, 1e-6, 20)),
+    ("n8", 8, (1000, 1e-6, 20)),
+    ("n32", 32, (1000, 1e-6, 20)),
+]
+
+
+def chunked_n4(cmd, n, args, chunks):
+    def one(c):
+        k0, k1 = c
+        out = subprocess.check_output([DRIVER, cmd, "0", str(n), *map(repr, args), "0.5", "0.01",
+                                       str(k0), str(k1)], text=True)
+        return json.loads(out)["runs"]
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        parts = list(ex.map(one, chunks))
+    runs = [r for p in parts for r in p]
+    return {"k": [r["k"] for r in runs], "iters": [r["iters"] for r in runs],
+            "fcalls": [r["fcalls"] for r in runs], "f": [r["f"] for r in runs]}
 
 
 def chunked(cmd, kind, D, n, max_iter, eps, no_change, x0, chunks, extra=()):
@@ -95,6 +123,18 @@ def main():
         print("pso", name, "done", flush=True)
     with open(os.path.join(HERE, "pso_stat.json"), "w") as fh:
         json.dump(pso, fh, separators=(",", ":"))
+        fh.write("\n")
+    n4 = {"K": K, "seed_rule": de["seed_rule"], "x0": "0.5 + 0.01 i", "sann": {}, "nmpso": {}}
+    for name, n, args in SANN_CONFIGS:
+        n4["sann"][name] = dict(n=n, max_iter=args[0], temperature_iter=args[1], temperature_max=args[2],
+                                **chunked_n4("sann-stat", n, args, chunks))
+        print("sann", name, "done", flush=True)
+    for name, n, args in NMPSO_CONFIGS:
+        n4["nmpso"][name] = dict(n=n, max_iter=args[0], eps=args[1], no_change=args[2],
+                                 **chunked_n4("nmpso-stat", n, args, chunks))
+        print("nmpso", name, "done", flush=True)
+    with open(os.path.join(HERE, "n4_stat.json"), "w") as fh:
+        json.dump(n4, fh, separators=(",", ":"))
         fh.write("\n")
 
 

@@ -103,3 +103,31 @@ def test_device_sample_is_the_oracle_sample(mod):
         st = eng.status()
         scores = eng.download()[1]
     assert int(st.iteration) == int(ref.s.iter) and np.array_equal(scores, ref.scores)
+
+
+N4 = S.load_n4()
+
+
+@pytest.mark.parametrize("name", list(N4["sann"]))
+def test_sann_device_vs_reference_distribution(mod, name):
+    """128 device chains (one engine call, chain k keyed by (seed, k)) against 128
+    seeded runs of the reference's SANN (tests/golden/n4_stat.json)."""
+    c, K = N4["sann"][name], N4["K"]
+    x0 = np.tile(0.5 + 0.01 * np.arange(c["n"]), (K, 1))
+    with mod.SANNEngine("rosenbrock", K, c["n"], max_iter=c["max_iter"],
+                        temperature_iter=c["temperature_iter"], temperature_max=c["temperature_max"],
+                        seed=S.N4_SEED) as eng:
+        _, st = eng.minimize(x0)
+    S.compare_n4("sann_" + name, c, [s.f_value for s in st], [s.iteration for s in st],
+                 [s.function_calls_used for s in st], REPORT)
+
+
+@pytest.mark.parametrize("name", list(N4["nmpso"]))
+def test_nmpso_device_vs_reference_distribution(mod, name):
+    c, K = N4["nmpso"][name], N4["K"]
+    x0 = np.tile(0.5 + 0.01 * np.arange(c["n"]), (K, 1))
+    with mod.NMPSOEngine("rosenbrock", K, c["n"], eps=c["eps"], max_iter=c["max_iter"],
+                         no_change_best_iter=c["no_change"], seed=S.N4_SEED) as eng:
+        _, st = eng.minimize(x0)
+    S.compare_n4("nmpso_" + name, c, [s.f_value for s in st], [s.iteration for s in st],
+                 [s.function_calls_used for s in st], REPORT)

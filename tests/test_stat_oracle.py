@@ -59,3 +59,32 @@ def test_pso_sync_oracle_vs_reference_distribution(name):
     smp = sample_pso_oracle(O.load(), c, PSO["gens"], PSO["K"],
                             threads=4 if c["particles"] >= 1024 else 1)
     S.compare(name, c, smp, PSO["gens"])
+
+
+N4 = S.load_n4()
+
+
+def n4_start(n):
+    return 0.5 + 0.01 * np.arange(n)
+
+
+@pytest.mark.parametrize("name", ["n2", "n16"])
+def test_sann_sync_oracle_vs_reference_distribution(name):
+    """SANN: 128 chains of the synchronous oracle (= the device, bit for bit) against
+    128 seeded runs of the reference (nlsolver.h:2744-2815): the chain is the same sequential Markov
+    chain, only the draws are keyed instead of streamed."""
+    c, lib = N4["sann"][name], O.load()
+    runs = [O.sann_sync(lib, "rosenbrock", n4_start(c["n"]), S.N4_SEED, k, max_iter=c["max_iter"],
+                        temp_iter=c["temperature_iter"], temp_max=c["temperature_max"])[0]
+            for k in range(N4["K"])]
+    S.compare_n4("sann_" + name, c, [r.f_value for r in runs], [r.iteration for r in runs],
+                 [r.function_calls_used for r in runs])
+
+
+@pytest.mark.parametrize("name", ["n2", "n8"])
+def test_nmpso_sync_oracle_vs_reference_distribution(name):
+    c, lib = N4["nmpso"][name], O.load()
+    runs = [O.nmpso_sync(lib, "rosenbrock", n4_start(c["n"]), S.N4_SEED, k, eps=c["eps"],
+                         max_iter=c["max_iter"], no_change=c["no_change"])[0] for k in range(N4["K"])]
+    S.compare_n4("nmpso_" + name, c, [r.f_value for r in runs], [r.iteration for r in runs],
+                 [r.function_calls_used for r in runs])
