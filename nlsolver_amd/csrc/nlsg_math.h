@@ -114,6 +114,7 @@ __device__ inline double div_unscaled(double n, double d) {
   const double r = __builtin_fma(-d, q, n);
   return __builtin_fma(r, y, q);
 }
+template <bool SPECIAL = true>  // SPECIAL = false: x is known to be a positive normal number
 __device__ inline double sqrt_unscaled(double x) {
   const double y = __builtin_amdgcn_rsq(x);
   double g = x * y, h = 0.5 * y;
@@ -124,6 +125,7 @@ __device__ inline double sqrt_unscaled(double x) {
   g = __builtin_fma(d, h, g);
   d = __builtin_fma(-g, g, x);
   g = __builtin_fma(d, h, g);
+  if constexpr (!SPECIAL) return g;
   return (x == 0.0 || x == __builtin_inf()) ? x : g;
 }
 
@@ -308,7 +310,12 @@ __device__ inline double det_log_unit(double x, const double *tab) {  // x in [2
 // oracle_math.c's orc_rnorm is the CPU mirror. The kernels that draw normal variates are bound
 // by the vector unit's instruction count: 265 -> ~120 vector instructions per variate since
 // round 1.
-__device__ inline double det_rnorm(uint64_t zbits, const double *tab) {  // tab: the LDS table
+// SPECIAL = false leaves out the two selects that only the draws z = 0 (u1 = 0: the logarithm is
+// -inf) and z >= 2^64 - 2^10 (u1 rounds to 1: the square root of -0) need — det_rnorm below takes
+// that path when no lane of the wave holds such a draw (all but 2^-53 of the time), six vector
+// instructions per variate fewer; same bits either way.
+template <bool SPECIAL>
+__device__ inline double det_rnorm_impl(uint64_t zbits, const double *tab) {  // tab: the LDS table
   constexpr double pio2_1 = 1.57079632673412561417e+00, pio2_1t = 6.07710050650619224932e-11;
   // u1 = (double)z 2^-64 rounded once, as the conversion rounds: hi 2^-32 + lo 2^-64 in one fma
   // (both terms exact); the angle y = 2 pi_ u2 = lo (2 pi_ 2^-32) — scaling by 2^-32 is exact, so
@@ -317,7 +324,7 @@ __device__ inline double det_rnorm(uint64_t zbits, const double *tab) {  // tab:
   const double lo_d = static_cast<double>(static_cast<uint32_t>(zbits));
   const double u1 = __builtin_fma(hi_d, 0x1p-32, lo_d * 0x1p-64);
   double lg = det_log_unit(u1, tab);  // (u1 = 0: garbage, replaced below)
-  lg = u1 == 0.0 ? -__builtin_inf() : lg;
+  if constexpr (SPECIAL) lg = u1 == 0.0 ? -__builtin_inf() : lg;
   // cos(2 pi_ u2), y in [0, 6.3]: cos y = -(-1)^g sin(r) with g = rint(y / pi - 1/2) in {0, 1, 2}
   // and r = y - (g + 1/2) pi in [-pi/2, pi/2] (two-term Cody-Waite, (2g + 1) pio2_1 exact), and
   // ONE odd polynomial for the sine there, sin r = r + r^3 Q(r^2) (degree 8: Chebyshev fit of
@@ -345,7 +352,12 @@ __device__ inline double det_rnorm(uint64_t zbits, const double *tab) {  // tab:
   const uint64_t flip = (hbits << 12) & 0x8000000000000000ull;
   const double cs = __longlong_as_double(static_cast<long long>(
       static_cast<uint64_t>(__double_as_longlong(nsn)) ^ flip));
-  return sqrt_unscaled(-2 * lg) * cs;  // -2 lg is 0, +inf or at least 2^-53
+  return sqrt_unscaled<SPECIAL>(-2 * lg) * cs;  // -2 lg is 0, +inf or at least 2^-53
+}
+__device__ inline double det_rnorm(uint64_t zbits, const double *tab) {
+  const bool special = zbits - 1 >= 0xFFFFFFFFFFFFFBFFull;  // z = 0 or z >= 2^64 - 2^10
+  if (__builtin_expect(__ballot(special) != 0, 0)) return det_rnorm_impl<true>(zbits, tab);  // wave-uniform
+  return det_rnorm_impl<false>(zbits, tab);
 }
 
 // cos(2 pi x) the way the reference's Rastrigin writes it (test_functions.h:74-76): the product
