@@ -365,7 +365,7 @@ __device__ inline void lm_solve_qr(LmQrShared &qs, int n) {
       // r^2 + 1 lies in [1, 2] (or is NaN): the square root and the reciprocal without the
       // compiler's operand scaling and fix-up steps — nine instructions off the chain that is
       // the workgroup's critical path, same correctly rounded values
-      const double tt = div_unscaled(1.0, sqrt_unscaled<false>(r * r + 1.0));
+      const double tt = div_unscaled(1.0, sqrt_unscaled(r * r + 1.0));
       const double tr = tt * r;
       cp = swap ? tr : tt;
       sp = swap ? tt : tr;

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(THREADS) void tinyqr_lm_kernel(TqrParams q) {
         // t = 1 / sqrt(r^2 + 1), {t, t r} — selected, not branched
         const bool swap = fabs(b) > fabs(a);
         const double r = (swap ? a : b) / (swap ? b : a);
-        const double tt = div_unscaled(1.0, sqrt_unscaled<false>(r * r + 1.0));  // r^2 + 1 in [1, 2] or NaN
+        const double tt = div_unscaled(1.0, sqrt_unscaled(r * r + 1.0));  // r^2 + 1 in [1, 2] or NaN
         const double tr = tt * r;
         const double c = swap ? tr : tt, s = swap ? tt : tr;
         cs[j] = make_double2(c, s);
