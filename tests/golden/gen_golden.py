@@ -80,6 +80,14 @@ def main():
     if os.path.exists(more):
         import runpy
         runpy.run_path(more, init_globals={"run": run, "write": write})["main"]()
+    # the distribution-level fixtures (de_stat.json, pso_stat.json, n4_stat.json: 128 seeded runs of
+    # the reference per configuration) take three more minutes on 8 cores: --with-stat, or run
+    # gen_golden_stat.py on its own; they regenerate byte-identically too
+    stat = os.path.join(HERE, "gen_golden_stat.py")
+    if "--with-stat" in sys.argv[1:]:
+        subprocess.check_call([sys.executable, stat])
+    else:
+        print("(de_stat / pso_stat / n4_stat: python tests/golden/gen_golden_stat.py, or --with-stat)")
 
 
 if __name__ == "__main__":
