@@ -11,8 +11,9 @@ statistic of the two samples:
     same distribution (everything except the cases below);
   * where a KS test of 128 against 128 runs DOES resolve a difference — DE at pop 40, D 2, where a
     synchronous generation needs about 1.13x the reference's in-place generations to reach the
-    std_err stop — the measured median ratio is asserted inside a band around the figure DESIGN.md
-    §3 records, so the difference is pinned rather than hidden.
+    std_err stop, and the D = 128 configurations with CR 0.1 (RATIO_BANDS below) — the measured
+    median ratio is asserted inside a band around the figure DESIGN.md §3 records, so the
+    difference is pinned rather than hidden.
 """
 import json
 import os
@@ -95,7 +96,8 @@ def _append(sample, gens, best, mean):
 
 # Where 128-vs-128 runs resolve a real difference between the synchronous generation and the
 # reference's in-place one (nlsolver.h:2449-2472: agent i's trial already sees the survivors of
-# agents < i of the same generation): DE at pop 40, D 2 only. (config, statistic) -> (lo, hi) band on
+# agents < i of the same generation): DE at pop 40, D 2, and the two D = 128 configurations with CR 0.1
+# below. (config, statistic) -> (lo, hi) band on
 # median(sample) / median(reference). Measured with the synchronous oracle = the device
 # (DESIGN.md §3 "Distribution-level parity"): iterations-to-stop 49 vs 43 (1.14) for strategy
 # random, 48 vs 43 (1.12) for best; population mean after 10 generations 1.12 / 1.40.
