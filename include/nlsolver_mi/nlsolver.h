@@ -397,6 +397,40 @@ inline uint64_t seed_from(RNG &generator) {
   const uint64_t lo = half();
   return (hi << 32) | lo;
 }
+
+// Summation order of the device solves whose results turn on the last bit of a sum: BFGS (dots,
+// norms, H y, and with the default gradient fin_diff's differences over 12 eps) and the
+// default-functor LevenbergMarquardt (fin_diff_h's differences over 600 eps^2).
+//   reference  every sum in index order, separate multiply and add — the reference's sequential
+//              loops (NLSG_BFGS_REFERENCE_ORDER / NLSG_LM_CHOLESKY_REFERENCE_ORDER): x, f and every
+//              counter are the reference's own, bit for bit. A sum costs n dependent additions:
+//              1.8 x (LM) to 10 x (BFGS, default gradient) the tree kernels' time on a large batch.
+//   tree       the wave's butterfly sums and fused multiply-adds: same algorithm, same branch
+//              decisions on the reference's runs, values within 1e-8 .. 1e-6 (fin_diff) or
+//              rounding (analytic gradient).
+//   automatic  (default) minimize() — the reference's own call, one start, latency-bound either
+//              way — solves in reference order wherever the engine has it (not Rastrigin, whose
+//              device cosine is not libm's, nor Custom or TanhRegression); minimize_batch(), this
+//              header's extension, solves in tree order.
+// Set once before the solves it should govern: `nlsolver::device::summation() = ...`, or the
+// environment variable NLSG_SUMMATION = reference | tree | automatic (read at first use).
+enum class sum_order { automatic, tree, reference };
+inline sum_order &summation() {
+  static sum_order order = [] {
+    const char *e = std::getenv("NLSG_SUMMATION");
+    const std::string v = e ? e : "";
+    if (v == "reference") return sum_order::reference;
+    if (v == "tree") return sum_order::tree;
+    if (!v.empty() && v != "automatic")
+      throw device_error("NLSG_SUMMATION must be reference, tree or automatic, not '" + v + "'");
+    return sum_order::automatic;
+  }();
+  return order;
+}
+inline bool reference_order_for(bool single_start) {
+  const sum_order o = summation();
+  return o == sum_order::reference || (o == sum_order::automatic && single_start);
+}
 }  // namespace device
 
 // ---------------------------------------------------------------------------
@@ -961,14 +995,14 @@ class BFGS {
   solver_status<scalar_t> minimize(std::vector<scalar_t> &x) {
     if constexpr (device::has_grad_objective<Callable>::value) {
       std::vector<std::vector<scalar_t>> one{x};
-      auto st = minimize_batch(one);
+      auto st = solve_device(one, true);
       x = one[0];
       return st[0];
     } else if constexpr (device_fd()) {
       if constexpr (Callable::nlsg_objective != NLSG_OBJ_CUSTOM)  // (Custom has no host evaluation)
         if (x.size() > 1024) return solve_host(x);  // beyond the device coverage: host functor path
       std::vector<std::vector<scalar_t>> one{x};
-      auto st = minimize_batch(one);
+      auto st = solve_device(one, true);
       x = one[0];
       return st[0];
     } else {
@@ -981,7 +1015,24 @@ class BFGS {
   }
   // Extension (BASELINE config 3): `xs.size()` independent starts solved in lock step on
   // the GPU; the reference solves one start per minimize() call.
+  // Summation order: device::summation() (tree unless set to reference).
   std::vector<solver_status<scalar_t>> minimize_batch(std::vector<std::vector<scalar_t>> &xs) {
+    return solve_device(xs, false);
+  }
+  // The reference's arithmetic exists on the device for the objectives given by their terms
+  // (Rastrigin's device cosine is not libm's; a Custom body is the user's own arithmetic).
+  static constexpr bool has_reference_order() {
+    if constexpr (device::has_grad_objective<Callable>::value)
+      return true;
+    else if constexpr (device_fd())
+      return Callable::nlsg_objective != NLSG_OBJ_RASTRIGIN && Callable::nlsg_objective != NLSG_OBJ_CUSTOM;
+    else
+      return false;
+  }
+
+ private:
+  std::vector<solver_status<scalar_t>> solve_device(std::vector<std::vector<scalar_t>> &xs,
+                                                    const bool single_start) {
     static_assert(device::has_grad_objective<Callable>::value || device_fd(),
                   "minimize_batch needs a device objective: one with an analytic gradient, or "
                   "Rosenbrock / Sphere / StyblinskiTang with the default finite-difference one");
@@ -991,6 +1042,8 @@ class BFGS {
     nlsg_bfgs_config cfg{};
     cfg.struct_size = sizeof(cfg);
     if (const char *d = std::getenv("NLSG_DEVICE")) cfg.device = std::atoi(d);
+    if (has_reference_order() && device::reference_order_for(single_start))
+      cfg.flags |= NLSG_BFGS_REFERENCE_ORDER;
     cfg.batch = B;
     cfg.dim = n;
     cfg.max_iter = max_iter;
@@ -1027,7 +1080,6 @@ class BFGS {
     return out;
   }
 
- private:
   // Host path for arbitrary callables: BFGS::solve (nlsolver.h:3196-3285) incl. the
   // literal rank-2 update of update_inverse_hessian (3130-3168).
   solver_status<scalar_t> solve_host(std::vector<scalar_t> &x) {
@@ -1756,14 +1808,14 @@ class LevenbergMarquardt {
   solver_status<scalar_t> minimize(std::vector<scalar_t> &x) {
     if constexpr (device::has_nlls_objective<Callable>::value) {
       std::vector<std::vector<scalar_t>> one{x};
-      auto st = minimize_batch(one);
+      auto st = solve_device(one, true);
       x = one[0];
       return st[0];
     } else if constexpr (device_fd()) {
       if constexpr (Callable::nlsg_objective != NLSG_OBJ_CUSTOM)  // (Custom has no host evaluation)
         if (x.size() > 1024) return solve_host(x);  // beyond the device coverage: host functor path
       std::vector<std::vector<scalar_t>> one{x};
-      auto st = minimize_batch(one);
+      auto st = solve_device(one, true);
       x = one[0];
       return st[0];
     } else {
@@ -1776,7 +1828,23 @@ class LevenbergMarquardt {
     return solver_status<scalar_t>(0, 0, 0);
   }
   // Extension (BASELINE config 4): one start per problem of the model, all solved by one launch.
+  // Summation order of the default-functor model: device::summation() (tree unless set to reference).
   std::vector<solver_status<scalar_t>> minimize_batch(std::vector<std::vector<scalar_t>> &thetas) {
+    return solve_device(thetas, false);
+  }
+  // The reference's arithmetic exists on the device for the default functors on the objectives
+  // given by their terms (not Rastrigin: its device cosine is not libm's; not Custom; not the
+  // TanhRegression model, whose tanh is the device's).
+  static constexpr bool has_reference_order() {
+    if constexpr (device_fd())
+      return Callable::nlsg_objective != NLSG_OBJ_RASTRIGIN && Callable::nlsg_objective != NLSG_OBJ_CUSTOM;
+    else
+      return false;
+  }
+
+ private:
+  std::vector<solver_status<scalar_t>> solve_device(std::vector<std::vector<scalar_t>> &thetas,
+                                                    const bool single_start) {
     static_assert(device::has_nlls_objective<Callable>::value || device_fd(),
                   "minimize_batch needs a device NLLS model, or Rosenbrock / Sphere / "
                   "StyblinskiTang with the default finite-difference functors");
@@ -1786,7 +1854,9 @@ class LevenbergMarquardt {
     nlsg_lm_config cfg{};
     cfg.struct_size = sizeof(cfg);
     if (const char *d = std::getenv("NLSG_DEVICE")) cfg.device = std::atoi(d);
-    cfg.solver = NLSG_LM_CHOLESKY;
+    cfg.solver = has_reference_order() && device::reference_order_for(single_start)
+                     ? NLSG_LM_CHOLESKY_REFERENCE_ORDER
+                     : NLSG_LM_CHOLESKY;
     cfg.batch = B;
     size_t n = 0;
     if constexpr (device::has_nlls_objective<Callable>::value) {
@@ -1835,7 +1905,6 @@ class LevenbergMarquardt {
     return out;
   }
 
- private:
   // Host path: LevenbergMarquardt::solve (nlsolver.h:3465-3544): damped Newton, the step is
   // always accepted, lambda / down on decrease else * up.
   solver_status<scalar_t> solve_host(std::vector<scalar_t> &x) {

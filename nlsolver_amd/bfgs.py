@@ -150,10 +150,15 @@ class BFGSEngine:
 
 
 class BFGS:
-    """Drop-in for nlsolver::BFGS on a device objective; x may be (n,) or (batch, n)."""
+    """Drop-in for nlsolver::BFGS on a device objective; x may be (n,) or (batch, n).
+    reference_order=None (automatic, as include/nlsolver_mi/nlsolver.h's device::summation()): one
+    start — the reference's own call — solves in reference order wherever the engine has it (the
+    quadratic, Rosenbrock / Sphere / Styblinski-Tang; literal update) and returns the reference's run
+    bit for bit; a (batch, n) array solves with the tree-order throughput kernels. True / False force
+    one or the other."""
 
     def __init__(self, f, g=None, max_iter=100, grad_eps=5e-3, alpha=1.0, *, device=0,
-                 symmetric=False, reference_order=False):
+                 symmetric=False, reference_order=None):
         if g is not None:
             raise TypeError("device objectives carry their analytic gradient or use the default "
                             "finite-difference one; pass g=None")
@@ -168,7 +173,11 @@ class BFGS:
         xb = x.reshape(1, -1) if x.ndim == 1 else x
         from .de import CustomObjective
         extra = dict(dim=xb.shape[1]) if isinstance(self.f, (str, CustomObjective)) else {}
-        with BFGSEngine(self.f, xb.shape[0], **extra, **self.args) as eng:
+        args = dict(self.args)
+        if args["reference_order"] is None:
+            has_it = isinstance(self.f, QuadDiagRank1) or self.f in ("rosenbrock", "sphere", "styblinski_tang")
+            args["reference_order"] = x.ndim == 1 and has_it and not args["symmetric"]
+        with BFGSEngine(self.f, xb.shape[0], **extra, **args) as eng:
             out, st = eng.minimize(xb)
         xb[...] = out
         return st[0] if x.ndim == 1 else st

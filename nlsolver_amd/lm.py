@@ -124,10 +124,13 @@ class LMEngine:
 
 class LevenbergMarquardt:
     """Drop-in for nlsolver::LevenbergMarquardt on a device NLLS model or a built-in objective
-    (by name); x: (n,) or (batch, n)."""
+    (by name); x: (n,) or (batch, n). solver=None (automatic, as include/nlsolver_mi/nlsolver.h's
+    device::summation()): one start of the default-functor model on Rosenbrock / Sphere /
+    Styblinski-Tang solves in reference order (LM_CHOLESKY_REFERENCE_ORDER: the reference's run bit
+    for bit); everything else, and every (batch, n) array, with LM_CHOLESKY."""
 
     def __init__(self, f, lam=10.0, upward_mult=10.0, downward_mult=10.0, max_iter=100,
-                 f_delta=1e-12, g=None, h=None, *, solver=_capi.LM_CHOLESKY, device=0):
+                 f_delta=1e-12, g=None, h=None, *, solver=None, device=0):
         if g is not None or h is not None:
             raise TypeError("device models carry their functors (Gauss-Newton for NLLS models, "
                             "the reference's finite-difference defaults for objectives)")
@@ -140,7 +143,11 @@ class LevenbergMarquardt:
             raise TypeError("x must be a float64 numpy array of shape (n,) or (batch, n)")
         xb = x.reshape(1, -1) if x.ndim == 1 else x
         shape = {} if hasattr(self.f, "A") else dict(batch=xb.shape[0], n=xb.shape[1])
-        with LMEngine(self.f, **self.args, **shape) as eng:
+        args = dict(self.args)
+        if args["solver"] is None:
+            has_it = isinstance(self.f, str) and self.f in ("rosenbrock", "sphere", "styblinski_tang")
+            args["solver"] = _capi.LM_CHOLESKY_REFERENCE_ORDER if x.ndim == 1 and has_it else _capi.LM_CHOLESKY
+        with LMEngine(self.f, **args, **shape) as eng:
             out, st, lam = eng.minimize(xb)
         xb[...] = out
         self.lambdas = lam  # the reference keeps lambda as a member across calls (:3436)

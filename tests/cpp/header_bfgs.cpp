@@ -2,11 +2,13 @@
 //   header_bfgs host n max_iter grad_eps alpha x0 x0_step    host functor + analytic Grad functor
 //   header_bfgs findiff                                      default fin_diff gradient (example.cpp style)
 //   header_bfgs device n batch max_iter grad_eps alpha       device objective, batched starts
-//   header_bfgs device-fd n max_iter grad_eps alpha x0 x0_step   device::Rosenbrock, default Grad
+//   header_bfgs device-fd n max_iter grad_eps alpha x0 x0_step [objective [batch]]  device objective, default Grad
+//   header_bfgs device-one n max_iter grad_eps alpha x0 x0_step   one start of the device quadratic
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 
 #include "nlsolver_mi/nlsolver.h"
 
@@ -52,6 +54,31 @@ static void print_status(const nlsolver::solver_status<double> &st, const std::v
               gcalls, f);
   for (size_t i = 0; i < x.size(); i++) std::printf("%s\"%a\"", i ? "," : "", x[i]);
   std::printf("]}");
+}
+
+template <typename F>
+static int run_device_fd(F &prob, char **argv, bool batch) {
+  const size_t n = std::strtoull(argv[2], nullptr, 10);
+  auto solver = nlsolver::BFGS<F, double>(prob, {}, std::strtoull(argv[3], nullptr, 10),
+                                          std::strtod(argv[4], nullptr), std::strtod(argv[5], nullptr));
+  std::vector<double> x(n);
+  for (size_t i = 0; i < n; i++)
+    x[i] = std::strtod(argv[6], nullptr) + std::strtod(argv[7], nullptr) * static_cast<double>(i);
+  try {
+    if (batch) {
+      std::vector<std::vector<double>> xs{x};
+      auto st = solver.minimize_batch(xs);
+      print_status(st[0], xs[0]);
+    } else {
+      auto st = solver.minimize(x);
+      print_status(st, x);
+    }
+    std::printf("\n");
+  } catch (const nlsolver::device_error &e) {
+    std::printf("{\"device_error\":\"%s\"}\n", e.what());
+    return 3;
+  }
+  return 0;
 }
 
 int main(int argc, char **argv) {
@@ -126,24 +153,27 @@ int main(int argc, char **argv) {
   }
   if (argc >= 8 && !std::strcmp(argv[1], "device-fd")) {
     // the reference's default-gradient call, objective type swapped for the device one:
-    // BFGS<Rosenbrock, double>(prob).minimize(x) (example.cpp:171-173)
-    const size_t n = std::strtoull(argv[2], nullptr, 10);
-    nlsolver::device::Rosenbrock<double> prob;
-    auto solver = nlsolver::BFGS<decltype(prob), double>(prob, {}, std::strtoull(argv[3], nullptr, 10),
-                                                         std::strtod(argv[4], nullptr),
-                                                         std::strtod(argv[5], nullptr));
-    std::vector<double> x(n);
-    for (size_t i = 0; i < n; i++)
-      x[i] = std::strtod(argv[6], nullptr) + std::strtod(argv[7], nullptr) * static_cast<double>(i);
-    try {
-      auto st = solver.minimize(x);
-      print_status(st, x);
-      std::printf("\n");
-    } catch (const nlsolver::device_error &e) {
-      std::printf("{\"device_error\":\"%s\"}\n", e.what());
-      return 3;
+    // BFGS<Rosenbrock, double>(prob).minimize(x) (example.cpp:171-173); optional: the objective's
+    // name, then "batch" to go through minimize_batch() with that one start
+    const std::string which = argc > 8 ? argv[8] : "rosenbrock";
+    const bool batch = argc > 9 && !std::strcmp(argv[9], "batch");
+    if (which == "sphere") {
+      nlsolver::device::Sphere<double> prob;
+      return run_device_fd(prob, argv, batch);
     }
-    return 0;
+    if (which == "styblinski_tang") {
+      nlsolver::device::StyblinskiTang<double> prob;
+      return run_device_fd(prob, argv, batch);
+    }
+    nlsolver::device::Rosenbrock<double> prob;
+    return run_device_fd(prob, argv, batch);
+  }
+  if (argc >= 8 && !std::strcmp(argv[1], "device-one")) {
+    // BFGS<QuadDiagRank1>(f).minimize(x): ONE start of the G6 quadratic through the reference's call
+    const size_t n = std::strtoull(argv[2], nullptr, 10);
+    QuadDR1 host(n);
+    nlsolver::device::QuadDiagRank1<double> f(host.d, host.b, host.c);
+    return run_device_fd(f, argv, false);
   }
   std::fprintf(stderr, "usage: header_bfgs host|findiff|device|device-fd ...\n");
   return 2;

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 
 #include "nlsolver_mi/nlsolver.h"
 
@@ -110,7 +111,8 @@ struct ExpHess {
 
 template <typename F>
 static int run_lm_fd_with(F &f, int argc, char **argv) {
-  // lm-device-fd n lambda max_iter f_delta x0 x0_step: default functors on a device objective
+  // lm-device-fd n lambda max_iter f_delta x0 x0_step [objective [batch]]: default functors on a
+  // device objective
   const size_t n = std::strtoull(argv[2], nullptr, 10);
   auto solver = nlsolver::LevenbergMarquardt<F, double>(
       f, std::strtod(argv[3], nullptr), 10, 10, std::strtoull(argv[4], nullptr, 10),
@@ -119,8 +121,14 @@ static int run_lm_fd_with(F &f, int argc, char **argv) {
   for (size_t i = 0; i < n; i++)
     x[i] = std::strtod(argv[6], nullptr) + (argc > 7 ? std::strtod(argv[7], nullptr) : 0.0) * static_cast<double>(i);
   try {
-    auto st = solver.minimize(x);
-    print_status(st, x);
+    if (argc > 9 && !std::strcmp(argv[9], "batch")) {  // minimize_batch() with that one start
+      std::vector<std::vector<double>> xs{x};
+      auto st = solver.minimize_batch(xs);
+      print_status(st[0], xs[0]);
+    } else {
+      auto st = solver.minimize(x);
+      print_status(st, x);
+    }
     std::printf("\n");
   } catch (const nlsolver::device_error &e) {
     std::printf("{\"device_error\":\"%s\"}\n", e.what());
@@ -132,6 +140,15 @@ static int run_lm_fd(int argc, char **argv) {
   if (!std::strcmp(argv[1], "lm-device-fd-custom")) {
     nlsolver::device::Custom<double> f(
         "double t1 = 1 - xi; double t2 = (xn - xi * xi); return t1 * t1 + 100 * t2 * t2;", true);
+    return run_lm_fd_with(f, argc, argv);
+  }
+  const std::string which = argc > 8 ? argv[8] : "rosenbrock";
+  if (which == "sphere") {
+    nlsolver::device::Sphere<double> f;
+    return run_lm_fd_with(f, argc, argv);
+  }
+  if (which == "styblinski_tang") {
+    nlsolver::device::StyblinskiTang<double> f;
     return run_lm_fd_with(f, argc, argv);
   }
   nlsolver::device::Rosenbrock<double> f;

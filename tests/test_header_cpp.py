@@ -185,11 +185,12 @@ def test_bfgs_device_batch_through_header_matches_oracle(built, oracle):
 @pytest.mark.parametrize("n", [2, 16, 128])
 def test_bfgs_default_gradient_on_device_objective_through_header(built, oracle, n, mode):
     """BFGS<device::Rosenbrock<double>>(f).minimize(x): the default fin_diff gradient runs on the
-    GPU (nlsolver.h:1385-1413 restated in the search kernel); bit-exact vs the tree oracle."""
+    GPU (nlsolver.h:1385-1413 restated in the search kernel); with NLSG_SUMMATION=tree (the throughput
+    kernels; a Custom objective always) bit-exact vs the tree oracle."""
     args = dict(max_iter=8, grad_eps=0.0, alpha=1.0)
     out = subprocess.check_output(
         [os.path.join(built, "header_bfgs"), mode, str(n), "8", "0.0", "1.0", "0.9", "0.001"],
-        env=dict(os.environ, NLSG_LIBRARY=LIB), text=True)
+        env=dict(os.environ, NLSG_LIBRARY=LIB, NLSG_SUMMATION="tree"), text=True)
     o = json.loads(out)
     assert "device_error" not in o, o
     x0 = 0.9 + 0.001 * np.arange(n, dtype=np.float64)
@@ -198,6 +199,88 @@ def test_bfgs_default_gradient_on_device_objective_through_header(built, oracle,
         (ref.function_calls_used, ref.iteration, ref.gradient_evals_used)
     assert hx(o["f"]) == ref.f_value
     assert np.array_equal(np.array([hx(v) for v in o["x"]]), xr)
+
+
+OBJECTIVE_NAMES = {0: "rosenbrock", 1: "sphere", 2: "styblinski_tang"}
+
+
+def _fnv(x):
+    h = 1469598103934665603  # FNV-1a over the bytes of x, as the reference driver hashed it
+    for byte in np.ascontiguousarray(np.asarray(x, dtype=np.float64)).view(np.uint8).tobytes():
+        h = ((h ^ byte) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def _bfgs_fd_args(g):
+    return [str(g["n"]), str(g["max_iter"]), repr(hx(g["grad_eps"])), repr(hx(g["alpha"])),
+            repr(hx(g["x0"])), repr(hx(g["x0_step"]))]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["rosenbrock_n2", "rosenbrock_n4", "rosenbrock_n16_default_stop",
+                                  "rosenbrock_n128_20iters", "sphere_n5", "sphere_n130_alpha_half",
+                                  "styblinski_tang_n8"])
+def test_bfgs_minimize_through_header_is_the_reference_run(built, golden, name):
+    """The drop-in's default: BFGS<device::Rosenbrock<double>, double>(f, ...).minimize(x) — the
+    reference's own call with the objective type swapped — solves in reference order
+    (device::summation() automatic) and returns the reference's run (tests/golden/bfgs_fd.json,
+    made by the unmodified reference): every count, f and x BIT FOR BIT."""
+    g = golden("bfgs_fd.json")[name]
+    env = {k: v for k, v in os.environ.items() if k != "NLSG_SUMMATION"}
+    o = json.loads(subprocess.check_output(
+        [os.path.join(built, "header_bfgs"), "device-fd", *_bfgs_fd_args(g), OBJECTIVE_NAMES[g["objective"]]],
+        env=dict(env, NLSG_LIBRARY=LIB), text=True))
+    assert "device_error" not in o, o
+    assert (o["fcalls"], o["iters"], o["gcalls"]) == (g["fcalls"], g["iters"], g["gcalls"])
+    assert o["f"] == g["f"] and o["x"] == g["x"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["n8", "n64", "n64_default_stop", "n100_ragged_start", "n130_alpha_half",
+                                  "n256_max_iter_5", "n1024"])
+def test_bfgs_quadratic_minimize_through_header_is_the_reference_run(built, golden, name):
+    """BFGS<device::QuadDiagRank1<double>, double>(f, ...).minimize(x): the reference's runs on the G6
+    quadratic with its analytic gradient functor (tests/golden/bfgs.json) bit for bit, n = 1024 —
+    BASELINE configs[2]'s dimension — included."""
+    g = golden("bfgs.json")[name]
+    env = {k: v for k, v in os.environ.items() if k != "NLSG_SUMMATION"}
+    o = json.loads(subprocess.check_output(
+        [os.path.join(built, "header_bfgs"), "device-one", *_bfgs_fd_args(g)],
+        env=dict(env, NLSG_LIBRARY=LIB), text=True))
+    assert "device_error" not in o, o
+    assert (o["fcalls"], o["iters"], o["gcalls"]) == (g["fcalls"], g["iters"], g["gcalls"])
+    assert o["f"] == g["f"] and o["x"][:8] == g["x_head"]
+    assert _fnv([hx(v) for v in o["x"]]) == int(g["x_fnv"])
+
+
+@pytest.mark.gpu
+def test_bfgs_summation_switch_through_header(built, oracle, golden):
+    """minimize_batch() (the header's extension) solves in tree order unless device::summation() says
+    reference; minimize() follows NLSG_SUMMATION=tree; a misspelt value is an error, not a default."""
+    g = golden("bfgs_fd.json")["rosenbrock_n16_default_stop"]
+    cmd = [os.path.join(built, "header_bfgs"), "device-fd", *_bfgs_fd_args(g), "rosenbrock"]
+    env = {k: v for k, v in os.environ.items() if k != "NLSG_SUMMATION"}
+    env["NLSG_LIBRARY"] = LIB
+    x0 = hx(g["x0"]) + hx(g["x0_step"]) * np.arange(g["n"], dtype=np.float64)
+    tree, xt, _, _ = O.bfgs_fd(oracle, "rosenbrock", x0, tree=1, max_iter=g["max_iter"],
+                               grad_eps=hx(g["grad_eps"]), alpha=hx(g["alpha"]))
+
+    def is_tree(o):
+        return hx(o["f"]) == tree.f_value and np.array_equal(np.array([hx(v) for v in o["x"]]), xt) and \
+            (o["fcalls"], o["iters"], o["gcalls"]) == \
+            (tree.function_calls_used, tree.iteration, tree.gradient_evals_used)
+
+    def is_reference(o):
+        return o["f"] == g["f"] and o["x"] == g["x"] and (o["fcalls"], o["iters"]) == (g["fcalls"], g["iters"])
+
+    run = lambda extra, **kw: json.loads(subprocess.check_output(cmd + extra, env=dict(env, **kw), text=True))
+    assert tree.f_value != hx(g["f"])  # (the two orders do differ on this run)
+    assert is_tree(run(["batch"]))
+    assert is_reference(run(["batch"], NLSG_SUMMATION="reference"))
+    assert is_tree(run([], NLSG_SUMMATION="tree"))
+    assert is_reference(run([], NLSG_SUMMATION="automatic"))
+    r = subprocess.run(cmd, env=dict(env, NLSG_SUMMATION="refrence"), capture_output=True, text=True)
+    assert r.returncode == 3 and "NLSG_SUMMATION" in r.stdout, (r.returncode, r.stdout, r.stderr)
 
 
 def test_bfgs_device_objective_without_library_fails_loudly(built):
@@ -290,10 +373,11 @@ def test_lm_device_model_through_header_matches_oracle(built, oracle, m, n, B, i
 @pytest.mark.parametrize("n,iters", [(2, 12), (5, 8), (16, 4), (70, 2)])
 def test_lm_default_functors_on_device_objective_through_header(built, oracle, n, iters, mode):
     """LevenbergMarquardt<device::Rosenbrock<double>, double>(f).minimize(x): fin_diff and
-    fin_diff_h (nlsolver.h:3494-3511) evaluated on the GPU; bit-exact vs the tree oracle."""
+    fin_diff_h (nlsolver.h:3494-3511) evaluated on the GPU; with NLSG_SUMMATION=tree (a Custom objective
+    always) bit-exact vs the tree oracle."""
     out = subprocess.check_output(
         [os.path.join(built, "header_nm_lm"), mode, str(n), "10", str(iters), "0.0",
-         "0.8", "0.01"], env=dict(os.environ, NLSG_LIBRARY=LIB), text=True)
+         "0.8", "0.01"], env=dict(os.environ, NLSG_LIBRARY=LIB, NLSG_SUMMATION="tree"), text=True)
     o = json.loads(out)
     assert "device_error" not in o, o
     x0 = 0.8 + 0.01 * np.arange(n, dtype=np.float64)
@@ -302,6 +386,51 @@ def test_lm_default_functors_on_device_objective_through_header(built, oracle, n
         (ref.iteration, ref.function_calls_used, ref.gradient_evals_used, ref.hessian_evals_used)
     assert hx(o["f"]) == ref.f_value
     assert np.array_equal(np.array([hx(v) for v in o["x"]]), xr)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["rosenbrock_n2_example_start", "rosenbrock_n4_near_minimum",
+                                  "rosenbrock_n4_indefinite_nan", "rosenbrock_n16_6iters", "sphere_n5",
+                                  "styblinski_tang_n8", "sphere_n64_3iters_lambda1", "rosenbrock_n100_2iters",
+                                  "styblinski_tang_n130_2iters"])
+def test_lm_minimize_through_header_is_the_reference_run(built, golden, name):
+    """The drop-in's default: LevenbergMarquardt<device::Rosenbrock<double>, double>(f, ...).minimize(x)
+    solves in reference order and returns the reference's run (tests/golden/lm_fd.json, made by the
+    unmodified reference) bit for bit — the run that ends in NaN and the ones past 64 parameters
+    included."""
+    g = golden("lm_fd.json")[name]
+    env = {k: v for k, v in os.environ.items() if k != "NLSG_SUMMATION"}
+    o = json.loads(subprocess.check_output(
+        [os.path.join(built, "header_nm_lm"), "lm-device-fd", str(g["n"]), repr(hx(g["lambda"])),
+         str(g["max_iter"]), repr(hx(g["f_delta"])), repr(hx(g["x0"])), repr(hx(g["x0_step"])),
+         OBJECTIVE_NAMES[g["objective"]]], env=dict(env, NLSG_LIBRARY=LIB), text=True))
+    assert "device_error" not in o, o
+    assert (o["iters"], o["fcalls"], o["gcalls"], o["hcalls"]) == \
+        (g["iters"], g["fcalls"], g["gcalls"], g["hcalls"])
+    if np.isnan(hx(g["f"])):
+        assert np.isnan(hx(o["f"])) and all(np.isnan(hx(v)) for v in o["x"])
+    else:
+        assert o["f"] == g["f"] and o["x"] == g["x"]
+
+
+@pytest.mark.gpu
+def test_lm_summation_switch_through_header(built, oracle, golden):
+    g = golden("lm_fd.json")["rosenbrock_n16_6iters"]
+    cmd = [os.path.join(built, "header_nm_lm"), "lm-device-fd", str(g["n"]), repr(hx(g["lambda"])),
+           str(g["max_iter"]), repr(hx(g["f_delta"])), repr(hx(g["x0"])), repr(hx(g["x0_step"])), "rosenbrock"]
+    env = {k: v for k, v in os.environ.items() if k != "NLSG_SUMMATION"}
+    env["NLSG_LIBRARY"] = LIB
+    x0 = hx(g["x0"]) + hx(g["x0_step"]) * np.arange(g["n"], dtype=np.float64)
+    tree, xt, _, _ = O.lm_fd(oracle, "rosenbrock", x0, lam=hx(g["lambda"]), max_iter=g["max_iter"],
+                             f_delta=hx(g["f_delta"]), order=1)
+    run = lambda extra, **kw: json.loads(subprocess.check_output(cmd + extra, env=dict(env, **kw), text=True))
+    is_tree = lambda o: hx(o["f"]) == tree.f_value and np.array_equal(np.array([hx(v) for v in o["x"]]), xt)
+    is_reference = lambda o: o["f"] == g["f"] and o["x"] == g["x"]
+    assert tree.f_value != hx(g["f"])
+    assert is_tree(run(["batch"]))
+    assert is_reference(run(["batch"], NLSG_SUMMATION="reference"))
+    assert is_tree(run([], NLSG_SUMMATION="tree"))
+    assert is_reference(run([]))
 
 
 def test_lm_device_objective_without_library_fails_loudly(built):

@@ -210,6 +210,7 @@ def test_lm_default_functors_match_reference_runs(mod, oracle, golden):
     terms per lane: tree and sequence coincide); over the following iterations the difference
     stays at 1e-9 .. 2e-7 — it does not compound, the always-accepted step contracts it. Asserted:
     1e-8 after iteration 1, 1e-6 at the end (the golden's own print precision is finer)."""
+    from nlsolver_amd._capi import LM_CHOLESKY  # (the tree-order kernels; one start defaults to reference order)
     from tests.test_oracle_golden import hx
     names = {0: "rosenbrock", 1: "sphere", 2: "styblinski_tang"}
     for name, g in golden("lm_fd.json").items():
@@ -220,7 +221,7 @@ def test_lm_default_functors_match_reference_runs(mod, oracle, golden):
         x0 = hx(g["x0"]) + hx(g["x0_step"]) * np.arange(g["n"], dtype=np.float64)
         x = x0.copy()
         solver = mod.lm.LevenbergMarquardt(names[g["objective"]], hx(g["lambda"]), 10.0, 10.0,
-                                           g["max_iter"], hx(g["f_delta"]))
+                                           g["max_iter"], hx(g["f_delta"]), solver=LM_CHOLESKY)
         st = solver.minimize(x)
         f_ref, x_ref = hx(g["f"]), np.array([hx(v) for v in g["x"]])
         if np.isnan(f_ref):
@@ -234,7 +235,7 @@ def test_lm_default_functors_match_reference_runs(mod, oracle, golden):
         # iteration 1 on its own, against the reference's arithmetic (serial oracle)
         x1 = x0.copy()
         st1 = mod.lm.LevenbergMarquardt(names[g["objective"]], hx(g["lambda"]), 10.0, 10.0, 1,
-                                        0.0).minimize(x1)
+                                        0.0, solver=LM_CHOLESKY).minimize(x1)
         ser, xs, _, _ = O.lm_fd(oracle, names[g["objective"]], x0, lam=hx(g["lambda"]), max_iter=1,
                                 f_delta=0.0, order=0)
         assert st1.iteration == ser.iteration == 1

@@ -136,3 +136,33 @@ def test_lm_reference_order_limits(mod):
         mod.lm.LMEngine("rosenbrock", batch=1, n=1100, solver=LM_CHOLESKY_REFERENCE_ORDER)
     with pytest.raises(NlsgError):
         mod.lm.LMEngine("rastrigin", batch=1, n=4, solver=LM_CHOLESKY_REFERENCE_ORDER)
+
+
+def test_one_start_defaults_to_reference_order_a_batch_to_tree(mod, oracle, golden):
+    """The drop-in classes' automatic rule (include/nlsolver_mi/nlsolver.h device::summation()): a 1-D x
+    — the reference's own call — returns the reference's run bit for bit; a (batch, n) array is solved by
+    the tree-order throughput kernels."""
+    g = golden("bfgs_fd.json")["rosenbrock_n16_default_stop"]
+    kw = dict(max_iter=g["max_iter"], grad_eps=hx(g["grad_eps"]), alpha=hx(g["alpha"]))
+    x = start(g)
+    st = mod.BFGS("rosenbrock", None, **kw).minimize(x)
+    assert st.f_value == hx(g["f"]) and x.tolist() == [hx(v) for v in g["x"]]
+    assert (st.iteration, st.function_calls_used) == (g["iters"], g["fcalls"])
+    xb = start(g).reshape(1, -1)
+    stb = mod.BFGS("rosenbrock", None, **kw).minimize(xb)
+    tree, xt, _, _ = O.bfgs_fd(oracle, "rosenbrock", start(g), tree=1, **kw)
+    assert stb[0].f_value == tree.f_value != st.f_value and np.array_equal(xb[0], xt)
+
+    g = golden("lm_fd.json")["rosenbrock_n16_6iters"]
+    args = (hx(g["lambda"]), 10.0, 10.0, g["max_iter"], hx(g["f_delta"]))
+    x = start(g)
+    st = mod.lm.LevenbergMarquardt("rosenbrock", *args).minimize(x)
+    assert st.f_value == hx(g["f"]) and x.tolist() == [hx(v) for v in g["x"]]
+    xb = start(g).reshape(1, -1)
+    stb = mod.lm.LevenbergMarquardt("rosenbrock", *args).minimize(xb)
+    tree, xt, _, _ = O.lm_fd(oracle, "rosenbrock", start(g), lam=hx(g["lambda"]), max_iter=g["max_iter"],
+                             f_delta=hx(g["f_delta"]), order=1)
+    assert stb[0].f_value == tree.f_value != st.f_value and np.array_equal(xb[0], xt)
+    # Rastrigin has no reference arithmetic on the device: one start still runs (tree order)
+    x = np.full(4, 0.3)
+    assert np.isfinite(mod.BFGS("rastrigin").minimize(x).f_value)
