@@ -60,24 +60,25 @@ namespace {
 
 // search / init kernels also depend on what is minimised
 #define BFGS_MODEL_CASE(KERNEL, C, V, grid, ...)                                                    \
+  const unsigned fd_lds_ = e->p.seq ? static_cast<unsigned>(bfgs_fd_seq_lds_bytes(C)) : 0u;          \
   switch (e->p.model) {                                                                             \
     case kBfgsQuad:                                                                                 \
       hipLaunchKernelGGL((KERNEL<C, V, kBfgsQuad>), dim3(grid), dim3(256), 0, e->stream, __VA_ARGS__); \
       break;                                                                                        \
     case NLSG_OBJ_ROSENBROCK:                                                                       \
-        hipLaunchKernelGGL((KERNEL<C, V, NLSG_OBJ_ROSENBROCK>), dim3(grid), dim3(256), 0, e->stream, \
+        hipLaunchKernelGGL((KERNEL<C, V, NLSG_OBJ_ROSENBROCK>), dim3(grid), dim3(256), fd_lds_,  e->stream, \
                            __VA_ARGS__);                                                            \
       break;                                                                                        \
     case NLSG_OBJ_SPHERE:                                                                           \
-        hipLaunchKernelGGL((KERNEL<C, V, NLSG_OBJ_SPHERE>), dim3(grid), dim3(256), 0, e->stream,    \
+        hipLaunchKernelGGL((KERNEL<C, V, NLSG_OBJ_SPHERE>), dim3(grid), dim3(256), fd_lds_,  e->stream,    \
                            __VA_ARGS__);                                                            \
       break;                                                                                        \
     case NLSG_OBJ_STYBLINSKI_TANG:                                                                  \
-        hipLaunchKernelGGL((KERNEL<C, V, NLSG_OBJ_STYBLINSKI_TANG>), dim3(grid), dim3(256), 0,      \
+        hipLaunchKernelGGL((KERNEL<C, V, NLSG_OBJ_STYBLINSKI_TANG>), dim3(grid), dim3(256), fd_lds_,       \
                            e->stream, __VA_ARGS__);                                                 \
       break;                                                                                        \
     case NLSG_OBJ_RASTRIGIN:                                                                        \
-        hipLaunchKernelGGL((KERNEL<C, V, NLSG_OBJ_RASTRIGIN>), dim3(grid), dim3(256), 0, e->stream, \
+        hipLaunchKernelGGL((KERNEL<C, V, NLSG_OBJ_RASTRIGIN>), dim3(grid), dim3(256), fd_lds_,  e->stream, \
                            __VA_ARGS__);                                                            \
       break;                                                                                        \
     default: break;                                                                                 \
@@ -85,14 +86,14 @@ namespace {
 #define BFGS_DISPATCH_MODEL(KERNEL, grid, ...)                           \
   do {                                                                   \
     switch (e->chunks * 2 + (e->vec ? 1 : 0)) {                          \
-      case 2: BFGS_MODEL_CASE(KERNEL, 1, false, grid, __VA_ARGS__) break; \
-      case 3: BFGS_MODEL_CASE(KERNEL, 1, true, grid, __VA_ARGS__) break;  \
-      case 4: BFGS_MODEL_CASE(KERNEL, 2, false, grid, __VA_ARGS__) break; \
-      case 5: BFGS_MODEL_CASE(KERNEL, 2, true, grid, __VA_ARGS__) break;  \
-      case 8: BFGS_MODEL_CASE(KERNEL, 4, false, grid, __VA_ARGS__) break; \
-      case 9: BFGS_MODEL_CASE(KERNEL, 4, true, grid, __VA_ARGS__) break;  \
-      case 16: BFGS_MODEL_CASE(KERNEL, 8, false, grid, __VA_ARGS__) break; \
-      case 17: BFGS_MODEL_CASE(KERNEL, 8, true, grid, __VA_ARGS__) break;  \
+      case 2: { BFGS_MODEL_CASE(KERNEL, 1, false, grid, __VA_ARGS__) } break; \
+      case 3: { BFGS_MODEL_CASE(KERNEL, 1, true, grid, __VA_ARGS__) } break;  \
+      case 4: { BFGS_MODEL_CASE(KERNEL, 2, false, grid, __VA_ARGS__) } break; \
+      case 5: { BFGS_MODEL_CASE(KERNEL, 2, true, grid, __VA_ARGS__) } break;  \
+      case 8: { BFGS_MODEL_CASE(KERNEL, 4, false, grid, __VA_ARGS__) } break; \
+      case 9: { BFGS_MODEL_CASE(KERNEL, 4, true, grid, __VA_ARGS__) } break;  \
+      case 16: { BFGS_MODEL_CASE(KERNEL, 8, false, grid, __VA_ARGS__) } break; \
+      case 17: { BFGS_MODEL_CASE(KERNEL, 8, true, grid, __VA_ARGS__) } break;  \
       default: break;                                                    \
     }                                                                    \
   } while (0)
@@ -102,7 +103,8 @@ void launch_iteration(nlsg_bfgs *e, bool timed) {
   const unsigned row_grid = static_cast<unsigned>(e->p.batch * e->bpp);
   if (e->p.model == NLSG_OBJ_CUSTOM) {
     void *args[] = {&e->p};
-    launch_module_kernel(e->rtc.search, wave_grid, 256, 0, e->stream, args);
+    launch_module_kernel(e->rtc.search, wave_grid, 256,
+                         e->p.seq ? static_cast<unsigned>(bfgs_fd_seq_lds_bytes(e->chunks)) : 0u, e->stream, args);
   } else {
     BFGS_DISPATCH_MODEL(bfgs_search_kernel, wave_grid, e->p);
   }
@@ -309,7 +311,8 @@ int nlsg_bfgs_init(nlsg_bfgs *e, const double *x0_host) {
   NLSG_HIP(hipStreamSynchronize(e->stream));
   if (e->p.model == NLSG_OBJ_CUSTOM) {
     void *args[] = {&e->p};
-    launch_module_kernel(e->rtc.init, static_cast<unsigned>((e->p.batch + 3) / 4), 256, 0, e->stream, args);
+    launch_module_kernel(e->rtc.init, static_cast<unsigned>((e->p.batch + 3) / 4), 256,
+                         e->p.seq ? static_cast<unsigned>(bfgs_fd_seq_lds_bytes(e->chunks)) : 0u, e->stream, args);
   } else {
     BFGS_DISPATCH_MODEL(bfgs_init_kernel, static_cast<unsigned>((e->p.batch + 3) / 4), e->p);
   }

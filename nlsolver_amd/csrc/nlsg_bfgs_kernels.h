@@ -139,14 +139,23 @@ __device__ inline void quad_g(const double (&x)[CHUNKS][2], const double (&d)[CH
 // evaluation in the lane-tree order (oracle_bfgs.c model_g).
 constexpr int kBfgsQuad = -1;
 
+// LDS of the search / init kernels: only the reference-order finite-difference gradient uses any — per
+// wave the point and its objective terms, 2 x 128 CHUNKS doubles (the launch passes 0 bytes otherwise)
+__host__ __device__ constexpr size_t bfgs_fd_seq_lds_bytes(int chunks) {
+  return 4 * 2 * 128 * static_cast<size_t>(chunks) * sizeof(double);
+}
+
 template <int MODEL, int CHUNKS>
 struct BfgsModel {  // finite differences on Objective<MODEL>
   uint64_t n;
   int seq;
+  double *lds;  // this wave's 2 x 128 CHUNKS doubles (reference order only)
   template <bool VEC>
   __device__ inline void load(const BfgsParams &p) {
+    extern __shared__ __align__(16) double bfgs_smem[];
     n = p.n;
     seq = p.seq;
+    lds = bfgs_smem + (threadIdx.x >> 6) * (2 * 128 * CHUNKS);
   }
   __device__ inline double value(const double (&x)[CHUNKS][2]) const {
     return seq ? wave_objective_seq<MODEL, CHUNKS>(x, n) : wave_objective<MODEL, CHUNKS>(x, n);
@@ -155,9 +164,118 @@ struct BfgsModel {  // finite differences on Objective<MODEL>
     fcalls++;
     return value(x);
   }
+  // fin_diff in REFERENCE ORDER, a probe per LANE. Probe (d, s) is the objective at x + delta_s e_d
+  // with its terms added in index order. Only the terms that contain x_d differ from the base
+  // point's (t_d; for a chain objective t_{d-1} too), and the running sum up to the first of them is
+  // the base point's own prefix sum — bit for bit, the additions are the same ones. So:
+  //   * the base terms t_e and the point go to LDS once;
+  //   * the prefix sums S_e = (..(0 + t_0) + ..) + t_e are ONE serial chain per gradient (not one
+  //     per probe), advanced pass by pass; lane L captures the one its coordinate starts from;
+  //   * a pass handles 64 coordinates, lane L = coordinate d0 + L, its four probes side by side
+  //     (four independent chains: the additions pipeline): start value, the one or two modified
+  //     terms, then the tail t_{d+1} .. t_{nt-1} read from LDS at a wave-uniform address (lanes
+  //     whose tail has not begun yet sit out);
+  //   * the pass's 64 gradient entries return to the wave layout through two lane gathers.
+  // 4 n probes cost n / 64 passes of ~n additions per lane instead of 4 n serial sums of n terms
+  // each by the whole wave: every probe's value has the bits of wave_objective_seq at that point
+  // (tests: the reference's own runs, tests/golden/bfgs_fd.json, and oracle tree 0 on batches).
+  __device__ inline void grad_seq(const double (&x)[CHUNKS][2], double (&g)[CHUNKS][2]) const {
+    using O = Objective<MODEL>;
+    constexpr double eps = 2.220446049250313e-16 * 10e7;
+    constexpr double coeff[4] = {1, -8, 8, -1}, coeff2[4] = {-2, -1, 1, 2};
+    constexpr double dd_val = 12 * eps;
+    constexpr int off = O::kChain ? 2 : 1;  // a coordinate's first modified term is t_{d - off + 1}
+    const int lane = lane_id();
+    const int D = static_cast<int>(n), nt = static_cast<int>(O::n_terms(n));
+    double *xs = lds, *ts = lds + 128 * CHUNKS;
+#pragma unroll
+    for (int c = 0; c < CHUNKS; c++) {
+      double xn = 0.0;
+      if (O::kChain) {
+        const double same = lane_down1(x[c][0]);
+        double next = 0.0;
+        if (c + 1 < CHUNKS) next = lane_first(x[c + 1][0]);
+        xn = (lane == 63) ? next : same;
+      }
+      *reinterpret_cast<double2 *>(xs + 128 * c + 2 * lane) = make_double2(x[c][0], x[c][1]);
+      *reinterpret_cast<double2 *>(ts + 128 * c + 2 * lane) =
+          make_double2(O::term(x[c][0], x[c][1]), O::term(x[c][1], xn));
+      g[c][0] = g[c][1] = 0.0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    double run = 0.0;  // S_{e_run - 1}
+    int e_run = 0;
+    for (int d0 = 0; d0 < D; d0 += 64) {
+      const int d = d0 + lane;
+      const int dc = d < D ? d : D - 1;
+      const double xd = xs[dc], xm = xs[dc > 0 ? dc - 1 : 0], xp = xs[dc + 1 < D ? dc + 1 : dc];
+      // the prefix chain up to the last start value this pass needs
+      double a = 0.0;
+      const int cap = d - off, e_hi = d0 + 63 - off < nt - 1 ? d0 + 63 - off : nt - 1;
+#pragma unroll 4
+      for (; e_run <= e_hi; e_run++) {
+        run = run + ts[e_run];
+        a = cap == e_run ? run : a;
+      }
+      double acc[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const double xq = xd + coeff2[q] * eps;
+        acc[q] = a;
+        if constexpr (O::kChain) {
+          const double m0 = acc[q] + O::term(xm, xq);
+          acc[q] = d >= 1 ? m0 : acc[q];
+          const double m1 = acc[q] + O::term(xq, xp);
+          acc[q] = d < nt ? m1 : acc[q];
+        } else {
+          acc[q] = acc[q] + O::term(xq, 0.0);
+        }
+      }
+      // the tail: t_e for e > d. Inside the pass's own window the lanes join one by one.
+      int e = d0 + 1;
+      const int e_win = d0 + 64 < nt ? d0 + 64 : nt;
+#pragma unroll 4
+      for (; e < e_win; e++) {
+        const double te = ts[e];
+        if (e > d) {
+#pragma unroll
+          for (int q = 0; q < 4; q++) acc[q] = acc[q] + te;
+        }
+      }
+#pragma unroll 8
+      for (; e < nt; e++) {
+        const double te = ts[e];
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[q] = acc[q] + te;
+      }
+      double ga = 0.0;
+#pragma unroll
+      for (int q = 0; q < 4; q++) ga = ga + coeff[q] * O::finish(acc[q], n);
+      const double gd = ga / dd_val;
+      // coordinate d0 + L sits in lane L; the wave layout wants 128 c + 2 l + k in lane l
+      const double r0 = __shfl(gd, (2 * lane) & 63, 64), r1 = __shfl(gd, (2 * lane + 1) & 63, 64);
+      const int c0 = d0 >> 7, half = (d0 >> 6) & 1;
+#pragma unroll
+      for (int c = 0; c < CHUNKS; c++)
+        if (c == c0 && (lane >> 5) == half) {
+          const int e0 = 128 * c + 2 * lane;
+          g[c][0] = e0 < D ? r0 : 0.0;
+          g[c][1] = e0 + 1 < D ? r1 : 0.0;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();  // (the next call's stores come after this call's reads)
+  }
   __device__ inline void grad(const double (&x)[CHUNKS][2], double (&g)[CHUNKS][2],
                               uint64_t &fcalls, uint64_t &gcalls) const {
     gcalls++;
+    if constexpr (!Objective<MODEL>::kWhole) {
+      if (seq) {  // wave-uniform
+        grad_seq(x, g);
+        fcalls += 4 * n;
+        return;
+      }
+    }
     constexpr double eps = 2.220446049250313e-16 * 10e7;
     constexpr double coeff[4] = {1, -8, 8, -1}, coeff2[4] = {-2, -1, 1, 2};
     constexpr double dd_val = 12 * eps;

@@ -37,3 +37,23 @@ for solver, name in ((_capi.LM_CHOLESKY, "tree"), (_capi.LM_CHOLESKY_REFERENCE_O
     dt, out = timed(lambda: nlsolver_amd.lm.LMEngine("rosenbrock", batch=4096, n=16, lam=10.0, max_iter=10,
                                                      f_delta=0.0, solver=solver), xl)
     print(f"lm-fd rosenbrock-16 x 4096, 10 iterations, {name} order: {dt * 1e3:.1f} ms")
+
+# ONE start (what minimize() of the drop-in classes solves in reference order by default): a warm engine's
+# whole solve, to its stop
+print("one start:")
+x1 = np.full((1, n), 1.0)
+for ref in (False, True):
+    dt, (xo, st) = timed(lambda: nlsolver_amd.BFGSEngine(nlsolver_amd.QuadDiagRank1(d, b, 0.01), 1, max_iter=100,
+                                                         grad_eps=1e-10, reference_order=ref), x1, reps=5)
+    print(f"  bfgs quadratic n=1024, {st[0].iteration} iterations, reference_order={ref}: {dt * 1e3:.2f} ms")
+x1 = (0.9 + 0.0005 * np.arange(128)).reshape(1, -1)
+for ref in (False, True):
+    dt, (xo, st) = timed(lambda: nlsolver_amd.BFGSEngine("rosenbrock", 1, dim=128, max_iter=20, grad_eps=0.0,
+                                                         reference_order=ref), x1, reps=5)
+    print(f"  bfgs-fd rosenbrock-128, {st[0].iteration} iterations, reference_order={ref}: {dt * 1e3:.2f} ms")
+for nn, iters in ((16, 6), (100, 2)):
+    x1 = (0.95 + 0.0005 * np.arange(nn)).reshape(1, -1)
+    for solver, name in ((_capi.LM_CHOLESKY, "tree"), (_capi.LM_CHOLESKY_REFERENCE_ORDER, "reference")):
+        dt, out = timed(lambda: nlsolver_amd.lm.LMEngine("rosenbrock", batch=1, n=nn, lam=10.0, max_iter=iters,
+                                                         f_delta=0.0, solver=solver), x1, reps=5)
+        print(f"  lm-fd rosenbrock-{nn}, {iters} iterations, {name} order: {dt * 1e3:.2f} ms")
