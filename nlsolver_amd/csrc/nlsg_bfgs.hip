@@ -41,23 +41,6 @@ namespace {
     }                                                                                            \
   } while (0)
 
-// reference-order mode: the H passes with every row's dot in index order
-#define BFGS_DISPATCH_SEQ(KERNEL, grid, ...)                                                          \
-  do {                                                                                                \
-    const dim3 g_(grid), b_(256);                                                                     \
-    switch (e->chunks * 2 + (e->vec ? 1 : 0)) {                                                       \
-      case 2: hipLaunchKernelGGL((KERNEL<1, false, true>), g_, b_, 0, e->stream, __VA_ARGS__); break; \
-      case 3: hipLaunchKernelGGL((KERNEL<1, true, true>), g_, b_, 0, e->stream, __VA_ARGS__); break;  \
-      case 4: hipLaunchKernelGGL((KERNEL<2, false, true>), g_, b_, 0, e->stream, __VA_ARGS__); break; \
-      case 5: hipLaunchKernelGGL((KERNEL<2, true, true>), g_, b_, 0, e->stream, __VA_ARGS__); break;  \
-      case 8: hipLaunchKernelGGL((KERNEL<4, false, true>), g_, b_, 0, e->stream, __VA_ARGS__); break; \
-      case 9: hipLaunchKernelGGL((KERNEL<4, true, true>), g_, b_, 0, e->stream, __VA_ARGS__); break;  \
-      case 16: hipLaunchKernelGGL((KERNEL<8, false, true>), g_, b_, 0, e->stream, __VA_ARGS__); break; \
-      case 17: hipLaunchKernelGGL((KERNEL<8, true, true>), g_, b_, 0, e->stream, __VA_ARGS__); break;  \
-      default: break;                                                                                 \
-    }                                                                                                 \
-  } while (0)
-
 // search / init kernels also depend on what is minimised
 #define BFGS_MODEL_CASE(KERNEL, C, V, grid, ...)                                                    \
   const unsigned fd_lds_ = e->p.seq ? static_cast<unsigned>(bfgs_fd_seq_lds_bytes(C)) : 0u;          \
@@ -115,9 +98,20 @@ void launch_iteration(nlsg_bfgs *e, bool timed) {
     hipLaunchKernelGGL(bfgs_sym_reduce_kernel<false>, probs, dim3(256), 0, e->stream, e->p);
     hipLaunchKernelGGL(bfgs_sym_update_kernel, blocks, dim3(256), 0, e->stream, e->p);
     hipLaunchKernelGGL(bfgs_sym_reduce_kernel<true>, probs, dim3(256), 0, e->stream, e->p);
-  } else if (e->p.seq) {
-    BFGS_DISPATCH_SEQ(bfgs_hy_kernel, row_grid, e->p, e->bpp);
-    BFGS_DISPATCH_SEQ(bfgs_update_kernel, row_grid, e->p, e->bpp);
+  } else if (e->p.seq) {  // reference order: a lane per row (nlsg_bfgs_kernels.h "at streaming speed")
+    const uint64_t n = e->p.n;
+    const uint32_t bpp = bfgs_seq_blocks_per_problem(n);
+    const dim3 grid(static_cast<unsigned>(e->p.batch * bpp)), probs(static_cast<unsigned>(e->p.batch));
+    const unsigned lds1 = static_cast<unsigned>(bfgs_seq_h_lds_bytes(n, 1)), lds3 = static_cast<unsigned>(bfgs_seq_h_lds_bytes(n, 3));
+    if (e->vec) {
+      hipLaunchKernelGGL(bfgs_hy_seq_kernel<true>, grid, dim3(256), lds1, e->stream, e->p, bpp);
+      hipLaunchKernelGGL(bfgs_denom_seq_kernel, probs, dim3(64), static_cast<unsigned>(n * sizeof(double)), e->stream, e->p);
+      hipLaunchKernelGGL(bfgs_update_seq_kernel<true>, grid, dim3(256), lds3, e->stream, e->p, bpp);
+    } else {
+      hipLaunchKernelGGL(bfgs_hy_seq_kernel<false>, grid, dim3(256), lds1, e->stream, e->p, bpp);
+      hipLaunchKernelGGL(bfgs_denom_seq_kernel, probs, dim3(64), static_cast<unsigned>(n * sizeof(double)), e->stream, e->p);
+      hipLaunchKernelGGL(bfgs_update_seq_kernel<false>, grid, dim3(256), lds3, e->stream, e->p, bpp);
+    }
   } else {
     BFGS_DISPATCH(bfgs_hy_kernel, row_grid, e->p, e->bpp);
     BFGS_DISPATCH(bfgs_update_kernel, row_grid, e->p, e->bpp);

@@ -696,8 +696,8 @@ __device__ inline void bfgs_store_h_row(double *__restrict__ row, uint64_t D, co
 constexpr int kBfgsRowsPerWave = 8;  // rows a wave streams per launch (vector kept in regs)
 
 // t = H y (first loop of update_inverse_hessian, 3139-3142). Block = 4 waves = 32 rows.
-// SEQ: the reference-order mode (every row's dot in index order; a parity mode)
-template <int CHUNKS, bool VEC, bool SEQ = false>
+// (Reference order: bfgs_hy_seq_kernel / bfgs_update_seq_kernel below.)
+template <int CHUNKS, bool VEC>
 __global__ __launch_bounds__(256) void bfgs_hy_kernel(BfgsParams p, uint32_t blocks_per_problem) {
   const uint64_t pid = blockIdx.x / blocks_per_problem;
   const BfgsProblem *pr = p.prob + pid;
@@ -725,13 +725,13 @@ __global__ __launch_bounds__(256) void bfgs_hy_kernel(BfgsParams p, uint32_t blo
     if (j >= n) break;
     double h[CHUNKS][2];
     bfgs_load_h_row<CHUNKS, VEC>(Hp + j * n, n, p.zero, h);
-    const double v = bfgs_dot<CHUNKS>(y, h, n, SEQ);  // dot(grad_diff, H row), :3140
+    const double v = wave_dot<CHUNKS>(y, h);  // dot(grad_diff, H row), :3140
     if (lane == 0) t[j] = v;
   }
 }
 
 // rank-2 update (3151-3164) fused with the next direction d = -H' g (3248-3251)
-template <int CHUNKS, bool VEC, bool SEQ = false>
+template <int CHUNKS, bool VEC>
 __global__ __launch_bounds__(256) void bfgs_update_kernel(BfgsParams p,
                                                         uint32_t blocks_per_problem) {
   const uint64_t pid = blockIdx.x / blocks_per_problem;
@@ -749,7 +749,7 @@ __global__ __launch_bounds__(256) void bfgs_update_kernel(BfgsParams p,
   load_vec<CHUNKS, VEC>(p.y + pid * n, n, p.zero, y);
   load_vec<CHUNKS, VEC>(p.g + pid * n, n, p.zero, g);
   const double rho = pr->rho;
-  double denom = bfgs_dot<CHUNKS>(y, t, n, SEQ);  // :3143-3145
+  double denom = wave_dot<CHUNKS>(y, t);  // :3143-3145
   denom = (denom * rho) + 1.0;
   const bool identity = pr->identity != 0;
   double *Hp = p.H + pid * n * n;
@@ -774,9 +774,180 @@ __global__ __launch_bounds__(256) void bfgs_update_kernel(BfgsParams p,
       }
     }
     bfgs_store_h_row<CHUNKS, VEC>(Hp + j * n, n, h);
-    const double dj = -bfgs_dot<CHUNKS>(h, g, n, SEQ);  // :3249-3250 with the updated row
+    const double dj = -wave_dot<CHUNKS>(h, g);  // :3249-3250 with the updated row
     if (lane == 0) dir[j] = dj;
   }
+}
+
+// ---- the H passes in REFERENCE ORDER at streaming speed ---------------------------------------
+// Every row's dot in index order — sum_i H[j][i] v[i], products rounded, added left to right — is a
+// serial chain per ROW, but the rows are independent: a LANE per row. A wave owns 64 rows and walks
+// their columns in tiles of sixteen: the tile is loaded the coalesced way (eight instructions, each
+// eight rows x 128 bytes), transposed through the wave's own LDS tile (row stride 17 doubles), and
+// lane l then reads its row's sixteen entries and extends its chain by sixteen products; the next
+// tile's loads are in flight meanwhile. ~0.1 instructions per matrix element instead of the ~2.5 of
+// one-row-at-a-time (a readlane and an addition per element by the whole wave): the passes are back
+// to being bound by the stream of H. The vectors of the products (and, for the update, s and t) sit
+// in the block's LDS. Same additions in the same order as wave_sum_seq: the same bits.
+constexpr int kBfgsSeqRows = 64, kBfgsSeqCols = 16, kBfgsSeqStride = kBfgsSeqCols + 1;
+__host__ __device__ constexpr size_t bfgs_seq_h_lds_bytes(uint64_t n, int vectors) {
+  return (static_cast<size_t>(vectors) * n + 4 * kBfgsSeqRows * kBfgsSeqStride) * sizeof(double);
+}
+__host__ __device__ constexpr uint32_t bfgs_seq_blocks_per_problem(uint64_t n) {
+  return static_cast<uint32_t>((n + 4 * kBfgsSeqRows - 1) / (4 * kBfgsSeqRows));
+}
+
+// the tile of rows row0 .. row0+63, columns c0 .. c0+15 as the wave loads it: instruction q, lane l
+// -> row 8 q + l / 8, columns 2 (l % 8), +1. VEC: n is even (16-byte aligned pairs).
+template <bool VEC>
+__device__ inline void bfgs_seq_load_tile(const double *__restrict__ Hp, uint64_t n, uint64_t row0, uint64_t c0,
+                                          double2 (&v)[8]) {
+  const int lane = lane_id();
+  const uint64_t col = c0 + 2 * static_cast<uint64_t>(lane & 7);
+#pragma unroll
+  for (int q = 0; q < 8; q++) {
+    const uint64_t row = row0 + 8 * q + (lane >> 3);
+    v[q] = make_double2(0.0, 0.0);
+    if (row < n && col < n) {
+      const double *src = Hp + row * n + col;
+      if (VEC) {
+        v[q] = bfgs_stream_load(src);
+      } else {
+        v[q].x = __builtin_nontemporal_load(src);
+        if (col + 1 < n) v[q].y = __builtin_nontemporal_load(src + 1);
+      }
+    }
+  }
+}
+
+// t = H y (update_inverse_hessian's first loop, 3139-3142), every row's dot in index order
+template <bool VEC>
+__global__ __launch_bounds__(256) void bfgs_hy_seq_kernel(BfgsParams p, uint32_t blocks_per_problem) {
+  extern __shared__ __align__(16) double bfgs_seq_smem[];
+  const uint64_t pid = blockIdx.x / blocks_per_problem;
+  const BfgsProblem *pr = p.prob + pid;
+  if (pr->done) return;
+  const uint64_t n = p.n;
+  const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6), lane = lane_id();
+  const uint64_t row0 = (static_cast<uint64_t>(blockIdx.x % blocks_per_problem) * 4 + wid) * kBfgsSeqRows;
+  double *t = p.t + pid * n;
+  const double *y = p.y + pid * n;
+  if (pr->identity) {  // H = I: t = y exactly
+    if (row0 + lane < n) t[row0 + lane] = y[row0 + lane];
+    return;
+  }
+  double *ys = bfgs_seq_smem, *tile = bfgs_seq_smem + n + wid * (kBfgsSeqRows * kBfgsSeqStride);
+  for (uint64_t i = threadIdx.x; i < n; i += 256) ys[i] = y[i];
+  __syncthreads();
+  if (row0 >= n) return;
+  const double *Hp = p.H + pid * n * n;
+  double2 v[8];
+  bfgs_seq_load_tile<VEC>(Hp, n, row0, 0, v);
+  double acc = 0.0;
+  for (uint64_t c0 = 0; c0 < n; c0 += kBfgsSeqCols) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      double *dst = tile + (8 * q + (lane >> 3)) * kBfgsSeqStride + 2 * (lane & 7);
+      dst[0] = v[q].x;
+      dst[1] = v[q].y;
+    }
+    if (c0 + kBfgsSeqCols < n) bfgs_seq_load_tile<VEC>(Hp, n, row0, c0 + kBfgsSeqCols, v);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int m = n - c0 < kBfgsSeqCols ? static_cast<int>(n - c0) : kBfgsSeqCols;  // wave-uniform
+    if (m == kBfgsSeqCols) {
+#pragma unroll
+      for (int j = 0; j < kBfgsSeqCols; j++) acc = acc + ys[c0 + j] * tile[lane * kBfgsSeqStride + j];
+    } else {
+      for (int j = 0; j < m; j++) acc = acc + ys[c0 + j] * tile[lane * kBfgsSeqStride + j];
+    }
+    __builtin_amdgcn_wave_barrier();  // the next tile's stores come after these reads
+  }
+  if (row0 + lane < n) t[row0 + lane] = acc;
+}
+
+// denom = rho y^T t + 1 (3143-3145), the sum in index order: once per problem, between the two passes
+__global__ __launch_bounds__(64) void bfgs_denom_seq_kernel(BfgsParams p) {
+  extern __shared__ __align__(16) double bfgs_seq_smem[];
+  const uint64_t pid = blockIdx.x, n = p.n;
+  BfgsProblem *pr = p.prob + pid;
+  if (pr->done) return;
+  const double *y = p.y + pid * n, *t = p.t + pid * n;
+  for (uint64_t i = threadIdx.x; i < n; i += 64) bfgs_seq_smem[i] = y[i] * t[i];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  double acc = 0.0;
+#pragma unroll 8
+  for (uint64_t i = 0; i < n; i++) acc = acc + bfgs_seq_smem[i];
+  if (threadIdx.x == 0) pr->denom = (acc * pr->rho) + 1.0;
+}
+
+// rank-2 update (3151-3164) fused with the next direction d = -H' g (3248-3251), reference order
+template <bool VEC>
+__global__ __launch_bounds__(256) void bfgs_update_seq_kernel(BfgsParams p, uint32_t blocks_per_problem) {
+  extern __shared__ __align__(16) double bfgs_seq_smem[];
+  const uint64_t pid = blockIdx.x / blocks_per_problem;
+  const BfgsProblem *pr = p.prob + pid;
+  if (pr->done) return;
+  const uint64_t n = p.n;
+  const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6), lane = lane_id();
+  const uint64_t row0 = (static_cast<uint64_t>(blockIdx.x % blocks_per_problem) * 4 + wid) * kBfgsSeqRows;
+  double *ss = bfgs_seq_smem, *ts = ss + n, *gs = ts + n;
+  double *tile = gs + n + wid * (kBfgsSeqRows * kBfgsSeqStride);
+  for (uint64_t i = threadIdx.x; i < n; i += 256) {
+    ss[i] = p.s[pid * n + i];
+    ts[i] = p.t[pid * n + i];
+    gs[i] = p.g[pid * n + i];
+  }
+  __syncthreads();
+  if (row0 >= n) return;
+  const double rho = pr->rho, denom = pr->denom;
+  const bool identity = pr->identity != 0;
+  double *Hp = p.H + pid * n * n;
+  double2 v[8];
+  if (!identity) bfgs_seq_load_tile<VEC>(Hp, n, row0, 0, v);
+  double acc = 0.0;
+  for (uint64_t c0 = 0; c0 < n; c0 += kBfgsSeqCols) {
+    const uint64_t col = c0 + 2 * static_cast<uint64_t>(lane & 7);
+    const bool c_in = col < n, c1_in = col + 1 < n;
+    const double si0 = c_in ? ss[col] : 0.0, ti0 = c_in ? ts[col] : 0.0;
+    const double si1 = c1_in ? ss[col + 1] : 0.0, ti1 = c1_in ? ts[col + 1] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const uint64_t row = row0 + 8 * q + (lane >> 3);
+      const bool r_in = row < n;
+      const double sj = r_in ? ss[row] : 0.0, tj = r_in ? ts[row] : 0.0;
+      // H = I is never materialised: identity rows are synthesised
+      const double h0 = identity ? (col == row ? 1.0 : 0.0) : v[q].x;
+      const double h1 = identity ? (col + 1 == row ? 1.0 : 0.0) : v[q].y;
+      const double w0 = h0 - rho * (si0 * tj + ti0 * sj + denom * si0 * sj);  // :3156-3163
+      const double w1 = h1 - rho * (si1 * tj + ti1 * sj + denom * si1 * sj);
+      double *dst = tile + (8 * q + (lane >> 3)) * kBfgsSeqStride + 2 * (lane & 7);
+      dst[0] = w0;
+      dst[1] = w1;
+      if (r_in && c_in) {
+        double *out = Hp + row * n + col;
+        if (VEC) {
+          bfgs_stream_store(out, make_double2(w0, w1));
+        } else {
+          __builtin_nontemporal_store(w0, out);
+          if (c1_in) __builtin_nontemporal_store(w1, out + 1);
+        }
+      }
+    }
+    if (!identity && c0 + kBfgsSeqCols < n) bfgs_seq_load_tile<VEC>(Hp, n, row0, c0 + kBfgsSeqCols, v);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int m = n - c0 < kBfgsSeqCols ? static_cast<int>(n - c0) : kBfgsSeqCols;  // wave-uniform
+    if (m == kBfgsSeqCols) {
+#pragma unroll
+      for (int j = 0; j < kBfgsSeqCols; j++) acc = acc + tile[lane * kBfgsSeqStride + j] * gs[c0 + j];
+    } else {
+      for (int j = 0; j < m; j++) acc = acc + tile[lane * kBfgsSeqStride + j] * gs[c0 + j];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (row0 + lane < n) p.dir[pid * n + row0 + lane] = -acc;  // :3249-3250 with the updated row
 }
 
 // ---- symmetric restatement of the rank-2 update (NLSG_BFGS_SYMMETRIC) ----------------------------

@@ -1,6 +1,7 @@
 """What the reference-order (bit-for-bit) modes cost against the tree-order kernels: default-gradient
 BFGS on Rosenbrock-128D x 4096 starts, BFGS on the configs[2] quadratic (n 1024 x 512 starts), and
 default-functor LM on Rosenbrock-16D x 4096. PYTHONPATH=. python scripts/ref_order_cost.py"""
+import sys
 import time
 
 import numpy as np
@@ -20,6 +21,10 @@ def timed(make, x0, reps=3):
 
 rng = np.random.default_rng(1)
 x0 = 0.8 + 0.4 * (rng.random((4096, 128)) - 0.5)
+if len(sys.argv) > 1 and sys.argv[1] == "profile-bfgs-fd":  # (under rocprofv3: reference order only)
+    timed(lambda: nlsolver_amd.BFGSEngine("rosenbrock", 4096, dim=128, max_iter=20, grad_eps=0.0,
+                                          reference_order=True), x0)
+    sys.exit(0)
 for ref in (False, True):
     dt, out = timed(lambda: nlsolver_amd.BFGSEngine("rosenbrock", 4096, dim=128, max_iter=20, grad_eps=0.0,
                                                     reference_order=ref), x0)
