@@ -46,7 +46,7 @@ namespace {
   const unsigned fd_lds_ = e->p.seq ? static_cast<unsigned>(bfgs_fd_seq_lds_bytes(C)) : 0u;          \
   switch (e->p.model) {                                                                             \
     case kBfgsQuad:                                                                                 \
-      hipLaunchKernelGGL((KERNEL<C, V, kBfgsQuad>), dim3(grid), dim3(256), 0, e->stream, __VA_ARGS__); \
+      hipLaunchKernelGGL((KERNEL<C, V, kBfgsQuad>), dim3(grid), dim3(256), fd_lds_, e->stream, __VA_ARGS__); \
       break;                                                                                        \
     case NLSG_OBJ_ROSENBROCK:                                                                       \
         hipLaunchKernelGGL((KERNEL<C, V, NLSG_OBJ_ROSENBROCK>), dim3(grid), dim3(256), fd_lds_,  e->stream, \

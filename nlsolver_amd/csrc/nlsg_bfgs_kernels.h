@@ -66,11 +66,55 @@ __device__ inline double wave_total(const double (&a)[CHUNKS][2]) {
   }
   return wave_sum(acc);
 }
+// wave_sum_seq (nlsg_common.h) through the wave's LDS buffer: the terms are stored once (the lane
+// layout IS index order) and every lane walks them at a wave-uniform address — a read that does
+// not depend on the chain, so the additions follow each other at the adder's latency instead of
+// behind two v_readlane each (measured: 80 -> ~10 cycles per term). `buf`: 128 CHUNKS doubles.
+template <int CHUNKS>
+__device__ inline void bfgs_stage_terms(const double (&t)[CHUNKS][2], double *buf) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int c = 0; c < CHUNKS; c++)
+    *reinterpret_cast<double2 *>(buf + 128 * c + 2 * lane) = make_double2(t[c][0], t[c][1]);
+}
+template <int CHUNKS>
+__device__ inline double wave_sum_seq_lds(const double (&t)[CHUNKS][2], uint64_t n, double *buf) {
+  bfgs_stage_terms<CHUNKS>(t, buf);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  double acc = 0.0;
+  const int m = static_cast<int>(n);
+#pragma unroll 8
+  for (int e = 0; e < m; e++) acc = acc + buf[e];
+  __builtin_amdgcn_wave_barrier();  // (the buffer's next stores come after these reads)
+  return acc;
+}
+// two sums side by side (two independent chains: their additions interleave); buf: 2 x 128 CHUNKS
+template <int CHUNKS>
+__device__ inline void wave_sum_seq_lds2(const double (&ta)[CHUNKS][2], const double (&tb)[CHUNKS][2], uint64_t n,
+                                         double *buf, double &sa, double &sb) {
+  double *bufb = buf + 128 * CHUNKS;
+  bfgs_stage_terms<CHUNKS>(ta, buf);
+  bfgs_stage_terms<CHUNKS>(tb, bufb);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  double a = 0.0, b = 0.0;
+  const int m = static_cast<int>(n);
+#pragma unroll 8
+  for (int e = 0; e < m; e++) {
+    a = a + buf[e];
+    b = b + bufb[e];
+  }
+  __builtin_amdgcn_wave_barrier();
+  sa = a;
+  sb = b;
+}
+
 // math::dot (nlsolver.h:58-67) in the engine's summation order: the lane tree, or — reference
-// order (`seq`, wave-uniform) — the products added in index order
+// order (`seq`, wave-uniform; lds = the wave's buffer) — the products added in index order
 template <int CHUNKS>
 __device__ inline double bfgs_dot(const double (&a)[CHUNKS][2], const double (&b)[CHUNKS][2],
-                                  uint64_t n, int seq) {
+                                  uint64_t n, int seq, double *lds) {
   if (!seq) return wave_dot<CHUNKS>(a, b);
   double t[CHUNKS][2];
 #pragma unroll
@@ -78,13 +122,14 @@ __device__ inline double bfgs_dot(const double (&a)[CHUNKS][2], const double (&b
     t[c][0] = a[c][0] * b[c][0];
     t[c][1] = a[c][1] * b[c][1];
   }
-  return wave_sum_seq<CHUNKS>(t, n);
+  return wave_sum_seq_lds<CHUNKS>(t, n, lds);
 }
 
 // The G6 quadratic and its gradient (operation order of oracle_bfgs.c quad_f / quad_g).
 template <int CHUNKS>
 __device__ inline double quad_f(const double (&x)[CHUNKS][2], const double (&d)[CHUNKS][2],
-                                const double (&b)[CHUNKS][2], double c, uint64_t n = 0, int seq = 0) {
+                                const double (&b)[CHUNKS][2], double c, uint64_t n = 0, int seq = 0,
+                                double *lds = nullptr) {
   if (seq) {  // reference order: the three sums of oracle_bfgs.c quad_f_raw, each in index order
     double tq[CHUNKS][2], tl[CHUNKS][2];
 #pragma unroll
@@ -94,9 +139,9 @@ __device__ inline double quad_f(const double (&x)[CHUNKS][2], const double (&d)[
         tq[k][h] = d[k][h] * x[k][h] * x[k][h];
         tl[k][h] = b[k][h] * x[k][h];
       }
-    const double qq = wave_sum_seq<CHUNKS>(tq, n);
-    const double sx = wave_sum_seq<CHUNKS>(x, n);
-    const double lin = wave_sum_seq<CHUNKS>(tl, n);
+    double qq, lin;
+    wave_sum_seq_lds2<CHUNKS>(tq, tl, n, lds, qq, lin);
+    const double sx = wave_sum_seq_lds<CHUNKS>(x, n, lds);
     return 0.5 * qq + 0.5 * c * (sx * sx) - lin;
   }
   double aq = 0.0, al = 0.0;
@@ -115,8 +160,8 @@ __device__ inline double quad_f(const double (&x)[CHUNKS][2], const double (&d)[
 template <int CHUNKS>
 __device__ inline void quad_g(const double (&x)[CHUNKS][2], const double (&d)[CHUNKS][2],
                               const double (&b)[CHUNKS][2], double c, uint64_t n,
-                              double (&g)[CHUNKS][2], int seq = 0) {
-  const double sx = seq ? wave_sum_seq<CHUNKS>(x, n) : wave_total<CHUNKS>(x);
+                              double (&g)[CHUNKS][2], int seq = 0, double *lds = nullptr) {
+  const double sx = seq ? wave_sum_seq_lds<CHUNKS>(x, n, lds) : wave_total<CHUNKS>(x);
   const int lane = lane_id();
 #pragma unroll
   for (int k = 0; k < CHUNKS; k++) {
@@ -158,7 +203,27 @@ struct BfgsModel {  // finite differences on Objective<MODEL>
     lds = bfgs_smem + (threadIdx.x >> 6) * (2 * 128 * CHUNKS);
   }
   __device__ inline double value(const double (&x)[CHUNKS][2]) const {
-    return seq ? wave_objective_seq<MODEL, CHUNKS>(x, n) : wave_objective<MODEL, CHUNKS>(x, n);
+    using O = Objective<MODEL>;
+    if (!seq) return wave_objective<MODEL, CHUNKS>(x, n);
+    if constexpr (O::kWhole) {
+      return wave_objective_seq<MODEL, CHUNKS>(x, n);  // (rejected at engine creation)
+    } else {  // wave_objective_seq with the serial sum through LDS
+      const int lane = lane_id();
+      double t[CHUNKS][2];
+#pragma unroll
+      for (int c = 0; c < CHUNKS; c++) {
+        double xn = 0.0;
+        if (O::kChain) {
+          const double same = lane_down1(x[c][0]);
+          double next = 0.0;
+          if (c + 1 < CHUNKS) next = lane_first(x[c + 1][0]);
+          xn = (lane == 63) ? next : same;
+        }
+        t[c][0] = O::term(x[c][0], x[c][1]);
+        t[c][1] = O::term(x[c][1], xn);
+      }
+      return O::finish(wave_sum_seq_lds<CHUNKS>(t, O::n_terms(n), lds), n);
+    }
   }
   __device__ inline double f(const double (&x)[CHUNKS][2], uint64_t &fcalls) const {
     fcalls++;
@@ -313,22 +378,25 @@ struct BfgsModel<kBfgsQuad, CHUNKS> {
   double qc;
   uint64_t n;
   int seq;
+  double *lds;  // this wave's 2 x 128 CHUNKS doubles (reference order only)
   template <bool VEC>
   __device__ inline void load(const BfgsParams &p) {
+    extern __shared__ __align__(16) double bfgs_smem[];
     n = p.n;
     seq = p.seq;
+    lds = bfgs_smem + (threadIdx.x >> 6) * (2 * 128 * CHUNKS);
     qc = p.qc;
     load_row<CHUNKS, VEC>(p.qd, n, p.zero, qd);
     load_row<CHUNKS, VEC>(p.qb, n, p.zero, qb);
   }
   __device__ inline double f(const double (&x)[CHUNKS][2], uint64_t &fcalls) const {
     fcalls++;
-    return quad_f<CHUNKS>(x, qd, qb, qc, n, seq);
+    return quad_f<CHUNKS>(x, qd, qb, qc, n, seq, lds);
   }
   __device__ inline void grad(const double (&x)[CHUNKS][2], double (&g)[CHUNKS][2],
                               uint64_t &, uint64_t &gcalls) const {
     gcalls++;
-    quad_g<CHUNKS>(x, qd, qb, qc, n, g, seq);
+    quad_g<CHUNKS>(x, qd, qb, qc, n, g, seq, lds);
   }
 };
 
@@ -503,7 +571,7 @@ bfgs_search_kernel(BfgsParams p) {
       dir[c][1] = -g[c][1];
     }
   }
-  const double phi = bfgs_dot<CHUNKS>(g, dir, n, p.seq);
+  const double phi = bfgs_dot<CHUNKS>(g, dir, n, p.seq, model.lds);
   if ((phi > 0) || isnan(phi) || cur_norm > prev_norm) {  // reset guard, :3253-3260
     identity = 1;
 #pragma unroll
@@ -526,7 +594,7 @@ bfgs_search_kernel(BfgsParams p) {
     const double xtol = 1e-15, ftol = 1e-4, gtol = 1e-2, stpmin = 1e-15, stpmax = 1e15, xtrapf = 4;
     const int maxfev = 20;
     int nfev = 0;
-    const double dginit = bfgs_dot<CHUNKS>(g, dir, n, p.seq);
+    const double dginit = bfgs_dot<CHUNKS>(g, dir, n, p.seq, model.lds);
     if (!(dginit >= 0.0)) {
       int brackt = 0, stage1 = 1;
       const double finit = f0, dgtest = ftol * dginit;
@@ -554,7 +622,7 @@ bfgs_search_kernel(BfgsParams p) {
         const double fcur = model.f(tmp, fcalls);
         model.grad(tmp, g, fcalls, gcalls);
         nfev++;
-        const double dg = bfgs_dot<CHUNKS>(g, dir, n, p.seq);
+        const double dg = bfgs_dot<CHUNKS>(g, dir, n, p.seq, model.lds);
         const double ftest1 = finit + stp * dgtest;
         if ((brackt & ((stp <= stmin) | (stp >= stmax))) | (infoc == 0)) info = 6;
         if ((stp == stpmax) & (fcur <= ftest1) & (dg <= dgtest)) info = 5;
@@ -597,13 +665,13 @@ bfgs_search_kernel(BfgsParams p) {
   }
   model.grad(x, g, fcalls, gcalls);
   prev_norm = cur_norm;
-  cur_norm = sqrt(bfgs_dot<CHUNKS>(g, g, n, p.seq));
+  cur_norm = sqrt(bfgs_dot<CHUNKS>(g, g, n, p.seq, model.lds));
 #pragma unroll
   for (int c = 0; c < CHUNKS; c++) {
     y[c][0] = g[c][0] - pg[c][0];
     y[c][1] = g[c][1] - pg[c][1];
   }
-  double rho = bfgs_dot<CHUNKS>(y, s, n, p.seq);
+  double rho = bfgs_dot<CHUNKS>(y, s, n, p.seq, model.lds);
   rho = 1 / rho;
   store_row<CHUNKS, VEC>(p.x + pid * n, n, x);
   store_row<CHUNKS, VEC>(p.g + pid * n, n, g);

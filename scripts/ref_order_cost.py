@@ -25,6 +25,14 @@ if len(sys.argv) > 1 and sys.argv[1] == "profile-bfgs-fd":  # (under rocprofv3: 
     timed(lambda: nlsolver_amd.BFGSEngine("rosenbrock", 4096, dim=128, max_iter=20, grad_eps=0.0,
                                           reference_order=True), x0)
     sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "profile-bfgs-quad":
+    nq = 1024
+    dq = np.array([1.0 + 9.0 * i / (nq - 1) for i in range(nq)])
+    bq = np.sin(0.1 * np.arange(nq))
+    xq0 = 1.0 + 0.5 * (rng.random((512, nq)) - 0.5)
+    timed(lambda: nlsolver_amd.BFGSEngine(nlsolver_amd.QuadDiagRank1(dq, bq, 0.01), 512, max_iter=20,
+                                          grad_eps=0.0, reference_order=True), xq0)
+    sys.exit(0)
 for ref in (False, True):
     dt, out = timed(lambda: nlsolver_amd.BFGSEngine("rosenbrock", 4096, dim=128, max_iter=20, grad_eps=0.0,
                                                     reference_order=ref), x0)
