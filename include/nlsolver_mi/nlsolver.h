@@ -403,15 +403,17 @@ inline uint64_t seed_from(RNG &generator) {
 // default-functor LevenbergMarquardt (fin_diff_h's differences over 600 eps^2).
 //   reference  every sum in index order, separate multiply and add — the reference's sequential
 //              loops (NLSG_BFGS_REFERENCE_ORDER / NLSG_LM_CHOLESKY_REFERENCE_ORDER): x, f and every
-//              counter are the reference's own, bit for bit. A sum costs n dependent additions:
-//              1.8 x (LM) to 10 x (BFGS, default gradient) the tree kernels' time on a large batch.
+//              counter are the reference's own, bit for bit.
 //   tree       the wave's butterfly sums and fused multiply-adds: same algorithm, same branch
 //              decisions on the reference's runs, values within 1e-8 .. 1e-6 (fin_diff) or
 //              rounding (analytic gradient).
-//   automatic  (default) minimize() — the reference's own call, one start, latency-bound either
-//              way — solves in reference order wherever the engine has it (not Rastrigin, whose
-//              device cosine is not libm's, nor Custom or TanhRegression); minimize_batch(), this
-//              header's extension, solves in tree order.
+//   automatic  (default) reference order wherever it costs nothing or the call is the reference's
+//              own: BFGS with the default gradient ALWAYS (its reference-order kernels evaluate a
+//              probe per lane and are the faster ones: Rosenbrock-128D x 4096 starts, 8.8 ms against
+//              32.7 ms for 20 iterations); minimize() — one start — of BFGS with a gradient functor
+//              and of LevenbergMarquardt; minimize_batch(), this header's extension, of those two in
+//              tree order (1.5 x and 1.8 x faster on large batches). Never for Rastrigin (its device
+//              cosine is not libm's), Custom or TanhRegression: no reference arithmetic exists there.
 // Set once before the solves it should govern: `nlsolver::device::summation() = ...`, or the
 // environment variable NLSG_SUMMATION = reference | tree | automatic (read at first use).
 enum class sum_order { automatic, tree, reference };
@@ -1015,7 +1017,8 @@ class BFGS {
   }
   // Extension (BASELINE config 3): `xs.size()` independent starts solved in lock step on
   // the GPU; the reference solves one start per minimize() call.
-  // Summation order: device::summation() (tree unless set to reference).
+  // Summation order: device::summation() (automatic: reference order with the default gradient,
+  // tree order with a gradient functor).
   std::vector<solver_status<scalar_t>> minimize_batch(std::vector<std::vector<scalar_t>> &xs) {
     return solve_device(xs, false);
   }
@@ -1031,6 +1034,22 @@ class BFGS {
   }
 
  private:
+  // device::summation(): with the default gradient the index-order kernels are the faster ones
+  // (a probe per lane), so `automatic` takes them for batches too — also for a Custom objective
+  // given by its terms, where index order is what the body's own loop on a CPU would do.
+  bool use_reference_order(const bool single_start) const {
+    if constexpr (device::has_grad_objective<Callable>::value) {
+      return device::reference_order_for(single_start);
+    } else if constexpr (device_fd()) {
+      if constexpr (Callable::nlsg_objective == NLSG_OBJ_CUSTOM)
+        return f.chain != NLSG_CUSTOM_VECTOR && device::reference_order_for(true);
+      else
+        return has_reference_order() && device::reference_order_for(true);
+    } else {
+      (void)single_start;
+      return false;
+    }
+  }
   std::vector<solver_status<scalar_t>> solve_device(std::vector<std::vector<scalar_t>> &xs,
                                                     const bool single_start) {
     static_assert(device::has_grad_objective<Callable>::value || device_fd(),
@@ -1042,8 +1061,7 @@ class BFGS {
     nlsg_bfgs_config cfg{};
     cfg.struct_size = sizeof(cfg);
     if (const char *d = std::getenv("NLSG_DEVICE")) cfg.device = std::atoi(d);
-    if (has_reference_order() && device::reference_order_for(single_start))
-      cfg.flags |= NLSG_BFGS_REFERENCE_ORDER;
+    if (use_reference_order(single_start)) cfg.flags |= NLSG_BFGS_REFERENCE_ORDER;
     cfg.batch = B;
     cfg.dim = n;
     cfg.max_iter = max_iter;

@@ -236,6 +236,23 @@ def test_bfgs_minimize_through_header_is_the_reference_run(built, golden, name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["rosenbrock_n2", "rosenbrock_n4", "rosenbrock_n16_default_stop",
+                                  "rosenbrock_n128_20iters"])
+def test_bfgs_custom_terms_through_header_run_in_index_order(built, golden, name):
+    """A Custom objective given by its terms (here the Rosenbrock chain as source text) is summed in
+    index order by default — what the body's own loop on a CPU does — so the same text as the
+    reference's functor gives the reference's run bit for bit."""
+    g = golden("bfgs_fd.json")[name]
+    env = {k: v for k, v in os.environ.items() if k != "NLSG_SUMMATION"}
+    o = json.loads(subprocess.check_output(
+        [os.path.join(built, "header_bfgs"), "device-fd-custom", *_bfgs_fd_args(g)],
+        env=dict(env, NLSG_LIBRARY=LIB), text=True))
+    assert "device_error" not in o, o
+    assert (o["fcalls"], o["iters"], o["gcalls"]) == (g["fcalls"], g["iters"], g["gcalls"])
+    assert o["f"] == g["f"] and o["x"] == g["x"]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["n8", "n64", "n64_default_stop", "n100_ragged_start", "n130_alpha_half",
                                   "n256_max_iter_5", "n1024"])
 def test_bfgs_quadratic_minimize_through_header_is_the_reference_run(built, golden, name):
@@ -255,8 +272,8 @@ def test_bfgs_quadratic_minimize_through_header_is_the_reference_run(built, gold
 
 @pytest.mark.gpu
 def test_bfgs_summation_switch_through_header(built, oracle, golden):
-    """minimize_batch() (the header's extension) solves in tree order unless device::summation() says
-    reference; minimize() follows NLSG_SUMMATION=tree; a misspelt value is an error, not a default."""
+    """With the default gradient both minimize() and minimize_batch() solve in reference order (the
+    faster kernels there) unless NLSG_SUMMATION=tree; a misspelt value is an error, not a default."""
     g = golden("bfgs_fd.json")["rosenbrock_n16_default_stop"]
     cmd = [os.path.join(built, "header_bfgs"), "device-fd", *_bfgs_fd_args(g), "rosenbrock"]
     env = {k: v for k, v in os.environ.items() if k != "NLSG_SUMMATION"}
@@ -275,8 +292,9 @@ def test_bfgs_summation_switch_through_header(built, oracle, golden):
 
     run = lambda extra, **kw: json.loads(subprocess.check_output(cmd + extra, env=dict(env, **kw), text=True))
     assert tree.f_value != hx(g["f"])  # (the two orders do differ on this run)
-    assert is_tree(run(["batch"]))
+    assert is_reference(run(["batch"]))
     assert is_reference(run(["batch"], NLSG_SUMMATION="reference"))
+    assert is_tree(run(["batch"], NLSG_SUMMATION="tree"))
     assert is_tree(run([], NLSG_SUMMATION="tree"))
     assert is_reference(run([], NLSG_SUMMATION="automatic"))
     r = subprocess.run(cmd, env=dict(env, NLSG_SUMMATION="refrence"), capture_output=True, text=True)

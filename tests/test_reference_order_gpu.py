@@ -148,10 +148,24 @@ def test_one_start_defaults_to_reference_order_a_batch_to_tree(mod, oracle, gold
     st = mod.BFGS("rosenbrock", None, **kw).minimize(x)
     assert st.f_value == hx(g["f"]) and x.tolist() == [hx(v) for v in g["x"]]
     assert (st.iteration, st.function_calls_used) == (g["iters"], g["fcalls"])
-    xb = start(g).reshape(1, -1)
+    xb = start(g).reshape(1, -1)  # (with the default gradient a batch solves in reference order too)
     stb = mod.BFGS("rosenbrock", None, **kw).minimize(xb)
+    assert stb[0].f_value == st.f_value and np.array_equal(xb[0], x)
+    xb = start(g).reshape(1, -1)
+    stb = mod.BFGS("rosenbrock", None, reference_order=False, **kw).minimize(xb)
     tree, xt, _, _ = O.bfgs_fd(oracle, "rosenbrock", start(g), tree=1, **kw)
     assert stb[0].f_value == tree.f_value != st.f_value and np.array_equal(xb[0], xt)
+    # the quadratic with its gradient functor: one start in reference order, a batch in tree order
+    gq = golden("bfgs.json")["n64"]
+    d, b, c = O.quad_problem(gq["n"])
+    kq = dict(max_iter=gq["max_iter"], grad_eps=hx(gq["grad_eps"]), alpha=hx(gq["alpha"]))
+    xq = start(gq)
+    sq = mod.BFGS(mod.QuadDiagRank1(d, b, c), None, **kq).minimize(xq)
+    assert sq.f_value == hx(gq["f"]) and xq[:8].tolist() == [hx(v) for v in gq["x_head"]]
+    xqb = start(gq).reshape(1, -1)
+    sqb = mod.BFGS(mod.QuadDiagRank1(d, b, c), None, **kq).minimize(xqb)
+    qt, xqt, _ = O.bfgs_quad(oracle, start(gq), tree=1, **kq)
+    assert sqb[0].f_value == qt.f_value and np.array_equal(xqb[0], xqt)
 
     g = golden("lm_fd.json")["rosenbrock_n16_6iters"]
     args = (hx(g["lambda"]), 10.0, 10.0, g["max_iter"], hx(g["f_delta"]))
