@@ -102,7 +102,8 @@ void launch_iteration(nlsg_bfgs *e, bool timed) {
     const uint64_t n = e->p.n;
     const uint32_t bpp = bfgs_seq_blocks_per_problem(n);
     const dim3 grid(static_cast<unsigned>(e->p.batch * bpp)), probs(static_cast<unsigned>(e->p.batch));
-    const unsigned lds1 = static_cast<unsigned>(bfgs_seq_h_lds_bytes(n, 1)), lds3 = static_cast<unsigned>(bfgs_seq_h_lds_bytes(n, 3));
+    const unsigned lds1 = static_cast<unsigned>(bfgs_seq_h_lds_bytes(n, kBfgsSeqColsHy));
+    const unsigned lds3 = static_cast<unsigned>(bfgs_seq_h_lds_bytes(n, kBfgsSeqColsUpdate));
     if (e->vec) {
       hipLaunchKernelGGL(bfgs_hy_seq_kernel<true>, grid, dim3(256), lds1, e->stream, e->p, bpp);
       hipLaunchKernelGGL(bfgs_denom_seq_kernel, probs, dim3(64), static_cast<unsigned>(n * sizeof(double)), e->stream, e->p);

@@ -857,24 +857,28 @@ __global__ __launch_bounds__(256) void bfgs_update_kernel(BfgsParams p,
 // one-row-at-a-time (a readlane and an addition per element by the whole wave): the passes are back
 // to being bound by the stream of H. The vectors of the products (and, for the update, s and t) sit
 // in the block's LDS. Same additions in the same order as wave_sum_seq: the same bits.
-constexpr int kBfgsSeqRows = 64, kBfgsSeqCols = 16, kBfgsSeqStride = kBfgsSeqCols + 1;
-__host__ __device__ constexpr size_t bfgs_seq_h_lds_bytes(uint64_t n, int vectors) {
-  return (static_cast<size_t>(vectors) * n + 4 * kBfgsSeqRows * kBfgsSeqStride) * sizeof(double);
+constexpr int kBfgsSeqRows = 64;
+// columns per tile: 16 = 128-byte row segments. (32 — 256-byte segments, 76 KiB of LDS per block —
+// measured the same in the read-only pass and 5 % slower in the update: not the segment size.)
+constexpr int kBfgsSeqColsHy = 16, kBfgsSeqColsUpdate = 16;
+__host__ __device__ constexpr size_t bfgs_seq_h_lds_bytes(uint64_t n, int cols) {
+  return (n + 4 * static_cast<size_t>(kBfgsSeqRows) * (cols + 1)) * sizeof(double);
 }
 __host__ __device__ constexpr uint32_t bfgs_seq_blocks_per_problem(uint64_t n) {
   return static_cast<uint32_t>((n + 4 * kBfgsSeqRows - 1) / (4 * kBfgsSeqRows));
 }
 
-// the tile of rows row0 .. row0+63, columns c0 .. c0+15 as the wave loads it: instruction q, lane l
-// -> row 8 q + l / 8, columns 2 (l % 8), +1. VEC: n is even (16-byte aligned pairs).
-template <bool VEC>
+// the tile of rows row0 .. row0+63, columns c0 .. c0+TC-1 as the wave loads it: instruction q, lane l
+// -> row (128 / TC) q + l / (TC / 2), columns 2 (l % (TC / 2)), +1. VEC: n is even (16-byte aligned pairs).
+template <bool VEC, int TC>
 __device__ inline void bfgs_seq_load_tile(const double *__restrict__ Hp, uint64_t n, uint64_t row0, uint64_t c0,
-                                          double2 (&v)[8]) {
+                                          double2 (&v)[TC / 2]) {
+  constexpr int LPR = TC / 2, RPI = 64 / LPR;  // lanes per row, rows per instruction
   const int lane = lane_id();
-  const uint64_t col = c0 + 2 * static_cast<uint64_t>(lane & 7);
+  const uint64_t col = c0 + 2 * static_cast<uint64_t>(lane % LPR);
 #pragma unroll
-  for (int q = 0; q < 8; q++) {
-    const uint64_t row = row0 + 8 * q + (lane >> 3);
+  for (int q = 0; q < TC / 2; q++) {
+    const uint64_t row = row0 + RPI * q + (lane / LPR);
     v[q] = make_double2(0.0, 0.0);
     if (row < n && col < n) {
       const double *src = Hp + row * n + col;
@@ -904,32 +908,40 @@ __global__ __launch_bounds__(256) void bfgs_hy_seq_kernel(BfgsParams p, uint32_t
     if (row0 + lane < n) t[row0 + lane] = y[row0 + lane];
     return;
   }
-  double *ys = bfgs_seq_smem, *tile = bfgs_seq_smem + n + wid * (kBfgsSeqRows * kBfgsSeqStride);
+  constexpr int TC = kBfgsSeqColsHy, ST = TC + 1, LPR = TC / 2, RPI = 64 / LPR;
+  double *ys = bfgs_seq_smem, *tile = bfgs_seq_smem + n + wid * (kBfgsSeqRows * ST);
   for (uint64_t i = threadIdx.x; i < n; i += 256) ys[i] = y[i];
   __syncthreads();
   if (row0 >= n) return;
   const double *Hp = p.H + pid * n * n;
-  double2 v[8];
-  bfgs_seq_load_tile<VEC>(Hp, n, row0, 0, v);
   double acc = 0.0;
-  for (uint64_t c0 = 0; c0 < n; c0 += kBfgsSeqCols) {
+  auto consume = [&](const double2 (&v)[TC / 2], uint64_t c0) {  // the tile at columns c0 .. c0+TC-1: TC more products
 #pragma unroll
-    for (int q = 0; q < 8; q++) {
-      double *dst = tile + (8 * q + (lane >> 3)) * kBfgsSeqStride + 2 * (lane & 7);
+    for (int q = 0; q < TC / 2; q++) {
+      double *dst = tile + (RPI * q + lane / LPR) * ST + 2 * (lane % LPR);
       dst[0] = v[q].x;
       dst[1] = v[q].y;
     }
-    if (c0 + kBfgsSeqCols < n) bfgs_seq_load_tile<VEC>(Hp, n, row0, c0 + kBfgsSeqCols, v);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const int m = n - c0 < kBfgsSeqCols ? static_cast<int>(n - c0) : kBfgsSeqCols;  // wave-uniform
-    if (m == kBfgsSeqCols) {
+    const int m = n - c0 < TC ? static_cast<int>(n - c0) : TC;  // wave-uniform
+    if (m == TC) {
 #pragma unroll
-      for (int j = 0; j < kBfgsSeqCols; j++) acc = acc + ys[c0 + j] * tile[lane * kBfgsSeqStride + j];
+      for (int j = 0; j < TC; j++) acc = acc + ys[c0 + j] * tile[lane * ST + j];
     } else {
-      for (int j = 0; j < m; j++) acc = acc + ys[c0 + j] * tile[lane * kBfgsSeqStride + j];
+      for (int j = 0; j < m; j++) acc = acc + ys[c0 + j] * tile[lane * ST + j];
     }
     __builtin_amdgcn_wave_barrier();  // the next tile's stores come after these reads
+  };
+  // two tiles in flight while a third is consumed
+  double2 va[TC / 2], vb[TC / 2];
+  bfgs_seq_load_tile<VEC, TC>(Hp, n, row0, 0, va);
+  bfgs_seq_load_tile<VEC, TC>(Hp, n, row0, TC, vb);
+  for (uint64_t c0 = 0; c0 < n; c0 += 2 * TC) {
+    consume(va, c0);
+    bfgs_seq_load_tile<VEC, TC>(Hp, n, row0, c0 + 2 * TC, va);
+    if (c0 + TC < n) consume(vb, c0 + TC);
+    bfgs_seq_load_tile<VEC, TC>(Hp, n, row0, c0 + 3 * TC, vb);
   }
   if (row0 + lane < n) t[row0 + lane] = acc;
 }
@@ -950,7 +962,10 @@ __global__ __launch_bounds__(64) void bfgs_denom_seq_kernel(BfgsParams p) {
   if (threadIdx.x == 0) pr->denom = (acc * pr->rho) + 1.0;
 }
 
-// rank-2 update (3151-3164) fused with the next direction d = -H' g (3248-3251), reference order
+// rank-2 update (3151-3164) fused with the next direction d = -H' g (3248-3251), reference order.
+// The wave's rows are fixed, so s_j and t_j of a lane's eight rows stay in registers; s_i and t_i of
+// a tile's columns travel with the tile's loads; only g (the dot's other factor, read at a uniform
+// address) sits in LDS.
 template <bool VEC>
 __global__ __launch_bounds__(256) void bfgs_update_seq_kernel(BfgsParams p, uint32_t blocks_per_problem) {
   extern __shared__ __align__(16) double bfgs_seq_smem[];
@@ -960,40 +975,50 @@ __global__ __launch_bounds__(256) void bfgs_update_seq_kernel(BfgsParams p, uint
   const uint64_t n = p.n;
   const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6), lane = lane_id();
   const uint64_t row0 = (static_cast<uint64_t>(blockIdx.x % blocks_per_problem) * 4 + wid) * kBfgsSeqRows;
-  double *ss = bfgs_seq_smem, *ts = ss + n, *gs = ts + n;
-  double *tile = gs + n + wid * (kBfgsSeqRows * kBfgsSeqStride);
-  for (uint64_t i = threadIdx.x; i < n; i += 256) {
-    ss[i] = p.s[pid * n + i];
-    ts[i] = p.t[pid * n + i];
-    gs[i] = p.g[pid * n + i];
-  }
+  constexpr int TC = kBfgsSeqColsUpdate, ST = TC + 1, LPR = TC / 2, RPI = 64 / LPR, NQ = TC / 2;
+  double *gs = bfgs_seq_smem, *tile = gs + n + wid * (kBfgsSeqRows * ST);
+  const double *sp = p.s + pid * n, *tp = p.t + pid * n;
+  for (uint64_t i = threadIdx.x; i < n; i += 256) gs[i] = p.g[pid * n + i];
   __syncthreads();
   if (row0 >= n) return;
   const double rho = pr->rho, denom = pr->denom;
   const bool identity = pr->identity != 0;
   double *Hp = p.H + pid * n * n;
-  double2 v[8];
-  if (!identity) bfgs_seq_load_tile<VEC>(Hp, n, row0, 0, v);
-  double acc = 0.0;
-  for (uint64_t c0 = 0; c0 < n; c0 += kBfgsSeqCols) {
-    const uint64_t col = c0 + 2 * static_cast<uint64_t>(lane & 7);
-    const bool c_in = col < n, c1_in = col + 1 < n;
-    const double si0 = c_in ? ss[col] : 0.0, ti0 = c_in ? ts[col] : 0.0;
-    const double si1 = c1_in ? ss[col + 1] : 0.0, ti1 = c1_in ? ts[col + 1] : 0.0;
+  double sj[NQ], tj[NQ];
 #pragma unroll
-    for (int q = 0; q < 8; q++) {
-      const uint64_t row = row0 + 8 * q + (lane >> 3);
-      const bool r_in = row < n;
-      const double sj = r_in ? ss[row] : 0.0, tj = r_in ? ts[row] : 0.0;
+  for (int q = 0; q < NQ; q++) {
+    const uint64_t row = row0 + RPI * q + (lane / LPR);
+    sj[q] = row < n ? sp[row] : 0.0;
+    tj[q] = row < n ? tp[row] : 0.0;
+  }
+  struct Tile {
+    double2 h[NQ];
+    double si0, si1, ti0, ti1;
+  };
+  auto load = [&](Tile &T, uint64_t c0) {
+    const uint64_t col = c0 + 2 * static_cast<uint64_t>(lane % LPR);
+    T.si0 = col < n ? sp[col] : 0.0;
+    T.ti0 = col < n ? tp[col] : 0.0;
+    T.si1 = col + 1 < n ? sp[col + 1] : 0.0;
+    T.ti1 = col + 1 < n ? tp[col + 1] : 0.0;
+    if (!identity) bfgs_seq_load_tile<VEC, TC>(Hp, n, row0, c0, T.h);
+  };
+  double acc = 0.0;
+  auto consume = [&](const Tile &T, uint64_t c0) {
+    const uint64_t col = c0 + 2 * static_cast<uint64_t>(lane % LPR);
+    const bool c_in = col < n, c1_in = col + 1 < n;
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      const uint64_t row = row0 + RPI * q + (lane / LPR);
       // H = I is never materialised: identity rows are synthesised
-      const double h0 = identity ? (col == row ? 1.0 : 0.0) : v[q].x;
-      const double h1 = identity ? (col + 1 == row ? 1.0 : 0.0) : v[q].y;
-      const double w0 = h0 - rho * (si0 * tj + ti0 * sj + denom * si0 * sj);  // :3156-3163
-      const double w1 = h1 - rho * (si1 * tj + ti1 * sj + denom * si1 * sj);
-      double *dst = tile + (8 * q + (lane >> 3)) * kBfgsSeqStride + 2 * (lane & 7);
+      const double h0 = identity ? (col == row ? 1.0 : 0.0) : T.h[q].x;
+      const double h1 = identity ? (col + 1 == row ? 1.0 : 0.0) : T.h[q].y;
+      const double w0 = h0 - rho * (T.si0 * tj[q] + T.ti0 * sj[q] + denom * T.si0 * sj[q]);  // :3156-3163
+      const double w1 = h1 - rho * (T.si1 * tj[q] + T.ti1 * sj[q] + denom * T.si1 * sj[q]);
+      double *dst = tile + (RPI * q + lane / LPR) * ST + 2 * (lane % LPR);
       dst[0] = w0;
       dst[1] = w1;
-      if (r_in && c_in) {
+      if (row < n && c_in) {
         double *out = Hp + row * n + col;
         if (VEC) {
           bfgs_stream_store(out, make_double2(w0, w1));
@@ -1003,17 +1028,25 @@ __global__ __launch_bounds__(256) void bfgs_update_seq_kernel(BfgsParams p, uint
         }
       }
     }
-    if (!identity && c0 + kBfgsSeqCols < n) bfgs_seq_load_tile<VEC>(Hp, n, row0, c0 + kBfgsSeqCols, v);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const int m = n - c0 < kBfgsSeqCols ? static_cast<int>(n - c0) : kBfgsSeqCols;  // wave-uniform
-    if (m == kBfgsSeqCols) {
+    const int m = n - c0 < TC ? static_cast<int>(n - c0) : TC;  // wave-uniform
+    if (m == TC) {
 #pragma unroll
-      for (int j = 0; j < kBfgsSeqCols; j++) acc = acc + tile[lane * kBfgsSeqStride + j] * gs[c0 + j];
+      for (int j = 0; j < TC; j++) acc = acc + tile[lane * ST + j] * gs[c0 + j];
     } else {
-      for (int j = 0; j < m; j++) acc = acc + tile[lane * kBfgsSeqStride + j] * gs[c0 + j];
+      for (int j = 0; j < m; j++) acc = acc + tile[lane * ST + j] * gs[c0 + j];
     }
     __builtin_amdgcn_wave_barrier();
+  };
+  Tile A, B;
+  load(A, 0);
+  load(B, TC);
+  for (uint64_t c0 = 0; c0 < n; c0 += 2 * TC) {
+    consume(A, c0);
+    load(A, c0 + 2 * TC);
+    if (c0 + TC < n) consume(B, c0 + TC);
+    load(B, c0 + 3 * TC);
   }
   if (row0 + lane < n) p.dir[pid * n + row0 + lane] = -acc;  // :3249-3250 with the updated row
 }
