@@ -57,7 +57,8 @@ bool lm_fd_objective(int objective) {
 // finite-difference model: step k + evaluation k + 1 (first: the evaluation at x0 only)
 void launch_fd_iter(nlsg_lm *e, int first) {
   const dim3 grid(static_cast<unsigned>(e->p.batch));
-  const unsigned lds = (64 * lm_fd_chunks(e->p.n) + 128) * sizeof(double);
+  // (+ 66: the point and a zero behind it, for the reference-order evaluation's lanes)
+  const unsigned lds = (64 * lm_fd_chunks(e->p.n) + 128 + 66) * sizeof(double);
   if (e->cfg.objective == NLSG_OBJ_CUSTOM) {
     void *args[] = {&e->p, &first};
     launch_module_kernel(e->rtc.iter, grid.x, 64, lds, e->stream, args);

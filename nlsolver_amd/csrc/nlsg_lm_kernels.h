@@ -897,6 +897,192 @@ __device__ inline void lm_fd_eval_groups(const LmParams &p, int first, uint64_t 
   }
 }
 
+// The same evaluation in REFERENCE ORDER (NLSG_LM_CHOLESKY_REFERENCE_ORDER), a probe per LANE. Every
+// probe is the objective at the base point with one or two coordinates moved, its terms added in
+// index order; only the terms that contain a moved coordinate differ from the base point's. So the
+// base terms t_e are computed once and sit in LDS, and a lane walks them at a wave-uniform address,
+// substituting its own few modified terms where they fall:
+//  * fin_diff: lane d = coordinate d, its four probes side by side; they start from the base point's
+//    prefix sum (one serial chain per gradient, captured on the way) and add the tail;
+//  * fin_diff_h: row i at a time, lane j = entry (i, j), its sixteen probes as two batches of eight
+//    chains; the moved pair comes from the literal += / -= replay (per lane: i == j aliases the
+//    two), the up to four modified terms (e = i-1, i, j-1, j for a chain objective) are computed
+//    up front, and the walk over e picks per lane between them and the base term.
+// ~30 instructions per probe instead of ~n / G * 3 + 60 for a serial sum by a group of lanes: the
+// reference-order evaluation is as fast as the tree-order one at n = 16 and faster past it, and has
+// the reference's bits (tests/golden/lm_fd.json; oracle order 0).
+// xs: 65 doubles (x, then a zero), ts: 64 doubles.
+template <int OBJ>
+__device__ inline void lm_fd_eval_lanes(const LmParams &p, int first, uint64_t pid, const double *theta,
+                                        double *xs, double *ts) {
+  using O = Objective<OBJ>;
+  LmProblem *pr = p.prob + pid;
+  const int lane = threadIdx.x, n = static_cast<int>(p.n), nt = static_cast<int>(O::n_terms(p.n));
+  const double xl = theta[lane];  // zero past n
+  xs[lane] = xl;
+  if (lane == 0) xs[64] = 0.0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const double xnext = xs[lane + 1], xprev = xs[lane > 0 ? lane - 1 : 0];
+  ts[lane] = O::term(xl, xnext);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // f, and on the way the prefix sum each coordinate's probes start from
+  constexpr int off = O::kChain ? 2 : 1;
+  double run = 0.0, start = 0.0;
+  for (int e = 0; e < nt; e++) {
+    run = run + ts[e];
+    start = e == lane - off ? run : start;
+  }
+  const double f = O::finish(run, p.n);
+  {  // fin_diff<1>: coeff {1,-8,8,-1}, coeff2 {-2,-1,1,2}, eps = DBL_EPSILON * 10e7
+    constexpr double eps = 2.220446049250313e-16 * 10e7;
+    constexpr double coeff[4] = {1, -8, 8, -1}, coeff2[4] = {-2, -1, 1, 2};
+    constexpr double dd_val = 12 * eps;
+    const int d = lane;
+    double acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const double xq = xl + coeff2[q] * eps;
+      acc[q] = start;
+      if constexpr (O::kChain) {
+        const double m0 = acc[q] + O::term(xprev, xq);
+        acc[q] = d >= 1 ? m0 : acc[q];
+        const double m1 = acc[q] + O::term(xq, xnext);
+        acc[q] = d < nt ? m1 : acc[q];
+      } else {
+        acc[q] = acc[q] + O::term(xq, 0.0);
+      }
+    }
+    for (int e = 1; e < nt; e++) {
+      const double te = ts[e];
+      if (e > d) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[q] = acc[q] + te;
+      }
+    }
+    double ga = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) ga = ga + coeff[q] * O::finish(acc[q], p.n);
+    p.gg[pid * kLmN + lane] = d < n ? ga / dd_val : 0.0;
+  }
+  // fin_diff_h<1>
+  const double e1 = p.eps_h, e2 = 2 * e1, e3 = 3 * e1, e4 = 4 * e1;
+  const double denom = (600.0 * e1 * e1);
+  const int j = lane;
+  const double xj0 = xl, xjm = xprev, xjp = xnext;
+  bool upper = false;
+  for (int i = 0; i < n; i++) {
+    const double xi0 = xs[i], xim = xs[i > 0 ? i - 1 : 0], xip = xs[i + 1];
+    const bool same = i == j;
+    double fv[16];
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      // the pairs of this half's eight probes: the literal sequence, captured where a probe is taken
+      double ci[8], cj[8];
+      {
+        double xi = xi0, xj = xj0;
+        auto add_i = [&](double d) { xi = xi + d; xj = same ? xi : xj; };
+        auto sub_i = [&](double d) { xi = xi - d; xj = same ? xi : xj; };
+        auto add_j = [&](double d) { xj = xj + d; xi = same ? xj : xi; };
+        auto sub_j = [&](double d) { xj = xj - d; xi = same ? xj : xi; };
+        auto at = [&](auto k) {
+          constexpr int K = decltype(k)::value;
+          if constexpr (K / 8 == 0) { if (half == 0) { ci[K % 8] = xi; cj[K % 8] = xj; } }
+          else { if (half == 1) { ci[K % 8] = xi; cj[K % 8] = xj; } }
+        };
+        add_i(e1); sub_j(e2); at(int_c<0>{});
+        add_i(e1); add_j(e1); at(int_c<1>{});
+        sub_i(e4); add_j(e2); at(int_c<2>{});
+        add_i(e1); add_j(e1); at(int_c<3>{});
+        sub_j(e4); at(int_c<4>{});
+        sub_i(e1); add_j(e1); at(int_c<5>{});
+        add_i(e3); add_j(e3); at(int_c<6>{});
+        add_i(e1); sub_j(e1); at(int_c<7>{});
+        sub_j(e3); at(int_c<8>{});
+        sub_i(e4); add_j(e4); at(int_c<9>{});
+        sub_j(e4); at(int_c<10>{});
+        add_i(e4); add_j(e4); at(int_c<11>{});
+        sub_i(e3); sub_j(e3); at(int_c<12>{});
+        add_i(e2); add_j(e2); at(int_c<13>{});
+        sub_j(e2); at(int_c<14>{});
+        sub_i(e2); add_j(e2); at(int_c<15>{});
+      }
+      // the modified terms: x_j -> cj takes precedence over x_i -> ci (they are equal when i == j)
+      double A[8], B[8], C[8], D[8];  // terms i-1, i, j-1, j
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const double vi = same ? cj[k] : ci[k];                    // x_i of the probe
+        if constexpr (O::kChain) {
+          const double vim = i - 1 == j ? cj[k] : xim;             // x_{i-1}
+          const double vip = i + 1 == j ? cj[k] : xip;             // x_{i+1}
+          const double vjm = j - 1 == i ? ci[k] : xjm;             // x_{j-1}
+          const double vjp = j + 1 == i ? ci[k] : xjp;             // x_{j+1}
+          A[k] = O::term(vim, vi);
+          B[k] = O::term(vi, vip);
+          C[k] = O::term(vjm, cj[k]);
+          D[k] = O::term(cj[k], vjp);
+        } else {
+          A[k] = C[k] = 0.0;
+          B[k] = O::term(vi, 0.0);
+          D[k] = O::term(cj[k], 0.0);
+        }
+      }
+      double acc[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) acc[k] = 0.0;
+      for (int e = 0; e < nt; e++) {
+        const double te = ts[e];
+        const bool at_j = e == j, at_jm = O::kChain && e == j - 1;
+        if (O::kChain && e == i - 1) {  // (wave-uniform branches)
+#pragma unroll
+          for (int k = 0; k < 8; k++) acc[k] = acc[k] + (at_j ? D[k] : at_jm ? C[k] : A[k]);
+        } else if (e == i) {
+#pragma unroll
+          for (int k = 0; k < 8; k++) acc[k] = acc[k] + (at_j ? D[k] : at_jm ? C[k] : B[k]);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; k++) acc[k] = acc[k] + (at_j ? D[k] : at_jm ? C[k] : te);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; k++) fv[8 * half + k] = O::finish(acc[k], p.n);
+    }
+    double result = 0.0, temp = 0.0;
+    temp = temp + fv[0];
+    temp = temp + fv[1];
+    temp = temp + fv[2];
+    temp = temp + fv[3];
+    result = result - 63 * temp;
+    temp = 0.0;
+    temp = temp + fv[4];
+    temp = temp + fv[5];
+    temp = temp + fv[6];
+    temp = temp + fv[7];
+    result = result + 63 * temp;
+    temp = 0.0;
+    temp = temp + fv[8];
+    temp = temp + fv[9];
+    temp = temp - fv[10];
+    temp = temp - fv[11];
+    result = result + 44 * temp;
+    temp = 0.0;
+    temp = temp + fv[12];
+    temp = temp + fv[13];
+    temp = temp - fv[14];
+    temp = temp - fv[15];
+    result = result + 74 * temp;
+    const double hij = result / denom;
+    if (lane <= i) p.Hg[pid * kLmTri + lm_tri_row(i) + lane] = hij;
+    upper |= lane > i && lane < n && hij > 2.220446049250313e-16 * 1e12;
+  }
+  const bool any_upper = __ballot(upper) != 0ull;
+  if (lane == 0) {
+    pr->upper = any_upper ? 1 : 0;
+    lm_publish_state(p, pr, first, f);
+  }
+}
+
 // LDS of the wave: `chunks` x 64 doubles of the triangle (rows 0 .. n-1) | g | upd
 __host__ __device__ inline int lm_fd_chunks(uint64_t n) {
   return (lm_tri_row(static_cast<int>(n)) + 63) / 64;
@@ -912,6 +1098,13 @@ __global__ __launch_bounds__(64) void lm_fd_iter_kernel(LmParams p, int first) {
     double *g = lm_fd_smem + 64 * chunks;
     if (!lm_step_wave<true, REF>(p, pid, LmStepShared{lm_fd_smem, g, g + 64}, chunks)) return;
     theta_lds = g + 64;
+  }
+  if constexpr (REF && !Objective<OBJ>::kWhole) {
+    // (the triangle's LDS image is dead during the evaluation; its first 64 doubles and the 65 past
+    // g | upd hold the base terms and the point)
+    double *xs = lm_fd_smem + 64 * lm_fd_chunks(p.n) + 128;
+    lm_fd_eval_lanes<OBJ>(p, first, pid, theta_lds ? theta_lds : p.theta + pid * kLmN, xs, lm_fd_smem);
+    return;
   }
   if (p.n <= 8)
     lm_fd_eval_groups<OBJ, 4, REF>(p, first, pid, theta_lds);
