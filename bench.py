@@ -610,16 +610,24 @@ def main_sann(args):
 def main_lm_fd(args):
     """LevenbergMarquardt with the reference's DEFAULT functors (fin_diff + fin_diff_h,
     nlsolver.h:3494-3511) on the device: Rosenbrock-16D, batch = 8192 independent starts, 10
-    iterations. One step = one LM iteration of every problem = 1 + 4 n + 16 n^2 = 4161 objective
-    evaluations per problem, several probe points per wave."""
+    iterations, in REFERENCE ORDER — what the drop-in classes run for this model (every sum in the
+    reference's index order: its results bit for bit). One step = one LM iteration of every problem =
+    1 + 4 n + 16 n^2 = 4161 objective evaluations per problem, a probe per lane on the base point's
+    shared terms. The tree-order kernels (a probe per group of lanes) are timed beside
+    it as `tree_order`."""
     import nlsolver_amd
+    from nlsolver_amd._capi import LM_CHOLESKY, LM_CHOLESKY_REFERENCE_ORDER
     n, iters = 16, 10
     batch = 8192 if args.pop_per_gpu == POP_PER_GPU else args.pop_per_gpu
     ranks = Ranks(args)
     rng = np.random.default_rng(ranks.slice_seed(12374563468 % 2**32))
     x0 = 0.8 + 0.4 * (rng.random((batch, n)) - 0.5)
+    with nlsolver_amd.lm.LMEngine("rosenbrock", batch=batch, n=n, lam=10.0, max_iter=iters, f_delta=0.0,
+                                  device=ranks.local_rank, solver=LM_CHOLESKY) as tree_eng:
+        tree_eng.minimize(x0.copy())
+        ms_tree = timed_solves(ranks, tree_eng, x0, 5)
     eng = nlsolver_amd.lm.LMEngine("rosenbrock", batch=batch, n=n, lam=10.0, max_iter=iters,
-                                   f_delta=0.0, device=ranks.local_rank)
+                                   f_delta=0.0, device=ranks.local_rank, solver=LM_CHOLESKY_REFERENCE_ORDER)
     x, st, lam = eng.minimize(x0.copy())
     ms = timed_solves(ranks, eng, x0, 5)
     fcalls = sum(s.function_calls_used for s in st)
@@ -632,14 +640,16 @@ def main_lm_fd(args):
             "steps": iters, "warmup": iters, "ms_per_step": ms / iters, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"Levenberg-Marquardt, default fin_diff / fin_diff_h functors, "
-                                   f"Rosenbrock-{n}D, batch={batch} independent starts per GPU",
+                                   f"Rosenbrock-{n}D, batch={batch} independent starts per GPU, reference order",
                        "objective_calls_per_s": ranks.world * fcalls / (ms * 1e-3),
+                       "tree_order": {"value": ranks.world * batch * iters / (ms_tree * 1e-3),
+                                      "ms_per_step": ms_tree / iters},
                        "finite_final_f": int(np.sum(np.isfinite([s.f_value for s in st]))),
                        "parallelism": ranks.replicas()},
             "roofline": {"bound": "valu", "achieved": None, "peak": None, "unit": None,
                          "frac": None, "traffic": None, "kernel": "lm_fd_iter_kernel",
                          "kernel_ms": ms / (iters + 1),
-                         "note": "fp64 VALU issue bound (objective probes, 8 per wave pass); "
+                         "note": "fp64 VALU issue bound (the probes' chains, a lane each); "
                                  "not roofline-graded"},
             **({} if (args.no_cpu_baseline or ranks.world > 1) else {"cpu_baseline": ref_baseline(
                 ["bench-lm-fd", n, 16384, iters], "iterations_per_s", "iteration-problems/s",

@@ -408,12 +408,15 @@ inline uint64_t seed_from(RNG &generator) {
 //              decisions on the reference's runs, values within 1e-8 .. 1e-6 (fin_diff) or
 //              rounding (analytic gradient).
 //   automatic  (default) reference order wherever it costs nothing or the call is the reference's
-//              own: BFGS with the default gradient ALWAYS (its reference-order kernels evaluate a
-//              probe per lane and are the faster ones: Rosenbrock-128D x 4096 starts, 8.8 ms against
-//              32.7 ms for 20 iterations); minimize() — one start — of BFGS with a gradient functor
-//              and of LevenbergMarquardt; minimize_batch(), this header's extension, of those two in
-//              tree order (1.5 x and 1.8 x faster on large batches). Never for Rastrigin (its device
-//              cosine is not libm's), Custom or TanhRegression: no reference arithmetic exists there.
+//              own: BFGS with the default gradient and LevenbergMarquardt with its default functors
+//              up to 64 parameters ALWAYS (their reference-order kernels evaluate a probe per lane on
+//              the base point's shared terms and are the faster ones: BFGS on Rosenbrock-128D x 4096
+//              starts 8.8 ms against 32.7 ms for 20 iterations, LM on Rosenbrock-16D x 4096 5.6
+//              against 7.0 ms for 10); minimize() — one start — of BFGS with a gradient functor and
+//              of LevenbergMarquardt past 64 parameters; minimize_batch(), this header's extension,
+//              of those two in tree order (1.5 x and 7 x faster there). Never for Rastrigin (its
+//              device cosine is not libm's), whole-vector Custom bodies or TanhRegression: no
+//              reference arithmetic exists there.
 // Set once before the solves it should govern: `nlsolver::device::summation() = ...`, or the
 // environment variable NLSG_SUMMATION = reference | tree | automatic (read at first use).
 enum class sum_order { automatic, tree, reference };
@@ -1846,7 +1849,8 @@ class LevenbergMarquardt {
     return solver_status<scalar_t>(0, 0, 0);
   }
   // Extension (BASELINE config 4): one start per problem of the model, all solved by one launch.
-  // Summation order of the default-functor model: device::summation() (tree unless set to reference).
+  // Summation order of the default-functor model: device::summation() (automatic: reference order
+  // up to 64 parameters, tree order past that).
   std::vector<solver_status<scalar_t>> minimize_batch(std::vector<std::vector<scalar_t>> &thetas) {
     return solve_device(thetas, false);
   }
@@ -1872,9 +1876,6 @@ class LevenbergMarquardt {
     nlsg_lm_config cfg{};
     cfg.struct_size = sizeof(cfg);
     if (const char *d = std::getenv("NLSG_DEVICE")) cfg.device = std::atoi(d);
-    cfg.solver = has_reference_order() && device::reference_order_for(single_start)
-                     ? NLSG_LM_CHOLESKY_REFERENCE_ORDER
-                     : NLSG_LM_CHOLESKY;
     cfg.batch = B;
     size_t n = 0;
     if constexpr (device::has_nlls_objective<Callable>::value) {
@@ -1887,6 +1888,10 @@ class LevenbergMarquardt {
       n = B ? thetas[0].size() : 0;
     }
     cfg.n = n;
+    // (up to 64 parameters the reference-order evaluation — a probe per lane — is the faster one)
+    cfg.solver = has_reference_order() && device::reference_order_for(single_start || n <= 64)
+                     ? NLSG_LM_CHOLESKY_REFERENCE_ORDER
+                     : NLSG_LM_CHOLESKY;
     cfg.lambda = lambda;
     cfg.up = upward_mult;
     cfg.down = downward_mult;

@@ -172,8 +172,12 @@ def test_one_start_defaults_to_reference_order_a_batch_to_tree(mod, oracle, gold
     x = start(g)
     st = mod.lm.LevenbergMarquardt("rosenbrock", *args).minimize(x)
     assert st.f_value == hx(g["f"]) and x.tolist() == [hx(v) for v in g["x"]]
-    xb = start(g).reshape(1, -1)
+    xb = start(g).reshape(1, -1)  # (n <= 64: a batch solves in reference order too)
     stb = mod.lm.LevenbergMarquardt("rosenbrock", *args).minimize(xb)
+    assert stb[0].f_value == st.f_value and np.array_equal(xb[0], x)
+    from nlsolver_amd._capi import LM_CHOLESKY
+    xb = start(g).reshape(1, -1)
+    stb = mod.lm.LevenbergMarquardt("rosenbrock", *args, solver=LM_CHOLESKY).minimize(xb)
     tree, xt, _, _ = O.lm_fd(oracle, "rosenbrock", start(g), lam=hx(g["lambda"]), max_iter=g["max_iter"],
                              f_delta=hx(g["f_delta"]), order=1)
     assert stb[0].f_value == tree.f_value != st.f_value and np.array_equal(xb[0], xt)
