@@ -97,12 +97,8 @@ void launch_fd_iter(nlsg_lm *e, int first) {
 // n > 64: evaluation (f, g, H at the current point) as one launch, a workgroup per problem
 template <int OBJ>
 void launch_wide_fd_ref(nlsg_lm *e, dim3 grid, int first) {  // NLSG_LM_CHOLESKY_REFERENCE_ORDER past 64 parameters
-  switch (lm_wide_chunks(e->p.n)) {
-    case 1: hipLaunchKernelGGL((lm_wide_fd_eval_kernel<OBJ, 1, true>), grid, dim3(lm_wide_fd_threads(1)), 0, e->stream, e->p, first); break;
-    case 2: hipLaunchKernelGGL((lm_wide_fd_eval_kernel<OBJ, 2, true>), grid, dim3(lm_wide_fd_threads(2)), 0, e->stream, e->p, first); break;
-    case 4: hipLaunchKernelGGL((lm_wide_fd_eval_kernel<OBJ, 4, true>), grid, dim3(lm_wide_fd_threads(4)), 0, e->stream, e->p, first); break;
-    default: hipLaunchKernelGGL((lm_wide_fd_eval_kernel<OBJ, 8, true>), grid, dim3(lm_wide_fd_threads(8)), 0, e->stream, e->p, first); break;
-  }
+  hipLaunchKernelGGL((lm_wide_fd_lanes_kernel<OBJ>), grid, dim3(256),
+                     static_cast<unsigned>(lm_wide_fd_lanes_lds_bytes(e->p.n)), e->stream, e->p, first);
 }
 template <int OBJ>
 void launch_wide_fd(nlsg_lm *e, dim3 grid, int first) {

@@ -1598,7 +1598,7 @@ __host__ __device__ constexpr int lm_wide_chunks(uint64_t n) { return n <= 128 ?
 __host__ __device__ constexpr int lm_wide_fd_threads(int chunks) {
   return chunks >= 8 ? 512 : 1024;  // the 1024-coordinate point needs more than 128 registers
 }
-template <int OBJ, int CHUNKS, bool REF = false>  // REF: every probe sums its objective in index order
+template <int OBJ, int CHUNKS>  // (reference order: lm_wide_fd_lanes_kernel below)
 __global__ __launch_bounds__(lm_wide_fd_threads(CHUNKS)) void lm_wide_fd_eval_kernel(LmParams p, int first) {
   const uint64_t pid = blockIdx.x;
   LmProblem *pr = p.prob + pid;
@@ -1624,7 +1624,6 @@ __global__ __launch_bounds__(lm_wide_fd_threads(CHUNKS)) void lm_wide_fd_eval_ke
         const uint64_t e = static_cast<uint64_t>(c) * 128 + 2 * static_cast<uint64_t>(lane) + k;
         xp[c][k] = e == j ? vj : e == i ? vi : xv[c][k];
       }
-    if constexpr (REF) return wave_objective_seq<OBJ, CHUNKS>(xp, n);
     return wave_objective<OBJ, CHUNKS>(xp, n);
   };
   {  // fin_diff<1> (:1385-1413)
@@ -1681,9 +1680,210 @@ __global__ __launch_bounds__(lm_wide_fd_threads(CHUNKS)) void lm_wide_fd_eval_ke
     if (lane == 0) H[en] = result / denom;
   }
   if (w == 0) {
-    const double fx = REF ? wave_objective_seq<OBJ, CHUNKS>(xv, n) : wave_objective<OBJ, CHUNKS>(xv, n);
+    const double fx = wave_objective<OBJ, CHUNKS>(xv, n);
     if (lane == 0) lm_publish_state(p, pr, first, fx);
   }
+}
+
+// The default functors for n > 64 in REFERENCE ORDER: lm_fd_eval_lanes' probe per lane, a workgroup
+// (or gridDim.y of them) per problem. The block keeps the point, the base terms t_e and their prefix
+// sums S_e in LDS (one serial chain, by wave 0); the waves deal out units of work:
+//   gradient   64 coordinates, lane = coordinate: start S_{d-off}, modified terms, tail;
+//   Hessian    row i x 64 columns, lane = entry (i, j): sixteen probes as two batches of eight
+//              chains that start from S just before the first term i or the unit's columns can
+//              touch, walk the base terms at a uniform address and substitute the lane's up to four
+//              modified terms where they fall — only inside the two short zones around i and around
+//              the unit's columns does a step cost selects, elsewhere it is eight additions.
+// Every probe has the bits of wave_objective_seq at its point (tests: the reference's runs at
+// n = 100 and 130, oracle order 0 up to n = 257). smem: xs[n + 2] | ts[n] | S[n].
+__host__ __device__ constexpr size_t lm_wide_fd_lanes_lds_bytes(uint64_t n) { return (3 * n + 2) * sizeof(double); }
+template <int OBJ>
+__global__ __launch_bounds__(256) void lm_wide_fd_lanes_kernel(LmParams p, int first) {
+  using O = Objective<OBJ>;
+  extern __shared__ __align__(16) double lm_wfl_smem[];
+  const uint64_t pid = blockIdx.x;
+  LmProblem *pr = p.prob + pid;
+  if (!first && pr->done) return;
+  const int n = static_cast<int>(p.n), nt = static_cast<int>(O::n_terms(p.n));
+  const int t = threadIdx.x, lane = lane_id();
+  const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int W = 4 * static_cast<int>(gridDim.y), w = wid + 4 * static_cast<int>(blockIdx.y);
+  double *xs = lm_wfl_smem, *ts = xs + n + 2, *S = ts + n;
+  const double *th = p.theta + pid * p.n;
+  for (int i = t; i < n + 2; i += 256) xs[i] = i < n ? th[i] : 0.0;
+  __syncthreads();
+  for (int e = t; e < nt; e += 256) ts[e] = O::term(xs[e], xs[e + 1]);
+  __syncthreads();
+  if (wid == 0) {
+    double run = 0.0;
+#pragma unroll 4
+    for (int e = 0; e < nt; e++) {
+      run = run + ts[e];
+      if (lane == 0) S[e] = run;
+    }
+  }
+  __syncthreads();
+  constexpr int off = O::kChain ? 2 : 1, back = O::kChain ? 1 : 0;
+  const int nb = (n + 63) >> 6;
+  // fin_diff<1> (:1385-1413)
+  for (int db = w; db < nb; db += W) {
+    constexpr double eps = 2.220446049250313e-16 * 10e7;
+    constexpr double coeff[4] = {1, -8, 8, -1}, coeff2[4] = {-2, -1, 1, 2};
+    constexpr double dd_val = 12 * eps;
+    const int d0 = 64 * db, d = d0 + lane, dc = d < n ? d : n - 1;
+    const double xd = xs[dc], xm = xs[dc > 0 ? dc - 1 : 0], xp = xs[dc + 1];
+    const double a = dc - off >= 0 ? S[dc - off] : 0.0;
+    double acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const double xq = xd + coeff2[q] * eps;
+      acc[q] = a;
+      if constexpr (O::kChain) {
+        const double m0 = acc[q] + O::term(xm, xq);
+        acc[q] = d >= 1 ? m0 : acc[q];
+        const double m1 = acc[q] + O::term(xq, xp);
+        acc[q] = d < nt ? m1 : acc[q];
+      } else {
+        acc[q] = acc[q] + O::term(xq, 0.0);
+      }
+    }
+    int e = d0 + 1;
+    const int e_win = d0 + 64 < nt ? d0 + 64 : nt;
+    for (; e < e_win; e++) {
+      const double te = ts[e];
+      if (e > d) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[q] = acc[q] + te;
+      }
+    }
+#pragma unroll 4
+    for (; e < nt; e++) {
+      const double te = ts[e];
+#pragma unroll
+      for (int q = 0; q < 4; q++) acc[q] = acc[q] + te;
+    }
+    double ga = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) ga = ga + coeff[q] * O::finish(acc[q], p.n);
+    if (d < n) p.gg[pid * p.n + d] = ga / dd_val;
+  }
+  // fin_diff_h<1> (:1446-1515)
+  const double e1 = p.eps_h, e2 = 2 * e1, e3 = 3 * e1, e4 = 4 * e1;
+  const double denom = (600.0 * e1 * e1);
+  double *H = p.Hw + pid * p.n * p.n;
+  for (int u = w; u < n * nb; u += W) {
+    const int i = u / nb, j0 = 64 * (u - i * nb), j = j0 + lane, jc = j < n ? j : n - 1;
+    const double xi0 = xs[i], xim = xs[i > 0 ? i - 1 : 0], xip = xs[i + 1];
+    const double xj0 = xs[jc], xjm = xs[jc > 0 ? jc - 1 : 0], xjp = xs[jc + 1];
+    const bool same = i == j;
+    const int lo = i < j0 ? i : j0;
+    const int e_first = lo - back > 0 ? lo - back : 0;   // the first term a moved coordinate can touch
+    const double base = e_first >= 1 ? S[e_first - 1] : 0.0;
+    const int jz_lo = j0 - back, jz_hi = j0 + 63;         // the zone of the unit's own columns
+    double fv[16];
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      double ci[8], cj[8];
+      {
+        double xi = xi0, xj = xj0;
+        auto add_i = [&](double d) { xi = xi + d; xj = same ? xi : xj; };
+        auto sub_i = [&](double d) { xi = xi - d; xj = same ? xi : xj; };
+        auto add_j = [&](double d) { xj = xj + d; xi = same ? xj : xi; };
+        auto sub_j = [&](double d) { xj = xj - d; xi = same ? xj : xi; };
+        auto at = [&](auto k) {
+          constexpr int K = decltype(k)::value;
+          if constexpr (K / 8 == 0) { if (half == 0) { ci[K % 8] = xi; cj[K % 8] = xj; } }
+          else { if (half == 1) { ci[K % 8] = xi; cj[K % 8] = xj; } }
+        };
+        add_i(e1); sub_j(e2); at(int_c<0>{});
+        add_i(e1); add_j(e1); at(int_c<1>{});
+        sub_i(e4); add_j(e2); at(int_c<2>{});
+        add_i(e1); add_j(e1); at(int_c<3>{});
+        sub_j(e4); at(int_c<4>{});
+        sub_i(e1); add_j(e1); at(int_c<5>{});
+        add_i(e3); add_j(e3); at(int_c<6>{});
+        add_i(e1); sub_j(e1); at(int_c<7>{});
+        sub_j(e3); at(int_c<8>{});
+        sub_i(e4); add_j(e4); at(int_c<9>{});
+        sub_j(e4); at(int_c<10>{});
+        add_i(e4); add_j(e4); at(int_c<11>{});
+        sub_i(e3); sub_j(e3); at(int_c<12>{});
+        add_i(e2); add_j(e2); at(int_c<13>{});
+        sub_j(e2); at(int_c<14>{});
+        sub_i(e2); add_j(e2); at(int_c<15>{});
+      }
+      double A[8], B[8], C[8], D[8];  // terms i-1, i, j-1, j (x_j -> cj takes precedence over x_i -> ci)
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const double vi = same ? cj[k] : ci[k];
+        if constexpr (O::kChain) {
+          const double vim = i - 1 == j ? cj[k] : xim;
+          const double vip = i + 1 == j ? cj[k] : xip;
+          const double vjm = j - 1 == i ? ci[k] : xjm;
+          const double vjp = j + 1 == i ? ci[k] : xjp;
+          A[k] = O::term(vim, vi);
+          B[k] = O::term(vi, vip);
+          C[k] = O::term(vjm, cj[k]);
+          D[k] = O::term(cj[k], vjp);
+        } else {
+          A[k] = C[k] = 0.0;
+          B[k] = O::term(vi, 0.0);
+          D[k] = O::term(cj[k], 0.0);
+        }
+      }
+      double acc[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) acc[k] = base;
+      for (int e = e_first; e < nt; e++) {
+        const double te = ts[e];
+        const bool zi = e == i || (O::kChain && e == i - 1), zj = e >= jz_lo && e <= jz_hi;  // wave-uniform
+        if (!zi && !zj) {
+#pragma unroll
+          for (int k = 0; k < 8; k++) acc[k] = acc[k] + te;
+        } else {
+          const bool at_j = e == j, at_jm = O::kChain && e == j - 1;
+          if (O::kChain && e == i - 1) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) acc[k] = acc[k] + (at_j ? D[k] : at_jm ? C[k] : A[k]);
+          } else if (e == i) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) acc[k] = acc[k] + (at_j ? D[k] : at_jm ? C[k] : B[k]);
+          } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) acc[k] = acc[k] + (at_j ? D[k] : at_jm ? C[k] : te);
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; k++) fv[8 * half + k] = O::finish(acc[k], p.n);
+    }
+    double result = 0.0, temp = 0.0;
+    temp = temp + fv[0];
+    temp = temp + fv[1];
+    temp = temp + fv[2];
+    temp = temp + fv[3];
+    result = result - 63 * temp;
+    temp = 0.0;
+    temp = temp + fv[4];
+    temp = temp + fv[5];
+    temp = temp + fv[6];
+    temp = temp + fv[7];
+    result = result + 63 * temp;
+    temp = 0.0;
+    temp = temp + fv[8];
+    temp = temp + fv[9];
+    temp = temp - fv[10];
+    temp = temp - fv[11];
+    result = result + 44 * temp;
+    temp = 0.0;
+    temp = temp + fv[12];
+    temp = temp + fv[13];
+    temp = temp - fv[14];
+    temp = temp - fv[15];
+    result = result + 74 * temp;
+    if (j < n) H[static_cast<uint64_t>(i) * p.n + j] = result / denom;
+  }
+  if (w == 0 && t == 0) lm_publish_state(p, pr, first, O::finish(nt > 0 ? S[nt - 1] : 0.0, p.n));
 }
 
 // Gauss-Newton functors of the tanh regression for n > 64: f = sum r^2, g = 2 J^T r, H = 2 J^T J
