@@ -409,14 +409,13 @@ inline uint64_t seed_from(RNG &generator) {
 //              rounding (analytic gradient).
 //   automatic  (default) reference order wherever it costs nothing or the call is the reference's
 //              own: BFGS with the default gradient and LevenbergMarquardt with its default functors
-//              up to 64 parameters ALWAYS (their reference-order kernels evaluate a probe per lane on
-//              the base point's shared terms and are the faster ones: BFGS on Rosenbrock-128D x 4096
-//              starts 8.8 ms against 32.7 ms for 20 iterations, LM on Rosenbrock-16D x 4096 5.6
-//              against 7.0 ms for 10); minimize() — one start — of BFGS with a gradient functor and
-//              of LevenbergMarquardt past 64 parameters; minimize_batch(), this header's extension,
-//              of those two in tree order (1.5 x and 7 x faster there). Never for Rastrigin (its
-//              device cosine is not libm's), whole-vector Custom bodies or TanhRegression: no
-//              reference arithmetic exists there.
+//              ALWAYS (their reference-order kernels evaluate a probe per lane on the base point's
+//              shared terms and prefix sums and are the faster ones: BFGS on Rosenbrock-128D x 4096
+//              starts 8.8 ms against 32.7 ms for 20 iterations, LM on Rosenbrock-16D x 4096 5.3
+//              against 6.9 ms for 10); BFGS with a gradient functor in minimize() — one start — only:
+//              its minimize_batch(), this header's extension, solves in tree order (1.5 x faster on
+//              large batches). Never for Rastrigin (its device cosine is not libm's), whole-vector
+//              Custom bodies or TanhRegression: no reference arithmetic exists there.
 // Set once before the solves it should govern: `nlsolver::device::summation() = ...`, or the
 // environment variable NLSG_SUMMATION = reference | tree | automatic (read at first use).
 enum class sum_order { automatic, tree, reference };
@@ -1849,8 +1848,7 @@ class LevenbergMarquardt {
     return solver_status<scalar_t>(0, 0, 0);
   }
   // Extension (BASELINE config 4): one start per problem of the model, all solved by one launch.
-  // Summation order of the default-functor model: device::summation() (automatic: reference order
-  // up to 64 parameters, tree order past that).
+  // Summation order of the default-functor model: device::summation() (automatic: reference order).
   std::vector<solver_status<scalar_t>> minimize_batch(std::vector<std::vector<scalar_t>> &thetas) {
     return solve_device(thetas, false);
   }
@@ -1888,8 +1886,9 @@ class LevenbergMarquardt {
       n = B ? thetas[0].size() : 0;
     }
     cfg.n = n;
-    // (up to 64 parameters the reference-order evaluation — a probe per lane — is the faster one)
-    cfg.solver = has_reference_order() && device::reference_order_for(single_start || n <= 64)
+    // (the reference-order evaluation — a probe per lane — is the faster one: batches too)
+    (void)single_start;
+    cfg.solver = has_reference_order() && device::reference_order_for(true)
                      ? NLSG_LM_CHOLESKY_REFERENCE_ORDER
                      : NLSG_LM_CHOLESKY;
     cfg.lambda = lambda;

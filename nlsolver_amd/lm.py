@@ -126,9 +126,8 @@ class LevenbergMarquardt:
     """Drop-in for nlsolver::LevenbergMarquardt on a device NLLS model or a built-in objective
     (by name); x: (n,) or (batch, n). solver=None (automatic, as include/nlsolver_mi/nlsolver.h's
     device::summation()): the default-functor model on Rosenbrock / Sphere / Styblinski-Tang solves
-    in reference order (LM_CHOLESKY_REFERENCE_ORDER: the reference's run bit for bit) — always up to 64
-    parameters, where a probe per lane makes it the faster evaluation, and for one start past that;
-    everything else with LM_CHOLESKY."""
+    in reference order (LM_CHOLESKY_REFERENCE_ORDER: the reference's run bit for bit, and — a probe
+    per lane — the faster evaluation); everything else with LM_CHOLESKY."""
 
     def __init__(self, f, lam=10.0, upward_mult=10.0, downward_mult=10.0, max_iter=100,
                  f_delta=1e-12, g=None, h=None, *, solver=None, device=0):
@@ -147,7 +146,7 @@ class LevenbergMarquardt:
         args = dict(self.args)
         if args["solver"] is None:
             has_it = isinstance(self.f, str) and self.f in ("rosenbrock", "sphere", "styblinski_tang")
-            ref = has_it and (x.ndim == 1 or xb.shape[1] <= 64)
+            ref = has_it
             args["solver"] = _capi.LM_CHOLESKY_REFERENCE_ORDER if ref else _capi.LM_CHOLESKY
         with LMEngine(self.f, **args, **shape) as eng:
             out, st, lam = eng.minimize(xb)

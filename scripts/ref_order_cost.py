@@ -70,3 +70,10 @@ for nn, iters in ((16, 6), (100, 2)):
         dt, out = timed(lambda: nlsolver_amd.lm.LMEngine("rosenbrock", batch=1, n=nn, lam=10.0, max_iter=iters,
                                                          f_delta=0.0, solver=solver), x1, reps=5)
         print(f"  lm-fd rosenbrock-{nn}, {iters} iterations, {name} order: {dt * 1e3:.2f} ms")
+
+# past 64 parameters, a batch
+xw = 0.95 + 0.1 * (rng.random((256, 128)) - 0.5)
+for solver, name in ((_capi.LM_CHOLESKY, "tree"), (_capi.LM_CHOLESKY_REFERENCE_ORDER, "reference")):
+    dt, out = timed(lambda: nlsolver_amd.lm.LMEngine("rosenbrock", batch=256, n=128, lam=10.0, max_iter=2,
+                                                     f_delta=0.0, solver=solver), xw)
+    print(f"lm-fd rosenbrock-128 x 256, 2 iterations, {name} order: {dt * 1e3:.1f} ms")
