@@ -1886,11 +1886,17 @@ class LevenbergMarquardt {
       n = B ? thetas[0].size() : 0;
     }
     cfg.n = n;
-    // (the reference-order evaluation — a probe per lane — is the faster one: batches too)
+    // (the reference-order evaluation — a probe per lane — is the faster one: batches too, and a
+    // Custom objective given by its terms, where index order is what the body's own loop would do)
     (void)single_start;
-    cfg.solver = has_reference_order() && device::reference_order_for(true)
-                     ? NLSG_LM_CHOLESKY_REFERENCE_ORDER
-                     : NLSG_LM_CHOLESKY;
+    bool ref = false;
+    if constexpr (device_fd()) {
+      if constexpr (Callable::nlsg_objective == NLSG_OBJ_CUSTOM)
+        ref = f.chain != NLSG_CUSTOM_VECTOR && device::reference_order_for(true);
+      else
+        ref = has_reference_order() && device::reference_order_for(true);
+    }
+    cfg.solver = ref ? NLSG_LM_CHOLESKY_REFERENCE_ORDER : NLSG_LM_CHOLESKY;
     cfg.lambda = lambda;
     cfg.up = upward_mult;
     cfg.down = downward_mult;

@@ -144,8 +144,12 @@ void launch_wide_eval(nlsg_lm *e, int first) {
   }
   if (e->cfg.objective == NLSG_OBJ_CUSTOM) {
     void *args[] = {&e->p, &first};
-    launch_module_kernel(e->rtc.iter, grid.x, lm_wide_fd_threads(lm_wide_chunks(e->p.n)), 0, e->stream,
-                         args, grid.y);
+    if (e->cfg.solver == NLSG_LM_CHOLESKY_REFERENCE_ORDER)
+      launch_module_kernel(e->rtc.iter, grid.x, 256, static_cast<unsigned>(lm_wide_fd_lanes_lds_bytes(e->p.n)),
+                           e->stream, args, grid.y);
+    else
+      launch_module_kernel(e->rtc.iter, grid.x, lm_wide_fd_threads(lm_wide_chunks(e->p.n)), 0, e->stream,
+                           args, grid.y);
     return;
   }
   switch (e->cfg.objective) {
@@ -246,10 +250,12 @@ static int lm_create(const nlsg_lm_config *cfg, const nlsg_custom_objective *cus
   if (fd && cfg->solver == NLSG_LM_QR)
     return fail(NLSG_ERR_UNSUPPORTED,
                 "the finite-difference model runs the reference's own solve (Cholesky) only");
-  if (ref_order && (!fd || cfg->objective == NLSG_OBJ_RASTRIGIN || cfg->objective == NLSG_OBJ_CUSTOM))
+  if (ref_order && (!fd || cfg->objective == NLSG_OBJ_RASTRIGIN ||
+                    (custom && custom->chain == NLSG_CUSTOM_VECTOR)))
     return fail(NLSG_ERR_UNSUPPORTED,
-                "NLSG_LM_CHOLESKY_REFERENCE_ORDER (a parity mode) covers the default functors on "
-                "Rosenbrock / Sphere / Styblinski-Tang");
+                "NLSG_LM_CHOLESKY_REFERENCE_ORDER covers the default functors on objectives given by "
+                "their terms (Rosenbrock / Sphere / Styblinski-Tang, custom term bodies): Rastrigin's "
+                "cosine is the device's own, a whole-vector body's x.sum() adds in the lane-tree order");
   if (cfg->n < 1 || (!fd && cfg->m < 1) || cfg->batch < 1)
     return fail(NLSG_ERR_INVALID_ARG, "need n >= 1, m >= 1, batch >= 1");
   const bool wide = cfg->n > kLmN;
@@ -338,8 +344,7 @@ static int lm_create(const nlsg_lm_config *cfg, const nlsg_custom_objective *cus
   }
   if (custom) {
     const uint64_t n = cfg->n;
-    const int rc2 = rtc_build_lm(custom, !wide ? 0 : lm_wide_chunks(n),
-                                 &e->rtc);
+    const int rc2 = rtc_build_lm(custom, !wide ? 0 : lm_wide_chunks(n), ref_order, &e->rtc);
     if (rc2) {
       nlsg_lm_destroy(e);
       return rc2;

@@ -40,7 +40,7 @@ struct LmRtcKernels {  // finite-difference model (default functors) around the 
 };
 // wide_chunks != 0: the evaluation kernel of the n > 64 path (a probe point of wide_chunks x 128
 // coordinates per wave) instead of the one-wave iteration kernel
-int rtc_build_lm(const nlsg_custom_objective *obj, int wide_chunks, LmRtcKernels *out);
+int rtc_build_lm(const nlsg_custom_objective *obj, int wide_chunks, bool reference_order, LmRtcKernels *out);
 void rtc_release(LmRtcKernels *k);
 struct HybRtcKernels {
   hipModule_t mod = nullptr;

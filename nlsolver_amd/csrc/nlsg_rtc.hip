@@ -324,13 +324,14 @@ void rtc_release(SannRtcKernels *k) {
   if (k) *k = SannRtcKernels();
 }
 
-int rtc_build_lm(const nlsg_custom_objective *obj, int wide_chunks, LmRtcKernels *out) {
+int rtc_build_lm(const nlsg_custom_objective *obj, int wide_chunks, bool reference_order, LmRtcKernels *out) {
   std::vector<hipFunction_t> f;
   LmRtcKernels k;
   const std::string id = std::to_string(static_cast<int>(NLSG_OBJ_CUSTOM));
-  const std::string name = wide_chunks ? "nlsg::lm_wide_fd_eval_kernel<" + id + ", " +
-                                             std::to_string(wide_chunks) + ">"
-                                       : "nlsg::lm_fd_iter_kernel<" + id + ">";
+  const std::string name =
+      wide_chunks ? (reference_order ? "nlsg::lm_wide_fd_lanes_kernel<" + id + ">"
+                                     : "nlsg::lm_wide_fd_eval_kernel<" + id + ", " + std::to_string(wide_chunks) + ">")
+                  : "nlsg::lm_fd_iter_kernel<" + id + (reference_order ? ", true>" : ">");
   const int rc = rtc_compile(obj, "nlsg_lm_kernels.h", {name}, &k.mod, &f);
   if (rc) return rc;
   k.iter = f[0];

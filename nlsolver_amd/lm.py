@@ -145,7 +145,9 @@ class LevenbergMarquardt:
         shape = {} if hasattr(self.f, "A") else dict(batch=xb.shape[0], n=xb.shape[1])
         args = dict(self.args)
         if args["solver"] is None:
-            has_it = isinstance(self.f, str) and self.f in ("rosenbrock", "sphere", "styblinski_tang")
+            from .de import CustomObjective
+            has_it = (isinstance(self.f, str) and self.f in ("rosenbrock", "sphere", "styblinski_tang")) or \
+                (isinstance(self.f, CustomObjective) and self.f.chain != 2)  # (given by its terms)
             ref = has_it
             args["solver"] = _capi.LM_CHOLESKY_REFERENCE_ORDER if ref else _capi.LM_CHOLESKY
         with LMEngine(self.f, **args, **shape) as eng:

@@ -432,6 +432,24 @@ def test_lm_minimize_through_header_is_the_reference_run(built, golden, name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["rosenbrock_n2_example_start", "rosenbrock_n4_near_minimum",
+                                  "rosenbrock_n16_6iters", "rosenbrock_n100_2iters"])
+def test_lm_custom_terms_through_header_run_in_index_order(built, golden, name):
+    """The Rosenbrock chain as source text through LevenbergMarquardt's default functors: summed in index
+    order by default, hence the reference's run bit for bit (one wave per problem, and past 64 parameters)."""
+    g = golden("lm_fd.json")[name]
+    env = {k: v for k, v in os.environ.items() if k != "NLSG_SUMMATION"}
+    o = json.loads(subprocess.check_output(
+        [os.path.join(built, "header_nm_lm"), "lm-device-fd-custom", str(g["n"]), repr(hx(g["lambda"])),
+         str(g["max_iter"]), repr(hx(g["f_delta"])), repr(hx(g["x0"])), repr(hx(g["x0_step"]))],
+        env=dict(env, NLSG_LIBRARY=LIB), text=True))
+    assert "device_error" not in o, o
+    assert (o["iters"], o["fcalls"], o["gcalls"], o["hcalls"]) == \
+        (g["iters"], g["fcalls"], g["gcalls"], g["hcalls"])
+    assert o["f"] == g["f"] and o["x"] == g["x"]
+
+
+@pytest.mark.gpu
 def test_lm_summation_switch_through_header(built, oracle, golden):
     g = golden("lm_fd.json")["rosenbrock_n16_6iters"]
     cmd = [os.path.join(built, "header_nm_lm"), "lm-device-fd", str(g["n"]), repr(hx(g["lambda"])),

@@ -136,9 +136,12 @@ def test_lm_reference_order_limits(mod):
         mod.lm.LMEngine("rosenbrock", batch=1, n=1100, solver=LM_CHOLESKY_REFERENCE_ORDER)
     with pytest.raises(NlsgError):
         mod.lm.LMEngine("rastrigin", batch=1, n=4, solver=LM_CHOLESKY_REFERENCE_ORDER)
+    with pytest.raises(NlsgError):  # a whole-vector body's x.sum() adds in the lane-tree order
+        mod.lm.LMEngine(mod.CustomObjective("return x(0) * x(0) + x(1) * x(1);", vector=True), batch=1, n=2,
+                        solver=LM_CHOLESKY_REFERENCE_ORDER)
 
 
-def test_one_start_defaults_to_reference_order_a_batch_to_tree(mod, oracle, golden):
+def test_drop_in_classes_default_to_reference_order(mod, oracle, golden):
     """The drop-in classes' automatic rule (include/nlsolver_mi/nlsolver.h device::summation()): a 1-D x
     — the reference's own call — returns the reference's run bit for bit; a (batch, n) array is solved by
     the tree-order throughput kernels."""
