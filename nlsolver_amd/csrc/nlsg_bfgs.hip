@@ -209,11 +209,12 @@ static int bfgs_create(const nlsg_bfgs_config *cfg, const double *diag_host, con
   }
   BfgsParams &p = e->p;
   std::memset(&p, 0, sizeof p);
+  p.ldh = seq && (n * sizeof(double)) % 4096 == 0 ? n + 16 : n;  // (BfgsParams::ldh)
   auto alloc = [&](void **ptr, size_t bytes) { return pool_malloc(ptr, bytes ? bytes : 8); };
   hipError_t he = hipSuccess;
   const size_t vec_bytes = B * n * sizeof(double);
   if (he == hipSuccess && !e->symmetric)
-    he = alloc(reinterpret_cast<void **>(&p.H), B * n * n * sizeof(double));
+    he = alloc(reinterpret_cast<void **>(&p.H), B * n * p.ldh * sizeof(double));
   if (he == hipSuccess && e->symmetric)
     he = alloc(reinterpret_cast<void **>(&p.Hs), B * nstored * kBfgsSymB * kBfgsSymB * sizeof(double));
   if (he == hipSuccess && e->symmetric)
@@ -390,7 +391,8 @@ int nlsg_bfgs_download_state(nlsg_bfgs *e, double *g_host, double *h_host) {
   const uint64_t B = e->p.batch, n = e->p.n;
   if (g_host) NLSG_HIP(hipMemcpy(g_host, e->p.g, B * n * sizeof(double), hipMemcpyDeviceToHost));
   if (h_host && !e->symmetric)
-    NLSG_HIP(hipMemcpy(h_host, e->p.H, B * n * n * sizeof(double), hipMemcpyDeviceToHost));
+    NLSG_HIP(hipMemcpy2D(h_host, n * sizeof(double), e->p.H, e->p.ldh * sizeof(double), n * sizeof(double),
+                         B * n, hipMemcpyDeviceToHost));
   if (h_host && e->symmetric) {  // the full matrix from its upper blocks
     const uint64_t tile = kBfgsSymB * kBfgsSymB;
     std::vector<double> blk(e->p.nstored * tile);

@@ -29,7 +29,10 @@ struct BfgsProblem {  // per-problem scalars
 };
 
 struct BfgsParams {
-  double *H;                  // [batch][n][n]
+  double *H;                  // [batch][n][ldh]
+  uint64_t ldh;               // doubles per row of H: n — or, reference order with a row of a multiple of 4 KiB,
+                              // n + 16: the lane-per-row passes touch 64 rows at one column offset, which
+                              // at such a stride is ONE memory channel (0.65 of the rate at n = 1008, measured)
   double *x, *g, *dir, *s, *y, *t;  // [batch][n]
   BfgsProblem *prob;          // [batch]
   const double *qd, *qb;      // objective parameters d, b [n]
@@ -871,8 +874,8 @@ __host__ __device__ constexpr uint32_t bfgs_seq_blocks_per_problem(uint64_t n) {
 // the tile of rows row0 .. row0+63, columns c0 .. c0+TC-1 as the wave loads it: instruction q, lane l
 // -> row (128 / TC) q + l / (TC / 2), columns 2 (l % (TC / 2)), +1. VEC: n is even (16-byte aligned pairs).
 template <bool VEC, int TC>
-__device__ inline void bfgs_seq_load_tile(const double *__restrict__ Hp, uint64_t n, uint64_t row0, uint64_t c0,
-                                          double2 (&v)[TC / 2]) {
+__device__ inline void bfgs_seq_load_tile(const double *__restrict__ Hp, uint64_t n, uint64_t ld, uint64_t row0,
+                                          uint64_t c0, double2 (&v)[TC / 2]) {
   constexpr int LPR = TC / 2, RPI = 64 / LPR;  // lanes per row, rows per instruction
   const int lane = lane_id();
   const uint64_t col = c0 + 2 * static_cast<uint64_t>(lane % LPR);
@@ -881,7 +884,7 @@ __device__ inline void bfgs_seq_load_tile(const double *__restrict__ Hp, uint64_
     const uint64_t row = row0 + RPI * q + (lane / LPR);
     v[q] = make_double2(0.0, 0.0);
     if (row < n && col < n) {
-      const double *src = Hp + row * n + col;
+      const double *src = Hp + row * ld + col;
       if (VEC) {
         v[q] = bfgs_stream_load(src);
       } else {
@@ -913,7 +916,8 @@ __global__ __launch_bounds__(256) void bfgs_hy_seq_kernel(BfgsParams p, uint32_t
   for (uint64_t i = threadIdx.x; i < n; i += 256) ys[i] = y[i];
   __syncthreads();
   if (row0 >= n) return;
-  const double *Hp = p.H + pid * n * n;
+  const double *Hp = p.H + pid * n * p.ldh;
+  const uint64_t ld = p.ldh;
   double acc = 0.0;
   auto consume = [&](const double2 (&v)[TC / 2], uint64_t c0) {  // the tile at columns c0 .. c0+TC-1: TC more products
 #pragma unroll
@@ -935,13 +939,13 @@ __global__ __launch_bounds__(256) void bfgs_hy_seq_kernel(BfgsParams p, uint32_t
   };
   // two tiles in flight while a third is consumed
   double2 va[TC / 2], vb[TC / 2];
-  bfgs_seq_load_tile<VEC, TC>(Hp, n, row0, 0, va);
-  bfgs_seq_load_tile<VEC, TC>(Hp, n, row0, TC, vb);
+  bfgs_seq_load_tile<VEC, TC>(Hp, n, ld, row0, 0, va);
+  bfgs_seq_load_tile<VEC, TC>(Hp, n, ld, row0, TC, vb);
   for (uint64_t c0 = 0; c0 < n; c0 += 2 * TC) {
     consume(va, c0);
-    bfgs_seq_load_tile<VEC, TC>(Hp, n, row0, c0 + 2 * TC, va);
+    bfgs_seq_load_tile<VEC, TC>(Hp, n, ld, row0, c0 + 2 * TC, va);
     if (c0 + TC < n) consume(vb, c0 + TC);
-    bfgs_seq_load_tile<VEC, TC>(Hp, n, row0, c0 + 3 * TC, vb);
+    bfgs_seq_load_tile<VEC, TC>(Hp, n, ld, row0, c0 + 3 * TC, vb);
   }
   if (row0 + lane < n) t[row0 + lane] = acc;
 }
@@ -983,7 +987,8 @@ __global__ __launch_bounds__(256) void bfgs_update_seq_kernel(BfgsParams p, uint
   if (row0 >= n) return;
   const double rho = pr->rho, denom = pr->denom;
   const bool identity = pr->identity != 0;
-  double *Hp = p.H + pid * n * n;
+  double *Hp = p.H + pid * n * p.ldh;
+  const uint64_t ld = p.ldh;
   double sj[NQ], tj[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; q++) {
@@ -1001,7 +1006,7 @@ __global__ __launch_bounds__(256) void bfgs_update_seq_kernel(BfgsParams p, uint
     T.ti0 = col < n ? tp[col] : 0.0;
     T.si1 = col + 1 < n ? sp[col + 1] : 0.0;
     T.ti1 = col + 1 < n ? tp[col + 1] : 0.0;
-    if (!identity) bfgs_seq_load_tile<VEC, TC>(Hp, n, row0, c0, T.h);
+    if (!identity) bfgs_seq_load_tile<VEC, TC>(Hp, n, ld, row0, c0, T.h);
   };
   double acc = 0.0;
   auto consume = [&](const Tile &T, uint64_t c0) {
@@ -1019,7 +1024,7 @@ __global__ __launch_bounds__(256) void bfgs_update_seq_kernel(BfgsParams p, uint
       dst[0] = w0;
       dst[1] = w1;
       if (row < n && c_in) {
-        double *out = Hp + row * n + col;
+        double *out = Hp + row * ld + col;
         if (VEC) {
           bfgs_stream_store(out, make_double2(w0, w1));
         } else {
