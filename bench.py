@@ -362,7 +362,8 @@ def main_bfgs(args):
     x0 = 1.0 + 0.5 * (rng.random((batch, n)) - 0.5)
     eng = nlsolver_amd.BFGSEngine(nlsolver_amd.QuadDiagRank1(d, b, 0.01), batch,
                                   max_iter=10**9, grad_eps=0.0, alpha=1.0, device=local_rank,
-                                  **({"symmetric": True} if args.bfgs_symmetric else {}))
+                                  **({"symmetric": True} if args.bfgs_symmetric else {}),
+                                  **({"reference_order": True} if args.bfgs_reference_order else {}))
     # The line describes ONE regime: iterations in which every problem streams a dense H. Iteration
     # 0 runs on H = I (never materialised); towards convergence the reset guard (nlsolver.h:
     # 3253-3260) re-identities H problem by problem and the passes skip their reads. An untimed
@@ -407,6 +408,27 @@ def main_bfgs(args):
                       else 3 * n * n * 8) * batch
     achieved = bytes_per_iter / (hess_ms * 1e-3) / 1e9
     within = check_kernel_within_step(hess_ms, dt / steps * 1e3, "bfgs")
+    ref_order = None
+    if not args.bfgs_symmetric and not args.bfgs_reference_order:
+        # the same iterations in REFERENCE ORDER (what the drop-in classes run: every sum in the reference's
+        # index order, its results bit for bit; H passes with a lane per row), reported beside `value`
+        eng.close()
+        eng = nlsolver_amd.BFGSEngine(nlsolver_amd.QuadDiagRank1(d, b, 0.01), batch, max_iter=10**9,
+                                      grad_eps=0.0, alpha=1.0, device=local_rank, reference_order=True)
+        eng.init(x0)
+        eng.step(warm)
+        ranks.barrier()
+        t2 = time.perf_counter()
+        eng.step(steps)
+        ranks.barrier()
+        dt_ref = ranks.max_over_ranks(time.perf_counter() - t2)
+        eng.init(x0)
+        eng.step(k0)
+        _, hess_ref = eng.time_steps(4)
+        ref_order = {"value": ranks.world * batch * steps / dt_ref, "ms_per_step": dt_ref / steps * 1e3,
+                     "kernel": "bfgs_hy_seq_kernel + bfgs_denom_seq_kernel + bfgs_update_seq_kernel",
+                     "kernel_ms": hess_ref / 4,
+                     "achieved_GBs": bytes_per_iter / (hess_ref / 4 * 1e-3) / 1e9}
     if ranks.rank == 0:
         print(json.dumps({
             "kernel_within_step": within,
@@ -418,7 +440,8 @@ def main_bfgs(args):
             "config": {"workload": f"BFGS + More-Thuente, convex quadratic dim={n}, batch={batch} "
                                    "independent starts per GPU (BASELINE configs[2]), "
                                    f"{'symmetric (upper blocks of H)' if args.bfgs_symmetric else 'literal'}"
-                                   " rank-2 update",
+                                   f" rank-2 update{', reference order' if args.bfgs_reference_order else ''}",
+                       **({"reference_order": ref_order} if ref_order else {}),
                        "timed_iterations": f"{warm} .. {warm + steps - 1} of a fresh run: every problem "
                                            "streams a dense inverse Hessian",
                        "dense_h_iterations_available": dense_upto, "dense_h_verified": dense_verified,
@@ -432,8 +455,11 @@ def main_bfgs(args):
                          "frac": achieved / HBM_PEAK_GBS,
                          **pmc_bytes("bfgs_sym" if args.bfgs_symmetric else "bfgs",
                                      ["bfgs_sym_hy_kernel", "bfgs_sym_update_kernel"] if args.bfgs_symmetric
-                                     else ["bfgs_hy_kernel", "bfgs_update_kernel"], batch == 4096),
+                                     else ["bfgs_hy_kernel", "bfgs_update_kernel"],
+                                     batch == 4096 and not args.bfgs_reference_order),
                          "kernel": ("bfgs_sym_hy_kernel + bfgs_sym_update_kernel" if args.bfgs_symmetric
+                                    else "bfgs_hy_seq_kernel + bfgs_denom_seq_kernel + bfgs_update_seq_kernel"
+                                    if args.bfgs_reference_order
                                     else "bfgs_hy_kernel + bfgs_update_kernel"), "kernel_ms": hess_ms,
                          "algorithmic_bytes_per_launch": bytes_per_iter},
             **({} if (args.no_cpu_baseline or ranks.world > 1) else {"cpu_baseline": ref_baseline(
@@ -928,7 +954,8 @@ def main_tts(args):
     ref = None if args.no_cpu_baseline else tts_reference(["tts-bfgs", 1024, sample, 100, 5e-3],
                                                           4096 / sample)
     batch.append({"solver": "BFGS<device::QuadDiagRank1>::minimize_batch (configs[2]: n 1024 x 4096 "
-                            "starts, defaults max_iter 100 grad_eps 5e-3)",
+                            "starts, defaults max_iter 100 grad_eps 5e-3; reference order, the header's "
+                            "default: the reference's results bit for bit)",
                   "cold": dev["cold"], "warm": dev["warm"], "reference_1core_ms": ref and ref["ms"],
                   "reference_sample": f"{sample} of 4096 problems, scaled",
                   "warm_speedup": ref and ref["ms"] / dev["warm"]["wall_ms"]})
@@ -1259,6 +1286,8 @@ def main():
     ap.add_argument("--bfgs-symmetric", action="store_true",
                     help="bfgs workload: the symmetric restatement of the rank-2 update (streams "
                          "the upper blocks of H only) instead of the reference's literal one")
+    ap.add_argument("--bfgs-reference-order", action="store_true",
+                    help="bfgs workload: NLSG_BFGS_REFERENCE_ORDER (every sum in the reference's index order)")
     ap.add_argument("--workload", choices=["de", "pso-accel", "pso-vanilla", "bfgs", "bfgs-fd", "lm", "lm-fd", "nm", "sann", "nmpso", "tinyqr", "tts"],
                     default="de",
                     help="de = the headline benchmark (BASELINE metric); pso-* = config 5's "

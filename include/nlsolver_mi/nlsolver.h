@@ -401,40 +401,35 @@ inline uint64_t seed_from(RNG &generator) {
 // Summation order of the device solves whose results turn on the last bit of a sum: BFGS (dots,
 // norms, H y, and with the default gradient fin_diff's differences over 12 eps) and the
 // default-functor LevenbergMarquardt (fin_diff_h's differences over 600 eps^2).
-//   reference  every sum in index order, separate multiply and add — the reference's sequential
-//              loops (NLSG_BFGS_REFERENCE_ORDER / NLSG_LM_CHOLESKY_REFERENCE_ORDER): x, f and every
-//              counter are the reference's own, bit for bit.
+//   reference  (default) every sum in index order, separate multiply and add — the reference's
+//              sequential loops (NLSG_BFGS_REFERENCE_ORDER / NLSG_LM_CHOLESKY_REFERENCE_ORDER): x, f
+//              and every counter are the reference's own, bit for bit, wherever the reference's
+//              arithmetic exists on the device (not Rastrigin, whose device cosine is not libm's;
+//              not whole-vector Custom bodies; not TanhRegression). With the default functors these
+//              are also the FASTER kernels — a probe per lane on the base point's shared terms and
+//              prefix sums: BFGS on Rosenbrock-128D x 4096 starts 8.3 ms against 32.5 ms for 20
+//              iterations, LM on Rosenbrock-16D x 4096 5.3 against 6.9 ms for 10 —; BFGS with a
+//              gradient functor pays 1.16 x on large batches (n 1024 x 4096: 19.1 against 16.4 ms
+//              per iteration; H passes with a lane per row), 9 x on ONE start of that size (12 ms
+//              against 1.3).
 //   tree       the wave's butterfly sums and fused multiply-adds: same algorithm, same branch
 //              decisions on the reference's runs, values within 1e-8 .. 1e-6 (fin_diff) or
 //              rounding (analytic gradient).
-//   automatic  (default) reference order wherever it costs nothing or the call is the reference's
-//              own: BFGS with the default gradient and LevenbergMarquardt with its default functors
-//              ALWAYS (their reference-order kernels evaluate a probe per lane on the base point's
-//              shared terms and prefix sums and are the faster ones: BFGS on Rosenbrock-128D x 4096
-//              starts 8.8 ms against 32.7 ms for 20 iterations, LM on Rosenbrock-16D x 4096 5.3
-//              against 6.9 ms for 10); BFGS with a gradient functor in minimize() — one start — only:
-//              its minimize_batch(), this header's extension, solves in tree order (1.5 x faster on
-//              large batches). Never for Rastrigin (its device cosine is not libm's), whole-vector
-//              Custom bodies or TanhRegression: no reference arithmetic exists there.
-// Set once before the solves it should govern: `nlsolver::device::summation() = ...`, or the
-// environment variable NLSG_SUMMATION = reference | tree | automatic (read at first use).
-enum class sum_order { automatic, tree, reference };
+// Set before the solves it should govern: `nlsolver::device::summation() = sum_order::tree`, or the
+// environment variable NLSG_SUMMATION = reference | tree (read at first use).
+enum class sum_order { reference, tree };
 inline sum_order &summation() {
   static sum_order order = [] {
     const char *e = std::getenv("NLSG_SUMMATION");
     const std::string v = e ? e : "";
-    if (v == "reference") return sum_order::reference;
     if (v == "tree") return sum_order::tree;
-    if (!v.empty() && v != "automatic")
-      throw device_error("NLSG_SUMMATION must be reference, tree or automatic, not '" + v + "'");
-    return sum_order::automatic;
+    if (!v.empty() && v != "reference")
+      throw device_error("NLSG_SUMMATION must be reference or tree, not '" + v + "'");
+    return sum_order::reference;
   }();
   return order;
 }
-inline bool reference_order_for(bool single_start) {
-  const sum_order o = summation();
-  return o == sum_order::reference || (o == sum_order::automatic && single_start);
-}
+inline bool reference_order() { return summation() == sum_order::reference; }
 }  // namespace device
 
 // ---------------------------------------------------------------------------
@@ -999,14 +994,14 @@ class BFGS {
   solver_status<scalar_t> minimize(std::vector<scalar_t> &x) {
     if constexpr (device::has_grad_objective<Callable>::value) {
       std::vector<std::vector<scalar_t>> one{x};
-      auto st = solve_device(one, true);
+      auto st = solve_device(one);
       x = one[0];
       return st[0];
     } else if constexpr (device_fd()) {
       if constexpr (Callable::nlsg_objective != NLSG_OBJ_CUSTOM)  // (Custom has no host evaluation)
         if (x.size() > 1024) return solve_host(x);  // beyond the device coverage: host functor path
       std::vector<std::vector<scalar_t>> one{x};
-      auto st = solve_device(one, true);
+      auto st = solve_device(one);
       x = one[0];
       return st[0];
     } else {
@@ -1019,10 +1014,9 @@ class BFGS {
   }
   // Extension (BASELINE config 3): `xs.size()` independent starts solved in lock step on
   // the GPU; the reference solves one start per minimize() call.
-  // Summation order: device::summation() (automatic: reference order with the default gradient,
-  // tree order with a gradient functor).
+  // Summation order: device::summation().
   std::vector<solver_status<scalar_t>> minimize_batch(std::vector<std::vector<scalar_t>> &xs) {
-    return solve_device(xs, false);
+    return solve_device(xs);
   }
   // The reference's arithmetic exists on the device for the objectives given by their terms
   // (Rastrigin's device cosine is not libm's; a Custom body is the user's own arithmetic).
@@ -1036,24 +1030,22 @@ class BFGS {
   }
 
  private:
-  // device::summation(): with the default gradient the index-order kernels are the faster ones
-  // (a probe per lane), so `automatic` takes them for batches too — also for a Custom objective
-  // given by its terms, where index order is what the body's own loop on a CPU would do.
-  bool use_reference_order(const bool single_start) const {
+  // device::summation(): reference order wherever the reference's arithmetic exists on the device —
+  // also for a Custom objective given by its terms, where index order is what the body's own loop
+  // on a CPU would do.
+  bool use_reference_order() const {
     if constexpr (device::has_grad_objective<Callable>::value) {
-      return device::reference_order_for(single_start);
+      return device::reference_order();
     } else if constexpr (device_fd()) {
       if constexpr (Callable::nlsg_objective == NLSG_OBJ_CUSTOM)
-        return f.chain != NLSG_CUSTOM_VECTOR && device::reference_order_for(true);
+        return f.chain != NLSG_CUSTOM_VECTOR && device::reference_order();
       else
-        return has_reference_order() && device::reference_order_for(true);
+        return has_reference_order() && device::reference_order();
     } else {
-      (void)single_start;
       return false;
     }
   }
-  std::vector<solver_status<scalar_t>> solve_device(std::vector<std::vector<scalar_t>> &xs,
-                                                    const bool single_start) {
+  std::vector<solver_status<scalar_t>> solve_device(std::vector<std::vector<scalar_t>> &xs) {
     static_assert(device::has_grad_objective<Callable>::value || device_fd(),
                   "minimize_batch needs a device objective: one with an analytic gradient, or "
                   "Rosenbrock / Sphere / StyblinskiTang with the default finite-difference one");
@@ -1063,7 +1055,7 @@ class BFGS {
     nlsg_bfgs_config cfg{};
     cfg.struct_size = sizeof(cfg);
     if (const char *d = std::getenv("NLSG_DEVICE")) cfg.device = std::atoi(d);
-    if (use_reference_order(single_start)) cfg.flags |= NLSG_BFGS_REFERENCE_ORDER;
+    if (use_reference_order()) cfg.flags |= NLSG_BFGS_REFERENCE_ORDER;
     cfg.batch = B;
     cfg.dim = n;
     cfg.max_iter = max_iter;
@@ -1828,14 +1820,14 @@ class LevenbergMarquardt {
   solver_status<scalar_t> minimize(std::vector<scalar_t> &x) {
     if constexpr (device::has_nlls_objective<Callable>::value) {
       std::vector<std::vector<scalar_t>> one{x};
-      auto st = solve_device(one, true);
+      auto st = solve_device(one);
       x = one[0];
       return st[0];
     } else if constexpr (device_fd()) {
       if constexpr (Callable::nlsg_objective != NLSG_OBJ_CUSTOM)  // (Custom has no host evaluation)
         if (x.size() > 1024) return solve_host(x);  // beyond the device coverage: host functor path
       std::vector<std::vector<scalar_t>> one{x};
-      auto st = solve_device(one, true);
+      auto st = solve_device(one);
       x = one[0];
       return st[0];
     } else {
@@ -1848,9 +1840,9 @@ class LevenbergMarquardt {
     return solver_status<scalar_t>(0, 0, 0);
   }
   // Extension (BASELINE config 4): one start per problem of the model, all solved by one launch.
-  // Summation order of the default-functor model: device::summation() (automatic: reference order).
+  // Summation order of the default-functor model: device::summation().
   std::vector<solver_status<scalar_t>> minimize_batch(std::vector<std::vector<scalar_t>> &thetas) {
-    return solve_device(thetas, false);
+    return solve_device(thetas);
   }
   // The reference's arithmetic exists on the device for the default functors on the objectives
   // given by their terms (not Rastrigin: its device cosine is not libm's; not Custom; not the
@@ -1863,8 +1855,7 @@ class LevenbergMarquardt {
   }
 
  private:
-  std::vector<solver_status<scalar_t>> solve_device(std::vector<std::vector<scalar_t>> &thetas,
-                                                    const bool single_start) {
+  std::vector<solver_status<scalar_t>> solve_device(std::vector<std::vector<scalar_t>> &thetas) {
     static_assert(device::has_nlls_objective<Callable>::value || device_fd(),
                   "minimize_batch needs a device NLLS model, or Rosenbrock / Sphere / "
                   "StyblinskiTang with the default finite-difference functors");
@@ -1886,15 +1877,14 @@ class LevenbergMarquardt {
       n = B ? thetas[0].size() : 0;
     }
     cfg.n = n;
-    // (the reference-order evaluation — a probe per lane — is the faster one: batches too, and a
-    // Custom objective given by its terms, where index order is what the body's own loop would do)
-    (void)single_start;
+    // (reference order: also for a Custom objective given by its terms, where index order is what
+    // the body's own loop would do)
     bool ref = false;
     if constexpr (device_fd()) {
       if constexpr (Callable::nlsg_objective == NLSG_OBJ_CUSTOM)
-        ref = f.chain != NLSG_CUSTOM_VECTOR && device::reference_order_for(true);
+        ref = f.chain != NLSG_CUSTOM_VECTOR && device::reference_order();
       else
-        ref = has_reference_order() && device::reference_order_for(true);
+        ref = has_reference_order() && device::reference_order();
     }
     cfg.solver = ref ? NLSG_LM_CHOLESKY_REFERENCE_ORDER : NLSG_LM_CHOLESKY;
     cfg.lambda = lambda;

@@ -152,11 +152,11 @@ class BFGSEngine:
 
 class BFGS:
     """Drop-in for nlsolver::BFGS on a device objective; x may be (n,) or (batch, n).
-    reference_order=None (automatic, as include/nlsolver_mi/nlsolver.h's device::summation()): the
-    default-gradient model on Rosenbrock / Sphere / Styblinski-Tang always solves in reference order
-    (bit for bit the reference's runs, and the faster kernels: a probe per lane); the quadratic with
-    its gradient functor does for one start — the reference's own call — while a (batch, n) array of
-    it solves with the tree-order throughput kernels. True / False force one or the other."""
+    reference_order=None (as include/nlsolver_mi/nlsolver.h's device::summation() default): reference
+    order wherever the reference's arithmetic exists on the device — the quadratic, the default
+    gradient on Rosenbrock / Sphere / Styblinski-Tang or a custom objective given by its terms; literal
+    update — i.e. the reference's runs bit for bit. With the default gradient those are also the
+    faster kernels; the quadratic pays 1.18 x on large batches. True / False force it."""
 
     def __init__(self, f, g=None, max_iter=100, grad_eps=5e-3, alpha=1.0, *, device=0,
                  symmetric=False, reference_order=None):
@@ -179,7 +179,7 @@ class BFGS:
             fd = (isinstance(self.f, str) and self.f in ("rosenbrock", "sphere", "styblinski_tang")) or \
                 (isinstance(self.f, CustomObjective) and self.f.chain != 2)  # (terms: index order is the body's own loop)
             quad = isinstance(self.f, QuadDiagRank1)
-            args["reference_order"] = (fd or (quad and x.ndim == 1)) and not args["symmetric"]
+            args["reference_order"] = (fd or quad) and not args["symmetric"]
         with BFGSEngine(self.f, xb.shape[0], **extra, **args) as eng:
             out, st = eng.minimize(xb)
         xb[...] = out

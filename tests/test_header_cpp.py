@@ -163,17 +163,23 @@ def test_bfgs_default_finite_difference_gradient_runs(built):
 
 
 @pytest.mark.gpu
-def test_bfgs_device_batch_through_header_matches_oracle(built, oracle):
+@pytest.mark.parametrize("summation,tree", [("reference", 0), ("tree", 1)])
+def test_bfgs_device_batch_through_header_matches_oracle(built, oracle, summation, tree):
+    """minimize_batch() of the quadratic: in reference order (the default) equal to the serial oracle —
+    the restatement pinned to the reference's runs —, with NLSG_SUMMATION=tree to the tree oracle."""
     n, B, max_iter, grad_eps, alpha = 96, 5, 60, 1e-8, 1.0
+    env = {k: v for k, v in os.environ.items() if k != "NLSG_SUMMATION"}
+    if summation == "tree":
+        env["NLSG_SUMMATION"] = "tree"
     out = subprocess.check_output(
         [os.path.join(built, "header_bfgs"), "device", str(n), str(B), str(max_iter),
-         repr(grad_eps), repr(alpha)], env=dict(os.environ, NLSG_LIBRARY=LIB), text=True)
+         repr(grad_eps), repr(alpha)], env=dict(env, NLSG_LIBRARY=LIB), text=True)
     res = json.loads(out)
     assert isinstance(res, list) and len(res) == B, res
     import math
     for p, o in enumerate(res):
         x0 = np.array([1.0 + 0.01 * p * math.cos(0.3 * i) for i in range(n)])
-        ref, xr, _ = O.bfgs_quad(oracle, x0, max_iter=max_iter, grad_eps=grad_eps, alpha=alpha, tree=1)
+        ref, xr, _ = O.bfgs_quad(oracle, x0, max_iter=max_iter, grad_eps=grad_eps, alpha=alpha, tree=tree)
         assert (o["fcalls"], o["iters"], o["gcalls"]) == \
             (ref.function_calls_used, ref.iteration, ref.gradient_evals_used)
         assert hx(o["f"]) == ref.f_value
@@ -223,7 +229,7 @@ def _bfgs_fd_args(g):
 def test_bfgs_minimize_through_header_is_the_reference_run(built, golden, name):
     """The drop-in's default: BFGS<device::Rosenbrock<double>, double>(f, ...).minimize(x) — the
     reference's own call with the objective type swapped — solves in reference order
-    (device::summation() automatic) and returns the reference's run (tests/golden/bfgs_fd.json,
+    (device::summation()) and returns the reference's run (tests/golden/bfgs_fd.json,
     made by the unmodified reference): every count, f and x BIT FOR BIT."""
     g = golden("bfgs_fd.json")[name]
     env = {k: v for k, v in os.environ.items() if k != "NLSG_SUMMATION"}
@@ -272,8 +278,8 @@ def test_bfgs_quadratic_minimize_through_header_is_the_reference_run(built, gold
 
 @pytest.mark.gpu
 def test_bfgs_summation_switch_through_header(built, oracle, golden):
-    """With the default gradient both minimize() and minimize_batch() solve in reference order (the
-    faster kernels there) unless NLSG_SUMMATION=tree; a misspelt value is an error, not a default."""
+    """minimize() and minimize_batch() solve in reference order unless NLSG_SUMMATION=tree; a misspelt
+    value is an error, not a default."""
     g = golden("bfgs_fd.json")["rosenbrock_n16_default_stop"]
     cmd = [os.path.join(built, "header_bfgs"), "device-fd", *_bfgs_fd_args(g), "rosenbrock"]
     env = {k: v for k, v in os.environ.items() if k != "NLSG_SUMMATION"}
@@ -296,7 +302,7 @@ def test_bfgs_summation_switch_through_header(built, oracle, golden):
     assert is_reference(run(["batch"], NLSG_SUMMATION="reference"))
     assert is_tree(run(["batch"], NLSG_SUMMATION="tree"))
     assert is_tree(run([], NLSG_SUMMATION="tree"))
-    assert is_reference(run([], NLSG_SUMMATION="automatic"))
+    assert is_reference(run([]))
     r = subprocess.run(cmd, env=dict(env, NLSG_SUMMATION="refrence"), capture_output=True, text=True)
     assert r.returncode == 3 and "NLSG_SUMMATION" in r.stdout, (r.returncode, r.stdout, r.stderr)
 

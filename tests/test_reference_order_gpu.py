@@ -142,9 +142,9 @@ def test_lm_reference_order_limits(mod):
 
 
 def test_drop_in_classes_default_to_reference_order(mod, oracle, golden):
-    """The drop-in classes' automatic rule (include/nlsolver_mi/nlsolver.h device::summation()): a 1-D x
-    — the reference's own call — returns the reference's run bit for bit; a (batch, n) array is solved by
-    the tree-order throughput kernels."""
+    """The drop-in classes' default (include/nlsolver_mi/nlsolver.h device::summation()): reference order
+    wherever the reference's arithmetic exists on the device — one start or a batch returns the
+    reference's run bit for bit; reference_order=False / solver=LM_CHOLESKY select the tree kernels."""
     g = golden("bfgs_fd.json")["rosenbrock_n16_default_stop"]
     kw = dict(max_iter=g["max_iter"], grad_eps=hx(g["grad_eps"]), alpha=hx(g["alpha"]))
     x = start(g)
@@ -158,7 +158,7 @@ def test_drop_in_classes_default_to_reference_order(mod, oracle, golden):
     stb = mod.BFGS("rosenbrock", None, reference_order=False, **kw).minimize(xb)
     tree, xt, _, _ = O.bfgs_fd(oracle, "rosenbrock", start(g), tree=1, **kw)
     assert stb[0].f_value == tree.f_value != st.f_value and np.array_equal(xb[0], xt)
-    # the quadratic with its gradient functor: one start in reference order, a batch in tree order
+    # the quadratic with its gradient functor: reference order too, one start or a batch
     gq = golden("bfgs.json")["n64"]
     d, b, c = O.quad_problem(gq["n"])
     kq = dict(max_iter=gq["max_iter"], grad_eps=hx(gq["grad_eps"]), alpha=hx(gq["alpha"]))
@@ -167,6 +167,9 @@ def test_drop_in_classes_default_to_reference_order(mod, oracle, golden):
     assert sq.f_value == hx(gq["f"]) and xq[:8].tolist() == [hx(v) for v in gq["x_head"]]
     xqb = start(gq).reshape(1, -1)
     sqb = mod.BFGS(mod.QuadDiagRank1(d, b, c), None, **kq).minimize(xqb)
+    assert sqb[0].f_value == sq.f_value and np.array_equal(xqb[0], xq)
+    xqb = start(gq).reshape(1, -1)
+    sqb = mod.BFGS(mod.QuadDiagRank1(d, b, c), None, reference_order=False, **kq).minimize(xqb)
     qt, xqt, _ = O.bfgs_quad(oracle, start(gq), tree=1, **kq)
     assert sqb[0].f_value == qt.f_value and np.array_equal(xqb[0], xqt)
 
