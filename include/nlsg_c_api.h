@@ -470,6 +470,16 @@ int nlsg_lm_time_qr_kernel(nlsg_lm *e, const double *theta0_host, uint32_t repea
 /* ========================================================================== */
 typedef struct nlsg_nm nlsg_nm;
 
+/* NLSG_NM_REFERENCE_ORDER: the objective's terms and std_err's two sums (nlsolver.h:2037-2052) are
+ * added in INDEX order, as the reference's sequential loops add them, instead of the kernels' lane
+ * tree (everything else — centroid, transforms, shrink — is per coordinate and already the
+ * reference's). With it the engine reproduces the reference's own runs bit for bit at every
+ * dimension; without it a run can fork where two vertices are equal under one order and one ulp
+ * apart under the other (same algorithm, another tie-break: Rosenbrock-128D from a constant start
+ * forks at its 262nd evaluation). Objectives given by their terms (not Rastrigin, not a
+ * whole-vector custom body). Costs the serial sums' latency per evaluation and scan. */
+#define NLSG_NM_REFERENCE_ORDER 1
+
 typedef struct {
   uint32_t struct_size;
   int32_t device;
@@ -477,7 +487,7 @@ typedef struct {
   int32_t objective;   /* nlsg_objective                                          */
   int32_t minimize;    /* 1 = minimize(), 0 = maximize()                           */
   int32_t bounded;     /* 1 = the (x, upper, lower) overloads (2136, 2155)         */
-  int32_t reserved;
+  int32_t flags;       /* 0 or NLSG_NM_REFERENCE_ORDER                             */
   uint64_t batch;
   uint64_t dim;        /* <= 1024 (past 128 the simplex lives in a global workspace) */
   double step, alpha, gamma, rho, sigma, eps; /* ctor args, nlsolver.h:2110-2113   */

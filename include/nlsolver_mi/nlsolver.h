@@ -399,8 +399,9 @@ inline uint64_t seed_from(RNG &generator) {
 }
 
 // Summation order of the device solves whose results turn on the last bit of a sum: BFGS (dots,
-// norms, H y, and with the default gradient fin_diff's differences over 12 eps) and the
-// default-functor LevenbergMarquardt (fin_diff_h's differences over 600 eps^2).
+// norms, H y, and with the default gradient fin_diff's differences over 12 eps), the
+// default-functor LevenbergMarquardt (fin_diff_h's differences over 600 eps^2) and NelderMead (ties
+// between vertices whose values differ only by the order their objective's terms were added in).
 //   reference  (default) every sum in index order, separate multiply and add — the reference's
 //              sequential loops (NLSG_BFGS_REFERENCE_ORDER / NLSG_LM_CHOLESKY_REFERENCE_ORDER): x, f
 //              and every counter are the reference's own, bit for bit, wherever the reference's
@@ -1560,6 +1561,13 @@ class NelderMead {
       cfg.objective = Callable::nlsg_objective;
       cfg.minimize = minimize ? 1 : 0;
       cfg.bounded = bound ? 1 : 0;
+      // device::summation(): the objective's terms and std_err's sums in the reference's index order
+      // wherever its arithmetic exists on the device — the reference's runs bit for bit
+      if constexpr (Callable::nlsg_objective == NLSG_OBJ_CUSTOM) {
+        if (f.chain != NLSG_CUSTOM_VECTOR && device::reference_order()) cfg.flags |= NLSG_NM_REFERENCE_ORDER;
+      } else if constexpr (Callable::nlsg_objective != NLSG_OBJ_RASTRIGIN) {
+        if (device::reference_order()) cfg.flags |= NLSG_NM_REFERENCE_ORDER;
+      }
       cfg.batch = 1;
       cfg.dim = x.size();
       cfg.step = step;

@@ -88,9 +88,12 @@ class LMConfig(C.Structure):
                 ("lambda_", f64), ("up", f64), ("down", f64), ("max_iter", u64), ("f_delta", f64)]
 
 
+NM_REFERENCE_ORDER = 1  # NLSG_NM_REFERENCE_ORDER
+
+
 class NMConfig(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", i32), ("stream", C.c_void_p),
-                ("objective", i32), ("minimize", i32), ("bounded", i32), ("reserved", i32),
+                ("objective", i32), ("minimize", i32), ("bounded", i32), ("flags", i32),
                 ("batch", u64), ("dim", u64),
                 ("step", f64), ("alpha", f64), ("gamma", f64), ("rho", f64), ("sigma", f64),
                 ("eps", f64), ("max_iter", u64), ("no_change_best_tol", u64), ("restarts", u64)]

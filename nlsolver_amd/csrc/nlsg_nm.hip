@@ -29,7 +29,7 @@ template <int OBJ, int CHUNKS>
 hipError_t prepare1() {
   return hipFuncSetAttribute(reinterpret_cast<const void *>(nm_solve_kernel<OBJ, CHUNKS>),
                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                             static_cast<int>(nm_lds_bytes(128ull * CHUNKS)));
+                             160 * 1024);  // (reference order adds term buffers behind the image)
 }
 template <int OBJ>
 hipError_t prepare(int chunks) {
@@ -115,6 +115,12 @@ static int nm_create(const nlsg_nm_config *cfg, const nlsg_custom_objective *cus
     return fail(NLSG_ERR_UNSUPPORTED, "dim %llu > 1024 is not covered by the device path",
                 (unsigned long long)cfg->dim);
   if (cfg->batch > 0x7fffffffull) return fail(NLSG_ERR_UNSUPPORTED, "batch too large");
+  if (cfg->flags & ~NLSG_NM_REFERENCE_ORDER) return fail(NLSG_ERR_INVALID_ARG, "unknown flags 0x%x", cfg->flags);
+  if ((cfg->flags & NLSG_NM_REFERENCE_ORDER) &&
+      (cfg->objective == NLSG_OBJ_RASTRIGIN || (custom && custom->chain == NLSG_CUSTOM_VECTOR)))
+    return fail(NLSG_ERR_UNSUPPORTED,
+                "NLSG_NM_REFERENCE_ORDER needs an objective given by its terms whose arithmetic the device "
+                "shares with the reference (not Rastrigin: its cosine is the device's own; not a whole-vector body)");
   int rc = check_device(cfg->device);
   if (rc) return rc;
   NLSG_HIP(hipSetDevice(cfg->device));
@@ -134,7 +140,8 @@ static int nm_create(const nlsg_nm_config *cfg, const nlsg_custom_objective *cus
   NmParams &p = e->p;
   std::memset(&p, 0, sizeof p);
   const uint64_t B = cfg->batch, n = cfg->dim;
-  e->lds = nm_lds_bytes(n);
+  const bool seq = (cfg->flags & NLSG_NM_REFERENCE_ORDER) != 0;
+  e->lds = nm_launch_lds_bytes(n, nm_block_threads(n) / 64, seq);
   hipError_t he = hipSuccess;
   const int chunks = nm_chunks(n);
   if (he == hipSuccess && chunks > 1)  // the simplexes themselves: past what LDS holds
@@ -147,7 +154,7 @@ static int nm_create(const nlsg_nm_config *cfg, const nlsg_custom_objective *cus
   if (he == hipSuccess) he = hipEventCreate(&e->ev1);
   {
     const char *sw = std::getenv("NLSG_NM_DRIVER");
-    e->driver = chunks == 1 && !(sw && sw[0] == '0');
+    e->driver = chunks == 1 && !(sw && sw[0] == '0') && !seq;  // (reference order: nm_solve_kernel with p.seq)
   }
   if (he == hipSuccess) he = prepare_driver<NLSG_OBJ_ROSENBROCK>();
   if (he == hipSuccess) he = prepare_driver<NLSG_OBJ_SPHERE>();
@@ -187,6 +194,7 @@ static int nm_create(const nlsg_nm_config *cfg, const nlsg_custom_objective *cus
   p.eps = cfg->eps;
   p.fmul = cfg->minimize ? 1.0 : -1.0;
   p.bounded = cfg->bounded ? 1 : 0;
+  p.seq = seq ? 1 : 0;
   *out = e;
   return NLSG_OK;
 }

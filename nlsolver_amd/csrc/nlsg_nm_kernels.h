@@ -43,7 +43,8 @@ struct NmParams {
   NmProblem *prob;      // [batch]
   uint64_t batch, n, max_iter, no_change_tol, restarts;
   double step, alpha, gamma, rho, sigma, eps, fmul;
-  int32_t bounded, pad;
+  int32_t bounded;
+  int32_t seq;  // NLSG_NM_REFERENCE_ORDER: the objective's terms and std_err's two sums in index order
   // measurement aid (nlsg_nm_phase_cycles; nullptr otherwise): [batch][kNmPhases] shader-clock
   // cycles the start's decision chain spent per phase, and two counts
   unsigned long long *phase;
@@ -60,6 +61,14 @@ struct NmCtl {  // control block in LDS
   int cmd;  // nm_solve_driver_kernel: what the driver wave asks of the others at the next barrier
 };
 
+__host__ __device__ inline int nm_chunks(uint64_t n) { return n <= 128 ? 1 : n <= 256 ? 2 : n <= 512 ? 4 : 8; }
+__host__ __device__ inline size_t nm_lds_bytes(uint64_t n) {  // the workgroup's LDS image (without term buffers)
+  const uint64_t nv = n + 1;
+  const uint64_t rows = nm_chunks(n) == 1 ? nv * n : 0;
+  return (rows + ((nv + 1) & ~1ull) + 7 * n) * sizeof(double) + sizeof(NmCtl) + 16 +
+         kNmPhases * sizeof(unsigned long long);  // (the driver kernel's phase counters)
+}
+
 // the point at `pt` in the lane layout of the other engines (element 128 c + 2 lane + k)
 template <int CHUNKS>
 __device__ inline void nm_load_point(const double *pt, uint64_t n, double (&xv)[CHUNKS][2]) {
@@ -71,12 +80,33 @@ __device__ inline void nm_load_point(const double *pt, uint64_t n, double (&xv)[
     xv[c][1] = (e0 + 1 < n) ? pt[e0 + 1] : 0.0;
   }
 }
-// objective of the point at `pt` (n <= 128 CHUNKS), evaluated by one wave; all lanes get it
+// objective of the point at `pt` (n <= 128 CHUNKS), evaluated by one wave; all lanes get it.
+// seq_buf != nullptr: reference order (the terms added in index order through the wave's buffer)
 template <int OBJ, int CHUNKS>
-__device__ inline double nm_wave_f(const double *pt, uint64_t n, double fmul) {
+__device__ inline double nm_wave_f(const double *pt, uint64_t n, double fmul, double *seq_buf = nullptr) {
   double xv[CHUNKS][2];
   nm_load_point<CHUNKS>(pt, n, xv);
+  if (seq_buf) return fmul * wave_objective_seq_buf<OBJ, CHUNKS>(xv, n, seq_buf);  // (wave-uniform)
   return fmul * wave_objective<OBJ, CHUNKS>(xv, n);
+}
+// Reference order (NLSG_NM_REFERENCE_ORDER): what separates the device run from the reference's is
+// the order of two kinds of sums — the objective's terms and std_err's mean and deviations (the
+// centroid already adds the vertices in the reference's order; everything else is per coordinate).
+// Ties between vertices that are equal under the reference's sequential sum and one ulp apart under
+// the lane tree send the two runs down different branches (Rosenbrock-128D from a constant start
+// forks at the 262nd evaluation). With both kinds taken in index order the engine reproduces the
+// reference's runs bit for bit: nm_solve_kernel with p.seq, every wave with a term buffer of its own
+// behind the workgroup's LDS image (as many waves as have room take part in a shrink's rescoring).
+__host__ __device__ inline size_t nm_seq_buffer_bytes(uint64_t n) { return 128ull * nm_chunks(n) * sizeof(double); }
+__host__ __device__ inline uint64_t nm_seq_buffers(uint64_t n, uint64_t nwaves, size_t lds_base) {
+  const size_t room = 160 * 1024 - ((lds_base + 15) & ~size_t(15));
+  const uint64_t fit = room / nm_seq_buffer_bytes(n);
+  return fit < nwaves ? fit : nwaves;
+}
+// dynamic LDS of a launch: the image, and in reference order the term buffers behind it
+__host__ __device__ inline size_t nm_launch_lds_bytes(uint64_t n, uint64_t nwaves, bool seq) {
+  const size_t base = nm_lds_bytes(n);
+  return seq ? ((base + 15) & ~size_t(15)) + nm_seq_buffers(n, nwaves, base) * nm_seq_buffer_bytes(n) : base;
 }
 
 template <int OBJ, int CHUNKS = 1>
@@ -95,6 +125,11 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_kernel(NmParams p) {
   const int t = threadIdx.x;
   const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
   const int lane = lane_id();
+  // reference order: term buffers of 128 CHUNKS doubles behind the image (nm_lds_bytes), one per wave
+  // as far as the CU's LDS goes; sbuf: this wave's (nullptr: tree order, or no room for this wave)
+  const uint64_t seq_waves = p.seq ? nm_seq_buffers(n, nwaves, nm_lds_bytes(n)) : 0;
+  double *const seq_base = reinterpret_cast<double *>(nm_smem + ((nm_lds_bytes(n) + 15) & ~size_t(15)));
+  double *const sbuf = static_cast<uint64_t>(wid) < seq_waves ? seq_base + static_cast<uint64_t>(wid) * (128 * CHUNKS) : nullptr;
 
   for (uint64_t j = t; j < n; j += nthreads) {
     x0[j] = p.x[pid * n + j];
@@ -144,9 +179,17 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_kernel(NmParams p) {
     }
     for (uint64_t j = t; j < n; j += nthreads) centroid[j] = 0.0;  // :2195
     __syncthreads();
-    for (uint64_t v = wid; v < nv; v += nwaves) {  // 2184-2186
-      const double f = nm_wave_f<OBJ, CHUNKS>(S + v * n, n, p.fmul);
-      if (lane == 0) scores[v] = f;
+    if (p.seq) {
+      if (sbuf)
+        for (uint64_t v = wid; v < nv; v += seq_waves) {
+          const double f = nm_wave_f<OBJ, CHUNKS>(S + v * n, n, p.fmul, sbuf);
+          if (lane == 0) scores[v] = f;
+        }
+    } else {
+      for (uint64_t v = wid; v < nv; v += nwaves) {  // 2184-2186
+        const double f = nm_wave_f<OBJ, CHUNKS>(S + v * n, n, p.fmul);
+        if (lane == 0) scores[v] = f;
+      }
     }
     __syncthreads();
     if (t == 0) {
@@ -192,6 +235,11 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_kernel(NmParams p) {
           argmin_combine(mnv, mni, omn, omni);
           argmax_combine(mxv, mxi, omx, omxi);
         });
+        if (p.seq) {  // std_err's mean (2037-2052) in index order: every lane walks the scores
+          acc = 0.0;
+#pragma unroll 8
+          for (uint64_t i = 0; i < nv; i++) acc = acc + scores[i];
+        }
         const double mean = acc / static_cast<double>(nv);
         const bool frozen = isnan(scores[0]);
         const uint64_t worst_i = (frozen || mxi == ~0ull) ? 0 : mxi;
@@ -212,6 +260,14 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_kernel(NmParams p) {
           acc = acc + oa;
           argmax_combine(sv, svi, osv, osvi);
         });
+        if (p.seq) {  // ... and the squared deviations
+          acc = 0.0;
+#pragma unroll 8
+          for (uint64_t i = 0; i < nv; i++) {
+            const double d = scores[i] - mean;
+            acc = acc + d * d;
+          }
+        }
         const double se = sqrt(acc / static_cast<double>(nv - 1));
         if (lane == 0) {
           const uint64_t best = (frozen || mni == ~0ull) ? 0 : mni;
@@ -260,7 +316,7 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_kernel(NmParams p) {
       }
       __syncthreads();
       if (wid == 0) {
-        const double rs = nm_wave_f<OBJ, CHUNKS>(tr, n, p.fmul);
+        const double rs = nm_wave_f<OBJ, CHUNKS>(tr, n, p.fmul, sbuf);
         if (lane == 0) {
           ctl->ref_score = rs;
           ctl->fcalls++;
@@ -284,7 +340,7 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_kernel(NmParams p) {
         }
         __syncthreads();
         if (wid == 0) {
-          const double es = nm_wave_f<OBJ, CHUNKS>(te, n, p.fmul);
+          const double es = nm_wave_f<OBJ, CHUNKS>(te, n, p.fmul, sbuf);
           if (lane == 0) {
             ctl->exp_score = es;
             ctl->fcalls++;
@@ -304,7 +360,7 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_kernel(NmParams p) {
         }
         __syncthreads();
         if (wid == 0) {
-          const double cs = nm_wave_f<OBJ, CHUNKS>(tc, n, p.fmul);
+          const double cs = nm_wave_f<OBJ, CHUNKS>(tc, n, p.fmul, sbuf);
           if (lane == 0) {
             ctl->cont_score = cs;
             ctl->fcalls++;
@@ -323,7 +379,31 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_kernel(NmParams p) {
           // and scores it from the registers it holds; four rows at a time so that their
           // lane trees overlap (the method spends most iterations here on Rosenbrock-128D:
           // the reference's second-worst rule, SURVEY B3, rarely accepts a reflection).
-          {
+          if (p.seq) {  // reference order: a row at a time on the waves that have a term buffer
+            if (sbuf) {
+              double bv[CHUNKS][2];
+              nm_load_point<CHUNKS>(S + best * n, n, bv);
+              for (uint64_t v = wid; v < nv; v += seq_waves) {
+                if (v == best) continue;
+                double *row = S + v * n;
+                double ov[CHUNKS][2], xv[CHUNKS][2];
+                nm_load_point<CHUNKS>(row, n, ov);
+#pragma unroll
+                for (int c = 0; c < CHUNKS; c++) {
+                  const uint64_t e0 = static_cast<uint64_t>(c) * 128 + 2 * static_cast<uint64_t>(lane);
+                  const bool in0 = e0 < n, in1 = e0 + 1 < n;
+                  xv[c][0] = bv[c][0] + p.sigma * (ov[c][0] - bv[c][0]);
+                  xv[c][1] = bv[c][1] + p.sigma * (ov[c][1] - bv[c][1]);
+                  if (in0) row[e0] = xv[c][0];
+                  if (in1) row[e0 + 1] = xv[c][1];
+                  if (!in0) xv[c][0] = 0.0;
+                  if (!in1) xv[c][1] = 0.0;
+                }
+                const double f = p.fmul * wave_objective_seq_buf<OBJ, CHUNKS>(xv, n, sbuf);
+                if (lane == 0) scores[v] = f;
+              }
+            }
+          } else {
             // ROWS rows at a time per wave (register budget: ROWS x CHUNKS x 2 doubles)
             constexpr int ROWS = CHUNKS == 1 ? 4 : CHUNKS == 2 ? 2 : 1;
             double bv[CHUNKS][2];
@@ -840,12 +920,5 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_driver_kernel(NmParams p)
 }
 
 // chunks of 128 coordinates per point: 1 = simplex in LDS, else in the global workspace
-__host__ __device__ inline int nm_chunks(uint64_t n) { return n <= 128 ? 1 : n <= 256 ? 2 : n <= 512 ? 4 : 8; }
-inline size_t nm_lds_bytes(uint64_t n) {
-  const uint64_t nv = n + 1;
-  const uint64_t rows = nm_chunks(n) == 1 ? nv * n : 0;
-  return (rows + ((nv + 1) & ~1ull) + 7 * n) * sizeof(double) + sizeof(NmCtl) + 16 +
-         kNmPhases * sizeof(unsigned long long);  // (the driver kernel's phase counters)
-}
 
 }  // namespace nlsg

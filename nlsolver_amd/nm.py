@@ -16,10 +16,15 @@ from ._capi import NMConfig, Status, check, lib
 
 
 class NMEngine:
+    """reference_order=True (NLSG_NM_REFERENCE_ORDER): the objective's terms and std_err's sums in index
+    order, as the reference adds them — its own runs bit for bit at every dimension (the lane-tree sums
+    can break a tie between two vertices the other way: same algorithm, another branch)."""
+
     def __init__(self, objective, batch, dim, *, minimize=True, bounded=False, step=-1.0, alpha=1.0,
                  gamma=2.0, rho=0.5, sigma=0.5, eps=1e-6, max_iter=500, no_change_best_tol=20,
-                 restarts=0, device=0, stream=None):
+                 restarts=0, device=0, stream=None, reference_order=False):
         cfg = NMConfig()
+        cfg.flags = _capi.NM_REFERENCE_ORDER if reference_order else 0
         cfg.struct_size = C.sizeof(NMConfig)
         cfg.device = device
         cfg.stream = None if stream is None else (stream or 1)
@@ -87,10 +92,18 @@ class NMEngine:
 
 
 class NelderMead:
-    """Drop-in for nlsolver::NelderMead on a device objective (same ctor args/defaults)."""
+    """Drop-in for nlsolver::NelderMead on a device objective (same ctor args/defaults).
+    reference_order=None: reference order (NMEngine) wherever the reference's arithmetic exists on the
+    device — Rosenbrock / Sphere / Styblinski-Tang, a custom objective given by its terms —: the
+    reference's runs bit for bit. True / False force it."""
 
     def __init__(self, f, step=-1.0, alpha=1.0, gamma=2.0, rho=0.5, sigma=0.5, eps=1e-6,
-                 max_iter=500, no_change_best_tol=20, restarts=0, *, device=0):
+                 max_iter=500, no_change_best_tol=20, restarts=0, *, device=0, reference_order=None):
+        from .de import CustomObjective
+        if reference_order is None:
+            reference_order = (isinstance(f, str) and f in ("rosenbrock", "sphere", "styblinski_tang")) or \
+                (isinstance(f, CustomObjective) and f.chain != 2)
+        self.reference_order = bool(reference_order)
         self.f = f
         self.eps = eps  # mutated by every solve like the reference's member (nlsolver.h:2189)
         self.args = dict(step=step, alpha=alpha, gamma=gamma, rho=rho, sigma=sigma,
@@ -103,7 +116,7 @@ class NelderMead:
         xb = x.reshape(1, -1) if x.ndim == 1 else x
         bounded = upper is not None
         with NMEngine(self.f, xb.shape[0], xb.shape[1], minimize=minimize, bounded=bounded,
-                      eps=self.eps, **self.args) as eng:
+                      eps=self.eps, reference_order=self.reference_order, **self.args) as eng:
             out, st, eps = eng.minimize(xb, upper, lower)
         xb[...] = out
         if x.ndim == 1:

@@ -190,3 +190,66 @@ def test_drop_in_classes_default_to_reference_order(mod, oracle, golden):
     # Rastrigin has no reference arithmetic on the device: one start still runs (tree order)
     x = np.full(4, 0.3)
     assert np.isfinite(mod.BFGS("rastrigin").minimize(x).f_value)
+
+
+# ---- Nelder-Mead in reference order (NLSG_NM_REFERENCE_ORDER) -----------------------------------------
+def _nm_case(g):
+    D = g["D"]
+    x0 = hx(g["x0"]) + hx(g["x0_step"]) * np.arange(D, dtype=np.float64)
+    kw = dict(step=hx(g["step"]), eps=hx(g["eps"]), max_iter=g["max_iter"],
+              no_change_best_tol=g["no_change"], restarts=g["restarts"], minimize=bool(g["minimize"]))
+    bounds = (hx(g["upper"]), hx(g["lower"])) if g["bounded"] else ()
+    return D, x0, kw, bounds
+
+
+@pytest.mark.parametrize("name", ["example_2d", "d4_200iters", "d4_fixed_step", "d16_bounded", "d8_restarts",
+                                  "d6_maximize_bounded", "d128_2000iters", "d130_ragged"])
+def test_nm_reference_order_equals_the_reference_runs(mod, golden, name):
+    """Every committed run of the reference's NelderMead on the device in reference order: counts, the
+    final value and the best vertex BIT FOR BIT — the 128-D run of 203 457 evaluations (which the
+    lane-tree sums fork from at its 262nd: a tie broken the other way) and the 130-D run whose collapsed
+    simplex shrinks a summation-order-dependent number of times included."""
+    g = golden("nm.json")[name]
+    D, x0, kw, bounds = _nm_case(g)
+    with mod.NMEngine("rosenbrock", 1, D, bounded=bool(bounds), reference_order=True, **kw) as eng:
+        x, st, _ = eng.minimize(x0[None].copy(), *bounds)
+    assert (st[0].function_calls_used, st[0].iteration) == (g["fcalls"], g["iters"])
+    assert st[0].f_value == hx(g["f"])
+    assert x[0].tolist() == [hx(v) for v in g["x"]]
+
+
+@pytest.mark.parametrize("obj,n,batch", [("rosenbrock", 3, 5), ("sphere", 17, 4), ("styblinski_tang", 64, 3),
+                                         ("rosenbrock", 100, 2), ("rosenbrock", 200, 2), ("sphere", 300, 1)])
+def test_nm_reference_order_batches_equal_the_serial_oracle(mod, oracle, obj, n, batch):
+    """Random starts, every simplex size class (LDS-resident and the global workspace past 128):
+    device in reference order == oracle order 0 (pinned to the reference's runs), bit for bit."""
+    rng = np.random.default_rng(700 + n)
+    x0 = 0.5 + 1.0 * (rng.random((batch, n)) - 0.5)
+    kw = dict(step=-1.0, eps=0.0, max_iter=60, no_change_best_tol=10**6, restarts=0)
+    with mod.NMEngine(obj, batch, n, reference_order=True, **kw) as eng:
+        x, st, _ = eng.minimize(x0.copy())
+    for b in range(batch):
+        ref, xr, _, _ = O.nm_run(oracle, x0[b], obj=obj, order=0, step=-1.0, eps=0.0, max_iter=60,
+                                 no_change=10**6, restarts=0)
+        assert (st[b].iteration, st[b].function_calls_used) == (ref.iteration, ref.function_calls_used), b
+        assert st[b].f_value == ref.f_value and np.array_equal(x[b], xr), b
+
+
+def test_nm_reference_order_limits_and_default(mod, golden):
+    with pytest.raises(mod.NlsgError):
+        mod.NMEngine("rastrigin", 1, 4, reference_order=True)
+    with pytest.raises(mod.NlsgError):
+        mod.NMEngine(mod.CustomObjective("return x(0) * x(0) + x(1) * x(1);", vector=True), 1, 2,
+                     reference_order=True)
+    # the drop-in class: reference order by default — the reference's example run bit for bit
+    g = golden("nm.json")["example_2d"]
+    x = np.array([2.0, 7.0])
+    st = mod.NelderMead("rosenbrock").minimize(x)
+    assert (st.function_calls_used, st.iteration) == (g["fcalls"], g["iters"])
+    assert st.f_value == hx(g["f"]) and x.tolist() == [hx(v) for v in g["x"]]
+    # the same chain as source text
+    x = np.array([2.0, 7.0])
+    obj = mod.CustomObjective("double t1 = 1 - xi; double t2 = (xn - xi * xi); return t1 * t1 + 100 * t2 * t2;",
+                              chain=True)
+    st = mod.NelderMead(obj).minimize(x)
+    assert st.f_value == hx(g["f"]) and x.tolist() == [hx(v) for v in g["x"]]
