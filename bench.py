@@ -866,6 +866,12 @@ def main_nm(args):
     ms = timed_solves(ranks, eng, x0, 2)
     x, st, _ = eng.minimize(x0.copy())
     fcalls = sum(s.function_calls_used for s in st)
+    # the same starts in REFERENCE ORDER (what the drop-in classes run: the objective's terms and std_err's
+    # sums in the reference's index order — its runs bit for bit), reported beside `value`
+    with nlsolver_amd.NMEngine("rosenbrock", batch, n, eps=0.0, max_iter=iters, no_change_best_tol=10**9,
+                               device=ranks.local_rank, reference_order=True) as ref_eng:
+        ref_eng.time_solve(x0, 1)
+        ms_ref = ranks.max_over_ranks(ref_eng.time_solve(x0, 1))
     if ranks.rank == 0:
         print(json.dumps({
             "metric": "Nelder-Mead iterations x starts / s (Rosenbrock-128D)",
@@ -876,6 +882,8 @@ def main_nm(args):
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"Nelder-Mead Rosenbrock-{n}D, {iters} iterations, batch={batch} per GPU",
                        "objective_calls_per_s": ranks.world * fcalls / (ms * 1e-3),
+                       "reference_order": {"value": ranks.world * batch * iters / (ms_ref * 1e-3),
+                                           "ms_per_step": ms_ref / iters, "kernel": "nm_solve_kernel<0, 1> (p.seq)"},
                        "parallelism": ranks.replicas()},
             "roofline": {"bound": "latency", "achieved": None, "peak": None, "unit": None,
                          # the whole solve is ONE launch of nm_solve_driver_kernel: its duration per

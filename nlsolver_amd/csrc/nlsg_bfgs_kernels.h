@@ -85,10 +85,7 @@ __device__ inline double wave_sum_seq_lds(const double (&t)[CHUNKS][2], uint64_t
   bfgs_stage_terms<CHUNKS>(t, buf);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  double acc = 0.0;
-  const int m = static_cast<int>(n);
-#pragma unroll 8
-  for (int e = 0; e < m; e++) acc = acc + buf[e];
+  const double acc = serial_sum_lds(buf, static_cast<int>(n));
   __builtin_amdgcn_wave_barrier();  // (the buffer's next stores come after these reads)
   return acc;
 }
@@ -190,7 +187,7 @@ constexpr int kBfgsQuad = -1;
 // LDS of the search / init kernels: only the reference-order finite-difference gradient uses any — per
 // wave the point and its objective terms, 2 x 128 CHUNKS doubles (the launch passes 0 bytes otherwise)
 __host__ __device__ constexpr size_t bfgs_fd_seq_lds_bytes(int chunks) {
-  return 4 * 2 * 128 * static_cast<size_t>(chunks) * sizeof(double);
+  return 4 * 2 * 128 * static_cast<size_t>(chunks) * sizeof(double);  // (serial_sum_lds reads ahead inside it)
 }
 
 template <int MODEL, int CHUNKS>

@@ -514,6 +514,39 @@ __device__ inline double wave_objective_seq(const double (&xv)[CHUNKS][2], uint6
 // that does not depend on the chain, so the additions follow each other at the adder's latency
 // instead of behind two v_readlane each (measured: 80 -> ~10 cycles per term). Same additions in
 // the same order: the same bits.
+// sum of buf[0 .. m) in index order, every lane the same chain. The reads of the NEXT eight values are
+// issued before the additions of the current eight (which only wait for each other), so a term
+// costs the adder's latency, not an LDS round trip per block. Reads up to 15 doubles past m (inside
+// the caller's allocation; never added).
+__device__ inline double serial_sum_lds(const double *buf, int m, double acc = 0.0) {
+  double a[8], b[8];
+#pragma unroll
+  for (int u = 0; u < 8; u++) a[u] = buf[u];
+  int e = 0;
+  for (; e + 16 <= m; e += 16) {
+#pragma unroll
+    for (int u = 0; u < 8; u++) b[u] = buf[e + 8 + u];
+#pragma unroll
+    for (int u = 0; u < 8; u++) acc = acc + a[u];
+#pragma unroll
+    for (int u = 0; u < 8; u++) a[u] = buf[e + 16 + u];
+#pragma unroll
+    for (int u = 0; u < 8; u++) acc = acc + b[u];
+  }
+  if (e + 8 <= m) {
+#pragma unroll
+    for (int u = 0; u < 8; u++) b[u] = buf[e + 8 + u];
+#pragma unroll
+    for (int u = 0; u < 8; u++) acc = acc + a[u];
+#pragma unroll
+    for (int u = 0; u < 8; u++) a[u] = b[u];
+    e += 8;
+  }
+#pragma unroll
+  for (int u = 0; u < 8; u++)
+    if (e + u < m) acc = acc + a[u];  // (wave-uniform)
+  return acc;
+}
 template <int CHUNKS>
 __device__ inline double wave_sum_seq_buf(const double (&t)[CHUNKS][2], uint64_t n, double *buf) {
   const int lane = lane_id();
@@ -522,10 +555,7 @@ __device__ inline double wave_sum_seq_buf(const double (&t)[CHUNKS][2], uint64_t
     *reinterpret_cast<double2 *>(buf + 128 * c + 2 * lane) = make_double2(t[c][0], t[c][1]);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  double acc = 0.0;
-  const int m = static_cast<int>(n);
-#pragma unroll 8
-  for (int e = 0; e < m; e++) acc = acc + buf[e];
+  const double acc = serial_sum_lds(buf, static_cast<int>(n));
   __builtin_amdgcn_wave_barrier();  // (the buffer's next stores come after these reads)
   return acc;
 }

@@ -42,13 +42,24 @@ hipError_t prepare(int chunks) {
 }
 template <int OBJ>
 hipError_t prepare_driver() {
-  return hipFuncSetAttribute(reinterpret_cast<const void *>(nm_solve_driver_kernel<OBJ>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize,
-                             static_cast<int>(nm_lds_bytes(128)));
+  hipError_t he = hipFuncSetAttribute(reinterpret_cast<const void *>(nm_solve_driver_kernel<OBJ>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      static_cast<int>(nm_lds_bytes(128)));
+  if constexpr (OBJ != NLSG_OBJ_RASTRIGIN)  // (reference order: term buffers behind the image)
+    if (he == hipSuccess)
+      he = hipFuncSetAttribute(reinterpret_cast<const void *>(nm_solve_driver_kernel<OBJ, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  return he;
 }
 template <int OBJ>
 void launch_obj(nlsg_nm *e, dim3 grid, dim3 block) {
   if (e->driver) {
+    if constexpr (OBJ != NLSG_OBJ_RASTRIGIN) {
+      if (e->p.seq) {
+        hipLaunchKernelGGL((nm_solve_driver_kernel<OBJ, true>), grid, block, e->lds, e->stream, e->p);
+        return;
+      }
+    }
     hipLaunchKernelGGL(nm_solve_driver_kernel<OBJ>, grid, block, e->lds, e->stream, e->p);
     return;
   }
@@ -154,7 +165,7 @@ static int nm_create(const nlsg_nm_config *cfg, const nlsg_custom_objective *cus
   if (he == hipSuccess) he = hipEventCreate(&e->ev1);
   {
     const char *sw = std::getenv("NLSG_NM_DRIVER");
-    e->driver = chunks == 1 && !(sw && sw[0] == '0') && !seq;  // (reference order: nm_solve_kernel with p.seq)
+    e->driver = chunks == 1 && !(sw && sw[0] == '0');
   }
   if (he == hipSuccess) he = prepare_driver<NLSG_OBJ_ROSENBROCK>();
   if (he == hipSuccess) he = prepare_driver<NLSG_OBJ_SPHERE>();
@@ -165,7 +176,7 @@ static int nm_create(const nlsg_nm_config *cfg, const nlsg_custom_objective *cus
   if (he == hipSuccess) he = prepare<NLSG_OBJ_STYBLINSKI_TANG>(chunks);
   if (he == hipSuccess) he = prepare<NLSG_OBJ_RASTRIGIN>(chunks);
   if (he == hipSuccess && custom) {
-    const int rc2 = rtc_build_nm(custom, e->driver ? 0 : chunks, &e->rtc);
+    const int rc2 = rtc_build_nm(custom, e->driver ? 0 : chunks, seq, &e->rtc);
     if (rc2) {
       nlsg_nm_destroy(e);
       return rc2;

@@ -99,14 +99,14 @@ __device__ inline double nm_wave_f(const double *pt, uint64_t n, double fmul, do
 // behind the workgroup's LDS image (as many waves as have room take part in a shrink's rescoring).
 __host__ __device__ inline size_t nm_seq_buffer_bytes(uint64_t n) { return 128ull * nm_chunks(n) * sizeof(double); }
 __host__ __device__ inline uint64_t nm_seq_buffers(uint64_t n, uint64_t nwaves, size_t lds_base) {
-  const size_t room = 160 * 1024 - ((lds_base + 15) & ~size_t(15));
+  const size_t room = 160 * 1024 - ((lds_base + 15) & ~size_t(15)) - 64;  // (64: serial_sum_lds reads ahead)
   const uint64_t fit = room / nm_seq_buffer_bytes(n);
   return fit < nwaves ? fit : nwaves;
 }
 // dynamic LDS of a launch: the image, and in reference order the term buffers behind it
 __host__ __device__ inline size_t nm_launch_lds_bytes(uint64_t n, uint64_t nwaves, bool seq) {
   const size_t base = nm_lds_bytes(n);
-  return seq ? ((base + 15) & ~size_t(15)) + nm_seq_buffers(n, nwaves, base) * nm_seq_buffer_bytes(n) : base;
+  return seq ? ((base + 15) & ~size_t(15)) + nm_seq_buffers(n, nwaves, base) * nm_seq_buffer_bytes(n) + 64 : base;
 }
 
 template <int OBJ, int CHUNKS = 1>
@@ -236,9 +236,7 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_kernel(NmParams p) {
           argmax_combine(mxv, mxi, omx, omxi);
         });
         if (p.seq) {  // std_err's mean (2037-2052) in index order: every lane walks the scores
-          acc = 0.0;
-#pragma unroll 8
-          for (uint64_t i = 0; i < nv; i++) acc = acc + scores[i];
+          acc = serial_sum_lds(scores, static_cast<int>(nv));
         }
         const double mean = acc / static_cast<double>(nv);
         const bool frozen = isnan(scores[0]);
@@ -575,6 +573,32 @@ __device__ inline void nm_shrink_rows_impl(double *S, double *scores, uint64_t n
     if ((lane & 15) == 0 && v < end && v != best) scores[v] = f;
   }
 }
+// reference order: a row at a time (its terms added in index order through the wave's buffer), on the
+// waves that have a buffer
+template <int OBJ>
+__device__ inline void nm_shrink_rows_seq(double *S, double *scores, uint64_t n, uint64_t nv, uint64_t best,
+                                          double sigma, double fmul, int wid, uint64_t seq_waves, double *sbuf) {
+  if (!sbuf) return;
+  const int lane = lane_id();
+  const uint64_t e0 = 2 * static_cast<uint64_t>(lane);
+  const bool in0 = e0 < n, in1 = e0 + 1 < n;
+  double bv[1][2];
+  nm_load_point<1>(S + best * n, n, bv);
+  for (uint64_t v = wid; v < nv; v += seq_waves) {
+    if (v == best) continue;
+    double *row = S + v * n;
+    double ov[1][2], xv[1][2];
+    nm_load_point<1>(row, n, ov);
+    xv[0][0] = bv[0][0] + sigma * (ov[0][0] - bv[0][0]);
+    xv[0][1] = bv[0][1] + sigma * (ov[0][1] - bv[0][1]);
+    if (in0) row[e0] = xv[0][0];
+    if (in1) row[e0 + 1] = xv[0][1];
+    if (!in0) xv[0][0] = 0.0;
+    if (!in1) xv[0][1] = 0.0;
+    const double f = fmul * wave_objective_seq_buf<OBJ, 1>(xv, n, sbuf);
+    if (lane == 0) scores[v] = f;
+  }
+}
 template <int OBJ>
 __device__ inline void nm_shrink_rows(double *S, double *scores, uint64_t n, uint64_t nv, uint64_t best,
                                       double sigma, double fmul, int wid, uint64_t nwaves) {
@@ -586,7 +610,7 @@ __device__ inline void nm_shrink_rows(double *S, double *scores, uint64_t n, uin
     nm_shrink_rows_impl<OBJ, false>(S, scores, n, nv, best, sigma, fmul, wid, nwaves);
 }
 
-template <int OBJ>
+template <int OBJ, bool SEQ = false>  // SEQ: NLSG_NM_REFERENCE_ORDER (nm_wave_f above)
 __global__ __launch_bounds__(kNmThreads) void nm_solve_driver_kernel(NmParams p) {
   const uint64_t nthreads = blockDim.x, nwaves = blockDim.x >> 6;
   extern __shared__ __align__(16) unsigned char nm_smem[];
@@ -605,6 +629,10 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_driver_kernel(NmParams p)
   const int lane = lane_id();
   const uint64_t e0 = 2 * static_cast<uint64_t>(lane), e1 = e0 + 1;
   const bool in0 = e0 < n, in1 = e1 < n;
+  // reference order: a term buffer of 128 doubles per wave behind the image (as in nm_solve_kernel)
+  const uint64_t seq_waves = SEQ ? nm_seq_buffers(n, nwaves, nm_lds_bytes(n)) : 0;
+  double *const seq_base = reinterpret_cast<double *>(nm_smem + ((nm_lds_bytes(n) + 15) & ~size_t(15)));
+  double *const sbuf = SEQ && static_cast<uint64_t>(wid) < seq_waves ? seq_base + static_cast<uint64_t>(wid) * 128 : nullptr;
 
   for (uint64_t j = t; j < n; j += nthreads) {
     x0[j] = p.x[pid * n + j];
@@ -644,9 +672,17 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_driver_kernel(NmParams p)
       S[e] = val;
     }
     __syncthreads();
-    for (uint64_t v = wid; v < nv; v += nwaves) {  // 2184-2186
-      const double f = nm_wave_f<OBJ, 1>(S + v * n, n, p.fmul);
-      if (lane == 0) scores[v] = f;
+    if constexpr (SEQ) {
+      if (sbuf)
+        for (uint64_t v = wid; v < nv; v += seq_waves) {
+          const double f = nm_wave_f<OBJ, 1>(S + v * n, n, p.fmul, sbuf);
+          if (lane == 0) scores[v] = f;
+        }
+    } else {
+      for (uint64_t v = wid; v < nv; v += nwaves) {  // 2184-2186
+        const double f = nm_wave_f<OBJ, 1>(S + v * n, n, p.fmul);
+        if (lane == 0) scores[v] = f;
+      }
     }
     __syncthreads();
 
@@ -655,7 +691,10 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_driver_kernel(NmParams p)
       for (;;) {
         __syncthreads();  // (A) the driver's request is in ctl
         if (ctl->cmd == kNmCmdEnd) break;
-        nm_shrink_rows<OBJ>(S, scores, n, nv, ctl->best, p.sigma, p.fmul, wid, nwaves);
+        if constexpr (SEQ)
+          nm_shrink_rows_seq<OBJ>(S, scores, n, nv, ctl->best, p.sigma, p.fmul, wid, seq_waves, sbuf);
+        else
+          nm_shrink_rows<OBJ>(S, scores, n, nv, ctl->best, p.sigma, p.fmul, wid, nwaves);
         __syncthreads();  // (B) every row is shrunk and rescored
       }
     } else {
@@ -685,6 +724,7 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_driver_kernel(NmParams p)
       };
       auto score = [&](double a, double b) {
         const double xv[1][2] = {{in0 ? a : 0.0, in1 ? b : 0.0}};
+        if constexpr (SEQ) return p.fmul * wave_objective_seq_buf<OBJ, 1>(xv, n, sbuf);  // (wave 0 always has a buffer)
         return p.fmul * wave_objective<OBJ, 1>(xv, n);
       };
       for (;;) {
@@ -727,6 +767,9 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_driver_kernel(NmParams p)
           mnv = __builtin_fmin(mnv, omn);
           mxv = __builtin_fmax(mxv, omx);
         });
+        if constexpr (SEQ) {  // std_err's mean (2037-2052) in index order: every lane walks the scores
+          acc = serial_sum_lds(scores, static_cast<int>(nv32));
+        }
         const double mean = acc / static_cast<double>(nv);
         const bool frozen = isnan(scores[0]);
         const uint32_t mni = first_holder(mnv, sc, nv32), mxi = first_holder(mxv, sc, nv32);
@@ -750,6 +793,14 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_driver_kernel(NmParams p)
           sv = __builtin_fmax(sv, osv);
         });
         const uint32_t svi = first_holder(sv, sc, worst_i);
+        if constexpr (SEQ) {  // ... and the squared deviations
+          acc = 0.0;
+#pragma unroll 8
+          for (uint32_t i = 0; i < nv32; i++) {
+            const double d = scores[i] - mean;
+            acc = acc + d * d;
+          }
+        }
         const double se = sqrt(acc / static_cast<double>(nv - 1));
         prev_worst = worst;
         best = (frozen || mni == ~0u) ? 0 : mni;
@@ -880,7 +931,10 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_driver_kernel(NmParams p)
               ctl->cmd = kNmCmdShrink;
             }
             __syncthreads();  // (A)
-            nm_shrink_rows<OBJ>(S, scores, n, nv, best, p.sigma, p.fmul, 0, nwaves);
+            if constexpr (SEQ)
+              nm_shrink_rows_seq<OBJ>(S, scores, n, nv, best, p.sigma, p.fmul, 0, seq_waves, sbuf);
+            else
+              nm_shrink_rows<OBJ>(S, scores, n, nv, best, p.sigma, p.fmul, 0, nwaves);
             __syncthreads();  // (B)
             fcalls += nv - 1;
             shrunk = 1;

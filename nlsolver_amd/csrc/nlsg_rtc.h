@@ -32,7 +32,7 @@ struct NmRtcKernels {
   hipModule_t mod = nullptr;
   hipFunction_t solve = nullptr;
 };
-int rtc_build_nm(const nlsg_custom_objective *obj, int chunks, NmRtcKernels *out);
+int rtc_build_nm(const nlsg_custom_objective *obj, int chunks, bool reference_order, NmRtcKernels *out);
 void rtc_release(NmRtcKernels *k);
 struct LmRtcKernels {  // finite-difference model (default functors) around the user's objective
   hipModule_t mod = nullptr;

@@ -266,13 +266,13 @@ void rtc_release(BfgsRtcKernels *k) {
   if (k) *k = BfgsRtcKernels();
 }
 
-int rtc_build_nm(const nlsg_custom_objective *obj, int chunks, NmRtcKernels *out) {
+int rtc_build_nm(const nlsg_custom_objective *obj, int chunks, bool reference_order, NmRtcKernels *out) {
   std::vector<hipFunction_t> f;
   NmRtcKernels k;
   const std::string id = std::to_string(static_cast<int>(NLSG_OBJ_CUSTOM));
   // chunks == 0: the driver-wave kernel (n <= 128)
   const int rc = rtc_compile(obj, "nlsg_nm_kernels.h",
-                             {chunks == 0 ? "nlsg::nm_solve_driver_kernel<" + id + ">"
+                             {chunks == 0 ? "nlsg::nm_solve_driver_kernel<" + id + (reference_order ? ", true>" : ">")
                                           : "nlsg::nm_solve_kernel<" + id + ", " + std::to_string(chunks) + ">"},
                              &k.mod, &f);
   if (rc) return rc;
