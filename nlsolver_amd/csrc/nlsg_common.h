@@ -514,11 +514,12 @@ __device__ inline double wave_objective_seq(const double (&xv)[CHUNKS][2], uint6
 // that does not depend on the chain, so the additions follow each other at the adder's latency
 // instead of behind two v_readlane each (measured: 80 -> ~10 cycles per term). Same additions in
 // the same order: the same bits.
-// sum of buf[0 .. m) in index order, every lane the same chain. The reads of the NEXT eight values are
-// issued before the additions of the current eight (which only wait for each other), so a term
-// costs the adder's latency, not an LDS round trip per block. Reads up to 15 doubles past m (inside
-// the caller's allocation; never added).
-__device__ inline double serial_sum_lds(const double *buf, int m, double acc = 0.0) {
+// sum of f(buf[0 .. m)) in index order, one chain. The reads of the NEXT eight values are issued before
+// the additions of the current eight (which only wait for each other), so a term costs the adder's
+// latency, not an LDS round trip per block. Reads up to 7 doubles past m (inside the caller's
+// allocation; never added).
+template <typename F>
+__device__ inline double serial_chain_lds(const double *buf, int m, double acc, F f) {
   double a[8], b[8];
 #pragma unroll
   for (int u = 0; u < 8; u++) a[u] = buf[u];
@@ -527,25 +528,28 @@ __device__ inline double serial_sum_lds(const double *buf, int m, double acc = 0
 #pragma unroll
     for (int u = 0; u < 8; u++) b[u] = buf[e + 8 + u];
 #pragma unroll
-    for (int u = 0; u < 8; u++) acc = acc + a[u];
+    for (int u = 0; u < 8; u++) acc = acc + f(a[u]);
 #pragma unroll
     for (int u = 0; u < 8; u++) a[u] = buf[e + 16 + u];
 #pragma unroll
-    for (int u = 0; u < 8; u++) acc = acc + b[u];
+    for (int u = 0; u < 8; u++) acc = acc + f(b[u]);
   }
   if (e + 8 <= m) {
 #pragma unroll
     for (int u = 0; u < 8; u++) b[u] = buf[e + 8 + u];
 #pragma unroll
-    for (int u = 0; u < 8; u++) acc = acc + a[u];
+    for (int u = 0; u < 8; u++) acc = acc + f(a[u]);
 #pragma unroll
     for (int u = 0; u < 8; u++) a[u] = b[u];
     e += 8;
   }
 #pragma unroll
   for (int u = 0; u < 8; u++)
-    if (e + u < m) acc = acc + a[u];  // (wave-uniform)
+    if (e + u < m) acc = acc + f(a[u]);  // (wave-uniform)
   return acc;
+}
+__device__ inline double serial_sum_lds(const double *buf, int m, double acc = 0.0) {
+  return serial_chain_lds(buf, m, acc, [](double v) { return v; });
 }
 template <int CHUNKS>
 __device__ inline double wave_sum_seq_buf(const double (&t)[CHUNKS][2], uint64_t n, double *buf) {

@@ -205,7 +205,12 @@ static int nm_create(const nlsg_nm_config *cfg, const nlsg_custom_objective *cus
   p.eps = cfg->eps;
   p.fmul = cfg->minimize ? 1.0 : -1.0;
   p.bounded = cfg->bounded ? 1 : 0;
-  p.seq = seq ? 1 : 0;
+  p.seq = 0;
+  if (seq) {
+    const char *sw = std::getenv("NLSG_NM_SEQ_WAVES");
+    const int w = sw ? std::atoi(sw) : 16;
+    p.seq = w < 1 ? 1 : (w > 16 ? 16 : w);
+  }
   *out = e;
   return NLSG_OK;
 }

@@ -44,7 +44,8 @@ struct NmParams {
   uint64_t batch, n, max_iter, no_change_tol, restarts;
   double step, alpha, gamma, rho, sigma, eps, fmul;
   int32_t bounded;
-  int32_t seq;  // NLSG_NM_REFERENCE_ORDER: the objective's terms and std_err's two sums in index order
+  int32_t seq;  // NLSG_NM_REFERENCE_ORDER: the objective's terms and std_err's two sums in index order; the
+                // value caps the waves that take part in a shrink's rescoring (NLSG_NM_SEQ_WAVES, default 16)
   // measurement aid (nlsg_nm_phase_cycles; nullptr otherwise): [batch][kNmPhases] shader-clock
   // cycles the start's decision chain spent per phase, and two counts
   unsigned long long *phase;
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_kernel(NmParams p) {
   const int lane = lane_id();
   // reference order: term buffers of 128 CHUNKS doubles behind the image (nm_lds_bytes), one per wave
   // as far as the CU's LDS goes; sbuf: this wave's (nullptr: tree order, or no room for this wave)
-  const uint64_t seq_waves = p.seq ? nm_seq_buffers(n, nwaves, nm_lds_bytes(n)) : 0;
+  const uint64_t seq_waves = p.seq ? nm_seq_buffers(n, static_cast<uint64_t>(p.seq) < nwaves ? p.seq : nwaves, nm_lds_bytes(n)) : 0;
   double *const seq_base = reinterpret_cast<double *>(nm_smem + ((nm_lds_bytes(n) + 15) & ~size_t(15)));
   double *const sbuf = static_cast<uint64_t>(wid) < seq_waves ? seq_base + static_cast<uint64_t>(wid) * (128 * CHUNKS) : nullptr;
 
@@ -258,14 +259,11 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_kernel(NmParams p) {
           acc = acc + oa;
           argmax_combine(sv, svi, osv, osvi);
         });
-        if (p.seq) {  // ... and the squared deviations
-          acc = 0.0;
-#pragma unroll 8
-          for (uint64_t i = 0; i < nv; i++) {
-            const double d = scores[i] - mean;
-            acc = acc + d * d;
-          }
-        }
+        if (p.seq)  // ... and the squared deviations
+          acc = serial_chain_lds(scores, static_cast<int>(nv), 0.0, [mean](double v) {
+            const double d = v - mean;
+            return d * d;
+          });
         const double se = sqrt(acc / static_cast<double>(nv - 1));
         if (lane == 0) {
           const uint64_t best = (frozen || mni == ~0ull) ? 0 : mni;
@@ -573,31 +571,76 @@ __device__ inline void nm_shrink_rows_impl(double *S, double *scores, uint64_t n
     if ((lane & 15) == 0 && v < end && v != best) scores[v] = f;
   }
 }
-// reference order: a row at a time (its terms added in index order through the wave's buffer), on the
-// waves that have a buffer
+// Reference order, many rows at once (LDS-resident simplex): a LANE per row. Row r's objective is a
+// serial chain over its terms — but 64 rows are 64 independent chains, one v_add_f64 advances them
+// all. Lane l walks row 64 wid + l and computes its terms from the row itself; it runs k l steps
+// behind lane 0 (k = 1 or 2, whichever makes n - k odd), so that at any step the lanes read
+// (n - k) l + s: 32 different banks instead of one (a row is n doubles: same column = same bank).
+// (A term buffer per wave and one row per wave at a time was LDS-bound: an LDS read at a uniform
+// address costs its 64 lane slots whatever the exec mask — 77 K cycles per shrink at n = 128.)
+// best: the row that keeps its score (~0: none).
+template <int OBJ>
+__device__ inline void nm_rescore_lanes(const double *S, double *scores, uint64_t n64, uint64_t nv64, uint64_t best,
+                                        double fmul, int wid) {
+  using O = Objective<OBJ>;
+  const int lane = lane_id();
+  const int n = static_cast<int>(n64), nv = static_cast<int>(nv64), nt = static_cast<int>(O::n_terms(n64));
+  const int r = 64 * wid + lane;
+  const int k = (n & 1) ? 2 : 1;
+  const double *row = S + (r < nv ? r : nv - 1) * n;
+  double acc = 0.0;
+  const int steps = nt + 63 * k;
+  // four steps' reads are in flight while the previous four are added (the reads are unconditional, at
+  // clamped indices; the additions happen inside the lane's window only)
+  const int kl = k * lane;
+  auto fetch = [&](int s0, double (&xe)[4], double (&xn)[4]) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      int e = s0 + u - kl;
+      e = e < 0 ? 0 : (e >= nt ? (nt > 0 ? nt - 1 : 0) : e);
+      xe[u] = row[e];
+      xn[u] = O::kChain ? row[e + 1] : 0.0;
+    }
+  };
+  double ae[4], an[4], be[4], bn[4];
+  fetch(0, ae, an);
+  for (int s = 0; s < steps; s += 8) {
+    fetch(s + 4, be, bn);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int e = s + u - kl;
+      if (e >= 0 && e < nt) acc = acc + O::term(ae[u], an[u]);
+    }
+    fetch(s + 8, ae, an);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int e = s + 4 + u - kl;
+      if (e >= 0 && e < nt) acc = acc + O::term(be[u], bn[u]);
+    }
+  }
+  if (r < nv && static_cast<uint64_t>(r) != best) scores[r] = fmul * O::finish(acc, n64);
+}
+// the shrink (2009-2035) and rescoring (2288-2294) in reference order: every wave transforms its rows,
+// then (a workgroup barrier later) the first ceil(nv / 64) waves rescore them, a lane per row.
+// Called by all waves of the workgroup.
 template <int OBJ>
 __device__ inline void nm_shrink_rows_seq(double *S, double *scores, uint64_t n, uint64_t nv, uint64_t best,
-                                          double sigma, double fmul, int wid, uint64_t seq_waves, double *sbuf) {
-  if (!sbuf) return;
+                                          double sigma, double fmul, int wid, uint64_t nwaves) {
   const int lane = lane_id();
   const uint64_t e0 = 2 * static_cast<uint64_t>(lane);
   const bool in0 = e0 < n, in1 = e0 + 1 < n;
   double bv[1][2];
   nm_load_point<1>(S + best * n, n, bv);
-  for (uint64_t v = wid; v < nv; v += seq_waves) {
+  for (uint64_t v = wid; v < nv; v += nwaves) {
     if (v == best) continue;
     double *row = S + v * n;
-    double ov[1][2], xv[1][2];
+    double ov[1][2];
     nm_load_point<1>(row, n, ov);
-    xv[0][0] = bv[0][0] + sigma * (ov[0][0] - bv[0][0]);
-    xv[0][1] = bv[0][1] + sigma * (ov[0][1] - bv[0][1]);
-    if (in0) row[e0] = xv[0][0];
-    if (in1) row[e0 + 1] = xv[0][1];
-    if (!in0) xv[0][0] = 0.0;
-    if (!in1) xv[0][1] = 0.0;
-    const double f = fmul * wave_objective_seq_buf<OBJ, 1>(xv, n, sbuf);
-    if (lane == 0) scores[v] = f;
+    if (in0) row[e0] = bv[0][0] + sigma * (ov[0][0] - bv[0][0]);
+    if (in1) row[e0 + 1] = bv[0][1] + sigma * (ov[0][1] - bv[0][1]);
   }
+  __syncthreads();
+  if (64ull * static_cast<uint64_t>(wid) < nv) nm_rescore_lanes<OBJ>(S, scores, n, nv, best, fmul, wid);
 }
 template <int OBJ>
 __device__ inline void nm_shrink_rows(double *S, double *scores, uint64_t n, uint64_t nv, uint64_t best,
@@ -630,7 +673,7 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_driver_kernel(NmParams p)
   const uint64_t e0 = 2 * static_cast<uint64_t>(lane), e1 = e0 + 1;
   const bool in0 = e0 < n, in1 = e1 < n;
   // reference order: a term buffer of 128 doubles per wave behind the image (as in nm_solve_kernel)
-  const uint64_t seq_waves = SEQ ? nm_seq_buffers(n, nwaves, nm_lds_bytes(n)) : 0;
+  const uint64_t seq_waves = SEQ ? nm_seq_buffers(n, static_cast<uint64_t>(p.seq) < nwaves ? p.seq : nwaves, nm_lds_bytes(n)) : 0;
   double *const seq_base = reinterpret_cast<double *>(nm_smem + ((nm_lds_bytes(n) + 15) & ~size_t(15)));
   double *const sbuf = SEQ && static_cast<uint64_t>(wid) < seq_waves ? seq_base + static_cast<uint64_t>(wid) * 128 : nullptr;
 
@@ -673,11 +716,7 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_driver_kernel(NmParams p)
     }
     __syncthreads();
     if constexpr (SEQ) {
-      if (sbuf)
-        for (uint64_t v = wid; v < nv; v += seq_waves) {
-          const double f = nm_wave_f<OBJ, 1>(S + v * n, n, p.fmul, sbuf);
-          if (lane == 0) scores[v] = f;
-        }
+      if (64ull * static_cast<uint64_t>(wid) < nv) nm_rescore_lanes<OBJ>(S, scores, n, nv, ~0ull, p.fmul, wid);
     } else {
       for (uint64_t v = wid; v < nv; v += nwaves) {  // 2184-2186
         const double f = nm_wave_f<OBJ, 1>(S + v * n, n, p.fmul);
@@ -692,7 +731,7 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_driver_kernel(NmParams p)
         __syncthreads();  // (A) the driver's request is in ctl
         if (ctl->cmd == kNmCmdEnd) break;
         if constexpr (SEQ)
-          nm_shrink_rows_seq<OBJ>(S, scores, n, nv, ctl->best, p.sigma, p.fmul, wid, seq_waves, sbuf);
+          nm_shrink_rows_seq<OBJ>(S, scores, n, nv, ctl->best, p.sigma, p.fmul, wid, nwaves);
         else
           nm_shrink_rows<OBJ>(S, scores, n, nv, ctl->best, p.sigma, p.fmul, wid, nwaves);
         __syncthreads();  // (B) every row is shrunk and rescored
@@ -793,14 +832,11 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_driver_kernel(NmParams p)
           sv = __builtin_fmax(sv, osv);
         });
         const uint32_t svi = first_holder(sv, sc, worst_i);
-        if constexpr (SEQ) {  // ... and the squared deviations
-          acc = 0.0;
-#pragma unroll 8
-          for (uint32_t i = 0; i < nv32; i++) {
-            const double d = scores[i] - mean;
-            acc = acc + d * d;
-          }
-        }
+        if constexpr (SEQ)  // ... and the squared deviations
+          acc = serial_chain_lds(scores, static_cast<int>(nv32), 0.0, [mean](double v) {
+            const double d = v - mean;
+            return d * d;
+          });
         const double se = sqrt(acc / static_cast<double>(nv - 1));
         prev_worst = worst;
         best = (frozen || mni == ~0u) ? 0 : mni;
@@ -932,7 +968,7 @@ __global__ __launch_bounds__(kNmThreads) void nm_solve_driver_kernel(NmParams p)
             }
             __syncthreads();  // (A)
             if constexpr (SEQ)
-              nm_shrink_rows_seq<OBJ>(S, scores, n, nv, best, p.sigma, p.fmul, 0, seq_waves, sbuf);
+              nm_shrink_rows_seq<OBJ>(S, scores, n, nv, best, p.sigma, p.fmul, 0, nwaves);
             else
               nm_shrink_rows<OBJ>(S, scores, n, nv, best, p.sigma, p.fmul, 0, nwaves);
             __syncthreads();  // (B)

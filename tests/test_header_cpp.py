@@ -348,9 +348,17 @@ def test_lm_host_path_through_header_matches_reference_bit_exact(built, golden, 
 @pytest.mark.parametrize("name", ["example_2d", "d4_200iters", "d16_bounded", "d8_restarts"])
 @pytest.mark.parametrize("mode", ["nm-device", "nm-device-custom"])
 def test_nm_device_objective_through_header_matches_oracle(built, oracle, golden, name, mode):
+    """NelderMead<device::Rosenbrock<double>, double>(f, ...).minimize(x): in reference order (the default)
+    the reference's own run (tests/golden/nm.json) bit for bit; with NLSG_SUMMATION=tree the tree oracle."""
     g = golden("nm.json")[name]
+    env = {k: v for k, v in os.environ.items() if k != "NLSG_SUMMATION"}
+    ref_run = json.loads(subprocess.check_output([os.path.join(built, "header_nm_lm"), mode, *_nm_args(g)],
+                                                 env=dict(env, NLSG_LIBRARY=LIB), text=True))
+    assert "device_error" not in ref_run, ref_run
+    assert (ref_run["fcalls"], ref_run["iters"]) == (g["fcalls"], g["iters"])
+    assert ref_run["f"] == g["f"] and ref_run["x"] == g["x"]
     out = subprocess.check_output([os.path.join(built, "header_nm_lm"), mode, *_nm_args(g)],
-                                  env=dict(os.environ, NLSG_LIBRARY=LIB), text=True)
+                                  env=dict(env, NLSG_LIBRARY=LIB, NLSG_SUMMATION="tree"), text=True)
     o = json.loads(out)
     assert "device_error" not in o, o
     D = g["D"]
