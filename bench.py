@@ -1201,6 +1201,11 @@ def other_configs_pass():
              "row a25; latency-bound, not roofline-graded)", ["--workload", "tinyqr", "--steps", "2"]),
             ("north_star's NelderMead simplex reflect / expand / contract: Rosenbrock-128D, 4096 starts x "
              "2000 iterations (SURVEY rows a16-a17; latency-bound, not roofline-graded)", ["--workload", "nm"]),
+            ("SURVEY §8f N2: BFGS with the reference's default finite-difference gradient, Rosenbrock-128D x "
+             "4096 starts (reference order: the reference's runs bit for bit, a probe per lane)",
+             ["--workload", "bfgs-fd"]),
+            ("SURVEY §8f N2: LevenbergMarquardt with its default finite-difference functors, Rosenbrock-16D x "
+             "8192 starts (reference order)", ["--workload", "lm-fd"]),
             ("configs[4] PSO Accelerated, one GPU's shard 131072 x 256",
              ["--workload", "pso-accel", "--steps", "100", "--warmup", "300"]),
             ("configs[4] PSO Vanilla, one GPU's shard 131072 x 256",
@@ -1230,7 +1235,9 @@ def other_configs_pass():
             for k in ("steps_timed", "solves_timed"):
                 if d.get(k) is not None:
                     entry[k] = d[k]
-            for k in ("solver", "solve_ms_per_iteration", "whole_run", "timed_iterations"):
+            # (reference_order / tree_order: the same workload in the other summation order)
+            for k in ("solver", "solve_ms_per_iteration", "whole_run", "timed_iterations", "reference_order",
+                      "tree_order"):
                 if k in d["config"]:
                     entry[k] = d["config"][k]
             other = d["config"].get("other_solver")

@@ -28,7 +28,8 @@ def test_other_configs_pass_summarises_children_and_survives_failures(monkeypatc
         if "lm" in cmd and "cholesky" in cmd:
             return types.SimpleNamespace(returncode=1, stdout="", stderr="boom: no GPU here")
         line = {"metric": "m", "value": 2.5, "unit": "u/s", "steps": 7, "ms_per_step": 0.4, "dtype": "f64",
-                "config": {"workload": "w", "solver": "qr", "whole_run": {"value": 3.0}, "other_solver": {"solver": "qr", "value": 1.0, "ms_per_step": 2.0,
+                "config": {"workload": "w", "solver": "qr", "whole_run": {"value": 3.0},
+                           "reference_order": {"value": 1.5}, "other_solver": {"solver": "qr", "value": 1.0, "ms_per_step": 2.0,
                                                             "extra": "dropped"}},
                 "roofline": {"bound": "hbm", "achieved": 1.0, "peak": 2.0, "unit": "GB/s", "frac": 0.5,
                              "kernel": "k", "kernel_ms": 0.1, "traffic": 123, "noise": "dropped"},
@@ -47,7 +48,10 @@ def test_other_configs_pass_summarises_children_and_survives_failures(monkeypatc
         assert e["other_solver"] == {"solver": "qr", "value": 1.0, "ms_per_step": 2.0}
         # every entry states whether its dominant kernel fits into its step (0.1 <= 0.4 here)
         assert e["kernel_within_step"] is True and e["solver"] == "qr" and e["whole_run"] == {"value": 3.0}
-    assert all(e["config"].startswith(("configs[", "north_star")) for e in out)
+        assert e["reference_order"] == {"value": 1.5}  # the same workload in the other summation order
+    assert all(e["config"].startswith(("configs[", "north_star", "SURVEY")) for e in out)
+    # the default-functor workloads (reference order) ride along
+    assert any("bfgs-fd" in c for c in calls) and any("lm-fd" in c for c in calls)
     # BASELINE words configs[3] with the tinyqr solve: that solver is an entry of its own, and it
     # comes before the Cholesky one
     lm = [c for c in calls if "lm" in c and "--lm-n" not in c]
