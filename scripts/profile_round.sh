@@ -32,6 +32,7 @@ run pso_accel --workload pso-accel --steps 100 --warmup 10 &&
 run pso_vanilla --workload pso-vanilla --steps 100 --warmup 10 --no-cpu-baseline &&
 run bfgs --workload bfgs &&
 run bfgs_sym --workload bfgs --bfgs-symmetric --no-cpu-baseline &&
+run bfgs_ref --workload bfgs --bfgs-reference-order --no-cpu-baseline &&
 run lm --workload lm &&
 run lm_qr --workload lm --lm-solver qr --no-cpu-baseline &&
 run nm --workload nm && run sann --workload sann && run nmpso --workload nmpso &&
