@@ -253,3 +253,44 @@ def test_nm_reference_order_limits_and_default(mod, golden):
                               chain=True)
     st = mod.NelderMead(obj).minimize(x)
     assert st.f_value == hx(g["f"]) and x.tolist() == [hx(v) for v in g["x"]]
+
+
+# ---- edges: one and two coordinates, the largest sizes ------------------------------------------------
+@pytest.mark.parametrize("obj,n", [("sphere", 1), ("rosenbrock", 1), ("rosenbrock", 2), ("styblinski_tang", 1),
+                                   ("rosenbrock", 1000), ("sphere", 1024)])
+def test_bfgs_reference_order_edge_sizes(mod, oracle, obj, n):
+    kw = dict(max_iter=4 if n > 64 else 12, grad_eps=0.0, alpha=1.0)
+    rng = np.random.default_rng(900 + n)
+    x0 = 0.8 + 0.4 * (rng.random((2, n)) - 0.5)
+    with mod.BFGSEngine(obj, 2, dim=n, reference_order=True, **kw) as eng:
+        x, st = eng.minimize(x0.copy())
+    for p in range(2):
+        ref, xr, _, _ = O.bfgs_fd(oracle, obj, x0[p], tree=0, **kw)
+        assert (st[p].iteration, st[p].function_calls_used, st[p].gradient_evals_used) == \
+            (ref.iteration, ref.function_calls_used, ref.gradient_evals_used), p
+        same_f = st[p].f_value == ref.f_value or (np.isnan(st[p].f_value) and np.isnan(ref.f_value))
+        assert same_f and np.array_equal(x[p], xr, equal_nan=True), p
+
+
+@pytest.mark.parametrize("obj,n", [("sphere", 1), ("rosenbrock", 1), ("rosenbrock", 2), ("styblinski_tang", 2)])
+def test_lm_and_nm_reference_order_edge_sizes(mod, oracle, obj, n):
+    from nlsolver_amd._capi import LM_CHOLESKY_REFERENCE_ORDER
+    rng = np.random.default_rng(950 + n)
+    x0 = 0.9 + 0.2 * (rng.random((2, n)) - 0.5)
+    kw = dict(lam=10.0, max_iter=4, f_delta=0.0)
+    with mod.lm.LMEngine(obj, batch=2, n=n, solver=LM_CHOLESKY_REFERENCE_ORDER, **kw) as eng:
+        x, st, lam = eng.minimize(x0.copy())
+    for b in range(2):
+        ref, xr, lam_r, _ = O.lm_fd(oracle, obj, x0[b], order=0, **kw)
+        assert (st[b].iteration, st[b].function_calls_used) == (ref.iteration, ref.function_calls_used)
+        same_f = st[b].f_value == ref.f_value or (np.isnan(st[b].f_value) and np.isnan(ref.f_value))
+        assert same_f and np.array_equal(x[b], xr, equal_nan=True), b
+    with mod.NMEngine(obj, 2, n, reference_order=True, step=-1.0, eps=0.0, max_iter=30,
+                      no_change_best_tol=10**6) as eng:
+        x, st, _ = eng.minimize(x0.copy())
+    for b in range(2):
+        ref, xr, _, _ = O.nm_run(oracle, x0[b], obj=obj, order=0, step=-1.0, eps=0.0, max_iter=30,
+                                 no_change=10**6, restarts=0)
+        assert (st[b].iteration, st[b].function_calls_used) == (ref.iteration, ref.function_calls_used), b
+        same_f = st[b].f_value == ref.f_value or (np.isnan(st[b].f_value) and np.isnan(ref.f_value))
+        assert same_f and np.array_equal(x[b], xr, equal_nan=True), b
