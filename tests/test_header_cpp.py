@@ -307,6 +307,17 @@ def test_bfgs_summation_switch_through_header(built, oracle, golden):
     assert r.returncode == 3 and "NLSG_SUMMATION" in r.stdout, (r.returncode, r.stdout, r.stderr)
 
 
+def test_summation_switch_rejects_a_misspelt_value_without_a_gpu(built):
+    """NLSG_SUMMATION is read before anything touches the device: a value that is neither `reference`
+    nor `tree` is an error (no silent default), here with the real library and no GPU in sight."""
+    for prog, args in (("header_bfgs", ["device-fd", "4", "5", "0.0", "1.0", "0.9", "0.01"]),
+                       ("header_nm_lm", ["lm-device-fd", "4", "10", "5", "0.0", "0.8", "0.01"])):
+        r = subprocess.run([os.path.join(built, prog), *args],
+                           env=dict(os.environ, NLSG_LIBRARY=LIB, NLSG_SUMMATION="automatic"),
+                           capture_output=True, text=True)
+        assert r.returncode == 3 and "NLSG_SUMMATION must be reference or tree" in r.stdout, (r.stdout, r.stderr)
+
+
 def test_bfgs_device_objective_without_library_fails_loudly(built):
     """No CPU fallback on the device path: without the HIP library the call throws."""
     r = subprocess.run([os.path.join(built, "header_bfgs"), "device-fd", "4", "5", "0.0", "1.0",
