@@ -883,7 +883,7 @@ def main_nm(args):
             "config": {"workload": f"Nelder-Mead Rosenbrock-{n}D, {iters} iterations, batch={batch} per GPU",
                        "objective_calls_per_s": ranks.world * fcalls / (ms * 1e-3),
                        "reference_order": {"value": ranks.world * batch * iters / (ms_ref * 1e-3),
-                                           "ms_per_step": ms_ref / iters, "kernel": "nm_solve_kernel<0, 1> (p.seq)"},
+                                           "ms_per_step": ms_ref / iters, "kernel": "nm_solve_driver_kernel<0, true>"},
                        "parallelism": ranks.replicas()},
             "roofline": {"bound": "latency", "achieved": None, "peak": None, "unit": None,
                          # the whole solve is ONE launch of nm_solve_driver_kernel: its duration per

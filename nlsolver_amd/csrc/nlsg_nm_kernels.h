@@ -573,8 +573,8 @@ __device__ inline void nm_shrink_rows_impl(double *S, double *scores, uint64_t n
 }
 // Reference order, many rows at once (LDS-resident simplex): a LANE per row. Row r's objective is a
 // serial chain over its terms — but 64 rows are 64 independent chains, one v_add_f64 advances them
-// all. Lane l walks row 64 wid + l and computes its terms from the row itself; it runs k l steps
-// behind lane 0 (k = 1 or 2, whichever makes n - k odd), so that at any step the lanes read
+// all. Lane l walks row 64 wid + l and computes its terms from the row itself; it runs k (l mod 32)
+// steps behind lane 0 (k = 1 or 2, whichever makes n - k odd), so that at any step a half-wave reads
 // (n - k) l + s: 32 different banks instead of one (a row is n doubles: same column = same bank).
 // (A term buffer per wave and one row per wave at a time was LDS-bound: an LDS read at a uniform
 // address costs its 64 lane slots whatever the exec mask — 77 K cycles per shrink at n = 128.)
@@ -589,35 +589,36 @@ __device__ inline void nm_rescore_lanes(const double *S, double *scores, uint64_
   const int k = (n & 1) ? 2 : 1;
   const double *row = S + (r < nv ? r : nv - 1) * n;
   double acc = 0.0;
-  const int steps = nt + 63 * k;
-  // four steps' reads are in flight while the previous four are added (the reads are unconditional, at
-  // clamped indices; the additions happen inside the lane's window only)
-  const int kl = k * lane;
-  auto fetch = [&](int s0, double (&xe)[4], double (&xn)[4]) {
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      int e = s0 + u - kl;
-      e = e < 0 ? 0 : (e >= nt ? (nt > 0 ? nt - 1 : 0) : e);
-      xe[u] = row[e];
-      xn[u] = O::kChain ? row[e + 1] : 0.0;
+  // the skew spans a half-wave (32 lanes = the 32 banks; lanes l and l + 32 share a bank either way)
+  const int kl = k * (lane & 31);
+  const int steps = nt + 31 * k;
+  // three stretches: the lanes join one by one, all lanes inside their windows (no mask, no clamp:
+  // most of the steps when n is large), the lanes leave one by one
+  const bool mid = 31 * k < nt;
+  const int a_end = mid ? 31 * k : steps, b_end = mid ? nt : steps;
+  auto masked = [&](int s) {
+    const int e = s - kl;
+    if (e >= 0 && e < nt) {
+      const double xe = row[e];
+      const double xn = O::kChain ? row[e + 1] : 0.0;
+      acc = acc + O::term(xe, xn);
     }
   };
-  double ae[4], an[4], be[4], bn[4];
-  fetch(0, ae, an);
-  for (int s = 0; s < steps; s += 8) {
-    fetch(s + 4, be, bn);
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int e = s + u - kl;
-      if (e >= 0 && e < nt) acc = acc + O::term(ae[u], an[u]);
-    }
-    fetch(s + 8, ae, an);
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int e = s + 4 + u - kl;
-      if (e >= 0 && e < nt) acc = acc + O::term(be[u], bn[u]);
+  int s = 0;
+#pragma unroll 4
+  for (; s < a_end; s++) masked(s);
+  {
+    const double *at = row + (s - kl);  // element e of this lane at step s, one further per step
+#pragma unroll 8
+    for (; s < b_end; s++) {
+      const double xe = at[0];
+      const double xn = O::kChain ? at[1] : 0.0;
+      acc = acc + O::term(xe, xn);
+      at++;
     }
   }
+#pragma unroll 4
+  for (; s < steps; s++) masked(s);
   if (r < nv && static_cast<uint64_t>(r) != best) scores[r] = fmul * O::finish(acc, n64);
 }
 // the shrink (2009-2035) and rescoring (2288-2294) in reference order: every wave transforms its rows,
