@@ -69,25 +69,14 @@ __device__ inline double wave_total(const double (&a)[CHUNKS][2]) {
   }
   return wave_sum(acc);
 }
-// wave_sum_seq (nlsg_common.h) through the wave's LDS buffer: the terms are stored once (the lane
-// layout IS index order) and every lane walks them at a wave-uniform address — a read that does
-// not depend on the chain, so the additions follow each other at the adder's latency instead of
-// behind two v_readlane each (measured: 80 -> ~10 cycles per term). `buf`: 128 CHUNKS doubles.
+// (the serial sums go through the wave's LDS buffer: wave_sum_seq_buf / wave_objective_seq_buf,
+// nlsg_common.h; `buf`: 128 CHUNKS doubles)
 template <int CHUNKS>
 __device__ inline void bfgs_stage_terms(const double (&t)[CHUNKS][2], double *buf) {
   const int lane = lane_id();
 #pragma unroll
   for (int c = 0; c < CHUNKS; c++)
     *reinterpret_cast<double2 *>(buf + 128 * c + 2 * lane) = make_double2(t[c][0], t[c][1]);
-}
-template <int CHUNKS>
-__device__ inline double wave_sum_seq_lds(const double (&t)[CHUNKS][2], uint64_t n, double *buf) {
-  bfgs_stage_terms<CHUNKS>(t, buf);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  const double acc = serial_sum_lds(buf, static_cast<int>(n));
-  __builtin_amdgcn_wave_barrier();  // (the buffer's next stores come after these reads)
-  return acc;
 }
 // two sums side by side (two independent chains: their additions interleave); buf: 2 x 128 CHUNKS
 template <int CHUNKS>
@@ -122,7 +111,7 @@ __device__ inline double bfgs_dot(const double (&a)[CHUNKS][2], const double (&b
     t[c][0] = a[c][0] * b[c][0];
     t[c][1] = a[c][1] * b[c][1];
   }
-  return wave_sum_seq_lds<CHUNKS>(t, n, lds);
+  return wave_sum_seq_buf<CHUNKS>(t, n, lds);
 }
 
 // The G6 quadratic and its gradient (operation order of oracle_bfgs.c quad_f / quad_g).
@@ -141,7 +130,7 @@ __device__ inline double quad_f(const double (&x)[CHUNKS][2], const double (&d)[
       }
     double qq, lin;
     wave_sum_seq_lds2<CHUNKS>(tq, tl, n, lds, qq, lin);
-    const double sx = wave_sum_seq_lds<CHUNKS>(x, n, lds);
+    const double sx = wave_sum_seq_buf<CHUNKS>(x, n, lds);
     return 0.5 * qq + 0.5 * c * (sx * sx) - lin;
   }
   double aq = 0.0, al = 0.0;
@@ -161,7 +150,7 @@ template <int CHUNKS>
 __device__ inline void quad_g(const double (&x)[CHUNKS][2], const double (&d)[CHUNKS][2],
                               const double (&b)[CHUNKS][2], double c, uint64_t n,
                               double (&g)[CHUNKS][2], int seq = 0, double *lds = nullptr) {
-  const double sx = seq ? wave_sum_seq_lds<CHUNKS>(x, n, lds) : wave_total<CHUNKS>(x);
+  const double sx = seq ? wave_sum_seq_buf<CHUNKS>(x, n, lds) : wave_total<CHUNKS>(x);
   const int lane = lane_id();
 #pragma unroll
   for (int k = 0; k < CHUNKS; k++) {
@@ -203,27 +192,8 @@ struct BfgsModel {  // finite differences on Objective<MODEL>
     lds = bfgs_smem + (threadIdx.x >> 6) * (2 * 128 * CHUNKS);
   }
   __device__ inline double value(const double (&x)[CHUNKS][2]) const {
-    using O = Objective<MODEL>;
     if (!seq) return wave_objective<MODEL, CHUNKS>(x, n);
-    if constexpr (O::kWhole) {
-      return wave_objective_seq<MODEL, CHUNKS>(x, n);  // (rejected at engine creation)
-    } else {  // wave_objective_seq with the serial sum through LDS
-      const int lane = lane_id();
-      double t[CHUNKS][2];
-#pragma unroll
-      for (int c = 0; c < CHUNKS; c++) {
-        double xn = 0.0;
-        if (O::kChain) {
-          const double same = lane_down1(x[c][0]);
-          double next = 0.0;
-          if (c + 1 < CHUNKS) next = lane_first(x[c + 1][0]);
-          xn = (lane == 63) ? next : same;
-        }
-        t[c][0] = O::term(x[c][0], x[c][1]);
-        t[c][1] = O::term(x[c][1], xn);
-      }
-      return O::finish(wave_sum_seq_lds<CHUNKS>(t, O::n_terms(n), lds), n);
-    }
+    return wave_objective_seq_buf<MODEL, CHUNKS>(x, n, lds);  // (whole-vector bodies: rejected at engine creation)
   }
   __device__ inline double f(const double (&x)[CHUNKS][2], uint64_t &fcalls) const {
     fcalls++;
