@@ -95,20 +95,62 @@ __global__ __launch_bounds__(THREADS) void tinyqr_lm_kernel(TqrParams q) {
   constexpr int SL = (MAXP + W - 1) / W;
   int col[SL];
   double carry[SL];
-  // wave-uniform per chain: first step (never, for a slot without a chain), last - first step, and
-  // the ring offsets of the rotation's rows i-1 and i, followed from step to step while it runs
-  int first[SL], span[SL], om[SL], oi[SL];
+  // wave-uniform per chain: the ring offsets of the rotation's rows i-1 and i, followed from step to
+  // step while it runs. EVENT DRIVEN (as the LM engine's step, nlsg_lm_kernels.h): a wave's chains
+  // start at steps 2 j and end at steps j + n - 2, both in slot order, so two compares per step find
+  // "a chain of mine starts now" / "ended in the previous step"; a slot's hot path is a bit test of
+  // `amask` (75 scalar instructions per wave and step went into per-slot window arithmetic before:
+  // profiles/r04/tinyqr_issue_summary.json, the CU's one scalar unit 44 % busy).
+  int om[SL], oi[SL];
 #pragma unroll
   for (int u = 0; u < SL; u++) {
     const int j = wid + u * W;
     const int c = j + 1 + lane;
     col[u] = c <= p ? c : p + 1;
     carry[u] = 0.0;
-    first[u] = j < nch ? 2 * j : 0x7fffffff;  // (k - first stays negative: never inside a window)
-    span[u] = j < nch ? n - 2 - j : 0;
     om[u] = oi[u] = 0;
   }
+  constexpr int kNever = 0x40000000;
+  uint32_t amask = 0;
+  int js = wid, je = wid;  // next chain of mine to start / to be finished
+  int next_start = js < nch ? 2 * js : kNever, next_fin = je < nch ? je + n - 1 : kNever;
+  uint32_t us = 0, ue = 0;  // their slots
+  auto on_slot = [&](uint32_t sl, auto &&f) {  // f(int_c<sl>) for a wave-uniform sl: static register indices
+    if constexpr (SL > 0) if (sl == 0) f(int_c<0>{});
+    if constexpr (SL > 1) if (sl == 1) f(int_c<1>{});
+    if constexpr (SL > 2) if (sl == 2) f(int_c<2>{});
+    if constexpr (SL > 3) if (sl == 3) f(int_c<3>{});
+    if constexpr (SL > 4) if (sl == 4) f(int_c<4>{});
+    if constexpr (SL > 5) if (sl == 5) f(int_c<5>{});
+    if constexpr (SL > 6) if (sl == 6) f(int_c<6>{});
+    if constexpr (SL > 7) if (sl == 7) f(int_c<7>{});
+  };
+  static_assert(SL <= 8, "on_slot covers eight slots");
   const int om_start = n >= 2 ? slot_of(n - 2) * S : 0, oi_start = slot_of(n - 1) * S;
+  auto events = [&](int k) {
+    if (k == next_fin) {  // chain je ended in the previous step: its carried row is row je of R, final
+      on_slot(ue, [&](auto c) {
+        constexpr int sl = decltype(c)::value;
+        ring[je * S + col[sl]] = carry[sl];
+        amask &= ~(1u << sl);
+      });
+      je += W;
+      ue++;
+      next_fin = je < nch ? je + n - 1 : kNever;
+    }
+    if (k == next_start) {  // chain js starts at the bottom: rows n-2, n-1
+      on_slot(us, [&](auto c) {
+        constexpr int sl = decltype(c)::value;
+        om[sl] = om_start;
+        oi[sl] = oi_start;
+        carry[sl] = ring[oi_start + col[sl]];
+        amask |= 1u << sl;
+      });
+      js += W;
+      us++;
+      next_start = js < nch ? 2 * js : kNever;
+    }
+  };
   __syncthreads();
 
   int s0 = slot_of(n - 1);  // slot of row i0 = n-1-k, chain 0's lower row at step k
@@ -140,24 +182,17 @@ __global__ __launch_bounds__(THREADS) void tinyqr_lm_kernel(TqrParams q) {
     }
     __syncthreads();
     // ---- phase B: rotate_matrix (tinyqr.h:126-139) on the columns right of each chain's pivot;
-    // one pass per chain (the ring slots are computed once; the SIMD's other waves cover the LDS
-    // round trip)
+    // one pass per chain (the SIMD's other waves cover the LDS round trip)
+    events(k);
 #pragma unroll
     for (int u = 0; u < SL; u++) {
-      const unsigned d = static_cast<unsigned>(k - first[u]);  // wave-uniform, like everything here but `col`
-      if (d <= static_cast<unsigned>(span[u])) {
-        if (d == 0) {  // the chain starts at the bottom: rows n-2, n-1
-          om[u] = om_start;
-          oi[u] = oi_start;
-          carry[u] = ring[oi_start + col[u]];
-        }
+      if (amask >> u & 1u) {  // wave-uniform
         const double2 g = cs[wid + u * W];
         const double t1 = ring[om[u] + col[u]];
         const double c = g.x, s = g.y, t2 = carry[u];
         const double lo = __builtin_fma(c, t1, s * t2);
         ring[oi[u] + col[u]] = __builtin_fma(c, t2, (-s) * t1);
         carry[u] = lo;
-        if (d == static_cast<unsigned>(span[u])) ring[om[u] + col[u]] = lo;  // the chain ends: row j of R is final
         oi[u] = om[u];
         om[u] = om[u] == 0 ? (RING - 1) * S : om[u] - S;
       }
@@ -167,6 +202,8 @@ __global__ __launch_bounds__(THREADS) void tinyqr_lm_kernel(TqrParams q) {
     __syncthreads();
   }
 
+  events(last + 1);  // the last chain's finished row
+  __syncthreads();
   // back_solve (tinyqr.h:437-459) on R beta = w; rows 0 .. p-1 sit in ring slots 0 .. p-1
   if (t < 64) {
     const double tol = q.tol;
