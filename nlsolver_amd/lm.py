@@ -124,8 +124,8 @@ class LMEngine:
 
 class LevenbergMarquardt:
     """Drop-in for nlsolver::LevenbergMarquardt on a device NLLS model or a built-in objective
-    (by name); x: (n,) or (batch, n). solver=None (automatic, as include/nlsolver_mi/nlsolver.h's
-    device::summation()): the default-functor model on Rosenbrock / Sphere / Styblinski-Tang solves
+    (by name); x: (n,) or (batch, n). solver=None (as include/nlsolver_mi/nlsolver.h's
+    device::summation() default): the default-functor model on Rosenbrock / Sphere / Styblinski-Tang solves
     in reference order (LM_CHOLESKY_REFERENCE_ORDER: the reference's run bit for bit, and — a probe
     per lane — the faster evaluation); everything else with LM_CHOLESKY."""
 
