@@ -47,6 +47,12 @@ def test_reference_systems_on_the_device(tq, oracle, golden, n, p, seed):
     assert np.array_equal(beta, oracle_lm(oracle, X, y, 1)), (n, p)
     ref = np.array([hx(v) for v in golden("tinyqr.json")[f"rect_{n}x{p}"]["beta"]])
     assert np.allclose(beta, ref, rtol=1e-9, atol=1e-12)
+    # the bound that belongs to the system, not a flat one: two backward-stable orthogonal
+    # factorisations of the same X agree to cond(X) eps (here with a factor of 8 for n p rotations'
+    # worth of rounding; measured: well inside)
+    cond = np.linalg.cond(X.T)
+    eps = np.finfo(np.float64).eps
+    assert np.max(np.abs(beta - ref)) <= 8 * cond * eps * max(np.max(np.abs(ref)), 1e-300), (n, p, cond)
 
 
 @pytest.mark.parametrize("n,p,batch", [(576, 64, 24), (64, 64, 40), (65, 64, 7), (130, 63, 9),
