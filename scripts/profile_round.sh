@@ -4,7 +4,8 @@
 # passes, FETCH_SIZE and WRITE_SIZE apart (they do not fit one pass, MI355X_MICROARCH.md), under
 # gpurun_out/prof_ROUND/. Summarised afterwards, off the box, by profiles/summarize_pmc.py into
 # profiles/ROUND/{pmc_summary,de_pmc_summary}.json; the csv / json files are copied there as they are.
-# scripts/profile_round.sh ROUND "tag tag ..." limits the run to those workloads.
+# scripts/profile_round.sh ROUND "tag tag ..." limits the run to those workloads;
+# NLSG_PROFILE_NO_PMC=1 skips the two counter passes (a refresh of the kernel-stats csv alone).
 round=${1:-r04}
 only=" ${2:-} "
 root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -18,6 +19,7 @@ run() {  # tag, bench args...
   rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats" -o "$tag" -- \
     python3 "$root/bench.py" "$@" > "$out/${tag}_bench.json" 2> "$out/${tag}_bench.err" || return 1
   cp "$(find "$out/${tag}_stats" -name '*kernel_stats.csv' | head -1)" "$out/${tag}_kernel_stats.csv"
+  [ -n "${NLSG_PROFILE_NO_PMC:-}" ] && return 0
   for ctr in FETCH_SIZE WRITE_SIZE; do
     NLSG_BENCH_NO_CONSISTENCY_CHECK=1 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$out/${tag}_$ctr" -o "$tag" -- \
       python3 "$root/bench.py" "$@" --steps 20 --warmup 2 --no-cpu-baseline --no-north-star --no-other-configs \
