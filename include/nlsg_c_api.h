@@ -339,7 +339,7 @@ typedef enum {
  * of a tree sum into 1e-8 .. 1e-6 of the result). Literal update only, objectives given by their
  * terms (not Rastrigin, not a whole-vector custom body). With the default gradient it is also the
  * FASTER mode — the 4 n probes share the base point's terms and prefix sums, a probe per lane —:
- * 1.07e7 against 2.6e6 iteration-problems/s at Rosenbrock-128D x 4096; with a gradient functor the H
+ * 9.4e6 against 2.6e6 iteration-problems/s at Rosenbrock-128D x 4096; with a gradient functor the H
  * passes (a lane per row) cost 1.5 x the tree kernels' time at dim = 1024. */
 #define NLSG_BFGS_REFERENCE_ORDER 2
 
